@@ -1,0 +1,124 @@
+/* str2str_hip.h — C ABI of libstr2str_hip.so (MI355X / gfx950 kernels for the Str2Str sampling path).
+ *
+ * Drop-in boundary: the reference has no FFI layer — its seams are Python call
+ * sites.  Each entry point below replaces the chain of eager PyTorch ops behind ONE such call site
+ * (cited per function as reference file:line) and is what a binding for that call site would load:
+ * plain device pointers, sizes and a HIP stream; no torch types.  INTEGRATION.md shows the ctypes
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory owned by the caller (in this repo: torch tensors); kernels never
+ *     allocate, free or synchronise; outputs must be pre-allocated, contiguous, 16-byte aligned;
+ *   - `stream` is a hipStream_t (0 = default stream); work is only enqueued;
+ *   - float = IEEE binary32; frames are "tensor_7": quaternion (w,x,y,z) + translation (x,y,z)
+ *     (Rigid.to_tensor_7, src/common/rigid_utils.py:1203-1215);
+ *   - return value: 0 on success, otherwise a hipError_t (argument errors = hipErrorInvalidValue);
+ *   - re-entrant across streams; the only global state is the immutable backbone table.
+ */
+#ifndef STR2STR_HIP_H
+#define STR2STR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Library ABI version (bumped on any signature change). */
+int s2s_abi_version(void);
+
+/* ---- Pair-stream MLPs (fp32 MFMA).  Weight blobs are "packed" for the kernels' lane order:
+ *      packed[((s4*T + t)*64 + lane)*4 + q] = W[32*t + (lane & 31)][8*s4 + 4*(lane >> 5) + q]
+ *      for W [32*T, 8*S4] row-major (str2str_amd.ops.pack_weight does this). ---- */
+
+/* EdgeTransition.forward (src/models/net/layers.py:170-185) followed by the edge-mask multiply of
+ * TranslationIPA.forward (src/models/net/ipa.py:371-372).
+ *   edge     [B,N,N,128]  in        node_ab [B,N,768] = [W1[:,128:256].n'+b1 | W1[:,256:384].n']
+ *   node_p   [B,N,128]    n' = initial_embed(node)
+ *   w1_packed: W1[:, :128] (384x128); w2_packed: W2 (384x384); wf_packed: final_layer.weight (128x384)
+ *   b2 [384], bf [128], ln_gamma/ln_beta [128], mask [B,N] or NULL, out [B,N,N,128] (may not alias edge). */
+int s2s_edge_transition(const float* edge, const float* node_ab, const float* node_p, const float* w1_packed,
+                        const float* w2_packed, const float* wf_packed, const float* b2, const float* bf,
+                        const float* ln_gamma, const float* ln_beta, const float* mask, float* out, int n_samples,
+                        int n_res, float ln_eps, void* stream);
+
+/* EmbeddingModule.forward, edge branch (src/models/net/denoising_ipa.py:137-158, calc_distogram
+ * src/common/geo_utils.py:44-56) + edge-mask multiply (denoising_ipa.py:187).
+ *   node_a/node_b [B,N,128]: row / column parts of the first Linear (incl. bias in node_a)
+ *   rel_table [n_rel,128]: first-layer image of posemb(d), d = idx_i - idx_j, row d + rel_offset
+ *   bin_table [n_bins,128]: first-layer columns of the distogram one-hot; bin_lower [n_bins]
+ *   residue_idx [B,N] int64; ca_xyz [B,N,3] (self-conditioning CA, Angstrom)
+ *   w2/w3 packed 128x128; b2,b3,ln_gamma,ln_beta [128]; out [B,N,N,128]. */
+int s2s_edge_embed(const float* node_a, const float* node_b, const float* rel_table, const float* bin_table,
+                   const float* bin_lower, const long long* residue_idx, const float* ca_xyz, const float* w2_packed,
+                   const float* w3_packed, const float* b2, const float* b3, const float* ln_gamma, const float* ln_beta,
+                   const float* mask, float* out, int n_samples, int n_res, int rel_offset, int n_rel, int n_bins,
+                   float ln_eps, void* stream);
+
+/* linear_b and down_z of InvariantPointAttention (src/models/net/ipa.py:177, :253) in one pass over z.
+ *   w_packed: [linear_b.weight (8 rows); down_z.weight (32 rows); 24 zero rows] (64x128) packed
+ *   bias_cat64 [64]; attn_bias [B,N,N,8]; pair_z [B,N,N,32]. */
+int s2s_pair_project(const float* edge, const float* w_packed, const float* bias_cat64, float* attn_bias, float* pair_z,
+                     int n_samples, int n_res, void* stream);
+
+/* ---- Invariant point attention ---- */
+
+/* Point generation: split/stack of the coordinate-major linear outputs and Rigid.apply
+ * (src/models/net/ipa.py:144-171; src/common/rigid_utils.py:1107-1120).
+ *   rigids7 [M,7] (translation already x coordinate_scaling), q_pts_lin [M,3*H*Pq], kv_pts_lin [M,3*H*(Pq+Pv)]
+ *   q_pts,k_pts [M,H,Pq*3]; v_pts [M,H,v_pts_stride] as (x,y,z,0) per point, zero padded (stride 64). */
+int s2s_ipa_prep_points(const float* rigids7, const float* q_pts_lin, const float* kv_pts_lin, float* q_pts, float* k_pts,
+                        float* v_pts, long long n_frames, int n_heads, int n_qk_points, int n_v_points, int v_pts_stride,
+                        void* stream);
+
+/* Attention core of InvariantPointAttention.forward (src/models/net/ipa.py:183-257): logits
+ * (scalar + pair bias + point distances + mask), softmax over keys, o / o_pt (inverse-transformed,
+ * with norms) / o_pair, written in linear_out's concat order (ipa.py:259-266):
+ *   out [B,N, H*C | H*Pv (x) | H*Pv (y) | H*Pv (z) | H*Pv (norm) | H*c_pair_z].
+ *   q [B,N,H,C]; kv [B,N,H,2C]; head_w_scaled [H] = softplus(head_weights)*sqrt(1/(3*(Pq*9/2))).
+ * Supported shape: C=256, Pq=8, Pv=12, c_pair_z=32, H multiple of 4 (configs/model/diffusion.yaml:29-40). */
+int s2s_ipa_attention(const float* q, const float* kv, const float* q_pts, const float* k_pts, const float* v_pts64,
+                      const float* attn_bias, const float* pair_z, const float* mask, const float* rigids7,
+                      const float* head_w_scaled, float* out, int n_samples, int n_res, int n_heads, int c_hidden,
+                      int n_qk_points, int n_v_points, int c_pair_z, float inf, float eps, void* stream);
+
+/* ---- Rigid frames ---- */
+
+/* Rigid.compose_q_update_vec (src/common/rigid_utils.py:1042-1066, :590-619, :268-277).
+ *   rigids7 [M,7], update6 [M,6], mask [M], out7 [M,7] (may alias rigids7). */
+int s2s_rigid_compose_update(const float* rigids7, const float* update6, const float* mask, float* out7,
+                             long long n_frames, void* stream);
+
+/* TranslationIPA scale_rigids / unscale_rigids (src/models/net/ipa.py:288-292): translation * scale,
+ * or translation / scale (true division) when divide != 0. */
+int s2s_rigid_scale_trans(const float* rigids7, float* out7, long long n_frames, float scale, int divide, void* stream);
+
+/* Upload the idealised-geometry tables used by s2s_frames_to_backbone (host pointers; synchronous;
+ * call once per process).  Values: src/common/residue_constants.py:775-852 via all_atom.py:13-18. */
+int s2s_set_backbone_tables(const float* pos_21x5x3, const float* mask_21x5, const int* is_psi_group_21x5,
+                            const float* default_frames_21x2x4x4);
+
+/* compute_backbone (src/common/all_atom.py:141-173).  rigids7 [M,7] (Angstrom), psi_sincos [M,2],
+ * aatype [M] int64 or NULL; atom14_bb5 [M,5,3] (N,CA,C,O,CB) or NULL; atom37 [M,37,3] or NULL. */
+int s2s_frames_to_backbone(const float* rigids7, const float* psi_sincos, const long long* aatype, float* atom14_bb5,
+                           float* atom37, long long n_frames, void* stream);
+
+/* ---- One reverse-diffusion geometry step ---- */
+
+/* FrameDiffuser.score + FrameDiffuser.reverse + Rigid.to_tensor_7
+ * (src/models/score/frame.py:109-143, :153-210; so3.py:274-309, :333-370; r3.py:79-137).
+ *   x0_7 [B,N,7] predicted frames, xt_7 [B,N,7] current frames, mask/diffuse_mask [B,N],
+ *   params8 [B,8] float: sigma(bin), g_rot^2, exp(-beta/2), 1-exp(-beta), b(t), g_trans^2, g_rot, g_trans
+ *   z_rot,z_trans [B,N,3] double noise (only read when probability_flow == 0),
+ *   rot_score_in/trans_score_in [B,N,3] double or NULL: when given, the score stage is skipped and
+ *   these are used (FrameDiffuser.reverse called with caller-provided scores; x0_7 may be NULL),
+ *   next7 [B,N,7] or NULL (score only); rot_score_out/trans_score_out [B,N,3] double or NULL. */
+int s2s_se3_step(const float* x0_7, const float* xt_7, const float* mask, const float* diffuse_mask,
+                 const float* params8, const double* z_rot, const double* z_trans,
+                 const double* rot_score_in, const double* trans_score_in, float* next7,
+                 double* rot_score_out, double* trans_score_out, int n_samples, int n_res, double dt,
+                 double coordinate_scaling, int probability_flow, int center_trans, double noise_scale,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STR2STR_HIP_H */

@@ -1,0 +1,359 @@
+// Pair-stream MLP kernels on fp32 MFMA (gfx950): the N x N part of the score network.
+//
+//   s2s_edge_transition   EdgeTransition.forward          src/models/net/layers.py:170-185 (+ mask, ipa.py:372)
+//   s2s_edge_embed        EmbeddingModule edge branch     src/models/net/denoising_ipa.py:137-158 (+ mask :187)
+//   s2s_pair_project      linear_b + down_z of IPA        src/models/net/ipa.py:177,253
+//
+// Design (one wave = one tile of 32 consecutive pairs of the flattened [B*N*N] pair stream):
+//   * Every layer is evaluated TRANSPOSED:  H^T[out, pair] = W[out, in] . X^T[in, pair]  with
+//     v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).  In that orientation the C/D register
+//     layout of one layer (lane&31 = pair, regs = 16 of the 32 output rows, lane>>5 picks which 16)
+//     IS the B-operand layout of the next layer, because the k-order of a dot product is free:
+//     step s of the next layer consumes register s&15 of accumulator tile s>>4 in both wave halves.
+//     Activations therefore never leave registers between layers; the [B*N*N, 384] hidden tensor
+//     that eager PyTorch materialises 4x (12.9 GB each at B=128, N=256) does not exist.
+//   * Weights are pre-packed on the host in exactly the order lanes consume them
+//     (pack index = ((s4*T + t)*64 + lane)*4 + q  ->  W[32t + (lane&31)][8*s4 + 4*(lane>>5) + q]),
+//     so a wave fetches the A operands of 4 MFMAs with ONE coalesced 1 KiB dwordx4 load; all waves
+//     stream the same ~1 MB of weights, which stays L2-resident.
+//   * "B layout" of a per-pair vector x[K]: lane (pair, h) holds x[8*g + 4*h + q] for all g, q<4 —
+//     loaded from / stored to HBM as float4 (pairs are 512 B rows, every byte of a row is used).
+//   * EdgeTransition's first layer only multiplies the 128 edge channels: the node halves of
+//     W1.[e|n_i|n_j] are per-node vectors precomputed once per call (A_i, B_j) and enter as the
+//     accumulator's initial value (491,520 FLOP/pair instead of 688,128).
+#include <hip/hip_runtime.h>
+
+#include "str2str_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+constexpr int kPrefetch = 4;  // weight fragments in flight per wave (x 1 KiB)
+
+// acc[t] += Wpacked . B   for T output tiles and S4 step-groups (K = 8*S4 inputs).
+// bop(s4, q) returns this lane's B operand for step 4*s4+q (must be compile-time selectable).
+template <int T, int S4, typename BOp>
+__device__ __forceinline__ void mlp_layer(f32x16 (&acc)[T], const float4* __restrict__ wp, int lane, BOp bop) {
+    constexpr int NIT = S4 * T;
+    constexpr int D = kPrefetch < NIT ? kPrefetch : NIT;
+    float4 w[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) w[d] = wp[d * 64 + lane];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const float4 cur = w[it % D];
+        if (it + D < NIT) w[it % D] = wp[(it + D) * 64 + lane];
+        const int s4 = it / T, t = it % T;
+        acc[t] = mfma32(cur.x, bop(s4, 0), acc[t]);
+        acc[t] = mfma32(cur.y, bop(s4, 1), acc[t]);
+        acc[t] = mfma32(cur.z, bop(s4, 2), acc[t]);
+        acc[t] = mfma32(cur.w, bop(s4, 3), acc[t]);
+    }
+}
+
+// this lane's 4 consecutive elements of group g of a B-layout vector
+__device__ __forceinline__ float4 ldg4(const float* __restrict__ base, int g, int h) {
+    return *reinterpret_cast<const float4*>(base + 8 * g + 4 * h);
+}
+
+__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+// LayerNorm over the 32*T channels a pair owns (half in this lane, half in lane^32), gamma/beta,
+// optional scale, then float4 stores in B layout.
+template <int T>
+__device__ __forceinline__ void ln_store(f32x16 (&acc)[T], const float* __restrict__ gamma, const float* __restrict__ beta,
+                                         float eps, float scale, float* __restrict__ out_row, int h, bool valid) {
+    constexpr float inv_n = 1.0f / (32 * T);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[t][r];
+    const float mean = xhalf_sum(s) * inv_n;
+    float v = 0.f;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float d = acc[t][r] - mean;
+            v += d * d;
+        }
+    const float rstd = 1.0f / sqrtf(xhalf_sum(v) * inv_n + eps);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int g = 4 * t + rq;
+            const float4 ga = ldg4(gamma, g, h), be = ldg4(beta, g, h);
+            float4 o;
+            o.x = ((acc[t][4 * rq + 0] - mean) * rstd * ga.x + be.x) * scale;
+            o.y = ((acc[t][4 * rq + 1] - mean) * rstd * ga.y + be.y) * scale;
+            o.z = ((acc[t][4 * rq + 2] - mean) * rstd * ga.z + be.z) * scale;
+            o.w = ((acc[t][4 * rq + 3] - mean) * rstd * ga.w + be.w) * scale;
+            if (valid) *reinterpret_cast<float4*>(out_row + 8 * g + 4 * h) = o;
+        }
+}
+
+template <int T>
+__device__ __forceinline__ void relu_(f32x16 (&acc)[T]) {
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
+}
+
+struct PairIdx {
+    long long p;   // clamped flat pair index
+    long long bi;  // b*N + i
+    long long bj;  // b*N + j
+    bool valid;
+};
+
+__device__ __forceinline__ PairIdx pair_index(long long tile, int lane, long long M, int N) {
+    PairIdx x;
+    long long p = tile * 32 + (lane & 31);
+    x.valid = p < M;
+    if (!x.valid) p = M - 1;
+    x.p = p;
+    const long long NN = (long long)N * N;
+    const long long b = p / NN;
+    const long long rem = p - b * NN;
+    const long long i = rem / N, j = rem - i * N;
+    x.bi = b * N + i;
+    x.bj = b * N + j;
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------
+// EdgeTransition: c_z = 128 edge channels, hidden 384 = 128 + 2*128.
+//   node_ab [B*N, 768] : [0,384)  = W1[:,128:256].n'_i + b1   (row-i contribution to layer 1)
+//                        [384,768) = W1[:,256:384].n'_j        (column-j contribution)
+//   node_p  [B*N, 128] : n' = initial_embed(node)
+//   w1p : packed W1[:, 0:128]  (384 x 128), w2p : packed W2 (384 x 384), wfp : packed Wf (128 x 384)
+__global__ void __launch_bounds__(256) edge_transition_kernel(
+    const float* __restrict__ edge, const float* __restrict__ node_ab, const float* __restrict__ node_p,
+    const float4* __restrict__ w1p, const float4* __restrict__ w2p, const float4* __restrict__ wfp,
+    const float* __restrict__ b2, const float* __restrict__ bf, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mask, float* __restrict__ out, long long M, int N,
+    float ln_eps) {
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile * 32 >= M) return;
+    const PairIdx px = pair_index(tile, lane, M, N);
+    const float* erow = edge + px.p * 128;
+    const float* arow = node_ab + px.bi * 768;
+    const float* brow = node_ab + px.bj * 768 + 384;
+
+    // ---- layer 1: 384 <- 128
+    f32x16 a1[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const float4 x = ldg4(arow, 4 * t + rq, h), y = ldg4(brow, 4 * t + rq, h);
+            a1[t][4 * rq + 0] = x.x + y.x; a1[t][4 * rq + 1] = x.y + y.y;
+            a1[t][4 * rq + 2] = x.z + y.z; a1[t][4 * rq + 3] = x.w + y.w;
+        }
+    {
+        float4 e[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) e[g] = ldg4(erow, g, h);
+        mlp_layer<12, 16>(a1, w1p, lane, [&](int s4, int q) { return q == 0 ? e[s4].x : q == 1 ? e[s4].y : q == 2 ? e[s4].z : e[s4].w; });
+    }
+    relu_<12>(a1);
+
+    // ---- layer 2: 384 <- 384
+    f32x16 a2[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const float4 x = ldg4(b2, 4 * t + rq, h);
+            a2[t][4 * rq + 0] = x.x; a2[t][4 * rq + 1] = x.y; a2[t][4 * rq + 2] = x.z; a2[t][4 * rq + 3] = x.w;
+        }
+    mlp_layer<12, 48>(a2, w2p, lane, [&](int s4, int q) { return a1[s4 >> 2][(s4 & 3) * 4 + q]; });
+    relu_<12>(a2);
+
+    // ---- residual: h2 + x, x = [e | n'_i | n'_j]   (layers.py:181 "trunk(x) + x")
+    {
+        const float* src[3] = {erow, node_p + px.bi * 128, node_p + px.bj * 128};
+#pragma unroll
+        for (int t = 0; t < 12; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const float4 x = ldg4(src[t >> 2], 4 * (t & 3) + rq, h);
+                a2[t][4 * rq + 0] += x.x; a2[t][4 * rq + 1] += x.y; a2[t][4 * rq + 2] += x.z; a2[t][4 * rq + 3] += x.w;
+            }
+    }
+
+    // ---- final layer: 128 <- 384, LayerNorm, edge mask
+    f32x16 a3[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const float4 x = ldg4(bf, 4 * t + rq, h);
+            a3[t][4 * rq + 0] = x.x; a3[t][4 * rq + 1] = x.y; a3[t][4 * rq + 2] = x.z; a3[t][4 * rq + 3] = x.w;
+        }
+    mlp_layer<4, 48>(a3, wfp, lane, [&](int s4, int q) { return a2[s4 >> 2][(s4 & 3) * 4 + q]; });
+    const float em = mask ? mask[px.bi] * mask[px.bj] : 1.0f;
+    ln_store<4>(a3, gamma, beta, ln_eps, em, out + px.p * 128, h, px.valid);
+}
+
+// ------------------------------------------------------------------------------------------
+// Edge embedding.  First Linear(120 -> 128) of edge_embed is a sum of four table rows:
+//   node_a[b,i] = W[:, 0:33].[t_emb, fixed_i] + bias,   node_b[b,j] = W[:, 33:66].[t_emb, fixed_j]
+//   rel_tab[d + rel_off] = W[:, 66:98].posemb(d),  d = idx_i - idx_j
+//   bin_tab[k] = W[:, 98+k]  for the distogram bin k of |ca_i - ca_j| (strict > lower, < upper;
+//   geo_utils.py:44-56), none when the distance sits exactly on an edge or is 0.
+// then two 128x128 MFMA layers, LayerNorm, edge mask.
+__global__ void __launch_bounds__(256) edge_embed_kernel(
+    const float* __restrict__ node_a, const float* __restrict__ node_b, const float* __restrict__ rel_tab,
+    const float* __restrict__ bin_tab, const float* __restrict__ bin_lower, const long long* __restrict__ residue_idx,
+    const float* __restrict__ ca, const float4* __restrict__ w2p, const float4* __restrict__ w3p,
+    const float* __restrict__ b2, const float* __restrict__ b3, const float* __restrict__ gamma,
+    const float* __restrict__ beta, const float* __restrict__ mask, float* __restrict__ out, long long M, int N,
+    int rel_off, int n_rel, int n_bins, float ln_eps) {
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile * 32 >= M) return;
+    const PairIdx px = pair_index(tile, lane, M, N);
+
+    // distogram bin of this pair (no FMA contraction: mirrors torch.linalg.norm of the difference)
+    const float dx = ca[px.bi * 3 + 0] - ca[px.bj * 3 + 0];
+    const float dy = ca[px.bi * 3 + 1] - ca[px.bj * 3 + 1];
+    const float dz = ca[px.bi * 3 + 2] - ca[px.bj * 3 + 2];
+    const float dist = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    int bin = -1;
+    for (int k = 0; k < n_bins; ++k) {
+        const float lo = bin_lower[k];
+        const float up = (k + 1 < n_bins) ? bin_lower[k + 1] : 1e8f;
+        if (dist > lo && dist < up) bin = k;
+    }
+    long long d = residue_idx[px.bi] - residue_idx[px.bj] + rel_off;
+    d = d < 0 ? 0 : (d >= n_rel ? n_rel - 1 : d);
+    const float* ra = node_a + px.bi * 128;
+    const float* rb = node_b + px.bj * 128;
+    const float* rr = rel_tab + d * 128;
+    const float* rk = bin_tab + (long long)(bin < 0 ? 0 : bin) * 128;
+    const float kb = bin < 0 ? 0.f : 1.f;
+
+    float4 h1[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const float4 a = ldg4(ra, g, h), b = ldg4(rb, g, h), r = ldg4(rr, g, h), k = ldg4(rk, g, h);
+        h1[g].x = fmaxf(a.x + b.x + r.x + kb * k.x, 0.f);
+        h1[g].y = fmaxf(a.y + b.y + r.y + kb * k.y, 0.f);
+        h1[g].z = fmaxf(a.z + b.z + r.z + kb * k.z, 0.f);
+        h1[g].w = fmaxf(a.w + b.w + r.w + kb * k.w, 0.f);
+    }
+    f32x16 a2[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const float4 x = ldg4(b2, 4 * t + rq, h);
+            a2[t][4 * rq + 0] = x.x; a2[t][4 * rq + 1] = x.y; a2[t][4 * rq + 2] = x.z; a2[t][4 * rq + 3] = x.w;
+        }
+    mlp_layer<4, 16>(a2, w2p, lane, [&](int s4, int q) { return q == 0 ? h1[s4].x : q == 1 ? h1[s4].y : q == 2 ? h1[s4].z : h1[s4].w; });
+    relu_<4>(a2);
+    f32x16 a3[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const float4 x = ldg4(b3, 4 * t + rq, h);
+            a3[t][4 * rq + 0] = x.x; a3[t][4 * rq + 1] = x.y; a3[t][4 * rq + 2] = x.z; a3[t][4 * rq + 3] = x.w;
+        }
+    mlp_layer<4, 16>(a3, w3p, lane, [&](int s4, int q) { return a2[s4 >> 2][(s4 & 3) * 4 + q]; });
+    const float em = mask ? mask[px.bi] * mask[px.bj] : 1.0f;
+    ln_store<4>(a3, gamma, beta, ln_eps, em, out + px.p * 128, h, px.valid);
+}
+
+// ------------------------------------------------------------------------------------------
+// IPA pair projections: out = Wcat . z + bcat with Wcat = [linear_b (H rows) ; down_z (c_z/4 rows)]
+// zero-padded to 64 rows.  Writes bias_out [M, H] and pairz_out [M, PZ] (H = 8, PZ = 32).
+__global__ void __launch_bounds__(256) pair_project_kernel(const float* __restrict__ edge, const float4* __restrict__ wp,
+                                                           const float* __restrict__ bcat, float* __restrict__ bias_out,
+                                                           float* __restrict__ pairz_out, long long M) {
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile * 32 >= M) return;
+    long long p = tile * 32 + (lane & 31);
+    const bool valid = p < M;
+    if (!valid) p = M - 1;
+    const float* erow = edge + p * 128;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const float4 x = ldg4(bcat, 4 * t + rq, h);
+            acc[t][4 * rq + 0] = x.x; acc[t][4 * rq + 1] = x.y; acc[t][4 * rq + 2] = x.z; acc[t][4 * rq + 3] = x.w;
+        }
+    float4 e[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) e[g] = ldg4(erow, g, h);
+    mlp_layer<2, 16>(acc, wp, lane, [&](int s4, int q) { return q == 0 ? e[s4].x : q == 1 ? e[s4].y : q == 2 ? e[s4].z : e[s4].w; });
+    if (!valid) return;
+    // rows 0..7 -> attention bias (rows 0..3 live in h=0 / rq=0, rows 4..7 in h=1 / rq=0)
+    *reinterpret_cast<float4*>(bias_out + p * 8 + 4 * h) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+    // rows 8..39 -> pair_z channel c = row - 8 : group g = row/8 in 1..4, i.e. (t, rq) = (0,1..3), (1,0)
+#pragma unroll
+    for (int g = 1; g <= 4; ++g) {
+        const int t = g >> 2, rq = g & 3;
+        *reinterpret_cast<float4*>(pairz_out + p * 32 + 8 * (g - 1) + 4 * h) =
+            make_float4(acc[t][4 * rq + 0], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]);
+    }
+}
+
+inline int tiles_grid(long long M, int waves_per_block) {
+    const long long tiles = (M + 31) / 32;
+    return (int)((tiles + waves_per_block - 1) / waves_per_block);
+}
+
+}  // namespace
+
+extern "C" {
+
+int s2s_edge_transition(const float* edge, const float* node_ab, const float* node_p, const float* w1_packed,
+                        const float* w2_packed, const float* wf_packed, const float* b2, const float* bf,
+                        const float* ln_gamma, const float* ln_beta, const float* mask, float* out, int n_samples,
+                        int n_res, float ln_eps, void* stream) {
+    const long long M = (long long)n_samples * n_res * n_res;
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(edge_transition_kernel, dim3(tiles_grid(M, 4)), dim3(256), 0, (hipStream_t)stream, edge, node_ab,
+                       node_p, (const float4*)w1_packed, (const float4*)w2_packed, (const float4*)wf_packed, b2, bf,
+                       ln_gamma, ln_beta, mask, out, M, n_res, ln_eps);
+    return (int)hipGetLastError();
+}
+
+int s2s_edge_embed(const float* node_a, const float* node_b, const float* rel_table, const float* bin_table,
+                   const float* bin_lower, const long long* residue_idx, const float* ca_xyz, const float* w2_packed,
+                   const float* w3_packed, const float* b2, const float* b3, const float* ln_gamma, const float* ln_beta,
+                   const float* mask, float* out, int n_samples, int n_res, int rel_offset, int n_rel, int n_bins,
+                   float ln_eps, void* stream) {
+    const long long M = (long long)n_samples * n_res * n_res;
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(edge_embed_kernel, dim3(tiles_grid(M, 4)), dim3(256), 0, (hipStream_t)stream, node_a, node_b,
+                       rel_table, bin_table, bin_lower, residue_idx, ca_xyz, (const float4*)w2_packed,
+                       (const float4*)w3_packed, b2, b3, ln_gamma, ln_beta, mask, out, M, n_res, rel_offset, n_rel, n_bins,
+                       ln_eps);
+    return (int)hipGetLastError();
+}
+
+int s2s_pair_project(const float* edge, const float* w_packed, const float* bias_cat64, float* attn_bias, float* pair_z,
+                     int n_samples, int n_res, void* stream) {
+    const long long M = (long long)n_samples * n_res * n_res;
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(pair_project_kernel, dim3(tiles_grid(M, 4)), dim3(256), 0, (hipStream_t)stream, edge,
+                       (const float4*)w_packed, bias_cat64, attn_bias, pair_z, M);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

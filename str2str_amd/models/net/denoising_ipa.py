@@ -1,0 +1,166 @@
+"""``EmbeddingModule`` and ``DenoisingNet`` (the SE(3) score network entry) on the HIP kernels.
+
+Interface and parameter names follow the reference's ``src/models/net/denoising_ipa.py``
+(get_positional_embedding :13-31, get_timestep_embedding :34-46, EmbeddingModule :49-159,
+DenoisingNet :162-211).  The N x N edge embedding never builds the [B, N^2, 120] feature tensor:
+its first Linear is a sum of four table rows (row part, column part, relative-position table,
+distogram-bin table) gathered inside ``s2s_edge_embed`` (csrc/pair_mlp.hip), which then runs the two
+128x128 layers on fp32 MFMA, LayerNorm and the edge mask and writes z once.
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ... import ops
+from ...common.all_atom import compute_backbone
+from ...common.rigid_utils import Rigid
+from .ipa import TranslationIPA  # noqa: F401  (re-exported like the reference module)
+from .layers import ParamCache
+
+
+def get_positional_embedding(indices: torch.Tensor, embedding_dim: int, max_len: int = 2056) -> torch.Tensor:
+    K = torch.arange(embedding_dim // 2, device=indices.device)
+    arg = indices[..., None] * math.pi / (max_len ** (2 * K[None] / embedding_dim))
+    return torch.cat([torch.sin(arg), torch.cos(arg)], dim=-1)
+
+
+def get_timestep_embedding(timesteps: torch.Tensor, embedding_dim: int, max_len: int = 10000) -> torch.Tensor:
+    assert timesteps.ndim == 1
+    timesteps = timesteps * max_len
+    half = embedding_dim // 2
+    freq = torch.exp(torch.arange(half, dtype=torch.float, device=timesteps.device) * -(math.log(max_len) / (half - 1)))
+    emb = timesteps.float()[:, None] * freq[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=1)
+    if embedding_dim % 2 == 1:
+        emb = F.pad(emb, (0, 1), mode="constant")
+    return emb
+
+
+class EmbeddingModule(nn.Module):
+    def __init__(self, init_embed_size: int, node_embed_size: int, edge_embed_size: int, num_bins: int = 22,
+                 min_bin: float = 1e-5, max_bin: float = 20.0, self_conditioning: bool = True):
+        super().__init__()
+        pos_embed_size = t_embed_size = init_embed_size
+        node_in = t_embed_size + 1 + pos_embed_size
+        edge_in = (t_embed_size + 1) * 2 + pos_embed_size
+        self.node_embed = nn.Sequential(
+            nn.Linear(node_in, node_embed_size), nn.ReLU(), nn.Linear(node_embed_size, node_embed_size), nn.ReLU(),
+            nn.Linear(node_embed_size, node_embed_size), nn.LayerNorm(node_embed_size),
+        )
+        self.self_conditioning = self_conditioning
+        if self_conditioning:
+            edge_in += num_bins
+        self.edge_embed = nn.Sequential(
+            nn.Linear(edge_in, edge_embed_size), nn.ReLU(), nn.Linear(edge_embed_size, edge_embed_size), nn.ReLU(),
+            nn.Linear(edge_embed_size, edge_embed_size), nn.LayerNorm(edge_embed_size),
+        )
+        self.time_embed = partial(get_timestep_embedding, embedding_dim=t_embed_size)
+        self.position_embed = partial(get_positional_embedding, embedding_dim=pos_embed_size)
+        self._dims = (init_embed_size, num_bins, float(min_bin), float(max_bin), edge_embed_size)
+        self._wcache = ParamCache()
+        self._idx_key = None
+        self._idx_val = None
+
+    # ---- derived tensors
+    def _weights(self):
+        e0, e2, e4 = self.edge_embed[0], self.edge_embed[2], self.edge_embed[4]
+        ie, nb = self._dims[0], self._dims[1]
+        t1 = ie + 1
+
+        def build():
+            w0 = e0.weight.float()
+            out = {
+                "w_row": w0[:, :t1].contiguous(), "w_col": w0[:, t1:2 * t1].contiguous(),
+                "w_rel": w0[:, 2 * t1:2 * t1 + ie].contiguous(), "b0": e0.bias.float().contiguous(),
+                "w2p": ops.pack_weight(e2.weight.float()), "w3p": ops.pack_weight(e4.weight.float()),
+            }
+            if self.self_conditioning:
+                out["bin_tab"] = w0[:, 2 * t1 + ie:2 * t1 + ie + nb].t().contiguous()
+            else:  # no distogram columns: a single zero row that is never selected (ca = 0 -> no bin)
+                out["bin_tab"] = w0.new_zeros(1, w0.shape[0])
+            out["bin_lower"] = torch.linspace(self._dims[2], self._dims[3], nb).to(w0.device)
+            return out
+
+        return self._wcache.get([e0.weight, e0.bias, e2.weight, e4.weight], build)
+
+    def _index_tables(self, residue_idx: torch.Tensor, w_rel: torch.Tensor):
+        """Per-target constants: node positional features and the relative-position table
+        rel_tab[d + off] = W_rel . posemb(d).  Cached on the index tensor (one host sync per target)."""
+        key = (residue_idx.data_ptr(), tuple(residue_idx.shape), residue_idx._version, w_rel.data_ptr(), w_rel._version)
+        if key != self._idx_key:
+            idx_cpu = residue_idx.detach().cpu()
+            span = int(idx_cpu.max() - idx_cpu.min())
+            d = torch.arange(-span, span + 1)
+            dev = w_rel.device
+            rel = F.linear(self.position_embed(d).float().to(dev), w_rel).contiguous()
+            node_pos = self.position_embed(idx_cpu).float().to(dev)
+            self._idx_val = (rel, span, node_pos, residue_idx.to(dev).contiguous())
+            self._idx_key = key
+        return self._idx_val
+
+    def forward(self, residue_idx, t, fixed_mask, self_conditioning_ca, node_mask: Optional[torch.Tensor] = None):
+        """-> node_embed [B,N,D_node], edge_embed [B,N,N,D_edge] (reference :107-159).  ``t`` may live on
+        the host (the sampler knows it there): its embedding is then computed on the host and uploaded.
+        ``node_mask`` optionally fuses DenoisingNet's mask multiplies (reference :186-187)."""
+        w = self._weights()
+        dev = w["b0"].device
+        if dev.type != "cuda":
+            raise ops.HipLibraryError("EmbeddingModule runs on the HIP device only (no CPU fallback)")
+        if self._dims[4] != 128:
+            raise ops.HipLibraryError("edge_embed kernel is built for edge_embed_size=128")
+        B, L = residue_idx.shape
+        rel_tab, span, node_pos, idx_dev = self._index_tables(residue_idx, w["w_rel"])
+        fixed = fixed_mask.to(dev)[..., None].float()
+        t_emb = self.time_embed(t).to(dev)  # [B, 32]
+        t_embed = torch.cat([t_emb[:, None, :].expand(B, L, -1), fixed], dim=-1)  # [B, L, 33]
+        node_embed = self.node_embed(torch.cat([t_embed, node_pos], dim=-1).float())
+        node_a = F.linear(t_embed, w["w_row"], w["b0"]).contiguous()
+        node_b = F.linear(t_embed, w["w_col"]).contiguous()
+        ca = self_conditioning_ca.to(dev).float().contiguous() if self.self_conditioning else t_embed.new_zeros(B, L, 3)
+        mask = None if node_mask is None else node_mask.to(dev).float().contiguous()
+        e2, e4, ln = self.edge_embed[2], self.edge_embed[4], self.edge_embed[5]
+        edge_embed = ops.edge_embed(node_a, node_b, rel_tab, w["bin_tab"], w["bin_lower"], idx_dev, ca, w["w2p"],
+                                    w["w3p"], e2.bias, e4.bias, ln.weight, ln.bias, mask, span, ln.eps)
+        if mask is not None:
+            node_embed = node_embed * mask[..., None]
+        return node_embed, edge_embed
+
+
+class DenoisingNet(nn.Module):
+    def __init__(self, embedder: nn.Module, translator: nn.Module):
+        super().__init__()
+        self.embedder = embedder
+        self.translator = translator
+        self.backbone_in_forward = True  # the sampler turns this off inside its loop (result unused there)
+
+    def forward(self, batch: dict, as_tensor_7: bool = False) -> dict:
+        """reference :171-211: {'rigids', 'psi', 'atom37', 'atom14'} (+ 'rigids7', the frames as one tensor)."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise ops.HipLibraryError(
+                "DenoisingNet.forward needs the HIP device (MI355X): the sampling path has no CPU fallback")
+        node_mask = batch["residue_mask"].to(dev).type(torch.float)
+        fixed_mask = batch["fixed_mask"].to(dev).type(torch.float)
+        node_embed, edge_embed = self.embedder(residue_idx=batch["residue_idx"], t=batch["t"], fixed_mask=fixed_mask,
+                                               self_conditioning_ca=batch["sc_ca_t"], node_mask=node_mask)
+        tb = dict(batch)
+        tb["residue_mask"], tb["fixed_mask"] = node_mask, fixed_mask
+        tb["rigids_t"] = batch["rigids_t"].to(dev)
+        model_out = self.translator(node_embed, edge_embed, tb)
+        gt_psi = batch["torsion_angles_sin_cos"].to(dev)[..., 2, :]
+        psi_pred = gt_psi * fixed_mask[..., None] + model_out["psi"] * (1 - fixed_mask[..., None])
+        rigids_pred = model_out["out_rigids"]
+        out = {"rigids": rigids_pred, "psi": psi_pred, "rigids7": model_out["out_rigids7"]}
+        if self.backbone_in_forward:
+            aatype = batch["aatype"].to(dev) if "aatype" in batch else None
+            bb = compute_backbone(rigids_pred, psi_pred, aatype=aatype, _rigids7=model_out["out_rigids7"])
+            out["atom37"], out["atom14"] = bb[0], bb[-1]
+        if as_tensor_7:
+            out["rigids"] = model_out["out_rigids7"]
+        return out

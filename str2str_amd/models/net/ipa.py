@@ -1,0 +1,156 @@
+"""Invariant Point Attention and the ``TranslationIPA`` trunk on the HIP kernels.
+
+Interface, constructor arguments and ``state_dict`` keys follow the reference's
+``src/models/net/ipa.py`` (InvariantPointAttention :34-268, TranslationIPA :271-387).  The input
+projections and ``linear_out`` are dense fp32 GEMMs; everything between them — point frames,
+pair projections (linear_b / down_z), logits, softmax, o / o_pt / o_pair — is three HIP launches:
+``s2s_ipa_prep_points``, ``s2s_pair_project`` and ``s2s_ipa_attention``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ... import ops
+from ...common.rigid_utils import Rigid, Rotation
+from .layers import BackboneUpdate, EdgeTransition, Linear, NodeTransition, ParamCache, TorsionAngleHead
+
+
+class InvariantPointAttention(nn.Module):
+    def __init__(self, c_s: int, c_z: int, c_hidden: int, no_heads: int, no_qk_points: int, no_v_points: int,
+                 inf: float = 1e5, eps: float = 1e-8):
+        super().__init__()
+        self.c_s, self.c_z, self.c_hidden = c_s, c_z, c_hidden
+        self.no_heads, self.no_qk_points, self.no_v_points = no_heads, no_qk_points, no_v_points
+        self.inf, self.eps = inf, eps
+        hc = c_hidden * no_heads
+        self.linear_q = Linear(c_s, hc)
+        self.linear_kv = Linear(c_s, 2 * hc)
+        self.linear_q_points = Linear(c_s, no_heads * no_qk_points * 3)
+        self.linear_kv_points = Linear(c_s, no_heads * (no_qk_points + no_v_points) * 3)
+        self.linear_b = Linear(c_z, no_heads)
+        self.down_z = Linear(c_z, c_z // 4)
+        self.head_weights = nn.Parameter(torch.full((no_heads,), 0.541324854612918))  # softplus^-1(1)
+        self.linear_out = Linear(no_heads * (c_z // 4 + c_hidden + no_v_points * 4), c_s, init="final")
+        self.softmax = nn.Softmax(dim=-1)
+        self.softplus = nn.Softplus()
+        self._cache = ParamCache()
+
+    def _derived(self):
+        def build():
+            wcat = torch.cat([self.linear_b.weight, self.down_z.weight], dim=0).float()
+            bcat = torch.cat([self.linear_b.bias, self.down_z.bias]).float()
+            b64 = bcat.new_zeros(64)
+            b64[: bcat.numel()] = bcat
+            hw = F.softplus(self.head_weights.float()) * math.sqrt(1.0 / (3 * (self.no_qk_points * 9.0 / 2)))
+            return {"wp": ops.pack_weight(wcat), "b64": b64.contiguous(), "hw": hw.contiguous()}
+
+        return self._cache.get([self.linear_b.weight, self.linear_b.bias, self.down_z.weight, self.down_z.bias,
+                                self.head_weights], build)
+
+    def forward(self, s: torch.Tensor, z: torch.Tensor, r, mask: torch.Tensor, _rigids7: Optional[torch.Tensor] = None):
+        """s [B,N,c_s], z [B,N,N,c_z], r Rigid [B,N] (translations already scaled), mask [B,N]
+        -> [B,N,c_s] (reference :100-268).  ``_rigids7`` lets the trunk pass its frame tensor directly."""
+        if not s.is_cuda:
+            raise ops.HipLibraryError("InvariantPointAttention runs on the HIP device only (no CPU fallback)")
+        if self.no_heads != 8 or self.c_z != 128:
+            raise ops.HipLibraryError("IPA kernels are built for the reference configuration (H=8, c_z=128)")
+        d = self._derived()
+        r7 = (_rigids7 if _rigids7 is not None else r.to_tensor_7()).type(torch.float32).contiguous()
+        mask = mask.type(torch.float32).contiguous()
+        q = self.linear_q(s)
+        kv = self.linear_kv(s)
+        q_pts, k_pts, v_pts = ops.ipa_prep_points(r7, self.linear_q_points(s).contiguous(),
+                                                  self.linear_kv_points(s).contiguous(), self.no_heads,
+                                                  self.no_qk_points, self.no_v_points)
+        attn_bias, pair_z = ops.pair_project(z.contiguous(), d["wp"], d["b64"])
+        feats = ops.ipa_attention(q.contiguous(), kv.contiguous(), q_pts, k_pts, v_pts, attn_bias, pair_z, mask, r7,
+                                  d["hw"], self.no_heads, self.c_hidden, self.no_qk_points, self.no_v_points,
+                                  self.c_z // 4, self.inf, self.eps)
+        return self.linear_out(feats)
+
+
+def encoder_forward(enc: nn.TransformerEncoder, x: torch.Tensor, key_padding_float: torch.Tensor) -> torch.Tensor:
+    """The 2-layer post-norm ``nn.TransformerEncoder`` of the trunk (reference ipa.py:312-317,357)
+    evaluated with explicit ops on its own parameters.  x is batch-first [B,N,D] here; the FLOAT
+    key-padding mask is ADDED to the logits, as PyTorch does for float masks."""
+    B, N, D = x.shape
+    for layer in enc.layers:
+        att = layer.self_attn
+        h = att.num_heads
+        dh = D // h
+        qkv = F.linear(x, att.in_proj_weight, att.in_proj_bias).view(B, N, 3, h, dh)
+        q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
+        bias = key_padding_float[:, None, None, :].expand(B, h, N, N)
+        sa = F.scaled_dot_product_attention(q, k, v, attn_mask=bias)
+        sa = att.out_proj(sa.transpose(1, 2).reshape(B, N, D))
+        x = layer.norm1(x + sa)
+        ff = layer.linear2(F.relu(layer.linear1(x)))
+        x = layer.norm2(x + ff)
+    return x
+
+
+class TranslationIPA(nn.Module):
+    def __init__(self, c_s: int, c_z: int, coordinate_scaling: float, no_ipa_blocks: int, skip_embed_size: int,
+                 transformer_num_heads: int = 4, transformer_num_layers: int = 2, c_hidden: int = 256, no_heads: int = 8,
+                 no_qk_points: int = 8, no_v_points: int = 12, dropout: float = 0.0):
+        super().__init__()
+        self.coordinate_scaling = coordinate_scaling
+        self.scale_pos = lambda x: x * coordinate_scaling
+        self.scale_rigids = lambda x: x.apply_trans_fn(self.scale_pos)
+        self.unscale_pos = lambda x: x / coordinate_scaling
+        self.unscale_rigids = lambda x: x.apply_trans_fn(self.unscale_pos)
+        self.trunk = nn.ModuleDict()
+        self.num_blocks = no_ipa_blocks
+        for b in range(no_ipa_blocks):
+            self.trunk[f"ipa_{b}"] = InvariantPointAttention(c_s=c_s, c_z=c_z, c_hidden=c_hidden, no_heads=no_heads,
+                                                            no_qk_points=no_qk_points, no_v_points=no_v_points)
+            self.trunk[f"ipa_ln_{b}"] = nn.LayerNorm(c_s)
+            self.trunk[f"skip_embed_{b}"] = Linear(c_s, skip_embed_size, init="final")
+            d = c_s + skip_embed_size
+            layer = nn.TransformerEncoderLayer(d_model=d, nhead=transformer_num_heads, dim_feedforward=d)
+            self.trunk[f"transformer_{b}"] = nn.TransformerEncoder(layer, transformer_num_layers, enable_nested_tensor=False)
+            self.trunk[f"linear_{b}"] = Linear(d, c_s, init="final")
+            self.trunk[f"node_transition_{b}"] = NodeTransition(c_s)
+            self.trunk[f"bb_update_{b}"] = BackboneUpdate(c_s)
+            if b < no_ipa_blocks - 1:
+                self.trunk[f"edge_transition_{b}"] = EdgeTransition(node_embed_size=c_s, edge_embed_in=c_z,
+                                                                    edge_embed_out=c_z)
+        self.torsion_pred = TorsionAngleHead(c_s, 1)
+
+    def forward(self, node_embed: torch.Tensor, edge_embed: torch.Tensor, batch: dict) -> dict:
+        """reference :331-387.  Frames travel as one [B,N,7] tensor between the fused kernels."""
+        if not node_embed.is_cuda:
+            raise ops.HipLibraryError("TranslationIPA runs on the HIP device only (no CPU fallback)")
+        T = self.trunk
+        node_mask = batch["residue_mask"].type(torch.float).contiguous()
+        diffuse_mask = ((1 - batch["fixed_mask"].type(torch.float)) * node_mask).contiguous()
+        init7 = batch["rigids_t"].type(torch.float).contiguous()
+        curr7 = ops.rigid_scale_trans(init7, self.coordinate_scaling, divide=False)
+        init_node = node_embed
+        pad = 1.0 - node_mask
+        for b in range(self.num_blocks):
+            ipa_embed = T[f"ipa_{b}"](node_embed, edge_embed, None, node_mask, _rigids7=curr7)
+            ipa_embed = ipa_embed * node_mask[..., None]
+            node_embed = T[f"ipa_ln_{b}"](node_embed + ipa_embed)
+            cat = torch.cat([node_embed, T[f"skip_embed_{b}"](init_node)], dim=-1)
+            tr = encoder_forward(T[f"transformer_{b}"], cat, pad)
+            node_embed = node_embed + T[f"linear_{b}"](tr)
+            node_embed = T[f"node_transition_{b}"](node_embed)
+            node_embed = node_embed * node_mask[..., None]
+            upd = T[f"bb_update_{b}"](node_embed * diffuse_mask[..., None]).contiguous()
+            curr7 = ops.rigid_compose_update(curr7, upd, diffuse_mask)
+            if b < self.num_blocks - 1:
+                edge_embed = T[f"edge_transition_{b}"](node_embed, edge_embed, edge_mask_1d=node_mask)
+        psi = self.torsion_pred(node_embed)
+        out7 = ops.rigid_scale_trans(curr7, self.coordinate_scaling, divide=True)
+        return {
+            "in_rigids": Rigid.from_tensor_7(init7),
+            "out_rigids": Rigid(Rotation(quats=out7[..., :4], normalize_quats=False), out7[..., 4:]),
+            "out_rigids7": out7,
+            "psi": psi,
+        }

@@ -1,0 +1,291 @@
+"""Python binding of libstr2str_hip.so (include/str2str_hip.h) over ctypes.
+
+torch is plumbing here: it owns device memory and the current HIP stream; every op below hands raw
+device pointers + sizes + the stream to one C-ABI entry point.  There is NO fallback: if the
+library is missing or a tensor is not a contiguous float32 CUDA(HIP) tensor the op raises.
+The ops are also registered as ``torch.ops.str2str_amd.*`` custom ops (``register_torch_ops``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libstr2str_hip.so")
+ABI_VERSION = 1
+
+_lib = None
+_tables_loaded = False
+
+_vp, _i, _f, _d, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_longlong
+
+_SIGNATURES = {
+    "s2s_abi_version": [],
+    "s2s_edge_transition": [_vp] * 12 + [_i, _i, _f, _vp],
+    "s2s_edge_embed": [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _vp],
+    "s2s_pair_project": [_vp] * 5 + [_i, _i, _vp],
+    "s2s_ipa_prep_points": [_vp] * 6 + [_ll, _i, _i, _i, _i, _vp],
+    "s2s_ipa_attention": [_vp] * 11 + [_i, _i, _i, _i, _i, _i, _i, _f, _f, _vp],
+    "s2s_rigid_compose_update": [_vp] * 4 + [_ll, _vp],
+    "s2s_rigid_scale_trans": [_vp, _vp, _ll, _f, _i, _vp],
+    "s2s_set_backbone_tables": [_vp] * 4,
+    "s2s_frames_to_backbone": [_vp] * 5 + [_ll, _vp],
+    "s2s_se3_step": [_vp] * 12 + [_i, _i, _d, _d, _i, _i, _d, _vp],
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the kernel library and type its entry points (no GPU needed for this)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise HipLibraryError(
+            f"{p} not found: the HIP kernels are not built. Run `python -m str2str_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the sampling path."
+        )
+    lib = ctypes.CDLL(p)
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
+        fn.argtypes = args
+        fn.restype = ctypes.c_int
+    v = lib.s2s_abi_version()
+    if v != ABI_VERSION:
+        raise HipLibraryError(f"libstr2str_hip.so ABI {v} != expected {ABI_VERSION}; rebuild")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise HipLibraryError(f"{what} failed with hipError_t {rc}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, dtype=torch.float32, name="tensor") -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise HipLibraryError(f"{name}: expected a tensor on the HIP device (no CPU fallback), got "
+                              f"{getattr(t, 'device', type(t))}")
+    if t.dtype != dtype:
+        raise HipLibraryError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise HipLibraryError(f"{name}: expected a contiguous tensor")
+    return t
+
+
+def pack_weight(w: torch.Tensor) -> torch.Tensor:
+    """[Mout, K] row-major -> kernel lane order (see include/str2str_hip.h).  Mout is zero-padded to
+    a multiple of 32; K must be a multiple of 8."""
+    mout, k = w.shape
+    if k % 8:
+        raise ValueError("K must be a multiple of 8")
+    pad = (-mout) % 32
+    if pad:
+        w = torch.cat([w, w.new_zeros(pad, k)], dim=0)
+    t, s4 = w.shape[0] // 32, k // 8
+    return w.reshape(t, 32, s4, 2, 4).permute(2, 0, 3, 1, 4).contiguous().reshape(-1)
+
+
+# ------------------------------------------------------------------------------------------ ops
+def edge_transition(edge, node_ab, node_p, w1p, w2p, wfp, b2, bf, gamma, beta, mask, ln_eps=1e-5, out=None):
+    lib = load_library()
+    B, N = edge.shape[0], edge.shape[1]
+    _req(edge, name="edge")
+    if edge.shape != (B, N, N, 128) or node_ab.shape != (B, N, 768) or node_p.shape != (B, N, 128):
+        raise HipLibraryError(f"edge_transition: bad shapes {tuple(edge.shape)} {tuple(node_ab.shape)} {tuple(node_p.shape)}")
+    for n, t in (("node_ab", node_ab), ("node_p", node_p), ("w1p", w1p), ("w2p", w2p), ("wfp", wfp), ("b2", b2),
+                 ("bf", bf), ("gamma", gamma), ("beta", beta)):
+        _req(t, name=n)
+    if mask is not None:
+        _req(mask, name="mask")
+    if out is None:
+        out = torch.empty_like(edge)
+    elif out.data_ptr() == edge.data_ptr():
+        raise HipLibraryError("edge_transition: out may not alias edge")
+    _check(lib.s2s_edge_transition(_p(edge), _p(node_ab), _p(node_p), _p(w1p), _p(w2p), _p(wfp), _p(b2), _p(bf),
+                                   _p(gamma), _p(beta), _p(mask), _p(_req(out, name="out")), B, N, ln_eps, _stream()),
+           "s2s_edge_transition")
+    return out
+
+
+def edge_embed(node_a, node_b, rel_table, bin_table, bin_lower, residue_idx, ca, w2p, w3p, b2, b3, gamma, beta, mask,
+               rel_offset: int, ln_eps=1e-5, out=None):
+    lib = load_library()
+    B, N = node_a.shape[0], node_a.shape[1]
+    for n, t in (("node_a", node_a), ("node_b", node_b), ("rel_table", rel_table), ("bin_table", bin_table),
+                 ("bin_lower", bin_lower), ("ca", ca), ("w2p", w2p), ("w3p", w3p), ("b2", b2), ("b3", b3),
+                 ("gamma", gamma), ("beta", beta)):
+        _req(t, name=n)
+    _req(residue_idx, torch.int64, "residue_idx")
+    if mask is not None:
+        _req(mask, name="mask")
+    if out is None:
+        out = torch.empty(B, N, N, 128, device=node_a.device, dtype=torch.float32)
+    _check(lib.s2s_edge_embed(_p(node_a), _p(node_b), _p(rel_table), _p(bin_table), _p(bin_lower), _p(residue_idx), _p(ca),
+                              _p(w2p), _p(w3p), _p(b2), _p(b3), _p(gamma), _p(beta), _p(mask), _p(out), B, N,
+                              int(rel_offset), rel_table.shape[0], bin_table.shape[0], ln_eps, _stream()), "s2s_edge_embed")
+    return out
+
+
+def pair_project(edge, wp, bias64, attn_bias=None, pair_z=None):
+    lib = load_library()
+    B, N = edge.shape[0], edge.shape[1]
+    _req(edge, name="edge"); _req(wp, name="wp"); _req(bias64, name="bias64")
+    if attn_bias is None:
+        attn_bias = torch.empty(B, N, N, 8, device=edge.device, dtype=torch.float32)
+    if pair_z is None:
+        pair_z = torch.empty(B, N, N, 32, device=edge.device, dtype=torch.float32)
+    _check(lib.s2s_pair_project(_p(edge), _p(wp), _p(bias64), _p(attn_bias), _p(pair_z), B, N, _stream()), "s2s_pair_project")
+    return attn_bias, pair_z
+
+
+def ipa_prep_points(rigids7, q_pts_lin, kv_pts_lin, n_heads=8, n_qk=8, n_v=12):
+    lib = load_library()
+    B, N = rigids7.shape[0], rigids7.shape[1]
+    for n, t in (("rigids7", rigids7), ("q_pts_lin", q_pts_lin), ("kv_pts_lin", kv_pts_lin)):
+        _req(t, name=n)
+    dev = rigids7.device
+    q_pts = torch.empty(B, N, n_heads, n_qk * 3, device=dev, dtype=torch.float32)
+    k_pts = torch.empty(B, N, n_heads, n_qk * 3, device=dev, dtype=torch.float32)
+    v_pts = torch.empty(B, N, n_heads, 64, device=dev, dtype=torch.float32)
+    _check(lib.s2s_ipa_prep_points(_p(rigids7), _p(q_pts_lin), _p(kv_pts_lin), _p(q_pts), _p(k_pts), _p(v_pts), B * N,
+                                   n_heads, n_qk, n_v, 64, _stream()), "s2s_ipa_prep_points")
+    return q_pts, k_pts, v_pts
+
+
+def ipa_attention(q, kv, q_pts, k_pts, v_pts, attn_bias, pair_z, mask, rigids7, head_w_scaled, n_heads=8, c_hidden=256,
+                  n_qk=8, n_v=12, c_pz=32, inf=1e5, eps=1e-8, out=None):
+    lib = load_library()
+    B, N = mask.shape
+    for n, t in (("q", q), ("kv", kv), ("q_pts", q_pts), ("k_pts", k_pts), ("v_pts", v_pts), ("attn_bias", attn_bias),
+                 ("pair_z", pair_z), ("mask", mask), ("rigids7", rigids7), ("head_w", head_w_scaled)):
+        _req(t, name=n)
+    if out is None:
+        out = torch.empty(B, N, n_heads * (c_hidden + 4 * n_v + c_pz), device=q.device, dtype=torch.float32)
+    _check(lib.s2s_ipa_attention(_p(q), _p(kv), _p(q_pts), _p(k_pts), _p(v_pts), _p(attn_bias), _p(pair_z), _p(mask),
+                                 _p(rigids7), _p(head_w_scaled), _p(out), B, N, n_heads, c_hidden, n_qk, n_v, c_pz,
+                                 inf, eps, _stream()), "s2s_ipa_attention")
+    return out
+
+
+def rigid_compose_update(rigids7, update6, mask, out=None):
+    lib = load_library()
+    _req(rigids7, name="rigids7"); _req(update6, name="update6"); _req(mask, name="mask")
+    if out is None:
+        out = torch.empty_like(rigids7)
+    _check(lib.s2s_rigid_compose_update(_p(rigids7), _p(update6), _p(mask), _p(out), rigids7.numel() // 7, _stream()),
+           "s2s_rigid_compose_update")
+    return out
+
+
+def rigid_scale_trans(rigids7, scale: float, divide: bool = False, out=None):
+    lib = load_library()
+    _req(rigids7, name="rigids7")
+    if out is None:
+        out = torch.empty_like(rigids7)
+    _check(lib.s2s_rigid_scale_trans(_p(rigids7), _p(out), rigids7.numel() // 7, scale, int(divide), _stream()),
+           "s2s_rigid_scale_trans")
+    return out
+
+
+def _ensure_tables():
+    global _tables_loaded
+    if _tables_loaded:
+        return
+    from .data import backbone_tables as bt
+
+    lib = load_library()
+    pos = np.ascontiguousarray(bt.BB_POS, dtype=np.float32)
+    msk = np.ascontiguousarray(bt.BB_MASK, dtype=np.float32)
+    grp = np.ascontiguousarray((bt.BB_GROUP == 3).astype(np.int32))
+    frm = np.ascontiguousarray(bt.BB_FRAMES, dtype=np.float32)
+    _check(lib.s2s_set_backbone_tables(pos.ctypes.data_as(_vp), msk.ctypes.data_as(_vp), grp.ctypes.data_as(_vp),
+                                       frm.ctypes.data_as(_vp)), "s2s_set_backbone_tables")
+    _tables_loaded = True
+
+
+def frames_to_backbone(rigids7, psi, aatype=None, want_atom37=True, want_atom14=False):
+    lib = load_library()
+    _ensure_tables()
+    _req(rigids7, name="rigids7"); _req(psi, name="psi")
+    if aatype is not None:
+        _req(aatype, torch.int64, "aatype")
+    lead = rigids7.shape[:-1]
+    dev = rigids7.device
+    a37 = torch.empty(*lead, 37, 3, device=dev, dtype=torch.float32) if want_atom37 else None
+    a14 = torch.empty(*lead, 5, 3, device=dev, dtype=torch.float32) if want_atom14 else None
+    _check(lib.s2s_frames_to_backbone(_p(rigids7), _p(psi), _p(aatype), _p(a14), _p(a37), rigids7.numel() // 7, _stream()),
+           "s2s_frames_to_backbone")
+    return a37, a14
+
+
+def se3_step(x0_7, xt_7, mask, diffuse_mask, params8, dt: float, coordinate_scaling: float = 0.1, probability_flow=True,
+             center=True, noise_scale: float = 1.0, z_rot=None, z_trans=None, want_next=True, want_scores=False,
+             rot_score_in=None, trans_score_in=None):
+    lib = load_library()
+    B, N = mask.shape
+    for n, t in (("xt_7", xt_7), ("mask", mask), ("diffuse_mask", diffuse_mask), ("params8", params8)):
+        _req(t, name=n)
+    if rot_score_in is not None:
+        _req(rot_score_in, torch.float64, "rot_score_in"); _req(trans_score_in, torch.float64, "trans_score_in")
+    else:
+        _req(x0_7, name="x0_7")
+    if params8.shape != (B, 8):
+        raise HipLibraryError("params8 must be [B, 8]")
+    if not probability_flow:
+        _req(z_rot, torch.float64, "z_rot"); _req(z_trans, torch.float64, "z_trans")
+    dev = xt_7.device
+    nxt = torch.empty(B, N, 7, device=dev, dtype=torch.float32) if want_next else None
+    rs = torch.empty(B, N, 3, device=dev, dtype=torch.float64) if want_scores else None
+    ts = torch.empty(B, N, 3, device=dev, dtype=torch.float64) if want_scores else None
+    _check(lib.s2s_se3_step(_p(x0_7), _p(xt_7), _p(mask), _p(diffuse_mask), _p(params8), _p(z_rot), _p(z_trans), _p(rot_score_in),
+                            _p(trans_score_in), _p(nxt),
+                            _p(rs), _p(ts), B, N, float(dt), float(coordinate_scaling), int(bool(probability_flow)),
+                            int(bool(center)), float(noise_scale), _stream()), "s2s_se3_step")
+    return nxt, rs, ts
+
+
+_registered = False
+
+
+def register_torch_ops():
+    """Expose the kernels as ``torch.ops.str2str_amd.<name>`` (CUDA/HIP dispatch key only)."""
+    global _registered
+    if _registered:
+        return
+    lib = torch.library.Library("str2str_amd", "DEF")
+    impl = torch.library.Library("str2str_amd", "IMPL", "CUDA")
+    defs = {
+        "edge_transition(Tensor edge, Tensor node_ab, Tensor node_p, Tensor w1p, Tensor w2p, Tensor wfp, Tensor b2, "
+        "Tensor bf, Tensor gamma, Tensor beta, Tensor? mask, float ln_eps) -> Tensor":
+            lambda *a: edge_transition(*a),
+        "pair_project(Tensor edge, Tensor wp, Tensor bias64) -> (Tensor, Tensor)": lambda *a: pair_project(*a),
+        "ipa_attention(Tensor q, Tensor kv, Tensor q_pts, Tensor k_pts, Tensor v_pts, Tensor attn_bias, Tensor pair_z, "
+        "Tensor mask, Tensor rigids7, Tensor head_w) -> Tensor": lambda *a: ipa_attention(*a),
+        "rigid_compose_update(Tensor rigids7, Tensor update6, Tensor mask) -> Tensor": lambda *a: rigid_compose_update(*a),
+        "frames_to_backbone(Tensor rigids7, Tensor psi, Tensor? aatype) -> Tensor":
+            lambda r, p, a: frames_to_backbone(r, p, a)[0],
+    }
+    for schema, fn in defs.items():
+        lib.define(schema)
+        impl.impl(schema.split("(")[0], fn)
+    register_torch_ops._libs = (lib, impl)  # keep alive
+    _registered = True

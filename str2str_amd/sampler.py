@@ -1,0 +1,126 @@
+"""The forward-backward diffusion sampler (device-resident loop).
+
+This is the closure ``forward_backward`` of the reference's ``DiffusionLitModule.predict_step``
+(src/models/diffusion_module.py:260-334) with the same schedule semantics:
+``n = int(num_timesteps*T)``, ``dt = 1/n`` (not the spacing of ``ts``), ``ts = linspace(min_t, T, n)[::-1]``,
+one extra network evaluation for self-conditioning, and the last step (``t == min_t``) returning the
+x0 prediction itself.  Differences in HOW:
+  * all per-step scalars (sigma bin, g(t)^2, exp(-beta/2), ...) are computed on the host once per
+    trajectory; the loop body is network forward -> ONE fused SE(3) kernel, with no device->host sync;
+  * the backbone projection runs once at the end (the reference recomputes it every forward and
+    throws the result away, denoising_ipa.py:197-201);
+  * replicas can be sharded over ranks (``shard=(rank, world)``): noise for the WHOLE chunk is drawn
+    on every rank from the same host generator state and sliced, so the union over ranks equals the
+    single-process result sample for sample ("parity" RNG mode).  ``rng="device"`` instead draws
+    nothing on the host inside the loop (throughput mode; different noise stream).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+from .common.all_atom import compute_backbone
+from .common.rigid_utils import Rigid
+
+_REPEAT_KEYS = ("aatype", "residue_mask", "fixed_mask", "residue_idx", "torsion_angles_sin_cos")
+
+
+def schedule(t_delta: float, num_timesteps: int, min_t: float):
+    T = t_delta if t_delta > 0 else 1.0
+    n = int(float(num_timesteps) * T)
+    return T, n, 1.0 / n, np.linspace(min_t, T, n)[::-1]
+
+
+def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous replica range of ``rank``: ceil split, rank-major order == replica order."""
+    per = -(-total // world)
+    lo = min(total, rank * per)
+    return lo, min(total, lo + per)
+
+
+@torch.no_grad()
+def forward_backward(net, diffuser, batch: dict, rigids_0: Rigid, t_delta: float, *, num_timesteps: int,
+                     min_t: float = 0.01, noise_scale: float = 1.0, probability_flow: bool = True,
+                     self_conditioning: bool = True, device=None, shard: Tuple[int, int] = (0, 1),
+                     rng: str = "host", trace: Optional[list] = None, return_rigids: bool = False):
+    """-> atom37 [b, N, 37, 3] float32 DEVICE tensor for this rank's replica slice (b = hi - lo)."""
+    device = torch.device(device) if device is not None else next(net.parameters()).device
+    if device.type != "cuda":
+        raise ops.HipLibraryError("the sampler needs the HIP device (MI355X); there is no CPU fallback")
+    B_total = rigids_0.shape[0]
+    lo, hi = shard_range(B_total, *shard)
+    b = hi - lo
+    T, n, dt, ts = schedule(t_delta, num_timesteps, min_t)
+
+    # ---- once per trajectory, on the host generator, for the WHOLE chunk (reference order)
+    if t_delta > 0:
+        rigids_t = diffuser.forward_marginal(rigids_0=rigids_0.to(device="cpu"), t=t_delta * torch.ones(B_total),
+                                             diffuse_mask=batch["residue_mask"].cpu().repeat(B_total, 1),
+                                             as_tensor_7=True)["rigids_t"]
+    else:
+        rigids_t = diffuser.sample_prior(shape=rigids_0.shape, device="cpu", as_tensor_7=True)["rigids_t"]
+    if b == 0:
+        return torch.zeros(0, rigids_0.shape[1], 37, 3, device=device)
+    rigids_t = rigids_t[lo:hi].to(device).float().contiguous()
+
+    feats = {k: batch[k].to(device).repeat(b, *(1,) * (batch[k].ndim - 1)) for k in _REPEAT_KEYS if k in batch}
+    mask = feats["residue_mask"].float().contiguous()
+    diffuse_mask = ((1 - feats["fixed_mask"].float()) * mask).contiguous()
+    # per-step scalars for every step at once: t is uniform over the chunk
+    t_all = torch.as_tensor(np.asarray(ts, dtype=np.float64)).float()  # fl32(t), as `t * torch.ones(B)` gives
+    p8_all = diffuser.step_params(t_all).to(device)  # [n, 8]
+    N = mask.shape[1]
+
+    keep_bb = getattr(net, "backbone_in_forward", None)
+    if keep_bb is not None:
+        net.backbone_in_forward = False
+    try:
+        feats["rigids_t"] = rigids_t
+        if self_conditioning:
+            feats["sc_ca_t"] = torch.zeros(b, N, 3, device=device)
+            feats["t"] = torch.full((b,), float(ts[0]), dtype=torch.float32)
+            feats["sc_ca_t"] = net(feats, as_tensor_7=True)["rigids7"][..., 4:]
+        else:
+            feats["sc_ca_t"] = torch.zeros(b, N, 3, device=device)
+        final = None
+        for k, t in enumerate(ts):
+            feats["t"] = torch.full((b,), float(t), dtype=torch.float32)
+            out = net(feats, as_tensor_7=False)
+            x0_7 = out["rigids7"]
+            if t == min_t:
+                final = out
+                if trace is not None:
+                    trace.append(dict(t=t, rigids_t=feats["rigids_t"], sc_ca_t=feats["sc_ca_t"], x0=x0_7, psi=out["psi"]))
+                break
+            sc_in = feats["sc_ca_t"]
+            if self_conditioning:
+                feats["sc_ca_t"] = x0_7[..., 4:]
+            z_rot = z_trans = None
+            if rng == "host":
+                # the reference consumes two float64 normal draws per step even under the probability-flow
+                # ODE (so3.py:360, r3.py:109): keep the generator in lock-step for later chunks
+                zr = torch.randn(B_total, N, 3, dtype=torch.float64)
+                zt = torch.randn(B_total, N, 3, dtype=torch.float64)
+                if not probability_flow:
+                    z_rot, z_trans = zr[lo:hi].to(device).contiguous(), zt[lo:hi].to(device).contiguous()
+            elif not probability_flow:
+                z_rot = torch.randn(b, N, 3, dtype=torch.float64, device=device)
+                z_trans = torch.randn(b, N, 3, dtype=torch.float64, device=device)
+            p8 = p8_all[k].expand(b, 8).contiguous()
+            nxt, rs, tsc = diffuser.step(x0_7, feats["rigids_t"], p8, dt, mask, diffuse_mask, center_trans=True,
+                                         noise_scale=noise_scale, probability_flow=probability_flow, z_rot=z_rot,
+                                         z_trans=z_trans, want_scores=trace is not None)
+            if trace is not None:
+                trace.append(dict(t=t, rigids_t=feats["rigids_t"], sc_ca_t=sc_in, x0=x0_7, psi=out["psi"], rot_score=rs,
+                                  trans_score=tsc, next7=nxt))
+            feats["rigids_t"] = nxt
+        atom37 = compute_backbone(final["rigids"], final["psi"], aatype=feats.get("aatype"), _rigids7=final["rigids7"])[0]
+    finally:
+        if keep_bb is not None:
+            net.backbone_in_forward = keep_bb
+    if return_rigids:
+        return atom37, final["rigids7"], final["psi"]
+    return atom37
