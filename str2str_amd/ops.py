@@ -43,6 +43,41 @@ class HipLibraryError(RuntimeError):
     pass
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events recorded on the launch stream (bench.py's
+    ``roofline`` leg).  ``with KernelTimer("s2s_edge_transition") as kt: ...; kt.mean_ms()``."""
+
+    active = None
+
+    def __init__(self, *names):
+        self.names = set(names)
+        self.events = {n: [] for n in names}
+
+    def __enter__(self):
+        KernelTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        KernelTimer.active = None
+
+    def mean_ms(self, name):
+        torch.cuda.synchronize()
+        ev = self.events[name]
+        return (sum(a.elapsed_time(b) for a, b in ev) / len(ev)) if ev else float("nan"), len(ev)
+
+
+def _timed(name, launch):
+    kt = KernelTimer.active
+    if kt is None or name not in kt.names:
+        return launch()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    rc = launch()
+    b.record()
+    kt.events[name].append((a, b))
+    return rc
+
+
 def load_library(path: Optional[str] = None):
     """dlopen the kernel library and type its entry points (no GPU needed for this)."""
     global _lib
@@ -120,9 +155,10 @@ def edge_transition(edge, node_ab, node_p, w1p, w2p, wfp, b2, bf, gamma, beta, m
         out = torch.empty_like(edge)
     elif out.data_ptr() == edge.data_ptr():
         raise HipLibraryError("edge_transition: out may not alias edge")
-    _check(lib.s2s_edge_transition(_p(edge), _p(node_ab), _p(node_p), _p(w1p), _p(w2p), _p(wfp), _p(b2), _p(bf),
-                                   _p(gamma), _p(beta), _p(mask), _p(_req(out, name="out")), B, N, ln_eps, _stream()),
-           "s2s_edge_transition")
+    _req(out, name="out")
+    _check(_timed("s2s_edge_transition", lambda: lib.s2s_edge_transition(
+        _p(edge), _p(node_ab), _p(node_p), _p(w1p), _p(w2p), _p(wfp), _p(b2), _p(bf), _p(gamma), _p(beta), _p(mask),
+        _p(out), B, N, ln_eps, _stream())), "s2s_edge_transition")
     return out
 
 
@@ -180,9 +216,9 @@ def ipa_attention(q, kv, q_pts, k_pts, v_pts, attn_bias, pair_z, mask, rigids7, 
         _req(t, name=n)
     if out is None:
         out = torch.empty(B, N, n_heads * (c_hidden + 4 * n_v + c_pz), device=q.device, dtype=torch.float32)
-    _check(lib.s2s_ipa_attention(_p(q), _p(kv), _p(q_pts), _p(k_pts), _p(v_pts), _p(attn_bias), _p(pair_z), _p(mask),
-                                 _p(rigids7), _p(head_w_scaled), _p(out), B, N, n_heads, c_hidden, n_qk, n_v, c_pz,
-                                 inf, eps, _stream()), "s2s_ipa_attention")
+    _check(_timed("s2s_ipa_attention", lambda: lib.s2s_ipa_attention(
+        _p(q), _p(kv), _p(q_pts), _p(k_pts), _p(v_pts), _p(attn_bias), _p(pair_z), _p(mask), _p(rigids7),
+        _p(head_w_scaled), _p(out), B, N, n_heads, c_hidden, n_qk, n_v, c_pz, inf, eps, _stream())), "s2s_ipa_attention")
     return out
 
 

@@ -70,7 +70,7 @@ def forward_backward(net, diffuser, batch: dict, rigids_0: Rigid, t_delta: float
     mask = feats["residue_mask"].float().contiguous()
     diffuse_mask = ((1 - feats["fixed_mask"].float()) * mask).contiguous()
     # per-step scalars for every step at once: t is uniform over the chunk
-    t_all = torch.as_tensor(np.asarray(ts, dtype=np.float64)).float()  # fl32(t), as `t * torch.ones(B)` gives
+    t_all = torch.as_tensor(np.ascontiguousarray(ts, dtype=np.float64)).float()  # fl32(t), as `t * torch.ones(B)` gives
     p8_all = diffuser.step_params(t_all).to(device)  # [n, 8]
     N = mask.shape[1]
 
