@@ -1,0 +1,81 @@
+"""Sample writers: atom37 coordinates -> multi-MODEL PDB, and ordered merging of PDB files.
+File layout and text identical to the reference's ``src/common/pdb_utils.py`` (merge_pdbfiles :31-83,
+protein_with_default_params :175-203, atom37_to_pdb :205-252)."""
+from __future__ import annotations
+
+import os
+import re
+from typing import Optional
+
+import numpy as np
+
+from . import protein
+
+
+def protein_with_default_params(atom_positions, atom_mask, aatype=None, b_factors=None, chain_index=None,
+                                residue_index=None) -> protein.Protein:
+    assert atom_positions.ndim == 3 and atom_positions.shape[-2:] == (37, 3)
+    n = atom_positions.shape[0]
+    sqz = lambda x: np.squeeze(x) if x.shape[0] == 1 and len(x.shape) > 1 else x  # noqa: E731
+    return protein.Protein(
+        atom_positions=atom_positions, atom_mask=atom_mask,
+        aatype=np.zeros(n, dtype=int) if aatype is None else sqz(aatype),
+        residue_index=np.arange(n) + 1 if residue_index is None else sqz(residue_index),
+        chain_index=np.zeros(n) if chain_index is None else sqz(chain_index),
+        b_factors=np.zeros([n, 37]) if b_factors is None else sqz(b_factors),
+    )
+
+
+def atom37_to_pdb(save_to: str, atom_positions: np.ndarray, aatype: Optional[np.ndarray] = None,
+                  b_factors: Optional[np.ndarray] = None, chain_index: Optional[np.ndarray] = None,
+                  residue_index: Optional[np.ndarray] = None, overwrite: bool = False, no_indexing: bool = True) -> str:
+    if not no_indexing:
+        idx = 0
+        if not overwrite:
+            d, stem = os.path.dirname(save_to), os.path.basename(save_to).strip(".pdb")
+            found = [re.findall(r"_(\d+).pdb", x) for x in os.listdir(d) if stem in x]
+            idx = max([int(f[0]) for f in found if f] + [0])
+        save_to = save_to.replace(".pdb", "") + f"_{idx + 1}.pdb"
+    if atom_positions.ndim == 3:
+        atom_positions = atom_positions[None]
+    elif atom_positions.ndim != 4:
+        raise ValueError(f"Invalid positions shape {atom_positions.shape}")
+    with open(save_to, "w") as f:
+        for mi, pos37 in enumerate(atom_positions):
+            mask = np.sum(np.abs(pos37), axis=-1) > 1e-7
+            prot = protein_with_default_params(pos37, mask, aatype=aatype, b_factors=b_factors, chain_index=chain_index,
+                                               residue_index=residue_index)
+            f.write(protein.to_pdb(prot, model=mi + 1, add_end=False))
+        f.write("END")
+    return save_to
+
+
+def merge_pdbfiles(input, output_file: str, verbose: bool = True) -> None:
+    files = [os.path.join(input, f) for f in os.listdir(input) if f.endswith(".pdb")] if isinstance(input, str) else list(input)
+    os.makedirs(os.path.dirname(output_file), exist_ok=True)
+    model_number = 0
+    out = []
+    for path in files:
+        with open(path, "r") as fh:
+            lines = fh.readlines()
+        if not any(ln.startswith("MODEL") or ln.startswith("ENDMDL") for ln in lines):
+            model_number += 1
+            out.append(f"MODEL     {model_number}")
+            out += [ln.strip() for ln in lines if ln.startswith("TER") or ln.startswith("ATOM")]
+            out.append("ENDMDL")
+        else:
+            for ln in lines:
+                if ln.startswith("MODEL"):
+                    model_number += 1
+                    if model_number > 1:
+                        out.append("ENDMDL")
+                    out.append(f"MODEL     {model_number}")
+                elif ln.startswith("END"):
+                    continue
+                elif ln.startswith("TER") or ln.startswith("ATOM"):
+                    out.append(ln.strip())
+    out += ["ENDMDL", "END"]
+    with open(output_file, "w") as fo:
+        fo.write("\n".join(x.ljust(80) for x in out) + "\n")
+    if verbose:
+        print(f"Merged {len(files)} PDB files into {output_file} with {model_number} models.")

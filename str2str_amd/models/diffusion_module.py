@@ -1,0 +1,128 @@
+"""``DiffusionLitModule``: the inference surface of the reference's LightningModule
+(src/models/diffusion_module.py:51-60 constructor, :214-369 predict_step).
+
+``predict_step`` keeps the reference's contract — hyper-parameters from the ``inference:`` block of
+configs/model/diffusion.yaml, one target per batch, replicas chunked by ``replica_per_batch``, one
+multi-MODEL PDB per t_delta under ``<output_dir>/<t_delta>/<accession>.pdb`` and the merged
+``<output_dir>/all_delta/<accession>.pdb`` — while the loop body runs on the HIP kernels
+(str2str_amd/sampler.py).  New: when ``torch.distributed`` is initialised, every chunk's replicas are
+sharded over the ranks (independent trajectories) and gathered to rank 0 with ONE collective
+per chunk (RCCL on GPUs); rank-major concatenation reproduces the reference's MODEL order, and because the
+host noise of the whole chunk is drawn identically on every rank the files equal a single-GPU run.
+Training hooks are out of scope (inference-only north star).  Lightning is optional: with it installed
+the class is a LightningModule, without it a plain nn.Module with the same attributes.
+"""
+from __future__ import annotations
+
+import os
+from types import SimpleNamespace
+from typing import Any, Optional
+
+import numpy as np
+import torch
+
+from ..common.pdb_utils import atom37_to_pdb, merge_pdbfiles
+from ..common.rigid_utils import Rigid
+from ..sampler import forward_backward, shard_range
+
+try:  # pragma: no cover - depends on the environment
+    from lightning import LightningModule as _Base
+except Exception:  # lightning is not a dependency of the sampling path
+    _Base = torch.nn.Module
+
+
+def _ns(obj):
+    if obj is None or isinstance(obj, SimpleNamespace):
+        return obj
+    if isinstance(obj, dict):
+        return SimpleNamespace(**obj)
+    return obj  # OmegaConf DictConfig / namespace: attribute access already works
+
+
+def gather_replicas(atom37: torch.Tensor, total: int, group=None) -> Optional[torch.Tensor]:
+    """Gather every rank's replica slice [b_r, N, 37, 3] to rank 0 in replica order (one collective).
+    Slices follow ``shard_range`` (ceil split), so they are padded to the common size for the gather."""
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = -(-total // world)
+    pad = atom37.new_zeros((per,) + tuple(atom37.shape[1:]))
+    pad[: atom37.shape[0]] = atom37
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, bufs, dst=0, group=group)
+    if rank != 0:
+        return None
+    parts = []
+    for r, buf in enumerate(bufs):
+        lo, hi = shard_range(total, r, world)
+        parts.append(buf[: hi - lo])
+    return torch.cat(parts, dim=0)
+
+
+class DiffusionLitModule(_Base):
+    def __init__(self, net: torch.nn.Module, optimizer: Any = None, scheduler: Any = None, diffuser: Any = None,
+                 loss: Any = None, compile: bool = False, inference: Any = None):
+        super().__init__()
+        self.net = net
+        self.diffuser = diffuser
+        hp = SimpleNamespace(optimizer=optimizer, scheduler=scheduler, loss=loss, compile=compile, inference=_ns(inference))
+        if _Base is torch.nn.Module:
+            self.hparams = hp
+        else:  # LightningModule: hparams is a managed attribute
+            self.save_hyperparameters(dict(optimizer=optimizer, scheduler=scheduler, loss=loss, compile=compile,
+                                           inference=inference), logger=False)
+        self.rng_mode = "host"  # reference-order host noise (fixed seed == reference noise); "device" = throughput
+
+    def forward(self, batch):
+        return self.net(batch)
+
+    def training_step(self, *a, **k):
+        raise NotImplementedError("training is outside the scope of this build (inference-only)")
+
+    @torch.no_grad()
+    def predict_step(self, batch: dict, batch_idx: int = 0) -> str:
+        import torch.distributed as dist
+
+        inf = _ns(self.hparams.inference if not isinstance(self.hparams, dict) else self.hparams["inference"])
+        n_replica, replica_per_batch = int(inf.n_replica), int(inf.replica_per_batch)
+        delta_range = np.around(np.arange(inf.delta_min, inf.delta_max + 1e-5, inf.delta_step), decimals=2)
+        self_cond = bool(inf.self_conditioning) and bool(self.net.embedder.self_conditioning)
+        output_dir = inf.output_dir
+        if inf.backward_only:
+            n_replica *= len(delta_range)
+            delta_range = [-1.0]
+        assert batch["aatype"].shape[0] == 1, "Batch size must be 1 for correct inference."
+        device = next(self.net.parameters()).device
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        shard = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
+        accession_code = batch["accession_code"][0]
+        extra = {k: batch[k][0].detach().cpu().numpy() for k in ("aatype", "chain_index", "residue_index")}
+        kw = dict(num_timesteps=inf.num_timesteps, min_t=inf.min_t, noise_scale=inf.noise_scale,
+                  probability_flow=inf.probability_flow, self_conditioning=self_cond, device=device, shard=shard,
+                  rng=self.rng_mode)
+        saved = []
+        for t_delta in delta_range:
+            gt4 = batch["rigidgroups_gt_frames"][..., 0, :, :].clone()
+            sizes = [replica_per_batch] * (n_replica // replica_per_batch)
+            if n_replica % replica_per_batch > 0:
+                sizes.append(n_replica % replica_per_batch)
+            chunks = []
+            for bsz in sizes:
+                rig0 = Rigid.from_tensor_4x4(gt4.repeat(bsz, *(1,) * (gt4.ndim - 1)))
+                a37 = forward_backward(self.net, self.diffuser, batch, rig0, float(t_delta), **kw)
+                if distributed:
+                    a37 = gather_replicas(a37, bsz)
+                if a37 is not None:
+                    chunks.append(a37.cpu().numpy())
+            if shard[0] == 0:
+                t_dir = os.path.join(output_dir, f"{t_delta}")
+                os.makedirs(t_dir, exist_ok=True)
+                saved.append(atom37_to_pdb(atom_positions=np.concatenate(chunks, axis=0),
+                                           save_to=os.path.join(t_dir, f"{accession_code}.pdb"), **extra))
+        all_dir = os.path.join(output_dir, "all_delta")
+        if shard[0] == 0:
+            os.makedirs(all_dir, exist_ok=True)
+            merge_pdbfiles(saved, os.path.join(all_dir, f"{accession_code}.pdb"), verbose=False)
+        if distributed:
+            dist.barrier()
+        return all_dir

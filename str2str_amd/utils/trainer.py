@@ -1,0 +1,46 @@
+"""A predict-only ``Trainer`` with the call surface eval.py uses from ``lightning.Trainer``
+(reference src/eval.py:129,154): device placement, eval mode, no-grad, ``predict`` over a dataloader.
+One process per GPU: under ``torch.distributed.run`` each rank binds to LOCAL_RANK and the model
+shards replicas over ranks (DiffusionLitModule.predict_step)."""
+from __future__ import annotations
+
+import os
+from typing import Any, List, Optional
+
+import torch
+
+from .. import ops
+
+
+class Trainer:
+    def __init__(self, accelerator: str = "gpu", devices: Any = 1, default_root_dir: Optional[str] = None,
+                 deterministic: bool = False, logger: Any = None, **_):
+        self.accelerator, self.devices, self.default_root_dir, self.logger = accelerator, devices, default_root_dir, logger
+
+    def _device(self) -> torch.device:
+        if self.accelerator in ("cpu",) or not torch.cuda.is_available():
+            raise ops.HipLibraryError(
+                "trainer.accelerator=cpu / no HIP device visible: the sampling path runs on MI355X only "
+                "(there is deliberately no CPU fallback; use the reference itself for CPU runs)")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        return torch.device("cuda", local)
+
+    def predict(self, model, dataloaders, ckpt_path: Optional[str] = None) -> List[Any]:
+        import torch.distributed as dist
+
+        dev = self._device()
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=dev)
+        if ckpt_path is not None:  # Lightning-style .ckpt: {'state_dict': {'net.…': tensor}}
+            sd = torch.load(ckpt_path, map_location="cpu")["state_dict"]
+            model.load_state_dict(sd, strict=False)
+        ops.load_library()
+        model = model.to(dev).eval()
+        out = []
+        with torch.no_grad():
+            for i, batch in enumerate(dataloaders):
+                batch = {k: (v.to(dev) if torch.is_tensor(v) and k != "residue_idx" else v) for k, v in batch.items()}
+                out.append(model.predict_step(batch, i))
+        return out

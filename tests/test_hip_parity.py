@@ -339,3 +339,60 @@ def test_sharded_sampler_equals_single(net_smooth, diffuser):
         parts.append(forward_backward(net_smooth, diffuser, feats, rig0, 1.0, shard=(r, 2), **kw))
     assert parts[0].shape[0] == 3 and parts[1].shape[0] == 2
     assert maxdiff(torch.cat(parts).cpu(), full.cpu()) < 1e-5
+
+
+def test_predict_step_entry_writes_reference_layout(tmp_path, monkeypatch):
+    """eval.py task_name=inference end to end on a bundled PDB: output tree, MODEL counts, and — because the
+    host generator is advanced exactly like the reference's (incl. the two unused float64 draws per step) —
+    chunk 2 of the replicas also matches the oracle run chunk after chunk under the same seed."""
+    import os
+    import sys
+
+    from conftest import GOLDEN, ROOT
+    from oracle import diffuser as OD
+    from oracle import geometry as OG
+    from oracle import net as ON
+    from str2str_amd.common import protein
+    from str2str_amd.data.components.dataset import ProteinFeatureTransform
+
+    monkeypatch.setenv("TEST_DATA", os.path.join(GOLDEN, "pdb"))
+    monkeypatch.setenv("CACHE_DIR", str(tmp_path / "cache"))
+    monkeypatch.setenv("PROJECT_ROOT", str(tmp_path))
+    sys.path.insert(0, ROOT)
+    import eval as entry
+
+    torch.manual_seed(11)
+    all_dir = entry.main(["task_name=inference", "ckpt_path=null", "data.dataset.accession_code_fillter=[CLN025]",
+                          "model.inference.n_replica=3", "model.inference.replica_per_batch=2",
+                          "model.inference.num_timesteps=10", "model.inference.delta_min=0.5",
+                          "model.inference.delta_max=0.6", "model.inference.delta_step=0.1", "extras.print_config=false"])
+    samples = os.path.dirname(all_dir)
+    assert sorted(os.listdir(samples)) == ["0.5", "0.6", "all_delta"]
+    txt = open(os.path.join(samples, "0.5", "CLN025.pdb")).read()
+    assert txt.count("MODEL ") == 3 and txt.endswith("END") and all(len(l) == 80 for l in txt.split("\n")[:-1])
+    assert open(os.path.join(all_dir, "CLN025.pdb")).read().count("MODEL ") == 6
+
+    # oracle, same seed, same chunking (2 + 1 replicas), t_delta = 0.5 first
+    feats = ProteinFeatureTransform(strip_missing_residues=False, recenter_and_scale=False)(
+        protein.from_pdb_string(open(os.path.join(GOLDEN, "pdb", "CLN025.pdb")).read()).to_dict())
+    sd = synth_sd(0, 0.002)
+    d = OD.FrameDiffuser()
+    torch.manual_seed(11)
+    ref = []
+    for B in (2, 1):
+        f = {k: feats[k][None].repeat(B, *(1,) * feats[k].ndim) for k in
+             ("aatype", "residue_mask", "fixed_mask", "residue_idx", "torsion_angles_sin_cos")}
+        rig0 = OG.Frames.from_tensor_4x4(feats["rigidgroups_gt_frames"][None, :, 0].repeat(B, 1, 1, 1))
+        ref.append(OD.forward_backward(lambda b: ON.denoising_net(sd, b), d, f, rig0, 0.5, num_timesteps=10))
+    ref = np.concatenate(ref)[..., :5, :]
+    got = np.array([[float(l[30:38]), float(l[38:46]), float(l[46:54])] for l in txt.split("\n") if l.startswith("ATOM")])
+    want = []
+    aat = feats["aatype"].numpy()
+    for m in range(3):
+        for i in range(ref.shape[1]):
+            for a in range(5):
+                if a == 3 and aat[i] == 7:
+                    continue  # GLY has no CB line
+                want.append(ref[m, i, a])
+    want = np.array(want)
+    assert got.shape == want.shape and np.abs(got - want).max() < 2e-3, np.abs(got - want).max()
