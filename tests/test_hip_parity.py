@@ -108,7 +108,12 @@ def _assert_rot_score_close(got, want, rotvec, sigma, what=""):
     mag = np.linalg.norm(want, axis=-1, keepdims=True) + 1e-6
     err = np.abs(got - want) / mag
     tol = 4e-5 + 8 * relb[..., None]
-    assert (err <= tol).all(), (what, float((err / tol).max()), float(err.max()))
+    # where the bound exceeds 5 % the reference's own float32 value is rounding noise (f + 1e-4 can even
+    # change sign): nothing meaningful to compare there beyond finiteness
+    judged = relb < 0.05
+    assert np.isfinite(got).all()
+    assert (err[judged] <= np.broadcast_to(tol, err.shape)[judged]).all(), (
+        what, float((err / tol)[judged].max()), float(err[judged].max()))
     # and the well-conditioned majority must agree to float32 accuracy
     good = relb < 1e-5
     if good.any():
@@ -361,16 +366,31 @@ def test_predict_step_entry_writes_reference_layout(tmp_path, monkeypatch):
     sys.path.insert(0, ROOT)
     import eval as entry
 
-    torch.manual_seed(11)
-    all_dir = entry.main(["task_name=inference", "ckpt_path=null", "data.dataset.accession_code_fillter=[CLN025]",
-                          "model.inference.n_replica=3", "model.inference.replica_per_batch=2",
-                          "model.inference.num_timesteps=10", "model.inference.delta_min=0.5",
-                          "model.inference.delta_max=0.6", "model.inference.delta_step=0.1", "extras.print_config=false"])
+    args = ["task_name=inference", "ckpt_path=null", "data.dataset.accession_code_fillter=[CLN025]",
+            "model.inference.n_replica=3", "model.inference.replica_per_batch=2", "model.inference.num_timesteps=10",
+            "model.inference.delta_min=0.5", "model.inference.delta_max=0.6", "model.inference.delta_step=0.1",
+            "extras.print_config=false"]
+    all_dir = entry.main(args)
     samples = os.path.dirname(all_dir)
     assert sorted(os.listdir(samples)) == ["0.5", "0.6", "all_delta"]
     txt = open(os.path.join(samples, "0.5", "CLN025.pdb")).read()
     assert txt.count("MODEL ") == 3 and txt.endswith("END") and all(len(l) == 80 for l in txt.split("\n")[:-1])
     assert open(os.path.join(all_dir, "CLN025.pdb")).read().count("MODEL ") == 6
+
+    # same objects, but seeded right before sampling (model construction itself consumes the generator)
+    from str2str_amd.synth import synth_state_dict
+    from str2str_amd.utils import config as C
+
+    cfg = C.compose(os.path.join(ROOT, "configs"), "eval.yaml", args)
+    model = C.instantiate(cfg.model)
+    man = [(k, tuple(v.shape)) for k, v in model.net.state_dict().items()]
+    model.net.load_state_dict(synth_state_dict(man, seed=0, sigma_final=0.002))
+    model = model.to(DEV).eval()
+    batch = C.instantiate(cfg.data).test_dataloader()[0]
+    batch = {k: (v.to(DEV) if torch.is_tensor(v) and k != "residue_idx" else v) for k, v in batch.items()}
+    torch.manual_seed(11)
+    all_dir = model.predict_step(batch, 0)
+    txt = open(os.path.join(os.path.dirname(all_dir), "0.5", "CLN025.pdb")).read()
 
     # oracle, same seed, same chunking (2 + 1 replicas), t_delta = 0.5 first
     feats = ProteinFeatureTransform(strip_missing_residues=False, recenter_and_scale=False)(
