@@ -27,7 +27,8 @@ int s2s_abi_version(void);
 
 /* ---- Pair-stream MLPs (fp32 MFMA).  Weight blobs are "packed" for the kernels' lane order:
  *      packed[((s4*T + t)*64 + lane)*4 + q] = W[32*t + (lane & 31)][8*s4 + 4*(lane >> 5) + q]
- *      for W [32*T, 8*S4] row-major (str2str_amd.ops.pack_weight does this). ---- */
+ *      for W [32*T, 8*S4] row-major (str2str_amd.ops.pack_weight does this).  s2s_edge_transition takes the
+ *      TILE-MAJOR order instead: packed[((t*S4 + s4)*64 + lane)*4 + q] (pack_weight(..., tile_major=True)). ---- */
 
 /* EdgeTransition.forward (src/models/net/layers.py:170-185) followed by the edge-mask multiply of
  * TranslationIPA.forward (src/models/net/ipa.py:371-372).

@@ -33,7 +33,10 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-constexpr int kPrefetch = 4;  // weight fragments in flight per wave (x 1 KiB)
+#ifndef S2S_PREFETCH
+#define S2S_PREFETCH 8
+#endif
+constexpr int kPrefetch = S2S_PREFETCH;  // weight fragments in flight per wave (x 1 KiB)
 
 // acc[t] += Wpacked . B   for T output tiles and S4 step-groups (K = 8*S4 inputs).
 // bop(s4, q) returns this lane's B operand for step 4*s4+q (must be compile-time selectable).
@@ -56,10 +59,48 @@ __device__ __forceinline__ void mlp_layer(f32x16 (&acc)[T], const float4* __rest
     }
 }
 
+// Tile-outer variant: output tile t is finished (all S4 step groups) before tile t+1 starts, so the
+// per-tile prologue (accumulator seed: bias / gathered node terms) and epilogue (ReLU, residual) run
+// in the shadow of the neighbouring tiles' MFMAs instead of in MFMA-free phases between layers.
+// Packed weight order for this routine: index = ((t*S4 + s4)*64 + lane)  (pack_weight(..., tile_major=True)).
+//   fetch(t)  : issue the loads tile t's prologue needs (called one tile ahead)
+//   begin(t)  : seed acc[t]
+//   end(t)    : finish acc[t]
+template <int T, int S4, typename BOp, typename Fetch, typename Begin, typename End>
+__device__ __forceinline__ void mlp_layer_tiles(f32x16 (&acc)[T], const float4* __restrict__ wp, int lane, BOp bop,
+                                                Fetch fetch, Begin begin, End end) {
+    constexpr int NIT = S4 * T;
+    constexpr int D = kPrefetch < NIT ? kPrefetch : NIT;
+    float4 w[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) w[d] = wp[d * 64 + lane];
+    fetch(0);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int t = it / S4, s4 = it % S4;
+        if (s4 == 0) {
+            begin(t);
+            if (t + 1 < T) fetch(t + 1);
+        }
+        const float4 cur = w[it % D];
+        if (it + D < NIT) w[it % D] = wp[(it + D) * 64 + lane];
+        acc[t] = mfma32(cur.x, bop(s4, 0), acc[t]);
+        acc[t] = mfma32(cur.y, bop(s4, 1), acc[t]);
+        acc[t] = mfma32(cur.z, bop(s4, 2), acc[t]);
+        acc[t] = mfma32(cur.w, bop(s4, 3), acc[t]);
+        if (s4 == S4 - 1) end(t);
+        // pin the software pipeline: without this fence hipcc sinks each ring refill down to its use and
+        // waits vmcnt(0) per fragment (one load in flight, 2x slower)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // this lane's 4 consecutive elements of group g of a B-layout vector
 __device__ __forceinline__ float4 ldg4(const float* __restrict__ base, int g, int h) {
     return *reinterpret_cast<const float4*>(base + 8 * g + 4 * h);
 }
+
+__device__ __forceinline__ float f4(const float4& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
 
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
@@ -149,58 +190,87 @@ __global__ void __launch_bounds__(256) edge_transition_kernel(
     const float* arow = node_ab + px.bi * 768;
     const float* brow = node_ab + px.bj * 768 + 384;
 
-    // ---- layer 1: 384 <- 128
+    // ---- layer 1: 384 <- 128.  Seed of tile t = A_i + B_j (row gathers, fetched one tile ahead), ReLU at tile end
     f32x16 a1[12];
+    float4 e[16];
 #pragma unroll
-    for (int t = 0; t < 12; ++t)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const float4 x = ldg4(arow, 4 * t + rq, h), y = ldg4(brow, 4 * t + rq, h);
-            a1[t][4 * rq + 0] = x.x + y.x; a1[t][4 * rq + 1] = x.y + y.y;
-            a1[t][4 * rq + 2] = x.z + y.z; a1[t][4 * rq + 3] = x.w + y.w;
-        }
+    for (int g = 0; g < 16; ++g) e[g] = ldg4(erow, g, h);
     {
-        float4 e[16];
+        float4 sa[4], sb[4];  // single staging set: begin(t) drains it before fetch(t+1) refills it
+        mlp_layer_tiles<12, 16>(
+            a1, w1p, lane, [&](int s4, int q) { return f4(e[s4], q); },
+            [&](int t) {
 #pragma unroll
-        for (int g = 0; g < 16; ++g) e[g] = ldg4(erow, g, h);
-        mlp_layer<12, 16>(a1, w1p, lane, [&](int s4, int q) { return q == 0 ? e[s4].x : q == 1 ? e[s4].y : q == 2 ? e[s4].z : e[s4].w; });
+                for (int rq = 0; rq < 4; ++rq) { sa[rq] = ldg4(arow, 4 * t + rq, h); sb[rq] = ldg4(brow, 4 * t + rq, h); }
+            },
+            [&](int t) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const float4 x = sa[rq], y = sb[rq];
+                    a1[t][4 * rq + 0] = x.x + y.x; a1[t][4 * rq + 1] = x.y + y.y;
+                    a1[t][4 * rq + 2] = x.z + y.z; a1[t][4 * rq + 3] = x.w + y.w;
+                }
+            },
+            [&](int t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a1[t][r] = fmaxf(a1[t][r], 0.f);
+            });
     }
-    relu_<12>(a1);
 
-    // ---- layer 2: 384 <- 384
+    // ---- layer 2: 384 <- 384.  Tile end: ReLU, then the residual  h2 + x,  x = [e | n'_i | n'_j]  (layers.py:181)
     f32x16 a2[12];
-#pragma unroll
-    for (int t = 0; t < 12; ++t)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const float4 x = ldg4(b2, 4 * t + rq, h);
-            a2[t][4 * rq + 0] = x.x; a2[t][4 * rq + 1] = x.y; a2[t][4 * rq + 2] = x.z; a2[t][4 * rq + 3] = x.w;
-        }
-    mlp_layer<12, 48>(a2, w2p, lane, [&](int s4, int q) { return a1[s4 >> 2][(s4 & 3) * 4 + q]; });
-    relu_<12>(a2);
-
-    // ---- residual: h2 + x, x = [e | n'_i | n'_j]   (layers.py:181 "trunk(x) + x")
     {
-        const float* src[3] = {erow, node_p + px.bi * 128, node_p + px.bj * 128};
+        const float* npi = node_p + px.bi * 128;
+        const float* npj = node_p + px.bj * 128;
+        // re-read the edge row instead of keeping the 64 layer-1 operand registers alive across layer 2:
+        // the asm launders the pointer so the compiler cannot CSE these loads with the earlier ones
+        const float* erow2 = erow;
+        asm volatile("" : "+v"(erow2));
+        float4 sx[4], sbias[4];  // residual of tile t is fetched at begin(t), used at end(t)
+        mlp_layer_tiles<12, 48>(
+            a2, w2p, lane, [&](int s4, int q) { return a1[s4 >> 2][(s4 & 3) * 4 + q]; },
+            [&](int t) {
 #pragma unroll
-        for (int t = 0; t < 12; ++t)
+                for (int rq = 0; rq < 4; ++rq) sbias[rq] = ldg4(b2, 4 * t + rq, h);
+            },
+            [&](int t) {
+                const float* src = t < 4 ? erow2 : (t < 8 ? npi : npj);
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const float4 x = ldg4(src[t >> 2], 4 * (t & 3) + rq, h);
-                a2[t][4 * rq + 0] += x.x; a2[t][4 * rq + 1] += x.y; a2[t][4 * rq + 2] += x.z; a2[t][4 * rq + 3] += x.w;
-            }
+                for (int rq = 0; rq < 4; ++rq) {
+                    const float4 x = sbias[rq];
+                    a2[t][4 * rq + 0] = x.x; a2[t][4 * rq + 1] = x.y; a2[t][4 * rq + 2] = x.z; a2[t][4 * rq + 3] = x.w;
+                    sx[rq] = ldg4(src, 4 * (t & 3) + rq, h);
+                }
+            },
+            [&](int t) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const float4 x = sx[rq];
+                    a2[t][4 * rq + 0] = fmaxf(a2[t][4 * rq + 0], 0.f) + x.x; a2[t][4 * rq + 1] = fmaxf(a2[t][4 * rq + 1], 0.f) + x.y;
+                    a2[t][4 * rq + 2] = fmaxf(a2[t][4 * rq + 2], 0.f) + x.z; a2[t][4 * rq + 3] = fmaxf(a2[t][4 * rq + 3], 0.f) + x.w;
+                }
+            });
     }
 
     // ---- final layer: 128 <- 384, LayerNorm, edge mask
     f32x16 a3[4];
+    {
+        float4 sbias[4];
+        mlp_layer_tiles<4, 48>(
+            a3, wfp, lane, [&](int s4, int q) { return a2[s4 >> 2][(s4 & 3) * 4 + q]; },
+            [&](int t) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+                for (int rq = 0; rq < 4; ++rq) sbias[rq] = ldg4(bf, 4 * t + rq, h);
+            },
+            [&](int t) {
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const float4 x = ldg4(bf, 4 * t + rq, h);
-            a3[t][4 * rq + 0] = x.x; a3[t][4 * rq + 1] = x.y; a3[t][4 * rq + 2] = x.z; a3[t][4 * rq + 3] = x.w;
-        }
-    mlp_layer<4, 48>(a3, wfp, lane, [&](int s4, int q) { return a2[s4 >> 2][(s4 & 3) * 4 + q]; });
+                for (int rq = 0; rq < 4; ++rq) {
+                    const float4 x = sbias[rq];
+                    a3[t][4 * rq + 0] = x.x; a3[t][4 * rq + 1] = x.y; a3[t][4 * rq + 2] = x.z; a3[t][4 * rq + 3] = x.w;
+                }
+            },
+            [&](int) {});
+    }
     const float em = mask ? mask[px.bi] * mask[px.bj] : 1.0f;
     ln_store<4>(a3, gamma, beta, ln_eps, em, out + px.p * 128, h, px.valid);
 }

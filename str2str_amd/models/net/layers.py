@@ -108,9 +108,9 @@ class EdgeTransition(nn.Module):
         def build():
             ce = self._shape[0]
             return {
-                "w1p": ops.pack_weight(w1.weight[:, :ce].float()),
-                "w2p": ops.pack_weight(w2.weight.float()),
-                "wfp": ops.pack_weight(wf.weight.float()),
+                "w1p": ops.pack_weight(w1.weight[:, :ce].float(), tile_major=True),
+                "w2p": ops.pack_weight(w2.weight.float(), tile_major=True),
+                "wfp": ops.pack_weight(wf.weight.float(), tile_major=True),
                 # node halves of layer 1: [W1[:, ce:ce+cb] ; W1[:, ce+cb:]] applied to n' (+ b1 on the row part)
                 "w_ab": torch.cat([w1.weight[:, ce:ce + self._shape[1]], w1.weight[:, ce + self._shape[1]:]], dim=0).float().contiguous(),
                 "b_ab": torch.cat([w1.bias, torch.zeros_like(w1.bias)]).float().contiguous(),

@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstr2str_hip.so")
+LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
 ABI_VERSION = 1
 
 _lib = None
@@ -126,9 +126,10 @@ def _req(t: torch.Tensor, dtype=torch.float32, name="tensor") -> torch.Tensor:
     return t
 
 
-def pack_weight(w: torch.Tensor) -> torch.Tensor:
+def pack_weight(w: torch.Tensor, tile_major: bool = False) -> torch.Tensor:
     """[Mout, K] row-major -> kernel lane order (see include/str2str_hip.h).  Mout is zero-padded to
-    a multiple of 32; K must be a multiple of 8."""
+    a multiple of 32; K must be a multiple of 8.  ``tile_major`` orders fragments [t][s4] (a whole output
+    tile is contiguous; s2s_edge_transition) instead of [s4][t]."""
     mout, k = w.shape
     if k % 8:
         raise ValueError("K must be a multiple of 8")
@@ -136,7 +137,8 @@ def pack_weight(w: torch.Tensor) -> torch.Tensor:
     if pad:
         w = torch.cat([w, w.new_zeros(pad, k)], dim=0)
     t, s4 = w.shape[0] // 32, k // 8
-    return w.reshape(t, 32, s4, 2, 4).permute(2, 0, 3, 1, 4).contiguous().reshape(-1)
+    perm = (0, 2, 3, 1, 4) if tile_major else (2, 0, 3, 1, 4)
+    return w.reshape(t, 32, s4, 2, 4).permute(*perm).contiguous().reshape(-1)
 
 
 # ------------------------------------------------------------------------------------------ ops
