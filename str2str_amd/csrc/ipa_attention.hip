@@ -2,21 +2,27 @@
 // Reference: InvariantPointAttention.forward, src/models/net/ipa.py:183-257 (the part between the
 // input projections and linear_out).  The [B,N,N,H,Pq,3] displacement tensor (6.4 GB at B=128,
 // N=256), the [B,H,N,N] attention matrix and the [B,H,3,N,N,Pv] product (9.7 GB) that eager
-// PyTorch materialises are never formed: one wave owns (sample, head, 32 query residues) and
-// streams 32-residue key tiles with an online softmax (flash-attention schedule).
+// PyTorch materialises are never formed: a workgroup of 4 waves owns (sample, head, 128 query residues),
+// one wave per 32 of them, and streams 32-residue key tiles with an online softmax (flash-attention
+// schedule).  The key tile (K, V, value points, key points, key mask: 77 KB) is fetched ONCE per
+// workgroup straight into LDS by the LDS-DMA (global_load_lds, no VGPR round trip), double buffered,
+// one barrier per tile, so all four waves (and the other workgroup sharing the head through L2) reuse it.
 //
 // MFMA orientation (v_mfma_f32_32x32x2_f32, exact fp32):
-//   S^T[j, i] = K[j, :] . Q[i, :]      A = key tile (row j per lane), B = Q held in 128 VGPRs
+//   S^T[j, i] = K[j, :] . Q[i, :]      A = key tile (row j per lane), B = Q held in registers
 //   O^T[c, i] += V^T[c, j] . P^T[j, i] A = value columns (coalesced 128 B per half wave),
 //                                       B = the S^T accumulator itself (C layout == B layout,
 //                                       k-order of the dot product is free)
 //   so a lane owns ONE query residue i: softmax statistics, the running rescale, the point term
 //   and the o_pair accumulation are per-lane scalars; only max/sum need one cross-half exchange.
+// LDS images: K rows padded to C+4 floats so the 16 lanes of a ds_read_b128 group hit 16 different bank
+// quads; V / value points row-major (ds_read_b32, 32 consecutive floats per half wave); key points and
+// mask are read as broadcasts.  The VALU work (point distances, o_pair) is written inside the MFMA loops so
+// it issues in the shadow of the matrix pipe.
 // Point term  -1/2 * softplus(w_h)*c * sum_p |q_ip - k_jp|^2  is evaluated with explicit differences on
-// the VALU (cheap: 9*Pq flops per (i,j,h)), exactly as the reference forms it — not through the
-// |q|^2+|k|^2-2q.k expansion, which loses ~2 digits to cancellation.
-// o_pair[i,h,:] = sum_j a_ij pair_z[i,j,:] is not a GEMM (the "value" depends on i): VALU too.
-// Output is written directly in linear_out's concat order (ipa.py:259-266):
+// the VALU exactly as the reference forms it — not through the |q|^2+|k|^2-2q.k expansion, which loses
+// ~2 digits to cancellation.  o_pair[i,h,:] = sum_j a_ij pair_z[i,j,:] is not a GEMM (the "value"
+// depends on i): VALU too.  Output is written directly in linear_out's concat order (ipa.py:259-266):
 //   [ o (H*C) | o_pt.x (H*Pv) | o_pt.y | o_pt.z | |o_pt| (H*Pv) | o_pair (H*PZ) ]
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -31,7 +37,6 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-__device__ __forceinline__ float f4get(const float4& v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
 
 struct IpaArgs {
     const float* q;         // [B,N,H,C]
@@ -49,34 +54,85 @@ struct IpaArgs {
     float inf, eps;
 };
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
+    // 16 B per lane, destination = wave-uniform base + lane*16 (LDS-DMA semantics)
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
+}
+
+template <int C, int PQ>
+struct KeyStage {
+    static constexpr int KS = C + 4;  // padded K row stride (floats)
+    float k[32 * KS];
+    float v[32 * C];
+    float vp[32 * 64];
+    float kp[32 * PQ * 3];
+    float km[32];
+};
+
 template <int C, int PQ, int PV, int PZ>
 __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
-    static_assert(C % 32 == 0 && PV <= 16 && PZ % 4 == 0, "shape");
+    static_assert(C == 256 && PV <= 16 && PZ % 4 == 0 && (PQ * 3) % 4 == 0 && 32 * PQ * 3 <= 3 * 256, "shape");
+    using Stage = KeyStage<C, PQ>;
+    constexpr int KS = Stage::KS;
     constexpr int CT = C / 32;      // value tiles
     constexpr int OT = CT + 2;      // + two tiles of packed value points
     constexpr int QG = C / 8;       // float4 groups of Q per lane
+    __shared__ __attribute__((aligned(16))) Stage stage[2];
+
     const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
     const int wave = threadIdx.x >> 6;
-    const int n_it = (a.N + 31) / 32;
-    const int hgroups = a.H / 4;
-    int bid = blockIdx.x;
-    const int hg = bid % hgroups; bid /= hgroups;
-    const int it = bid % n_it;
-    const int b = bid / n_it;
-    const int head = hg * 4 + wave;
     const int N = a.N, H = a.H;
-    const int i = it * 32 + c;
+    const int n_qb = (N + 127) / 128;
+    int bid = blockIdx.x;
+    const int qb = bid % n_qb; bid /= n_qb;
+    const int head = bid % H;
+    const int b = bid / H;
+    const int i = qb * 128 + wave * 32 + c;
     const bool ivalid = i < N;
     const int ic = ivalid ? i : N - 1;
     const long long row_i = (long long)b * N + ic;
+    const long long kvrow_stride = (long long)H * 2 * C;
+    const float* kv_bh = a.kv + (long long)b * N * kvrow_stride + (long long)head * 2 * C;
+
+    // cooperative LDS-DMA of the key tile starting at key j0 into stage st (19 x 1 KiB per wave)
+    auto load_tile = [&](Stage& st, int j0) {
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr) {
+            const int row = wave * 8 + rr;
+            const float* src = kv_bh + (long long)min(j0 + row, N - 1) * kvrow_stride + lane * 4;
+            dma16(src, st.k + row * KS);
+            dma16(src + C, st.v + row * C);
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int row0 = wave * 8 + x * 4;
+            const int row = row0 + (lane >> 4);
+            dma16(a.v_pts + (((long long)b * N + min(j0 + row, N - 1)) * H + head) * 64 + (lane & 15) * 4, st.vp + row0 * 64);
+        }
+        if (wave < 3) {
+            const int f = (wave * 64 + lane) * 4;
+            if (f < 32 * PQ * 3) {
+                const int row = f / (PQ * 3), col = f % (PQ * 3);
+                dma16(a.k_pts + (((long long)b * N + min(j0 + row, N - 1)) * H + head) * (PQ * 3) + col, st.kp + wave * 256);
+            }
+        } else if (lane < 32) {
+            st.km[lane] = a.mask[(long long)b * N + min(j0 + lane, N - 1)];
+        }
+    };
+
+    load_tile(stage[0], 0);
 
     // ---- this lane's query row (B operand of QK^T), points and mask
-    float4 qreg[QG];
-    {
-        const float* qp = a.q + (row_i * H + head) * C;
+    // half of the query row lives in registers; the other half is re-read (L1/L2 hits) through a small
+    // ring every key tile: 64 fewer live VGPRs is what keeps this kernel out of scratch
+    constexpr int QR = QG / 2;
+    const float* qrow = a.q + (row_i * H + head) * C + 4 * h;
+    float4 qreg[QR];
 #pragma unroll
-        for (int g = 0; g < QG; ++g) qreg[g] = *reinterpret_cast<const float4*>(qp + 8 * g + 4 * h);
-    }
+    for (int g = 0; g < QR; ++g) qreg[g] = *reinterpret_cast<const float4*>(qrow + 8 * g);
     float qpt[PQ * 3];
     {
         const float* p = a.q_pts + (row_i * H + head) * (PQ * 3);
@@ -98,75 +154,65 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
     for (int x = 0; x < PZ; ++x) opair[x] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    const long long kvrow_stride = (long long)H * 2 * C;
-    const float* kv_bh = a.kv + (long long)b * N * kvrow_stride + (long long)head * 2 * C;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 
-    // wave-private LDS: the key tile's points (32 x PQ*3) and key mask (32); every lane of a half
-    // wave reads the same key, so these are broadcast ds_reads instead of 64 redundant global loads
-    __shared__ float s_kpts[4][32 * PQ * 3 + 32];
-    float* kl = s_kpts[wave];
-    constexpr int KPL = (32 * PQ * 3) / 64;  // floats of the key-point tile per lane
-    static_assert(KPL % 4 == 0 && (PQ * 3) % KPL == 0, "key point tile split");
+    int cur = 0;
+    for (int j0 = 0; j0 < N; j0 += 32, cur ^= 1) {
+        const Stage& st = stage[cur];
+        if (j0 + 32 < N) load_tile(stage[cur ^ 1], j0 + 32);  // in flight during this tile's compute
 
-    for (int j0 = 0; j0 < N; j0 += 32) {
-        // ---------------- stage key points / key mask of this tile
-        {
-            const int jj = (lane * KPL) / (PQ * 3), col = (lane * KPL) % (PQ * 3);
-            const int jr = min(j0 + jj, N - 1);
-            const float* src = a.k_pts + (((long long)b * N + jr) * H + head) * (PQ * 3) + col;
-#pragma unroll
-            for (int x = 0; x < KPL / 4; ++x)
-                *reinterpret_cast<float4*>(kl + lane * KPL + 4 * x) = *reinterpret_cast<const float4*>(src + 4 * x);
-            if (lane < 32) kl[32 * PQ * 3 + lane] = a.mask[(long long)b * N + min(j0 + lane, N - 1)];
-        }
-        // ---------------- S^T = K . Q^T   (K fragments through a 4-deep prefetch ring)
+        // ---------------- S^T = K . Q^T, with the point distances issued between the MFMAs
         f32x16 S;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] = 0.f;
-        {
-            const int ja = min(j0 + c, N - 1);
-            const float* kp = kv_bh + ja * kvrow_stride + 4 * h;
-            constexpr int D = 4;
-            float4 kf[D];
+        float pt[16];
+        constexpr int QD = 4;
+        float4 qring[QD];
 #pragma unroll
-            for (int d = 0; d < D; ++d) kf[d] = *reinterpret_cast<const float4*>(kp + 8 * d);
+        for (int d = 0; d < QD; ++d) qring[d] = *reinterpret_cast<const float4*>(qrow + 8 * (QR + d));
 #pragma unroll
-            for (int g = 0; g < QG; ++g) {
-                const float4 cur = kf[g % D];
-                if (g + D < QG) kf[g % D] = *reinterpret_cast<const float4*>(kp + 8 * (g + D));
-                S = mfma32(cur.x, qreg[g].x, S);
-                S = mfma32(cur.y, qreg[g].y, S);
-                S = mfma32(cur.z, qreg[g].z, S);
-                S = mfma32(cur.w, qreg[g].w, S);
+        for (int g = 0; g < QG; ++g) {
+            const float4 kf = *reinterpret_cast<const float4*>(st.k + c * KS + 8 * g + 4 * h);
+            float4 qf;
+            if (g < QR) {
+                qf = qreg[g];
+            } else {
+                qf = qring[(g - QR) % QD];
+                if (g + QD < QG) qring[(g - QR) % QD] = *reinterpret_cast<const float4*>(qrow + 8 * (g + QD));
+            }
+            S = mfma32(kf.x, qf.x, S);
+            S = mfma32(kf.y, qf.y, S);
+            S = mfma32(kf.z, qf.z, S);
+            S = mfma32(kf.w, qf.w, S);
+            if ((g & 1) == 0) {
+                const int r = g >> 1;
+                const float* kp = st.kp + rowmap(r, h) * (PQ * 3);
+                float acc = 0.f;
+#pragma unroll
+                for (int p = 0; p < PQ; ++p) {
+                    const float dx = qpt[p * 3 + 0] - kp[p * 3 + 0];
+                    const float dy = qpt[p * 3 + 1] - kp[p * 3 + 1];
+                    const float dz = qpt[p * 3 + 2] - kp[p * 3 + 2];
+                    acc += (dx * dx + dy * dy + dz * dz) * hw;
+                }
+                pt[r] = acc;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---------------- logits (ipa.py:183-214)
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = j0 + rowmap(r, h);
             const int jc = min(j, N - 1);
-            const float* kp = kl + rowmap(r, h) * (PQ * 3);
-            float pt = 0.f;
-#pragma unroll
-            for (int p = 0; p < PQ; ++p) {
-                const float dx = qpt[p * 3 + 0] - kp[p * 3 + 0];
-                const float dy = qpt[p * 3 + 1] - kp[p * 3 + 1];
-                const float dz = qpt[p * 3 + 2] - kp[p * 3 + 2];
-                pt += (dx * dx + dy * dy + dz * dz) * hw;
-            }
             const float bias = a.attn_bias[(row_i * N + jc) * H + head];
-            const float sq = a.inf * (mask_i * kl[32 * PQ * 3 + rowmap(r, h)] - 1.0f);
+            const float sq = a.inf * (mask_i * st.km[rowmap(r, h)] - 1.0f);
             float s = S[r] * c1 + c2 * bias;
-            s = s + pt * (-0.5f);
+            s = s + pt[r] * (-0.5f);
             s = s + sq;
             s = (j < N) ? s : -INFINITY;
             S[r] = s;
             tmax = fmaxf(tmax, s);
-            if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
@@ -180,41 +226,48 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
         }
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (!__all(alpha == 1.0f)) {  // the running max settles after a few tiles: skip the rescale then
 #pragma unroll
-        for (int t = 0; t < OT; ++t)
+            for (int t = 0; t < OT; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
+                for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
 #pragma unroll
-        for (int x = 0; x < PZ; ++x) opair[x] *= alpha;
-
-        // ---------------- O^T += V^T . P^T   (+ value points as two extra tiles)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int jc = min(j0 + rowmap(r, h), N - 1);
-            const float* vp = kv_bh + jc * kvrow_stride + C + c;
-            const float p = S[r];
-#pragma unroll
-            for (int t = 0; t < CT; ++t) O[t] = mfma32(vp[32 * t], p, O[t]);
-            const float* pp = a.v_pts + (((long long)b * N + jc) * H + head) * 64 + c;
-            O[CT] = mfma32(pp[0], p, O[CT]);
-            O[CT + 1] = mfma32(pp[32], p, O[CT + 1]);
-            if (r & 1) __builtin_amdgcn_sched_barrier(0);
+            for (int x = 0; x < PZ; ++x) opair[x] *= alpha;
         }
-        // ---------------- o_pair partial sums over this lane's 16 keys (ipa.py:253-257)
+
+        // ---------------- O^T += V^T . P^T (+ value points), o_pair FMAs in the MFMA shadow (ipa.py:221-257)
+        float4 z[PZ / 4];
+        {
+            const float* pz = a.pair_z + (row_i * N + min(j0 + rowmap(0, h), N - 1)) * PZ;
+#pragma unroll
+            for (int x = 0; x < PZ / 4; ++x) z[x] = *reinterpret_cast<const float4*>(pz + 4 * x);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int jc = min(j0 + rowmap(r, h), N - 1);
-            const float* pz = a.pair_z + (row_i * N + jc) * PZ;
+            const int kr = rowmap(r, h);
             const float p = S[r];
+            float4 zc[PZ / 4];
+#pragma unroll
+            for (int x = 0; x < PZ / 4; ++x) zc[x] = z[x];
+            if (r + 1 < 16) {
+                const float* pz = a.pair_z + (row_i * N + min(j0 + rowmap(r + 1, h), N - 1)) * PZ;
+#pragma unroll
+                for (int x = 0; x < PZ / 4; ++x) z[x] = *reinterpret_cast<const float4*>(pz + 4 * x);
+            }
+            const float* vrow = st.v + kr * C + c;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) O[t] = mfma32(vrow[32 * t], p, O[t]);
+            O[CT] = mfma32(st.vp[kr * 64 + c], p, O[CT]);
+            O[CT + 1] = mfma32(st.vp[kr * 64 + 32 + c], p, O[CT + 1]);
 #pragma unroll
             for (int x = 0; x < PZ / 4; ++x) {
-                const float4 z = *reinterpret_cast<const float4*>(pz + 4 * x);
-                opair[4 * x + 0] += p * z.x; opair[4 * x + 1] += p * z.y;
-                opair[4 * x + 2] += p * z.z; opair[4 * x + 3] += p * z.w;
+                opair[4 * x + 0] += p * zc[x].x; opair[4 * x + 1] += p * zc[x].y;
+                opair[4 * x + 2] += p * zc[x].z; opair[4 * x + 3] += p * zc[x].w;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_wave_barrier();  // all lanes done with this tile's LDS before it is restaged
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile's DMA has landed
+        __syncthreads();                                   // ... and everyone is done reading this one
     }
 
     // ---------------- epilogue: normalise, inverse-transform points, write concat layout
@@ -234,17 +287,17 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
     {
         // frame of residue i: R = quat_to_rot(q) (rigid_utils.py:187-207), o_pt = R^T (x - t) (:1122-1133)
         const float* f = a.rigids7 + row_i * 7;
-        const float qa = f[0], qb = f[1], qc = f[2], qd = f[3];
+        const float qa = f[0], qb_ = f[1], qc = f[2], qd = f[3];
         const float tx = f[4], ty = f[5], tz = f[6];
-        const float r00 = qa * qa + qb * qb - qc * qc - qd * qd, r01 = 2 * qb * qc - 2 * qa * qd, r02 = 2 * qb * qd + 2 * qa * qc;
-        const float r10 = 2 * qb * qc + 2 * qa * qd, r11 = qa * qa - qb * qb + qc * qc - qd * qd, r12 = 2 * qc * qd - 2 * qa * qb;
-        const float r20 = 2 * qb * qd - 2 * qa * qc, r21 = 2 * qc * qd + 2 * qa * qb, r22 = qa * qa - qb * qb - qc * qc + qd * qd;
+        const float r00 = qa * qa + qb_ * qb_ - qc * qc - qd * qd, r01 = 2 * qb_ * qc - 2 * qa * qd, r02 = 2 * qb_ * qd + 2 * qa * qc;
+        const float r10 = 2 * qb_ * qc + 2 * qa * qd, r11 = qa * qa - qb_ * qb_ + qc * qc - qd * qd, r12 = 2 * qc * qd - 2 * qa * qb_;
+        const float r20 = 2 * qb_ * qd - 2 * qa * qc, r21 = 2 * qc * qd + 2 * qa * qb_, r22 = qa * qa - qb_ * qb_ - qc * qc + qd * qd;
         float* ox = orow + H * C + head * PV;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                const int pt = 8 * t + 2 * rq + h;  // point whose (x,y,z,0) group this lane holds
+                const int pt_idx = 8 * t + 2 * rq + h;  // point whose (x,y,z,0) group this lane holds
                 const float dx = O[CT + t][4 * rq + 0] * inv - tx;
                 const float dy = O[CT + t][4 * rq + 1] * inv - ty;
                 const float dz = O[CT + t][4 * rq + 2] * inv - tz;
@@ -252,11 +305,11 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
                 const float ly = r01 * dx + r11 * dy + r21 * dz;
                 const float lz = r02 * dx + r12 * dy + r22 * dz;
                 const float nr = sqrtf(lx * lx + ly * ly + lz * lz + a.eps);
-                if (ivalid && pt < PV) {
-                    ox[pt] = lx;
-                    ox[H * PV + pt] = ly;
-                    ox[2 * H * PV + pt] = lz;
-                    ox[3 * H * PV + pt] = nr;
+                if (ivalid && pt_idx < PV) {
+                    ox[pt_idx] = lx;
+                    ox[H * PV + pt_idx] = ly;
+                    ox[2 * H * PV + pt_idx] = lz;
+                    ox[3 * H * PV + pt_idx] = nr;
                 }
             }
     }
@@ -281,11 +334,11 @@ extern "C" int s2s_ipa_attention(const float* q, const float* kv, const float* q
                                  const float* head_w_scaled, float* out, int n_samples, int n_res, int n_heads, int c_hidden,
                                  int n_qk_points, int n_v_points, int c_pair_z, float inf, float eps, void* stream) {
     if (n_samples <= 0 || n_res <= 0) return 0;
-    if (c_hidden != 256 || n_qk_points != 8 || n_v_points != 12 || c_pair_z != 32 || n_heads % 4 != 0)
+    if (c_hidden != 256 || n_qk_points != 8 || n_v_points != 12 || c_pair_z != 32 || n_heads < 1)
         return (int)hipErrorInvalidValue;  // the reference configuration (configs/model/diffusion.yaml:29-40)
     IpaArgs a{q, kv, q_pts, k_pts, v_pts64, attn_bias, pair_z, mask, rigids7, head_w_scaled, out, n_samples, n_res, n_heads, inf, eps};
-    const int n_it = (n_res + 31) / 32;
-    const long long blocks = (long long)n_samples * n_it * (n_heads / 4);
+    const int n_qb = (n_res + 127) / 128;
+    const long long blocks = (long long)n_samples * n_heads * n_qb;
     hipLaunchKernelGGL((ipa_attention_kernel<256, 8, 12, 32>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }

@@ -343,7 +343,9 @@ def test_sharded_sampler_equals_single(net_smooth, diffuser):
         torch.manual_seed(5)
         parts.append(forward_backward(net_smooth, diffuser, feats, rig0, 1.0, shard=(r, 2), **kw))
     assert parts[0].shape[0] == 3 and parts[1].shape[0] == 2
-    assert maxdiff(torch.cat(parts).cpu(), full.cpu()) < 1e-5
+    # dense per-node layers go through rocBLAS, whose kernel choice (hence summation order) depends on the row
+    # count B*N; the HIP kernels themselves are batch-independent bit for bit
+    assert maxdiff(torch.cat(parts).cpu(), full.cpu()) < 5e-5
 
 
 def test_predict_step_entry_writes_reference_layout(tmp_path, monkeypatch):
