@@ -111,7 +111,9 @@ int s2s_frames_to_backbone(const float* rigids7, const float* psi_sincos, const 
  *   z_rot,z_trans [B,N,3] double noise (only read when probability_flow == 0),
  *   rot_score_in/trans_score_in [B,N,3] double or NULL: when given, the score stage is skipped and
  *   these are used (FrameDiffuser.reverse called with caller-provided scores; x0_7 may be NULL),
- *   next7 [B,N,7] or NULL (score only); rot_score_out/trans_score_out [B,N,3] double or NULL. */
+ *   next7 [B,N,7] or NULL (score only); rot_score_out/trans_score_out [B,N,3] double or NULL.
+ *   center_trans: 0 = off, 1 = centre of mass over all N residues (reference behaviour), 2 = over the
+ *   residues with mask > 0 only (padded mixed-length batches). */
 int s2s_se3_step(const float* x0_7, const float* xt_7, const float* mask, const float* diffuse_mask,
                  const float* params8, const double* z_rot, const double* z_trans,
                  const double* rot_score_in, const double* trans_score_in, float* next7,

@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(kThreads) se3_step_kernel(
     double noise_scale) {
     __shared__ float s_cw[kL];       // (2l+1) * exp(-l(l+1) sigma^2 / 2), float32 like the reference
     __shared__ int s_leff;
-    __shared__ double s_red[3][kThreads / 64];
+    __shared__ double s_red[4][kThreads / 64];
     __shared__ double s_com[3];
 
     const int b = blockIdx.x;
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(kThreads) se3_step_kernel(
     const int leff = s_leff;
 
     double x1[kMaxPerThread][3];
-    double part[3] = {0.0, 0.0, 0.0};
+    double part[4] = {0.0, 0.0, 0.0, 0.0};  // x, y, z sums and the residue count of the centre of mass
     const double half_or_one = probability_flow ? 0.5 : 1.0;
 
 #pragma unroll
@@ -166,23 +166,26 @@ __global__ void __launch_bounds__(kThreads) se3_step_kernel(
             double diff = 0.0;
             if (!probability_flow) diff = (double)(g_trans * (float)sqrt(dt)) * (noise_scale * z_trans[r * 3 + c]);
             x1[it][c] = (double)xts[c] - (drift + diff);
-            part[c] += x1[it][c];
+            part[c] += (center == 2) ? m * x1[it][c] : x1[it][c];
         }
+        part[3] += (center == 2) ? m : 1.0;
     }
     if (!next7) return;
 
-    // ---- centre of mass over ALL residues of the sample (r3.py:117-122 with mask=None)
+    // ---- centre of mass: center == 1 over ALL residues of the sample, as the reference does (r3.py:117-122
+    //      is called with mask=None); center == 2 over the residues with mask > 0 only, which is what makes
+    //      a padded (mixed-length) batch reproduce each chain's un-padded run
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < 4; ++c) {
         double v = part[c];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if ((tid & 63) == 0) s_red[c][tid >> 6] = v;
     }
     __syncthreads();
     if (tid < 3) {
-        double v = 0.0;
-        for (int w = 0; w < kThreads / 64; ++w) v += s_red[tid][w];
-        s_com[tid] = center ? v / (double)(float)N : 0.0;
+        double v = 0.0, cnt = 0.0;
+        for (int w = 0; w < kThreads / 64; ++w) { v += s_red[tid][w]; cnt += s_red[3][w]; }
+        s_com[tid] = center ? v / (double)(float)cnt : 0.0;
     }
     __syncthreads();
 

@@ -74,11 +74,16 @@ class InvariantPointAttention(nn.Module):
         return self.linear_out(feats)
 
 
-def encoder_forward(enc: nn.TransformerEncoder, x: torch.Tensor, key_padding_float: torch.Tensor) -> torch.Tensor:
+def encoder_forward(enc: nn.TransformerEncoder, x: torch.Tensor, key_padding_float: torch.Tensor,
+                    exact_padding: bool = False) -> torch.Tensor:
     """The 2-layer post-norm ``nn.TransformerEncoder`` of the trunk (reference ipa.py:312-317,357)
     evaluated with explicit ops on its own parameters.  x is batch-first [B,N,D] here; the FLOAT
-    key-padding mask is ADDED to the logits, as PyTorch does for float masks."""
+    key-padding mask (1 - node_mask) is ADDED to the logits, as PyTorch does for float masks
+    — a no-op for the all-ones masks of every reference run.  ``exact_padding`` instead removes padded keys
+    (-inf), which is what a mixed-length padded batch needs to reproduce each chain's un-padded run."""
     B, N, D = x.shape
+    if exact_padding:
+        key_padding_float = torch.where(key_padding_float > 0, float("-inf"), 0.0).to(x.dtype)
     for layer in enc.layers:
         att = layer.self_attn
         h = att.num_heads
@@ -121,6 +126,7 @@ class TranslationIPA(nn.Module):
                 self.trunk[f"edge_transition_{b}"] = EdgeTransition(node_embed_size=c_s, edge_embed_in=c_z,
                                                                     edge_embed_out=c_z)
         self.torsion_pred = TorsionAngleHead(c_s, 1)
+        self.exact_padding = False  # see encoder_forward; set by the mixed-length sampler
 
     def forward(self, node_embed: torch.Tensor, edge_embed: torch.Tensor, batch: dict) -> dict:
         """reference :331-387.  Frames travel as one [B,N,7] tensor between the fused kernels."""
@@ -138,7 +144,7 @@ class TranslationIPA(nn.Module):
             ipa_embed = ipa_embed * node_mask[..., None]
             node_embed = T[f"ipa_ln_{b}"](node_embed + ipa_embed)
             cat = torch.cat([node_embed, T[f"skip_embed_{b}"](init_node)], dim=-1)
-            tr = encoder_forward(T[f"transformer_{b}"], cat, pad)
+            tr = encoder_forward(T[f"transformer_{b}"], cat, pad, self.exact_padding)
             node_embed = node_embed + T[f"linear_{b}"](tr)
             node_embed = T[f"node_transition_{b}"](node_embed)
             node_embed = node_embed * node_mask[..., None]

@@ -297,7 +297,7 @@ def se3_step(x0_7, xt_7, mask, diffuse_mask, params8, dt: float, coordinate_scal
     _check(lib.s2s_se3_step(_p(x0_7), _p(xt_7), _p(mask), _p(diffuse_mask), _p(params8), _p(z_rot), _p(z_trans), _p(rot_score_in),
                             _p(trans_score_in), _p(nxt),
                             _p(rs), _p(ts), B, N, float(dt), float(coordinate_scaling), int(bool(probability_flow)),
-                            int(bool(center)), float(noise_scale), _stream()), "s2s_se3_step")
+                            int(center), float(noise_scale), _stream()), "s2s_se3_step")
     return nxt, rs, ts
 
 

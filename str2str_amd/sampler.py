@@ -42,6 +42,63 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 @torch.no_grad()
+def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: float, *, min_t: float,
+                 noise_scale: float = 1.0, probability_flow: bool = True, self_conditioning: bool = True,
+                 center_mode: int = 1, host_noise=None, trace: Optional[list] = None):
+    """The loop body of forward_backward over ALREADY EXPANDED per-sample features (every tensor has the
+    sample dimension b) starting from the noised frames ``rigids_t`` [b,N,7]: 1 self-conditioning evaluation,
+    then per step  network -> fused SE(3) step, last step returns the x0 prediction.  ``host_noise()`` (optional)
+    returns the (z_rot, z_trans) float64 [b,N,3] device tensors of a step or None.  -> (atom37, final rigids7, psi)."""
+    device = rigids_t.device
+    b, N = rigids_t.shape[:2]
+    feats = dict(feats)
+    mask = feats["residue_mask"].float().contiguous()
+    diffuse_mask = ((1 - feats["fixed_mask"].float()) * mask).contiguous()
+    t_all = torch.as_tensor(np.ascontiguousarray(ts, dtype=np.float64)).float()  # fl32(t), as `t * torch.ones(B)` gives
+    p8_all = diffuser.step_params(t_all).to(device)  # [n, 8]: t is uniform over the chunk
+    keep_bb = getattr(net, "backbone_in_forward", None)
+    if keep_bb is not None:
+        net.backbone_in_forward = False
+    try:
+        feats["rigids_t"] = rigids_t
+        feats["sc_ca_t"] = torch.zeros(b, N, 3, device=device)
+        if self_conditioning:
+            feats["t"] = torch.full((b,), float(ts[0]), dtype=torch.float32)
+            feats["sc_ca_t"] = net(feats, as_tensor_7=True)["rigids7"][..., 4:]
+        final = None
+        for k, t in enumerate(ts):
+            feats["t"] = torch.full((b,), float(t), dtype=torch.float32)
+            out = net(feats, as_tensor_7=False)
+            x0_7 = out["rigids7"]
+            if t == min_t:
+                final = out
+                if trace is not None:
+                    trace.append(dict(t=t, rigids_t=feats["rigids_t"], sc_ca_t=feats["sc_ca_t"], x0=x0_7, psi=out["psi"]))
+                break
+            sc_in = feats["sc_ca_t"]
+            if self_conditioning:
+                feats["sc_ca_t"] = x0_7[..., 4:]
+            z = host_noise() if host_noise is not None else None
+            z_rot, z_trans = z if z is not None else (None, None)
+            if not probability_flow and z_rot is None:
+                z_rot = torch.randn(b, N, 3, dtype=torch.float64, device=device)
+                z_trans = torch.randn(b, N, 3, dtype=torch.float64, device=device)
+            p8 = p8_all[k].expand(b, 8).contiguous()
+            nxt, rs, tsc = diffuser.step(x0_7, feats["rigids_t"], p8, dt, mask, diffuse_mask, center_trans=center_mode,
+                                         noise_scale=noise_scale, probability_flow=probability_flow, z_rot=z_rot,
+                                         z_trans=z_trans, want_scores=trace is not None)
+            if trace is not None:
+                trace.append(dict(t=t, rigids_t=feats["rigids_t"], sc_ca_t=sc_in, x0=x0_7, psi=out["psi"], rot_score=rs,
+                                  trans_score=tsc, next7=nxt))
+            feats["rigids_t"] = nxt
+        atom37 = compute_backbone(final["rigids"], final["psi"], aatype=feats.get("aatype"), _rigids7=final["rigids7"])[0]
+    finally:
+        if keep_bb is not None:
+            net.backbone_in_forward = keep_bb
+    return atom37, final["rigids7"], final["psi"]
+
+
+@torch.no_grad()
 def forward_backward(net, diffuser, batch: dict, rigids_0: Rigid, t_delta: float, *, num_timesteps: int,
                      min_t: float = 0.01, noise_scale: float = 1.0, probability_flow: bool = True,
                      self_conditioning: bool = True, device=None, shard: Tuple[int, int] = (0, 1),
@@ -62,65 +119,77 @@ def forward_backward(net, diffuser, batch: dict, rigids_0: Rigid, t_delta: float
                                              as_tensor_7=True)["rigids_t"]
     else:
         rigids_t = diffuser.sample_prior(shape=rigids_0.shape, device="cpu", as_tensor_7=True)["rigids_t"]
+    N = rigids_0.shape[1]
     if b == 0:
-        return torch.zeros(0, rigids_0.shape[1], 37, 3, device=device)
+        return torch.zeros(0, N, 37, 3, device=device)
     rigids_t = rigids_t[lo:hi].to(device).float().contiguous()
-
     feats = {k: batch[k].to(device).repeat(b, *(1,) * (batch[k].ndim - 1)) for k in _REPEAT_KEYS if k in batch}
-    mask = feats["residue_mask"].float().contiguous()
-    diffuse_mask = ((1 - feats["fixed_mask"].float()) * mask).contiguous()
-    # per-step scalars for every step at once: t is uniform over the chunk
-    t_all = torch.as_tensor(np.ascontiguousarray(ts, dtype=np.float64)).float()  # fl32(t), as `t * torch.ones(B)` gives
-    p8_all = diffuser.step_params(t_all).to(device)  # [n, 8]
-    N = mask.shape[1]
 
-    keep_bb = getattr(net, "backbone_in_forward", None)
-    if keep_bb is not None:
-        net.backbone_in_forward = False
-    try:
-        feats["rigids_t"] = rigids_t
-        if self_conditioning:
-            feats["sc_ca_t"] = torch.zeros(b, N, 3, device=device)
-            feats["t"] = torch.full((b,), float(ts[0]), dtype=torch.float32)
-            feats["sc_ca_t"] = net(feats, as_tensor_7=True)["rigids7"][..., 4:]
-        else:
-            feats["sc_ca_t"] = torch.zeros(b, N, 3, device=device)
-        final = None
-        for k, t in enumerate(ts):
-            feats["t"] = torch.full((b,), float(t), dtype=torch.float32)
-            out = net(feats, as_tensor_7=False)
-            x0_7 = out["rigids7"]
-            if t == min_t:
-                final = out
-                if trace is not None:
-                    trace.append(dict(t=t, rigids_t=feats["rigids_t"], sc_ca_t=feats["sc_ca_t"], x0=x0_7, psi=out["psi"]))
-                break
-            sc_in = feats["sc_ca_t"]
-            if self_conditioning:
-                feats["sc_ca_t"] = x0_7[..., 4:]
-            z_rot = z_trans = None
-            if rng == "host":
-                # the reference consumes two float64 normal draws per step even under the probability-flow
-                # ODE (so3.py:360, r3.py:109): keep the generator in lock-step for later chunks
-                zr = torch.randn(B_total, N, 3, dtype=torch.float64)
-                zt = torch.randn(B_total, N, 3, dtype=torch.float64)
-                if not probability_flow:
-                    z_rot, z_trans = zr[lo:hi].to(device).contiguous(), zt[lo:hi].to(device).contiguous()
-            elif not probability_flow:
-                z_rot = torch.randn(b, N, 3, dtype=torch.float64, device=device)
-                z_trans = torch.randn(b, N, 3, dtype=torch.float64, device=device)
-            p8 = p8_all[k].expand(b, 8).contiguous()
-            nxt, rs, tsc = diffuser.step(x0_7, feats["rigids_t"], p8, dt, mask, diffuse_mask, center_trans=True,
-                                         noise_scale=noise_scale, probability_flow=probability_flow, z_rot=z_rot,
-                                         z_trans=z_trans, want_scores=trace is not None)
-            if trace is not None:
-                trace.append(dict(t=t, rigids_t=feats["rigids_t"], sc_ca_t=sc_in, x0=x0_7, psi=out["psi"], rot_score=rs,
-                                  trans_score=tsc, next7=nxt))
-            feats["rigids_t"] = nxt
-        atom37 = compute_backbone(final["rigids"], final["psi"], aatype=feats.get("aatype"), _rigids7=final["rigids7"])[0]
-    finally:
-        if keep_bb is not None:
-            net.backbone_in_forward = keep_bb
+    def host_noise():
+        # the reference consumes two float64 normal draws per step even under the probability-flow ODE
+        # (so3.py:360, r3.py:109): keep the host generator in lock-step for later chunks
+        zr = torch.randn(B_total, N, 3, dtype=torch.float64)
+        zt = torch.randn(B_total, N, 3, dtype=torch.float64)
+        if probability_flow:
+            return None
+        return zr[lo:hi].to(device).contiguous(), zt[lo:hi].to(device).contiguous()
+
+    atom37, r7, psi = denoise_loop(net, diffuser, feats, rigids_t, ts, dt, min_t=min_t, noise_scale=noise_scale,
+                                   probability_flow=probability_flow, self_conditioning=self_conditioning, center_mode=1,
+                                   host_noise=host_noise if rng == "host" else None, trace=trace)
     if return_rigids:
-        return atom37, final["rigids7"], final["psi"]
+        return atom37, r7, psi
     return atom37
+
+
+@torch.no_grad()
+def sample_mixed_lengths(net, diffuser, targets, replicas: int, t_delta: float, *, num_timesteps: int,
+                         min_t: float = 0.01, noise_scale: float = 1.0, probability_flow: bool = True,
+                         self_conditioning: bool = True, device=None, rigids_t_init=None):
+    """BASELINE configs[4]: several chains of different length in ONE padded batch (``replicas`` each).
+
+    The reference cannot do this (`assert batch size == 1`, diffusion_module.py:249) and its padding semantics
+    would be wrong for it (float key-padding mask added to the transformer logits, centre of mass over padded
+    residues).  Here padding is exact: padded keys are removed from both attentions, pair rows/cols are
+    masked, the centre of mass runs over real residues only — so every chain reproduces its own un-padded run.
+    ``targets``: list of single-target feature dicts (batch dim 1).  -> list of atom37 [replicas, N_k, 37, 3]."""
+    device = torch.device(device) if device is not None else next(net.parameters()).device
+    n_max = max(int(t["aatype"].shape[1]) for t in targets)
+    T, n, dt, ts = schedule(t_delta, num_timesteps, min_t)
+    rows, r_t = {k: [] for k in _REPEAT_KEYS}, []
+    for ti, tg in enumerate(targets):
+        L = int(tg["aatype"].shape[1])
+        for k in _REPEAT_KEYS:
+            v = tg[k]
+            pad = torch.zeros((1, n_max - L) + tuple(v.shape[2:]), dtype=v.dtype)
+            if k == "residue_idx" and L < n_max:  # keep padded indices inside the real range (table lookups stay in bounds)
+                pad = pad + v[:, -1:]
+            rows[k].append(torch.cat([v.cpu(), pad], dim=1).repeat(replicas, *(1,) * (v.ndim - 1)))
+        if rigids_t_init is not None:
+            rt = rigids_t_init[ti].cpu()
+        else:
+            gt4 = tg["rigidgroups_gt_frames"][..., 0, :, :].cpu()
+            rig0 = Rigid.from_tensor_4x4(gt4.repeat(replicas, 1, 1, 1))
+            if t_delta > 0:
+                rt = diffuser.forward_marginal(rig0, t_delta * torch.ones(replicas), tg["residue_mask"].cpu().repeat(replicas, 1))["rigids_t"]
+            else:
+                rt = diffuser.sample_prior(shape=rig0.shape, device="cpu", as_tensor_7=True)["rigids_t"]
+        ident = torch.zeros(replicas, n_max - L, 7)
+        ident[..., 0] = 1.0  # identity frames on the padding: finite everywhere, masked out of every result
+        r_t.append(torch.cat([rt.float(), ident], dim=1))
+    feats = {k: torch.cat(v, dim=0).to(device) for k, v in rows.items()}
+    rigids_t = torch.cat(r_t, dim=0).to(device).contiguous()
+    tr = net.translator
+    keep = tr.exact_padding
+    tr.exact_padding = True
+    try:
+        atom37, _, _ = denoise_loop(net, diffuser, feats, rigids_t, ts, dt, min_t=min_t, noise_scale=noise_scale,
+                                    probability_flow=probability_flow, self_conditioning=self_conditioning, center_mode=2)
+    finally:
+        tr.exact_padding = keep
+    out, o = [], 0
+    for tg in targets:
+        L = int(tg["aatype"].shape[1])
+        out.append(atom37[o:o + replicas, :L])
+        o += replicas
+    return out
