@@ -75,9 +75,17 @@ class EmbeddingModule(nn.Module):
 
         def build():
             w0 = e0.weight.float()
+            n0 = self.node_embed[0]
+            wn = n0.weight.float()
             out = {
-                "w_row": w0[:, :t1].contiguous(), "w_col": w0[:, t1:2 * t1].contiguous(),
+                # first Linear of both MLPs split by feature block: the timestep embedding is one vector per
+                # SAMPLE, so its image is a [B, width] GEMM; the fixed-mask column and the positional block are
+                # added per residue.  (Also avoids K = 33 / 65 GEMMs, which hit slow BLAS paths at some row counts.)
+                "w_row_t": w0[:, :ie].contiguous(), "w_row_f": w0[:, ie].contiguous(),
+                "w_col_t": w0[:, t1:t1 + ie].contiguous(), "w_col_f": w0[:, t1 + ie].contiguous(),
                 "w_rel": w0[:, 2 * t1:2 * t1 + ie].contiguous(), "b0": e0.bias.float().contiguous(),
+                "wn_t": wn[:, :ie].contiguous(), "wn_f": wn[:, ie].contiguous(), "wn_pos": wn[:, t1:t1 + ie].contiguous(),
+                "bn0": n0.bias.float().contiguous(),
                 "w2p": ops.pack_weight(e2.weight.float()), "w3p": ops.pack_weight(e4.weight.float()),
             }
             if self.self_conditioning:
@@ -87,19 +95,20 @@ class EmbeddingModule(nn.Module):
             out["bin_lower"] = torch.linspace(self._dims[2], self._dims[3], nb).to(w0.device)
             return out
 
-        return self._wcache.get([e0.weight, e0.bias, e2.weight, e4.weight], build)
+        return self._wcache.get([e0.weight, e0.bias, e2.weight, e4.weight, self.node_embed[0].weight, self.node_embed[0].bias], build)
 
-    def _index_tables(self, residue_idx: torch.Tensor, w_rel: torch.Tensor):
-        """Per-target constants: node positional features and the relative-position table
-        rel_tab[d + off] = W_rel . posemb(d).  Cached on the index tensor (one host sync per target)."""
-        key = (residue_idx.data_ptr(), tuple(residue_idx.shape), residue_idx._version, w_rel.data_ptr(), w_rel._version)
+    def _index_tables(self, residue_idx: torch.Tensor, w_rel: torch.Tensor, wn_pos: torch.Tensor):
+        """Per-target constants: first-layer image of the node positional features and the relative-position
+        table rel_tab[d + off] = W_rel . posemb(d).  Cached on the index tensor (one host sync per target)."""
+        key = (residue_idx.data_ptr(), tuple(residue_idx.shape), residue_idx._version, w_rel.data_ptr(), w_rel._version,
+               wn_pos.data_ptr(), wn_pos._version)
         if key != self._idx_key:
             idx_cpu = residue_idx.detach().cpu()
             span = int(idx_cpu.max() - idx_cpu.min())
             d = torch.arange(-span, span + 1)
             dev = w_rel.device
             rel = F.linear(self.position_embed(d).float().to(dev), w_rel).contiguous()
-            node_pos = self.position_embed(idx_cpu).float().to(dev)
+            node_pos = F.linear(self.position_embed(idx_cpu).float().to(dev), wn_pos).contiguous()  # [B, L, node width]
             self._idx_val = (rel, span, node_pos, residue_idx.to(dev).contiguous())
             self._idx_key = key
         return self._idx_val
@@ -115,14 +124,15 @@ class EmbeddingModule(nn.Module):
         if self._dims[4] != 128:
             raise ops.HipLibraryError("edge_embed kernel is built for edge_embed_size=128")
         B, L = residue_idx.shape
-        rel_tab, span, node_pos, idx_dev = self._index_tables(residue_idx, w["w_rel"])
+        rel_tab, span, node_pos, idx_dev = self._index_tables(residue_idx, w["w_rel"], w["wn_pos"])
         fixed = fixed_mask.to(dev)[..., None].float()
         t_emb = self.time_embed(t).to(dev)  # [B, 32]
-        t_embed = torch.cat([t_emb[:, None, :].expand(B, L, -1), fixed], dim=-1)  # [B, L, 33]
-        node_embed = self.node_embed(torch.cat([t_embed, node_pos], dim=-1).float())
-        node_a = F.linear(t_embed, w["w_row"], w["b0"]).contiguous()
-        node_b = F.linear(t_embed, w["w_col"]).contiguous()
-        ca = self_conditioning_ca.to(dev).float().contiguous() if self.self_conditioning else t_embed.new_zeros(B, L, 3)
+        ne = self.node_embed
+        h = F.relu(F.linear(t_emb, w["wn_t"], w["bn0"])[:, None, :] + fixed * w["wn_f"] + node_pos)
+        node_embed = ne[5](ne[4](F.relu(ne[2](h))))
+        node_a = (F.linear(t_emb, w["w_row_t"], w["b0"])[:, None, :] + fixed * w["w_row_f"]).contiguous()
+        node_b = (F.linear(t_emb, w["w_col_t"])[:, None, :] + fixed * w["w_col_f"]).contiguous()
+        ca = self_conditioning_ca.to(dev).float().contiguous() if self.self_conditioning else t_emb.new_zeros(B, L, 3)
         mask = None if node_mask is None else node_mask.to(dev).float().contiguous()
         e2, e4, ln = self.edge_embed[2], self.edge_embed[4], self.edge_embed[5]
         edge_embed = ops.edge_embed(node_a, node_b, rel_tab, w["bin_tab"], w["bin_lower"], idx_dev, ca, w["w2p"],
