@@ -43,7 +43,7 @@ constexpr int kPrefetch = S2S_PREFETCH;  // weight fragments in flight per wave 
 template <int T, int S4, typename BOp>
 __device__ __forceinline__ void mlp_layer(f32x16 (&acc)[T], const float4* __restrict__ wp, int lane, BOp bop) {
     constexpr int NIT = S4 * T;
-    constexpr int D = kPrefetch < NIT ? kPrefetch : NIT;
+    constexpr int D = 4 < NIT ? 4 : NIT;  // the streaming kernels (edge_embed, pair_project) run 2+ waves/SIMD: short ring
     float4 w[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) w[d] = wp[d * 64 + lane];
