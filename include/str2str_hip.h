@@ -35,11 +35,14 @@ int s2s_abi_version(void);
  *   edge     [B,N,N,128]  in        node_ab [B,N,768] = [W1[:,128:256].n'+b1 | W1[:,256:384].n']
  *   node_p   [B,N,128]    n' = initial_embed(node)
  *   w1_packed: W1[:, :128] (384x128); w2_packed: W2 (384x384); wf_packed: final_layer.weight (128x384)
- *   b2 [384], bf [128], ln_gamma/ln_beta [128], mask [B,N] or NULL, out [B,N,N,128] (may not alias edge). */
+ *   b2 [384], bf [128], ln_gamma/ln_beta [128], mask [B,N] or NULL, out [B,N,N,128] (may not alias edge).
+ *   Optional fused epilogue (proj_w_packed != NULL): the NEXT IPA block's linear_b/down_z (see s2s_pair_project)
+ *   applied to the freshly produced pair vectors while they are still in registers -> proj_attn_bias, proj_pair_z. */
 int s2s_edge_transition(const float* edge, const float* node_ab, const float* node_p, const float* w1_packed,
                         const float* w2_packed, const float* wf_packed, const float* b2, const float* bf,
                         const float* ln_gamma, const float* ln_beta, const float* mask, float* out, int n_samples,
-                        int n_res, float ln_eps, void* stream);
+                        int n_res, float ln_eps, const float* proj_w_packed, const float* proj_bias_cat64,
+                        float* proj_attn_bias, float* proj_pair_z, void* stream);
 
 /* EmbeddingModule.forward, edge branch (src/models/net/denoising_ipa.py:137-158, calc_distogram
  * src/common/geo_utils.py:44-56) + edge-mask multiply (denoising_ipa.py:187).
@@ -47,12 +50,13 @@ int s2s_edge_transition(const float* edge, const float* node_ab, const float* no
  *   rel_table [n_rel,128]: first-layer image of posemb(d), d = idx_i - idx_j, row d + rel_offset
  *   bin_table [n_bins,128]: first-layer columns of the distogram one-hot; bin_lower [n_bins]
  *   residue_idx [B,N] int64; ca_xyz [B,N,3] (self-conditioning CA, Angstrom)
- *   w2/w3 packed 128x128; b2,b3,ln_gamma,ln_beta [128]; out [B,N,N,128]. */
+ *   w2/w3 packed 128x128; b2,b3,ln_gamma,ln_beta [128]; out [B,N,N,128]; proj_*: optional fused pair projection as above. */
 int s2s_edge_embed(const float* node_a, const float* node_b, const float* rel_table, const float* bin_table,
                    const float* bin_lower, const long long* residue_idx, const float* ca_xyz, const float* w2_packed,
                    const float* w3_packed, const float* b2, const float* b3, const float* ln_gamma, const float* ln_beta,
                    const float* mask, float* out, int n_samples, int n_res, int rel_offset, int n_rel, int n_bins,
-                   float ln_eps, void* stream);
+                   float ln_eps, const float* proj_w_packed, const float* proj_bias_cat64, float* proj_attn_bias,
+                   float* proj_pair_z, void* stream);
 
 /* linear_b and down_z of InvariantPointAttention (src/models/net/ipa.py:177, :253) in one pass over z.
  *   w_packed: [linear_b.weight (8 rows); down_z.weight (32 rows); 24 zero rows] (64x128) packed

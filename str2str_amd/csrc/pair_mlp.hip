@@ -137,7 +137,33 @@ __device__ __forceinline__ void ln_store(f32x16 (&acc)[T], const float* __restri
             o.z = ((acc[t][4 * rq + 2] - mean) * rstd * ga.z + be.z) * scale;
             o.w = ((acc[t][4 * rq + 3] - mean) * rstd * ga.w + be.w) * scale;
             if (valid) *reinterpret_cast<float4*>(out_row + 8 * g + 4 * h) = o;
+            acc[t][4 * rq + 0] = o.x; acc[t][4 * rq + 1] = o.y; acc[t][4 * rq + 2] = o.z; acc[t][4 * rq + 3] = o.w;
         }
+}
+
+// Optional fused epilogue: the IPA pair projections of the NEXT block (linear_b + down_z, ipa.py:177,253) applied
+// to the pair vector this kernel has just produced and still holds in registers in B layout (acc after ln_store).
+// Same arithmetic as pair_project_kernel on the stored values (bit-identical), minus a 512 B/pair re-read of z.
+__device__ __forceinline__ void project_store(f32x16 (&zacc)[4], const float4* __restrict__ wp, const float* __restrict__ bcat,
+                                              float* __restrict__ bias_out, float* __restrict__ pairz_out, long long p,
+                                              int lane, int h, bool valid) {
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const float4 x = ldg4(bcat, 4 * t + rq, h);
+            acc[t][4 * rq + 0] = x.x; acc[t][4 * rq + 1] = x.y; acc[t][4 * rq + 2] = x.z; acc[t][4 * rq + 3] = x.w;
+        }
+    mlp_layer<2, 16>(acc, wp, lane, [&](int s4, int q) { return zacc[s4 >> 2][(s4 & 3) * 4 + q]; });
+    if (!valid) return;
+    *reinterpret_cast<float4*>(bias_out + p * 8 + 4 * h) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+#pragma unroll
+    for (int g = 1; g <= 4; ++g) {
+        const int t = g >> 2, rq = g & 3;
+        *reinterpret_cast<float4*>(pairz_out + p * 32 + 8 * (g - 1) + 4 * h) =
+            make_float4(acc[t][4 * rq + 0], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]);
+    }
 }
 
 template <int T>
@@ -181,7 +207,8 @@ __global__ void __launch_bounds__(256) edge_transition_kernel(
     const float4* __restrict__ w1p, const float4* __restrict__ w2p, const float4* __restrict__ wfp,
     const float* __restrict__ b2, const float* __restrict__ bf, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mask, float* __restrict__ out, long long M, int N,
-    float ln_eps) {
+    float ln_eps, const float4* __restrict__ proj_wp, const float* __restrict__ proj_b, float* __restrict__ proj_bias_out,
+    float* __restrict__ proj_pz_out) {
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (tile * 32 >= M) return;
@@ -273,6 +300,7 @@ __global__ void __launch_bounds__(256) edge_transition_kernel(
     }
     const float em = mask ? mask[px.bi] * mask[px.bj] : 1.0f;
     ln_store<4>(a3, gamma, beta, ln_eps, em, out + px.p * 128, h, px.valid);
+    if (proj_wp) project_store(a3, proj_wp, proj_b, proj_bias_out, proj_pz_out, px.p, lane, h, px.valid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -288,7 +316,8 @@ __global__ void __launch_bounds__(256) edge_embed_kernel(
     const float* __restrict__ ca, const float4* __restrict__ w2p, const float4* __restrict__ w3p,
     const float* __restrict__ b2, const float* __restrict__ b3, const float* __restrict__ gamma,
     const float* __restrict__ beta, const float* __restrict__ mask, float* __restrict__ out, long long M, int N,
-    int rel_off, int n_rel, int n_bins, float ln_eps) {
+    int rel_off, int n_rel, int n_bins, float ln_eps, const float4* __restrict__ proj_wp, const float* __restrict__ proj_b,
+    float* __restrict__ proj_bias_out, float* __restrict__ proj_pz_out) {
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (tile * 32 >= M) return;
@@ -343,6 +372,7 @@ __global__ void __launch_bounds__(256) edge_embed_kernel(
     mlp_layer<4, 16>(a3, w3p, lane, [&](int s4, int q) { return a2[s4 >> 2][(s4 & 3) * 4 + q]; });
     const float em = mask ? mask[px.bi] * mask[px.bj] : 1.0f;
     ln_store<4>(a3, gamma, beta, ln_eps, em, out + px.p * 128, h, px.valid);
+    if (proj_wp) project_store(a3, proj_wp, proj_b, proj_bias_out, proj_pz_out, px.p, lane, h, px.valid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -394,12 +424,14 @@ extern "C" {
 int s2s_edge_transition(const float* edge, const float* node_ab, const float* node_p, const float* w1_packed,
                         const float* w2_packed, const float* wf_packed, const float* b2, const float* bf,
                         const float* ln_gamma, const float* ln_beta, const float* mask, float* out, int n_samples,
-                        int n_res, float ln_eps, void* stream) {
+                        int n_res, float ln_eps, const float* proj_w_packed, const float* proj_bias_cat64,
+                        float* proj_attn_bias, float* proj_pair_z, void* stream) {
     const long long M = (long long)n_samples * n_res * n_res;
     if (M <= 0) return 0;
     hipLaunchKernelGGL(edge_transition_kernel, dim3(tiles_grid(M, 4)), dim3(256), 0, (hipStream_t)stream, edge, node_ab,
                        node_p, (const float4*)w1_packed, (const float4*)w2_packed, (const float4*)wf_packed, b2, bf,
-                       ln_gamma, ln_beta, mask, out, M, n_res, ln_eps);
+                       ln_gamma, ln_beta, mask, out, M, n_res, ln_eps, (const float4*)proj_w_packed, proj_bias_cat64,
+                       proj_attn_bias, proj_pair_z);
     return (int)hipGetLastError();
 }
 
@@ -407,13 +439,14 @@ int s2s_edge_embed(const float* node_a, const float* node_b, const float* rel_ta
                    const float* bin_lower, const long long* residue_idx, const float* ca_xyz, const float* w2_packed,
                    const float* w3_packed, const float* b2, const float* b3, const float* ln_gamma, const float* ln_beta,
                    const float* mask, float* out, int n_samples, int n_res, int rel_offset, int n_rel, int n_bins,
-                   float ln_eps, void* stream) {
+                   float ln_eps, const float* proj_w_packed, const float* proj_bias_cat64, float* proj_attn_bias,
+                   float* proj_pair_z, void* stream) {
     const long long M = (long long)n_samples * n_res * n_res;
     if (M <= 0) return 0;
     hipLaunchKernelGGL(edge_embed_kernel, dim3(tiles_grid(M, 4)), dim3(256), 0, (hipStream_t)stream, node_a, node_b,
                        rel_table, bin_table, bin_lower, residue_idx, ca_xyz, (const float4*)w2_packed,
                        (const float4*)w3_packed, b2, b3, ln_gamma, ln_beta, mask, out, M, n_res, rel_offset, n_rel, n_bins,
-                       ln_eps);
+                       ln_eps, (const float4*)proj_w_packed, proj_bias_cat64, proj_attn_bias, proj_pair_z);
     return (int)hipGetLastError();
 }
 

@@ -113,10 +113,12 @@ class EmbeddingModule(nn.Module):
             self._idx_key = key
         return self._idx_val
 
-    def forward(self, residue_idx, t, fixed_mask, self_conditioning_ca, node_mask: Optional[torch.Tensor] = None):
+    def forward(self, residue_idx, t, fixed_mask, self_conditioning_ca, node_mask: Optional[torch.Tensor] = None,
+                next_proj=None):
         """-> node_embed [B,N,D_node], edge_embed [B,N,N,D_edge] (reference :107-159).  ``t`` may live on
         the host (the sampler knows it there): its embedding is then computed on the host and uploaded.
-        ``node_mask`` optionally fuses DenoisingNet's mask multiplies (reference :186-187)."""
+        ``node_mask`` optionally fuses DenoisingNet's mask multiplies (reference :186-187); ``next_proj`` (packed
+        pair-projection weights of the first IPA block) adds (attn_bias, pair_z) as a third return value."""
         w = self._weights()
         dev = w["b0"].device
         if dev.type != "cuda":
@@ -136,9 +138,12 @@ class EmbeddingModule(nn.Module):
         mask = None if node_mask is None else node_mask.to(dev).float().contiguous()
         e2, e4, ln = self.edge_embed[2], self.edge_embed[4], self.edge_embed[5]
         edge_embed = ops.edge_embed(node_a, node_b, rel_tab, w["bin_tab"], w["bin_lower"], idx_dev, ca, w["w2p"],
-                                    w["w3p"], e2.bias, e4.bias, ln.weight, ln.bias, mask, span, ln.eps)
+                                    w["w3p"], e2.bias, e4.bias, ln.weight, ln.bias, mask, span, ln.eps, proj=next_proj)
         if mask is not None:
             node_embed = node_embed * mask[..., None]
+        if next_proj is not None:
+            edge_embed, *proj = edge_embed
+            return node_embed, edge_embed, tuple(proj)
         return node_embed, edge_embed
 
 
@@ -157,12 +162,15 @@ class DenoisingNet(nn.Module):
                 "DenoisingNet.forward needs the HIP device (MI355X): the sampling path has no CPU fallback")
         node_mask = batch["residue_mask"].to(dev).type(torch.float)
         fixed_mask = batch["fixed_mask"].to(dev).type(torch.float)
-        node_embed, edge_embed = self.embedder(residue_idx=batch["residue_idx"], t=batch["t"], fixed_mask=fixed_mask,
-                                               self_conditioning_ca=batch["sc_ca_t"], node_mask=node_mask)
+        fuse = getattr(self.translator, "fuse_pair_projection", False)
+        emb = self.embedder(residue_idx=batch["residue_idx"], t=batch["t"], fixed_mask=fixed_mask,
+                            self_conditioning_ca=batch["sc_ca_t"], node_mask=node_mask,
+                            next_proj=self.translator.trunk["ipa_0"].pair_proj_weights() if fuse else None)
+        node_embed, edge_embed = emb[0], emb[1]
         tb = dict(batch)
         tb["residue_mask"], tb["fixed_mask"] = node_mask, fixed_mask
         tb["rigids_t"] = batch["rigids_t"].to(dev)
-        model_out = self.translator(node_embed, edge_embed, tb)
+        model_out = self.translator(node_embed, edge_embed, tb, **({"_first_proj": emb[2]} if fuse else {}))
         gt_psi = batch["torsion_angles_sin_cos"].to(dev)[..., 2, :]
         psi_pred = gt_psi * fixed_mask[..., None] + model_out["psi"] * (1 - fixed_mask[..., None])
         rigids_pred = model_out["out_rigids"]

@@ -52,9 +52,17 @@ class InvariantPointAttention(nn.Module):
         return self._cache.get([self.linear_b.weight, self.linear_b.bias, self.down_z.weight, self.down_z.bias,
                                 self.head_weights], build)
 
-    def forward(self, s: torch.Tensor, z: torch.Tensor, r, mask: torch.Tensor, _rigids7: Optional[torch.Tensor] = None):
+    def pair_proj_weights(self):
+        """(packed [linear_b; down_z] weight, bias64): what a pair-stream producer needs to emit this block's
+        attention bias / pair_z in its own epilogue."""
+        d = self._derived()
+        return d["wp"], d["b64"]
+
+    def forward(self, s: torch.Tensor, z: torch.Tensor, r, mask: torch.Tensor, _rigids7: Optional[torch.Tensor] = None,
+                _pair_proj=None):
         """s [B,N,c_s], z [B,N,N,c_z], r Rigid [B,N] (translations already scaled), mask [B,N]
-        -> [B,N,c_s] (reference :100-268).  ``_rigids7`` lets the trunk pass its frame tensor directly."""
+        -> [B,N,c_s] (reference :100-268).  ``_rigids7`` lets the trunk pass its frame tensor directly;
+        ``_pair_proj`` = (attn_bias, pair_z) already produced by the kernel that wrote z."""
         if not s.is_cuda:
             raise ops.HipLibraryError("InvariantPointAttention runs on the HIP device only (no CPU fallback)")
         if self.no_heads != 8 or self.c_z != 128:
@@ -67,7 +75,7 @@ class InvariantPointAttention(nn.Module):
         q_pts, k_pts, v_pts = ops.ipa_prep_points(r7, self.linear_q_points(s).contiguous(),
                                                   self.linear_kv_points(s).contiguous(), self.no_heads,
                                                   self.no_qk_points, self.no_v_points)
-        attn_bias, pair_z = ops.pair_project(z.contiguous(), d["wp"], d["b64"])
+        attn_bias, pair_z = _pair_proj if _pair_proj is not None else ops.pair_project(z.contiguous(), d["wp"], d["b64"])
         feats = ops.ipa_attention(q.contiguous(), kv.contiguous(), q_pts, k_pts, v_pts, attn_bias, pair_z, mask, r7,
                                   d["hw"], self.no_heads, self.c_hidden, self.no_qk_points, self.no_v_points,
                                   self.c_z // 4, self.inf, self.eps)
@@ -127,8 +135,9 @@ class TranslationIPA(nn.Module):
                                                                     edge_embed_out=c_z)
         self.torsion_pred = TorsionAngleHead(c_s, 1)
         self.exact_padding = False  # see encoder_forward; set by the mixed-length sampler
+        self.fuse_pair_projection = True  # producers of z also emit the next IPA block's linear_b / down_z
 
-    def forward(self, node_embed: torch.Tensor, edge_embed: torch.Tensor, batch: dict) -> dict:
+    def forward(self, node_embed: torch.Tensor, edge_embed: torch.Tensor, batch: dict, _first_proj=None) -> dict:
         """reference :331-387.  Frames travel as one [B,N,7] tensor between the fused kernels."""
         if not node_embed.is_cuda:
             raise ops.HipLibraryError("TranslationIPA runs on the HIP device only (no CPU fallback)")
@@ -139,8 +148,10 @@ class TranslationIPA(nn.Module):
         curr7 = ops.rigid_scale_trans(init7, self.coordinate_scaling, divide=False)
         init_node = node_embed
         pad = 1.0 - node_mask
+        proj = _first_proj
         for b in range(self.num_blocks):
-            ipa_embed = T[f"ipa_{b}"](node_embed, edge_embed, None, node_mask, _rigids7=curr7)
+            ipa_embed = T[f"ipa_{b}"](node_embed, edge_embed, None, node_mask, _rigids7=curr7, _pair_proj=proj)
+            proj = None
             ipa_embed = ipa_embed * node_mask[..., None]
             node_embed = T[f"ipa_ln_{b}"](node_embed + ipa_embed)
             cat = torch.cat([node_embed, T[f"skip_embed_{b}"](init_node)], dim=-1)
@@ -151,7 +162,11 @@ class TranslationIPA(nn.Module):
             upd = T[f"bb_update_{b}"](node_embed * diffuse_mask[..., None]).contiguous()
             curr7 = ops.rigid_compose_update(curr7, upd, diffuse_mask)
             if b < self.num_blocks - 1:
-                edge_embed = T[f"edge_transition_{b}"](node_embed, edge_embed, edge_mask_1d=node_mask)
+                if self.fuse_pair_projection:
+                    edge_embed, *proj = T[f"edge_transition_{b}"](node_embed, edge_embed, edge_mask_1d=node_mask,
+                                                                 next_proj=T[f"ipa_{b + 1}"].pair_proj_weights())
+                else:
+                    edge_embed = T[f"edge_transition_{b}"](node_embed, edge_embed, edge_mask_1d=node_mask)
         psi = self.torsion_pred(node_embed)
         out7 = ops.rigid_scale_trans(curr7, self.coordinate_scaling, divide=True)
         return {

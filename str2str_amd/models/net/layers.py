@@ -118,9 +118,11 @@ class EdgeTransition(nn.Module):
 
         return self._cache.get([w1.weight, w1.bias, w2.weight, wf.weight], build)
 
-    def forward(self, node_embed: torch.Tensor, edge_embed: torch.Tensor, edge_mask_1d: Optional[torch.Tensor] = None):
+    def forward(self, node_embed: torch.Tensor, edge_embed: torch.Tensor, edge_mask_1d: Optional[torch.Tensor] = None,
+                next_proj=None):
         """edge_embed [B,N,N,c_z] -> [B,N,N,c_z].  ``edge_mask_1d`` (node mask [B,N]) optionally fuses
-        the caller's ``* edge_mask[..., None]`` (reference ipa.py:372) into the kernel epilogue."""
+        the caller's ``* edge_mask[..., None]`` (reference ipa.py:372) into the kernel epilogue; ``next_proj``
+        = (packed [linear_b; down_z], bias64) of the NEXT IPA block additionally returns its (attn_bias, pair_z)."""
         if self._shape != (128, 128, 384, 128, 2):
             raise ops.HipLibraryError(f"EdgeTransition kernel is built for c_z=128, c_s=256 (got {self._shape})")
         pk = self._packed()
@@ -129,7 +131,7 @@ class EdgeTransition(nn.Module):
         mask = None if edge_mask_1d is None else edge_mask_1d.type(torch.float32).contiguous()
         return ops.edge_transition(edge_embed.contiguous(), node_ab, n_p, pk["w1p"], pk["w2p"], pk["wfp"],
                                    self.trunk[2].bias, self.final_layer.bias, self.layer_norm.weight,
-                                   self.layer_norm.bias, mask, self.layer_norm.eps)
+                                   self.layer_norm.bias, mask, self.layer_norm.eps, proj=next_proj)
 
 
 class TorsionAngleHead(nn.Module):

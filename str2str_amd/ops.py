@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 _tables_loaded = False
@@ -25,8 +25,8 @@ _vp, _i, _f, _d, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_d
 
 _SIGNATURES = {
     "s2s_abi_version": [],
-    "s2s_edge_transition": [_vp] * 12 + [_i, _i, _f, _vp],
-    "s2s_edge_embed": [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _vp],
+    "s2s_edge_transition": [_vp] * 12 + [_i, _i, _f, _vp, _vp, _vp, _vp, _vp],
+    "s2s_edge_embed": [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "s2s_pair_project": [_vp] * 5 + [_i, _i, _vp],
     "s2s_ipa_prep_points": [_vp] * 6 + [_ll, _i, _i, _i, _i, _vp],
     "s2s_ipa_attention": [_vp] * 11 + [_i, _i, _i, _i, _i, _i, _i, _f, _f, _vp],
@@ -142,7 +142,18 @@ def pack_weight(w: torch.Tensor, tile_major: bool = False) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------ ops
-def edge_transition(edge, node_ab, node_p, w1p, w2p, wfp, b2, bf, gamma, beta, mask, ln_eps=1e-5, out=None):
+def _proj_args(proj, B, N, dev):
+    """(wp, b64) of the next IPA block -> (wp, b64, attn_bias_out, pair_z_out) or four Nones."""
+    if proj is None:
+        return None, None, None, None
+    wp, b64 = proj
+    _req(wp, name="proj.wp"); _req(b64, name="proj.b64")
+    return (wp, b64, torch.empty(B, N, N, 8, device=dev, dtype=torch.float32),
+            torch.empty(B, N, N, 32, device=dev, dtype=torch.float32))
+
+
+def edge_transition(edge, node_ab, node_p, w1p, w2p, wfp, b2, bf, gamma, beta, mask, ln_eps=1e-5, out=None, proj=None):
+    """-> out, or (out, attn_bias, pair_z) when ``proj`` = (packed Wcat, bias64) of the next IPA block is given."""
     lib = load_library()
     B, N = edge.shape[0], edge.shape[1]
     _req(edge, name="edge")
@@ -158,14 +169,15 @@ def edge_transition(edge, node_ab, node_p, w1p, w2p, wfp, b2, bf, gamma, beta, m
     elif out.data_ptr() == edge.data_ptr():
         raise HipLibraryError("edge_transition: out may not alias edge")
     _req(out, name="out")
+    pw, pb, pbias, ppz = _proj_args(proj, B, N, edge.device)
     _check(_timed("s2s_edge_transition", lambda: lib.s2s_edge_transition(
         _p(edge), _p(node_ab), _p(node_p), _p(w1p), _p(w2p), _p(wfp), _p(b2), _p(bf), _p(gamma), _p(beta), _p(mask),
-        _p(out), B, N, ln_eps, _stream())), "s2s_edge_transition")
-    return out
+        _p(out), B, N, ln_eps, _p(pw), _p(pb), _p(pbias), _p(ppz), _stream())), "s2s_edge_transition")
+    return out if proj is None else (out, pbias, ppz)
 
 
 def edge_embed(node_a, node_b, rel_table, bin_table, bin_lower, residue_idx, ca, w2p, w3p, b2, b3, gamma, beta, mask,
-               rel_offset: int, ln_eps=1e-5, out=None):
+               rel_offset: int, ln_eps=1e-5, out=None, proj=None):
     lib = load_library()
     B, N = node_a.shape[0], node_a.shape[1]
     for n, t in (("node_a", node_a), ("node_b", node_b), ("rel_table", rel_table), ("bin_table", bin_table),
@@ -177,10 +189,12 @@ def edge_embed(node_a, node_b, rel_table, bin_table, bin_lower, residue_idx, ca,
         _req(mask, name="mask")
     if out is None:
         out = torch.empty(B, N, N, 128, device=node_a.device, dtype=torch.float32)
+    pw, pb, pbias, ppz = _proj_args(proj, B, N, node_a.device)
     _check(lib.s2s_edge_embed(_p(node_a), _p(node_b), _p(rel_table), _p(bin_table), _p(bin_lower), _p(residue_idx), _p(ca),
                               _p(w2p), _p(w3p), _p(b2), _p(b3), _p(gamma), _p(beta), _p(mask), _p(out), B, N,
-                              int(rel_offset), rel_table.shape[0], bin_table.shape[0], ln_eps, _stream()), "s2s_edge_embed")
-    return out
+                              int(rel_offset), rel_table.shape[0], bin_table.shape[0], ln_eps, _p(pw), _p(pb), _p(pbias),
+                              _p(ppz), _stream()), "s2s_edge_embed")
+    return out if proj is None else (out, pbias, ppz)
 
 
 def pair_project(edge, wp, bias64, attn_bias=None, pair_z=None):
