@@ -9,6 +9,7 @@ Per-node (N-linear) layers are dense projections on the GPU BLAS (fp32 MFMA GEMM
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -101,6 +102,12 @@ class EdgeTransition(nn.Module):
         self.layer_norm = nn.LayerNorm(edge_embed_out)
         self._shape = (edge_embed_in, bias_embed_size, hidden, edge_embed_out, num_layers)
         self._cache = ParamCache()
+        # "bf16x6" (default): exact 3-way bf16 split of both operands, six plane-pair products on the bf16 MFMA with
+        # fp32 accumulation — error <= 2^-26 per product, i.e. fp32-equivalent (csrc/pair_mlp_bf16.hip), 1.36x faster.
+        # "f32": v_mfma_f32_32x32x2_f32 (csrc/pair_mlp.hip).  Both pass the same parity suite.
+        self.mfma_mode = os.environ.get("S2S_EDGE_MFMA", "bf16x6")
+        if self.mfma_mode not in ("bf16x6", "f32"):
+            raise ValueError(f"S2S_EDGE_MFMA={self.mfma_mode!r}: expected 'bf16x6' or 'f32'")
 
     def _packed(self):
         w1, w2, wf = self.trunk[0], self.trunk[2], self.final_layer
@@ -112,6 +119,7 @@ class EdgeTransition(nn.Module):
                 "w2p": ops.pack_weight(w2.weight.float(), tile_major=True),
                 "wfp": ops.pack_weight(wf.weight.float(), tile_major=True),
                 # node halves of layer 1: [W1[:, ce:ce+cb] ; W1[:, ce+cb:]] applied to n' (+ b1 on the row part)
+                "wstream": ops.pack_bf16x3_stream(w1.weight[:, :ce].float(), w2.weight.float(), wf.weight.float()),
                 "w_ab": torch.cat([w1.weight[:, ce:ce + self._shape[1]], w1.weight[:, ce + self._shape[1]:]], dim=0).float().contiguous(),
                 "b_ab": torch.cat([w1.bias, torch.zeros_like(w1.bias)]).float().contiguous(),
             }
@@ -129,6 +137,11 @@ class EdgeTransition(nn.Module):
         n_p = self.initial_embed(node_embed).contiguous()
         node_ab = F.linear(n_p, pk["w_ab"], pk["b_ab"]).contiguous()
         mask = None if edge_mask_1d is None else edge_mask_1d.type(torch.float32).contiguous()
+        if self.mfma_mode == "bf16x6":
+            out = ops.edge_transition_bf16x6(edge_embed.contiguous(), node_ab, n_p, pk["wstream"], self.trunk[2].bias,
+                                             self.final_layer.bias, self.layer_norm.weight, self.layer_norm.bias, mask,
+                                             self.layer_norm.eps)
+            return out if next_proj is None else (out, *ops.pair_project(out, *next_proj))
         return ops.edge_transition(edge_embed.contiguous(), node_ab, n_p, pk["w1p"], pk["w2p"], pk["wfp"],
                                    self.trunk[2].bias, self.final_layer.bias, self.layer_norm.weight,
                                    self.layer_norm.bias, mask, self.layer_norm.eps, proj=next_proj)

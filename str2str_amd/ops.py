@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 _tables_loaded = False
@@ -26,6 +26,7 @@ _vp, _i, _f, _d, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_d
 _SIGNATURES = {
     "s2s_abi_version": [],
     "s2s_edge_transition": [_vp] * 12 + [_i, _i, _f, _vp, _vp, _vp, _vp, _vp],
+    "s2s_edge_transition_bf16x6": [_vp] * 10 + [_i, _i, _f, _vp],
     "s2s_edge_embed": [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "s2s_pair_project": [_vp] * 5 + [_i, _i, _vp],
     "s2s_ipa_prep_points": [_vp] * 6 + [_ll, _i, _i, _i, _i, _vp],
@@ -141,7 +142,77 @@ def pack_weight(w: torch.Tensor, tile_major: bool = False) -> torch.Tensor:
     return w.reshape(t, 32, s4, 2, 4).permute(*perm).contiguous().reshape(-1)
 
 
+def split_bf16x3(w: torch.Tensor):
+    """Exact three-way bf16 split x = h + m + l (round-to-nearest residues)."""
+    h = w.to(torch.bfloat16)
+    r1 = w - h.float()
+    m = r1.to(torch.bfloat16)
+    l = (r1 - m.float()).to(torch.bfloat16)
+    return h, m, l
+
+
+def pack_bf16x3_layer(w: torch.Tensor, kind: str) -> torch.Tensor:
+    """[Mout, K] fp32 -> bf16 fragments [K/16 k-steps][Mout/32 tiles][3 planes][64 lanes][8] for
+    v_mfma_f32_32x32x16_bf16 A operands.  Element j of lane (m, g) in k-step ks is W[32t+m][k(ks,g,j)] with
+      kind "row"  : k = 16*ks + 8*g + j                                   (B operand read from a memory row)
+      kind "chain": k = 32*t' + (r&3) + 8*(r>>2) + 4*g, t' = ks>>1, r = 8*(ks&1) + j   (B operand = accumulator
+                    registers of the previous layer in MFMA C layout)."""
+    mout, k = w.shape
+    if mout % 32 or k % 32:
+        raise ValueError("Mout and K must be multiples of 32")
+    T, KS = mout // 32, k // 16
+    ks = torch.arange(KS)[:, None, None]
+    g = torch.arange(2)[None, :, None]
+    j = torch.arange(8)[None, None, :]
+    if kind == "row":
+        lab = 16 * ks + 8 * g + j
+    elif kind == "chain":
+        r = 8 * (ks & 1) + j
+        lab = 32 * (ks >> 1) + (r & 3) + 8 * (r >> 2) + 4 * g
+    else:
+        raise ValueError(kind)
+    wg = w.float()[:, lab.to(w.device)]  # [Mout, KS, 2, 8]
+    wg = wg.reshape(T, 32, KS, 2, 8).permute(2, 0, 3, 1, 4).reshape(KS, T, 64, 8)  # lane = 32*g + m
+    planes = torch.stack(split_bf16x3(wg), dim=2)  # [KS, T, 3, 64, 8]
+    return planes.contiguous()
+
+
+def pack_bf16x3_stream(w1_edge: torch.Tensor, w2: torch.Tensor, wf: torch.Tensor) -> torch.Tensor:
+    """The 30-stage (48 KiB = 4 k-steps x 4 tiles x 3 planes) weight stream of s2s_edge_transition_bf16x6 as int16,
+    in the kernel's consumption order: layer 1 output parts 0..2 (4 tiles each, 8 k-steps); then for each part p:
+    layer-2 output tiles 4p..4p+3 over all 24 k-steps, followed by the final layer's k-steps 8p..8p+7 (all 4 tiles)."""
+    l1, l2, lf = pack_bf16x3_layer(w1_edge, "row"), pack_bf16x3_layer(w2, "chain"), pack_bf16x3_layer(wf, "chain")
+    pieces = [l1[:, 4 * p:4 * p + 4] for p in range(3)]
+    for p in range(3):
+        pieces += [l2[:, 4 * p:4 * p + 4], lf[8 * p:8 * p + 8]]
+    blob = torch.cat([x.contiguous().reshape(-1) for x in pieces]).view(torch.int16).contiguous()
+    assert blob.numel() * 2 == 30 * 48 * 1024, blob.numel()
+    return blob
+
+
 # ------------------------------------------------------------------------------------------ ops
+def edge_transition_bf16x6(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps=1e-5, out=None):
+    """EdgeTransition on split-bf16 MFMA (fp32-equivalent accuracy); same contract as ``edge_transition``."""
+    lib = load_library()
+    B, N = edge.shape[0], edge.shape[1]
+    _req(edge, name="edge")
+    if edge.shape != (B, N, N, 128) or node_ab.shape != (B, N, 768) or node_p.shape != (B, N, 128):
+        raise HipLibraryError("edge_transition_bf16x6: bad shapes")
+    for n, t in (("node_ab", node_ab), ("node_p", node_p), ("b2", b2), ("bf", bf), ("gamma", gamma), ("beta", beta)):
+        _req(t, name=n)
+    _req(wstream, torch.int16, "wstream")
+    if mask is not None:
+        _req(mask, name="mask")
+    if out is None:
+        out = torch.empty_like(edge)
+    elif out.data_ptr() == edge.data_ptr():
+        raise HipLibraryError("edge_transition: out may not alias edge")
+    _check(_timed("s2s_edge_transition", lambda: lib.s2s_edge_transition_bf16x6(
+        _p(edge), _p(node_ab), _p(node_p), _p(wstream), _p(b2), _p(bf), _p(gamma), _p(beta), _p(mask), _p(out), B, N,
+        ln_eps, _stream())), "s2s_edge_transition_bf16x6")
+    return out
+
+
 def _proj_args(proj, B, N, dev):
     """(wp, b64) of the next IPA block -> (wp, b64, attn_bias_out, pair_z_out) or four Nones."""
     if proj is None:

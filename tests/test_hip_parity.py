@@ -125,11 +125,55 @@ def _edge_transition_module(net):
     return net.translator.trunk["edge_transition_0"]
 
 
-def test_edge_transition_golden(net_rough):
+def _set_edge_mode(net, mode):
+    prev = []
+    for m in net.modules():
+        if hasattr(m, "mfma_mode"):
+            prev.append((m, m.mfma_mode))
+            m.mfma_mode = mode
+    return prev
+
+
+@pytest.mark.parametrize("mode", ["bf16x6", "f32"])
+def test_edge_transition_golden(net_rough, mode):
     g = golden("edge_transition.npz")
     et = _edge_transition_module(net_rough)
-    out = et(T(g["node"]).to(DEV), T(g["edge"]).to(DEV))
+    prev = _set_edge_mode(net_rough, mode)
+    try:
+        out = et(T(g["node"]).to(DEV), T(g["edge"]).to(DEV))
+    finally:
+        for m, v in prev:
+            m.mfma_mode = v
     assert rel(out, g["out"]) < 2e-5, rel(out, g["out"])
+
+
+def test_edge_transition_split_bf16_is_fp32_equivalent(net_rough):
+    """bf16x6 (exact 3-way split, 6 plane pairs, fp32 accumulate) vs the fp32-MFMA kernel on the same inputs: the two
+    differ by fp32 rounding only, and the split kernel is no further from a float64 evaluation than the fp32 one."""
+    import torch.nn.functional as F
+
+    et = _edge_transition_module(net_rough)
+    g = torch.Generator().manual_seed(77)
+    node = torch.randn(2, 48, 256, generator=g).to(DEV)
+    edge = (3 * torch.randn(2, 48, 48, 128, generator=g)).to(DEV)
+    outs = {}
+    for mode in ("f32", "bf16x6"):
+        prev = _set_edge_mode(net_rough, mode)
+        outs[mode] = et(node, edge)
+        for m, v in prev:
+            m.mfma_mode = v
+    # float64 evaluation of the reference formula (layers.py:170-185) on the GPU
+    with torch.no_grad():
+        n = et.initial_embed(node).double()
+        Bn, Nn = n.shape[:2]
+        x = torch.cat([edge.double(), n[:, :, None, :].expand(Bn, Nn, Nn, -1), n[:, None, :, :].expand(Bn, Nn, Nn, -1)], -1)
+        h = F.relu(F.linear(x, et.trunk[0].weight.double(), et.trunk[0].bias.double()))
+        h = F.relu(F.linear(h, et.trunk[2].weight.double(), et.trunk[2].bias.double()))
+        y = F.linear(h + x, et.final_layer.weight.double(), et.final_layer.bias.double())
+        ref = F.layer_norm(y, (128,), et.layer_norm.weight.double(), et.layer_norm.bias.double(), et.layer_norm.eps)
+    e32, e16 = float((outs["f32"].double() - ref).abs().max()), float((outs["bf16x6"].double() - ref).abs().max())
+    assert float((outs["f32"] - outs["bf16x6"]).abs().max()) < 2e-5
+    assert e16 < 2e-5 and e16 < 3 * e32 + 1e-6, (e32, e16)
 
 
 @pytest.mark.parametrize("B,N", [(1, 5), (2, 37), (3, 64)])
@@ -307,6 +351,29 @@ def test_teacher_forced_trajectory(net_rough, diffuser):
             assert maxdiff(nxt.cpu()[..., 4:], g["next7"][i][..., 4:]) < 2e-5
     assert worst_x0 < 1e-3, worst_x0
     assert n_good > 100 and worst_next < 2e-5, (n_good, worst_next)
+
+
+@pytest.mark.parametrize("mode", ["bf16x6", "f32"])
+def test_free_running_trajectory_rmsd_both_edge_kernels(net_smooth, diffuser, mode):
+    """The 1e-4 Angstrom criterion holds with either EdgeTransition kernel (split-bf16 default, exact fp32 MFMA)."""
+    from str2str_amd.common.rigid_utils import Rigid
+    from str2str_amd.sampler import forward_backward
+    from str2str_amd.synth import synth_chain
+
+    g = golden("traj_free_cfg1_n64_s20.npz")
+    N, B = int(g["n_res"]), int(g["B"])
+    feats = synth_chain(N)
+    rig0 = Rigid.from_tensor_4x4(feats["rigidgroups_gt_frames"][..., 0, :, :].repeat(B, 1, 1, 1))
+    prev = _set_edge_mode(net_smooth, mode)
+    try:
+        torch.manual_seed(int(g["seed"]))
+        a37 = forward_backward(net_smooth, diffuser, feats, rig0, float(g["t_delta"]),
+                               num_timesteps=int(g["num_timesteps"]), device=DEV)
+    finally:
+        for m, v in prev:
+            m.mfma_mode = v
+    rmsd = backbone_rmsd(a37.cpu().numpy()[..., :5, :], g["atom37"])
+    assert rmsd < 1e-4, (mode, rmsd)
 
 
 @pytest.mark.parametrize("tag", ["n16_s20", "n12_prior", "n24_delta", "cfg1_n64_s20"])
