@@ -25,8 +25,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_RES, REPLICAS, DENOISE_STEPS = 256, 128, 100
-FLOPS_PER_PAIR_ET = 491520          # 2*(128*384 + 384*384 + 384*128)
+FLOPS_PER_PAIR_ET = 491520          # 2*(128*384 + 384*384 + 384*128) fp32 multiply-adds x2
 MFMA_FP32_PEAK = 157.3e12           # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
+MFMA_BF16_PEAK = 2500e12            # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 
 
 def cpu_baseline(n_res, steps_sampled=5, replicas=2):
@@ -55,6 +56,17 @@ def cpu_baseline(n_res, steps_sampled=5, replicas=2):
     return {"value": conf_per_s, "unit": "conformations/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{replicas} replica x (1 self-conditioning + {steps_sampled} denoise) network evaluations of the "
                       f"{n_res}-residue workload = {dt:.1f} s on the host, scaled linearly to {DENOISE_STEPS}+1 evaluations"}
+
+
+def traffic_bytes(pairs):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, read side doubled per the gfx950 correction), scaled by
+    the pairs of this launch.  None if the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+            return json.load(f)["kernels"]["edge_transition"]["bytes_per_pair_corrected"] * pairs
+    except Exception:
+        return None
 
 
 def main():
@@ -130,21 +142,31 @@ def main():
         assert res is not None and torch.isfinite(res).all()
         total = a.steps * B * world
         pairs = B * N * N
-        ach = pairs * FLOPS_PER_PAIR_ET / (et_ms * 1e-3)
+        mode = net.translator.trunk["edge_transition_0"].mfma_mode
+        alg = pairs * FLOPS_PER_PAIR_ET                       # fp32 multiply-add flops the operator needs
+        executed = alg * (6 if mode == "bf16x6" else 1)       # bf16x6: six bf16 plane-pair products per fp32 product
+        peak = MFMA_BF16_PEAK if mode == "bf16x6" else MFMA_FP32_PEAK
+        ach = executed / (et_ms * 1e-3)
         ipa_bytes = B * 4 * (9512 * N + 40 * N * N)
         line = {
             "metric": "sampled conformations/sec (whole node), 256-res chain, 100 denoise steps",
             "value": total / elapsed, "unit": "conformations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if mode == "f32" else "f32 (pair MLP on exact 3-way bf16 split MFMA, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": f"configs[1]: single {N}-residue synthetic chain, {B} replicas per GPU x {S} denoise "
                                    f"steps (+1 self-conditioning forward), probability-flow ODE, seeded synthetic weights",
                        "n_res": N, "replicas_per_gpu": B, "denoise_steps": S, "parallelism": f"replica-shard x{world}",
+                       "edge_mfma_mode": mode,
                        "step_definition": "one replica chunk sampled end to end incl. gather + D2H"},
-            "roofline": {"bound": "mfma", "kernel": "s2s_edge_transition (edge_transition_kernel)", "achieved": ach / 1e12,
-                         "peak": MFMA_FP32_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / MFMA_FP32_PEAK, "traffic": None,
-                         "launches_timed": et_n, "mean_launch_ms": et_ms,
-                         "algorithmic_flops_per_launch": pairs * FLOPS_PER_PAIR_ET},
+            "roofline": {"bound": "mfma",
+                         "kernel": "s2s_edge_transition" + ("_bf16x6 (edge_transition_bf16_kernel)" if mode == "bf16x6"
+                                                            else " (edge_transition_kernel)"),
+                         "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
+                         "traffic": traffic_bytes(pairs), "launches_timed": et_n, "mean_launch_ms": et_ms,
+                         "algorithmic_flops_per_launch": alg, "executed_mfma_flops_per_launch": executed,
+                         "fp32_equivalent_tflops": alg / (et_ms * 1e-3) / 1e12,
+                         "fp32_equivalent_vs_fp32_mfma_peak": alg / (et_ms * 1e-3) / MFMA_FP32_PEAK},
             "ipa_kernel": {"bound": "hbm", "kernel": "s2s_ipa_attention", "mean_launch_ms": ipa_ms, "launches_timed": ipa_n,
                            "achieved": ipa_bytes / (ipa_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                            "frac": ipa_bytes / (ipa_ms * 1e-3) / 8e12},
