@@ -46,7 +46,8 @@ int s2s_edge_transition(const float* edge, const float* node_ab, const float* no
 
 /* The same operator on split-bf16 MFMA ("bf16x6": every fp32 operand split exactly into three bf16 planes, six
  * plane-pair products per MFMA block, fp32 accumulation; error <= 2^-26 per product, i.e. fp32-equivalent) at
- * 2.67x the fp32-MFMA rate.  weight_stream: 30 stages x 48 KiB of bf16 A fragments (ops.pack_bf16x3_stream). */
+ * 2.67x the fp32-MFMA rate.  weight_stream: 30 stages x 48 KiB of bf16 A fragments in the kernel's
+ * slot order (ops.pack_bf16x3_stream; the order is part of ABI v4). */
 int s2s_edge_transition_bf16x6(const float* edge, const float* node_ab, const float* node_p, const void* weight_stream,
                                const float* b2, const float* bf, const float* ln_gamma, const float* ln_beta,
                                const float* mask, float* out, int n_samples, int n_res, float ln_eps, void* stream);

@@ -1,26 +1,27 @@
-// EdgeTransition on split-bf16 MFMA ("bf16x6"): fp32-equivalent accuracy at 2.67x the fp32-MFMA rate.
+// EdgeTransition on split-bf16 MFMA ("bf16x6"): fp32-equivalent accuracy on the bf16 matrix cores.
 //
 // Same operator and contract as s2s_edge_transition (csrc/pair_mlp.hip; reference EdgeTransition.forward,
 // src/models/net/layers.py:170-185 + mask ipa.py:372).  Every fp32 operand is split EXACTLY into three bf16
-// planes  x = x_h + x_m + x_l  (round-to-nearest residues: |x - x_h - x_m - x_l| <= 2^-27 |x|), weights once on
-// the host, activations on the fly; a product keeps the six plane pairs (h,h) (h,m) (m,h) (h,l) (l,h) (m,m) — the
-// dropped ones are <= 2^-26 of the product, below one fp32 rounding — on v_mfma_f32_32x32x16_bf16 with fp32
-// accumulation: 6 MFMAs x 32 cycles per 32x32x16 block instead of 8 x 64 cycles on the fp32 MFMA.
+// planes  x = x_h + x_m + x_l  (round-to-nearest residues), weights once on the host, activations on the fly; a
+// product keeps the six plane pairs (h,h) (h,m) (m,h) (h,l) (l,h) (m,m) -- the dropped ones are below one fp32
+// rounding of the product -- on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
 //
-// Structure per wave (32 pairs).  Output tiles are processed in PARTS of 4 (128 channels): layer 1 part by part, then for
-// each part p: layer-2 tiles 4p..4p+3 over all 384 inputs, ReLU + residual, and immediately the final layer's k-steps that
-// consume those 128 hidden channels.  Only one part of the layer-2 activations is ever live (a1 192 + a3 64 + part 64
-// registers instead of 384 + 64), which is what leaves room for the weight staging registers.  Inside a part the k-step is
-// the outer loop, so an activation group is split once per part and feeds 4 tiles x 6 plane pairs = 24 MFMAs:
-//   * the C->B register chaining of pair_mlp.hip carries over: element j of lane (pair, g) in k-step 2t'+u is
-//     accumulator register 8u+j of tile t' (row 32t' + (r&3) + 8(r>>2) + 4g); the host packs A fragments in that
-//     k order (pack_bf16x3_stream), so no data movement between layers;
-//   * the weight stream (1.41 MB for the three layers, all stages 72 KiB) is shared by the 4 waves of a workgroup
-//     through LDS, double buffered, one barrier per stage (144 MFMAs per wave): each wave copies a quarter of the next
-//     stage global -> VGPR -> LDS in three batches of 6 KiB slotted between the tile groups of the current stage
-//     (measured: the LDS-DMA form of the same copy costs ~150 issue cycles per 1 KiB piece and held the MFMA pipe
-//     at 40 %); lanes read their fragments with conflict-free ds_read_b128;
-//   * two output tiles advance together so consecutive MFMAs hit different accumulators.
+// One wave owns 32 pairs; the 4 waves of a workgroup share the weight stream (1.41 MB, 30 stages of 48 KiB, double
+// buffered in LDS).  A stage is 8 SLOTS of 12 MFMAs / 6 A fragments.  Schedule per pair tile (240 slots):
+//   A_t  (4 slots)  layer-1 output tile t (32 of the 384 hidden channels) over the 8 k-steps of the 128 edge channels;
+//                   the edge row is split once into 8 x 3 bf16 plane registers, so A_t is pure MFMA work.
+//   B_t  (12 slots) layer-2 k-steps 2t, 2t+1 (= the 32 channels of a1 tile t) into all 12 output tiles; the 192
+//                   layer-2 accumulators stay resident, a1 is never materialised beyond two tiles.
+//   order: A_0 A_1 | B_0 A_2 | B_1 A_3 | ... | B_9 A_11 | B_10 B_11 | final layer (48 slots, k-step major).
+//   The ReLU + per-node seeds + split of a1 tile t (VALU) runs under A_{t+1}; the final layer's splits run under its
+//   own MFMAs.  Every activation is split exactly once: ~1.2 VALU instructions per MFMA (microbenchmark
+//   tools/ubench/mfma_fill.hip: at most 5 independent VALU issue slots hide under one 32-cycle MFMA, a dependent one
+//   or a v_accvgpr_read costs 8 cycles, one v_pk_add_f32 costs 18).
+//   C->B chaining as in pair_mlp.hip: element j of lane (pair, g) in k-step 2t'+u is accumulator register 8u+j of
+//   tile t' (row 32t' + (r&3) + 8(r>>2) + 4g); the host packs A fragments in that k order (ops.pack_bf16x3_stream).
+//   Weight pipe: this wave's quarter of the next stage travels global -> VGPR -> LDS in two halves, each loaded (buffer
+//   loads: SGPR base + constant lane offset) three slots before it is stored; the workgroup barrier sits at the top
+//   of the last slot of a stage, after which the next stage's first fragments are fetched one slot ahead.
 #include <hip/hip_runtime.h>
 
 #include "str2str_hip.h"
@@ -28,49 +29,57 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kStageBytes = 48 * 1024;  // 4 k-steps x 4 output tiles x 3 planes x 1 KiB
-constexpr int kStages = 30;             // layer 1: 3 parts x 2; then per part: layer 2 x 6, final x 2
+constexpr int kStageBytes = 48 * 1024;  // 8 slots x 6 fragments x 1 KiB
+constexpr int kStages = 30;
+constexpr int kSlots = 8 * kStages;
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
-
 __device__ __forceinline__ float4 ldg4(const float* __restrict__ base, int g, int h) {
     return *reinterpret_cast<const float4*>(base + 8 * g + 4 * h);
 }
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
-// exact 3-way bf16 split of 8 floats
-__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 a = (__bf16)x[j];
-        const float r1 = x[j] - (float)a;
-        const __bf16 b = (__bf16)r1;
-        const float r2 = r1 - (float)b;
-        h[j] = a; m[j] = b; l[j] = (__bf16)r2;
+template <int I> struct IC { static constexpr int value = I; };
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(IC<B>{});
+        static_for<B + 1, E>(f);
     }
 }
 
-// one tile group (2 output tiles x 6 plane pairs) of a k-step; lds_ks = this k-step's fragments [T][3 planes][64 lanes]
-template <int T>
-__device__ __forceinline__ void tile_group(f32x16 (&acc)[T], int tg, const bf16x8* lds_ks, int lane, const bf16x8& xh,
-                                           const bf16x8& xm, const bf16x8& xl) {
-    const bf16x8* p = lds_ks + (2 * tg) * 3 * 64 + lane;
-    const bf16x8 w0h = p[0], w0m = p[64], w0l = p[128], w1h = p[192], w1m = p[256], w1l = p[320];
-    f32x16 a0 = acc[2 * tg], a1 = acc[2 * tg + 1];
-    a0 = mfma_bf16(w0l, xh, a0); a1 = mfma_bf16(w1l, xh, a1);   // small terms first
-    a0 = mfma_bf16(w0h, xl, a0); a1 = mfma_bf16(w1h, xl, a1);
-    a0 = mfma_bf16(w0m, xm, a0); a1 = mfma_bf16(w1m, xm, a1);
-    a0 = mfma_bf16(w0m, xh, a0); a1 = mfma_bf16(w1m, xh, a1);
-    a0 = mfma_bf16(w0h, xm, a0); a1 = mfma_bf16(w1h, xm, a1);
-    a0 = mfma_bf16(w0h, xh, a0); a1 = mfma_bf16(w1h, xh, a1);
-    acc[2 * tg] = a0; acc[2 * tg + 1] = a1;
+// slot s of the schedule: phase 0 = A (layer 1), 1 = B (layer 2), 2 = F (final layer)
+struct SlotDesc { int phase, t, a, b; };  // A: tile t, a = k-step pair 0..3;  B: tile t, a = u (k-step 2t+u), b = tile pair 0..5;
+                                          // F: a = k-step 0..23, b = tile pair 0..1
+constexpr SlotDesc slot_desc(int s) {
+    if (s < 8) return {0, s / 4, s % 4, 0};
+    if (s < 168) {
+        const int tau = s - 8, blk = tau / 16, o = tau % 16;
+        if (o < 12) return {1, blk, o / 6, o % 6};
+        return {0, blk + 2, o - 12, 0};
+    }
+    if (s < 192) {
+        const int tau = s - 168;
+        return {1, 10 + tau / 12, (tau % 12) / 6, tau % 6};
+    }
+    return {2, 0, (s - 192) / 2, (s - 192) % 2};
 }
+
+#define S2S_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// Timeline probe (tools/et_probe.py; only in -DS2S_ET_PROBE=<block> builds): s_memtime stamps of one workgroup's waves.
+#ifdef S2S_ET_PROBE
+__device__ unsigned long long s2s_et_probe[4][512];
+#define PROBE(idx) do { if (blockIdx.x == S2S_ET_PROBE) s2s_et_probe[wave][idx] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PROBE(idx) do { } while (0)
+#endif
 
 __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     const float* __restrict__ edge, const float* __restrict__ node_ab, const float* __restrict__ node_p,
@@ -78,43 +87,48 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask,
     float* __restrict__ out, long long M, int N, float ln_eps) {
     __shared__ __attribute__((aligned(16))) char s_w[2][kStageBytes];
-    const int lane = threadIdx.x & 63, h = lane >> 5;
-    // ---- weight pipe: 12 slots per stage (one per tile group); the next stage is copied global -> VGPR -> LDS
-    //      by this wave's quarter (12 KiB) in three batches of four 1 KiB pieces
-    const int wave = threadIdx.x >> 6;
-    float4 stg0, stg1, stg2, stg3;  // scalars on purpose: an array captured by the lambdas is demoted to LDS by hipcc
-    const int piece0 = wave * 1024 + lane * 16;
-    auto load_batch = [&](int s, int b) {
-        const char* g = wblob + (long long)s * kStageBytes + piece0 + 16 * 1024 * b;
-        stg0 = *reinterpret_cast<const float4*>(g);
-        stg1 = *reinterpret_cast<const float4*>(g + 4096);
-        stg2 = *reinterpret_cast<const float4*>(g + 8192);
-        stg3 = *reinterpret_cast<const float4*>(g + 12288);
-    };
-    auto store_batch = [&](int par, int b) {  // par = parity of the stage being filled (compile-time after inlining)
-        char* d = &s_w[par][piece0 + 16 * 1024 * b];
-        *reinterpret_cast<float4*>(d) = stg0;
-        *reinterpret_cast<float4*>(d + 4096) = stg1;
-        *reinterpret_cast<float4*>(d + 8192) = stg2;
-        *reinterpret_cast<float4*>(d + 12288) = stg3;
-    };
-    // slot i (0..7) while stage `cur` (buffer `par`) is being computed: pump the copy of stage cur + 1
-    auto slot = [&](int cur, int par, int i) {
-        const int nxt = cur + 1;
-        if (nxt >= kStages) return;  // wave-uniform
-        if (i == 0) load_batch(nxt, 0);
-        else if (i == 2) { store_batch(par ^ 1, 0); load_batch(nxt, 1); }
-        else if (i == 5) { store_batch(par ^ 1, 1); load_batch(nxt, 2); }
-        else if (i == 7) store_batch(par ^ 1, 2);
-    };
-    auto stage_image = [&](int par) -> const bf16x8* {
-        __syncthreads();  // this stage is complete in LDS for every wave; the other buffer is free to refill
-        return reinterpret_cast<const bf16x8*>(s_w[par]);
-    };
-#pragma unroll
-    for (int b = 0; b < 3; ++b) { load_batch(0, b); store_batch(0, b); }
+    __shared__ __attribute__((aligned(16))) float s_vec[768];  // b2 | bf | gamma | beta
+    const int lane = threadIdx.x & 63, h = lane >> 5, wave = threadIdx.x >> 6;
 
-    const long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // ---- weight pipe (see header).  Each wave moves one contiguous 12 KiB of every stage.
+    const unsigned voff = wave * 12288 + lane * 16;
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* lds_image[2] = {(lds_char*)&s_w[0][lane * 16], (lds_char*)&s_w[1][lane * 16]};
+    asm volatile("" : "+v"(lds_image[0]), "+v"(lds_image[1]));  // opaque: every LDS access = base register + immediate
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wblob, 0, kStages * kStageBytes, 0x00020000);
+    auto ldw = [&](unsigned vo, int so) -> f32x4 {
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, vo, so, 0);
+        return f32x4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+    };
+    // scalars on purpose: an array captured by the lambdas is demoted to memory by hipcc
+    f32x4 c0, c1, c2, c3, c4, c5;  // staging group A (first half of the quarter)
+    f32x4 e0, e1, e2, e3, e4, e5;  // staging group B (second half)
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    auto cp_load_a = [&](int stage) {
+        const int so = stage * kStageBytes;  // compile-time at every call site
+        c0 = ldw(voff, so); c1 = ldw(voff + 1024, so); c2 = ldw(voff + 2048, so);
+        c3 = ldw(voff + 3072, so); c4 = ldw(voff + 1024, so + 3072); c5 = ldw(voff + 2048, so + 3072);
+    };
+    auto cp_load_b = [&](int stage) {
+        const int so = stage * kStageBytes + 6144;
+        e0 = ldw(voff, so); e1 = ldw(voff + 1024, so); e2 = ldw(voff + 2048, so);
+        e3 = ldw(voff + 3072, so); e4 = ldw(voff + 1024, so + 3072); e5 = ldw(voff + 2048, so + 3072);
+    };
+    auto cp_store_a = [&](int par) {
+        lds_char* d = lds_image[par] + wave * 12288;
+        *(lds_f4*)(d) = c0; *(lds_f4*)(d + 1024) = c1; *(lds_f4*)(d + 2048) = c2;
+        *(lds_f4*)(d + 3072) = c3; *(lds_f4*)(d + 4096) = c4; *(lds_f4*)(d + 5120) = c5;
+    };
+    auto cp_store_b = [&](int par) {
+        lds_char* d = lds_image[par] + (wave * 12288 + 6144);
+        *(lds_f4*)(d) = e0; *(lds_f4*)(d + 1024) = e1; *(lds_f4*)(d + 2048) = e2;
+        *(lds_f4*)(d + 3072) = e3; *(lds_f4*)(d + 4096) = e4; *(lds_f4*)(d + 5120) = e5;
+    };
+    PROBE(0);
+    cp_load_a(0);
+    cp_load_b(0);
+
+    const long long tile = (long long)blockIdx.x * 4 + wave;
     long long p = tile * 32 + (lane & 31);
     const bool valid = p < M;
     if (!valid) p = M - 1;  // waves / lanes past the end run on the last pair and store nothing
@@ -123,139 +137,187 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     const long long rem = p - bb * NN;
     const long long bi = bb * N + rem / N, bj = bb * N + rem % N;
     const float* erow = edge + p * 128;
-    const float* arow = node_ab + bi * 768;
-    const float* brow = node_ab + bj * 768 + 384;
+    const float* arow = node_ab + bi * 768;        // A_i + b1, 384 channels
+    const float* brow = node_ab + bj * 768 + 384;  // B_j
+    const float* const npi = node_p + bi * 128;
+    const float* const npj = node_p + bj * 128;
 
-    // one stage = 4 k-steps x 2 tile groups = 8 slots; xsrc(kk, x) fills the 8 inputs of k-step kk of this stage.
-    // Explicit software pipeline (hipcc issues each ds_read right before its MFMA otherwise, exposing the LDS latency
-    // once per tile group): slot i+1's six A fragments are fetched and, at odd slots, the next k-step's activations
-    // are split while slot i's 12 MFMAs run; the fence at the end of a slot keeps that order.
-    auto run_stage = [&](int cur, int par, f32x16 (&acc)[4], auto xsrc) {
-        const bf16x8* st = stage_image(par);
-        bf16x8 fr[2][12];  // [buffer][tile*3 + plane]
-        bf16x8 xp[2][3];
-        auto fetch = [&](int kk, bf16x8 (&f)[12]) {
-            const bf16x8* p = st + kk * 4 * 3 * 64 + lane;
+    // ---- the pair's 128 edge channels, split once: xpl[ks][plane] = B operand of layer-1 k-step ks (channels 16ks + 8h + j)
+    bf16x8 xpl[8][3];
+    auto split4 = [&](const float (&x)[4], bf16x8& ph, bf16x8& pm, bf16x8& pl, int at) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) f[k] = p[64 * k];
-        };
-        fetch(0, fr[0]);
-        {
-            float x[8];
-            xsrc(0, x);
-            split8(x, xp[0][0], xp[0][1], xp[0][2]);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            if (kk + 1 < 4) fetch(kk + 1, fr[(kk + 1) & 1]);
-            slot(cur, par, 2 * kk);
-            const bf16x8 (&f)[12] = fr[kk & 1];
-            const bf16x8 &xh = xp[kk & 1][0], &xm = xp[kk & 1][1], &xl = xp[kk & 1][2];
-            // 24 MFMAs round-robin over the 4 accumulators (each one is touched every 4th issue)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(f[3 * t + 2], xh, acc[t]);  // (l,h)   small terms first
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(f[3 * t + 0], xl, acc[t]);  // (h,l)
-            if (kk + 1 < 4) {  // next k-step's split rides in the MFMA shadow
-                float x[8];
-                xsrc(kk + 1, x);
-                split8(x, xp[(kk + 1) & 1][0], xp[(kk + 1) & 1][1], xp[(kk + 1) & 1][2]);
-            }
-            slot(cur, par, 2 * kk + 1);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(f[3 * t + 1], xm, acc[t]);  // (m,m)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(f[3 * t + 1], xh, acc[t]);  // (m,h)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(f[3 * t + 0], xm, acc[t]);  // (h,m)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = mfma_bf16(f[3 * t + 0], xh, acc[t]);  // (h,h)
-            __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < 4; ++j) {
+            const __bf16 a = (__bf16)x[j];
+            const float r1 = x[j] - (float)a;
+            const __bf16 b = (__bf16)r1;
+            const float r2 = r1 - (float)b;
+            ph[at + j] = a; pm[at + j] = b; pl[at + j] = (__bf16)r2;
         }
     };
-
-    // (The part loops are fully unrolled: rolled into real loops the code shrinks from 93 KB to 78 KB but the register
-    //  shuffling hipcc adds around the loop-carried accumulators costs more than it saves: 3.6 vs 3.2 ms at B=16, N=256.)
-
-    // ---- layer 1: 384 <- 128 (edge channels), part by part; accumulators seeded with the per-node terms A_i + B_j (+ b1)
-    f32x16 a1[12];
+    {
+        float4 xv[16];
 #pragma unroll
-    for (int part = 0; part < 3; ++part) {
-        f32x16 acc[4];
+        for (int i = 0; i < 16; ++i) xv[i] = *reinterpret_cast<const float4*>(erow + 16 * (i >> 1) + 8 * h + 4 * (i & 1));
+        for (int i = threadIdx.x; i < 768; i += 256)
+            s_vec[i] = i < 384 ? b2[i] : (i < 512 ? bf[i - 384] : (i < 640 ? gamma[i - 512] : beta[i - 640]));
+        cp_store_a(0);
+        cp_load_a(1);
+        cp_store_b(0);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const float4 x = ldg4(arow + 128 * part, 4 * t + rq, h), y = ldg4(brow + 128 * part, 4 * t + rq, h);
-                acc[t][4 * rq + 0] = x.x + y.x; acc[t][4 * rq + 1] = x.y + y.y;
-                acc[t][4 * rq + 2] = x.z + y.z; acc[t][4 * rq + 3] = x.w + y.w;
-            }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-            run_stage(2 * part + s, s, acc, [&](int kk, float (&x)[8]) {
-                const int ks = 4 * s + kk;  // edge channels 16*ks + 8*h + j
-                const float4 u = *reinterpret_cast<const float4*>(erow + 16 * ks + 8 * h);
-                const float4 v = *reinterpret_cast<const float4*>(erow + 16 * ks + 8 * h + 4);
-                x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w; x[4] = v.x; x[5] = v.y; x[6] = v.z; x[7] = v.w;
-            });
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                a1[4 * part + t][r] = fmaxf(acc[t][r], 0.f);
-            }
+        for (int i = 0; i < 16; ++i) {
+            const float x[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+            split4(x, xpl[i >> 1][0], xpl[i >> 1][1], xpl[i >> 1][2], 4 * (i & 1));
+        }
     }
 
-    // ---- layer 2 (384 <- 384) and final layer (128 <- 384), fused part by part
+    f32x16 a1t[2];     // layer-1 tiles t (even / odd)
+    f32x16 a2[12];     // layer-2 accumulators, then relu(.)+residual = the final layer's input
     f32x16 a3[4];
+    float sa[16], sb[16];  // per-node seeds A_i(+b1), B_j of the a1 tile that is split next
+    auto seeds_load = [&](int t) {  // C layout of tile t: register 4rq + e = channel 32t + 8rq + 4h + e
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const float4 x = ldg4(arow + 32 * t, rq, h), y = ldg4(brow + 32 * t, rq, h);
+            sa[4 * rq + 0] = x.x; sa[4 * rq + 1] = x.y; sa[4 * rq + 2] = x.z; sa[4 * rq + 3] = x.w;
+            sb[4 * rq + 0] = y.x; sb[4 * rq + 1] = y.y; sb[4 * rq + 2] = y.z; sb[4 * rq + 3] = y.w;
+        }
+    };
+    seeds_load(0);
+
+    bf16x8 fr[2][6];  // A fragments of the current / next slot
+    bf16x8 xp[2][3];  // layer 2: planes of k-steps 2t, 2t+1 of the current a1 tile; final layer: current / next k-step
+    auto fetch = [&](int par, int slot_in_stage, bf16x8 (&f)[6]) {
+        typedef __attribute__((address_space(3))) bf16x8 lds_frag;
+        const lds_frag* s = (const lds_frag*)lds_image[par] + slot_in_stage * 6 * 64;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) f[k] = s[64 * k];
+    };
+    // quarter qd (registers 4qd..4qd+3) of  relu(a1 tile + seeds)  -> planes of k-step qd>>1, elements 4(qd&1)..
+    auto s_quarter = [&](const f32x16& tile_acc, auto qc) {
+        constexpr int qd = decltype(qc)::value;
+        float x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = fmaxf(tile_acc[4 * qd + j] + sa[4 * qd + j] + sb[4 * qd + j], 0.f);
+        split4(x, xp[qd >> 1][0], xp[qd >> 1][1], xp[qd >> 1][2], 4 * (qd & 1));
+    };
+    float rs[64];  // one 128-channel residual row in accumulator layout
+    auto row_load = [&](const float* r) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float4 v = ldg4(r, g, h);
+            rs[4 * g + 0] = v.x; rs[4 * g + 1] = v.y; rs[4 * g + 2] = v.z; rs[4 * g + 3] = v.w;
+        }
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    PROBE(1);
+    S2S_LDS_BARRIER();  // stage 0 and s_vec are in LDS
+    PROBE(2);
+    fetch(0, 0, fr[0]);
+
+    static_for<0, kSlots>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr SlotDesc d = slot_desc(s);
+        constexpr int stage = s / 8, ss = s % 8, par = stage & 1;
+        constexpr bool more = stage + 1 < kStages;
+
+        // ---------------- top of the slot: next slot's fragments, weight copy, loads that land under later slots
+#ifdef S2S_ET_PROBE_SLOTS
+        PROBE(200 + s);
+#endif
+        // weight pipe: group A of stage+2 is loaded at slot 4 and stored after slot 1 of the next stage (5 slots later);
+        // group B of stage+1 is loaded at slot 0 and stored after slot 5.  Both land in the buffer this stage's
+        // predecessor used, which is free from that stage's barrier (top of its slot 7) on.
+        if constexpr (ss < 7) {
+            fetch(par, ss + 1, fr[(s + 1) & 1]);
+            if constexpr (ss == 0 && more) cp_load_b(stage + 1);
+            if constexpr (ss == 4 && stage + 2 < kStages) cp_load_a(stage + 2);
+        } else if constexpr (more) {
+            PROBE(4 + 2 * stage);
+            S2S_LDS_BARRIER();
+            PROBE(5 + 2 * stage);
+            fetch(par ^ 1, 0, fr[(s + 1) & 1]);
+        }
+        // seeds of a1 tile t+1 are fetched late in B_t (they are consumed under A_{t+2}, or right after B_10 for tile 11)
+        if constexpr (d.phase == 1 && d.a == 1 && d.b == 3 && d.t + 1 < 12) seeds_load(d.t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---------------- the 12 MFMAs
+        const bf16x8 (&f)[6] = fr[s & 1];
+        if constexpr (d.phase == 0) {
+            f32x16& acc = a1t[d.t & 1];
+            const bf16x8 (&x0)[3] = xpl[2 * d.a], (&x1)[3] = xpl[2 * d.a + 1];
+            if constexpr (d.a == 0) acc = mfma_bf16(f[2], x0[0], zero16); else acc = mfma_bf16(f[2], x0[0], acc);  // (l,h)
+            acc = mfma_bf16(f[0], x0[2], acc);  // (h,l)
+            acc = mfma_bf16(f[1], x0[1], acc);  // (m,m)
+            acc = mfma_bf16(f[1], x0[0], acc);  // (m,h)
+            acc = mfma_bf16(f[0], x0[1], acc);  // (h,m)
+            acc = mfma_bf16(f[0], x0[0], acc);  // (h,h)
+            acc = mfma_bf16(f[5], x1[0], acc);
+            acc = mfma_bf16(f[3], x1[2], acc);
+            acc = mfma_bf16(f[4], x1[1], acc);
+            acc = mfma_bf16(f[4], x1[0], acc);
+            acc = mfma_bf16(f[3], x1[1], acc);
+            acc = mfma_bf16(f[3], x1[0], acc);
+            // under A_t: relu + seeds + split of tile t-1, a quarter per slot
+            if constexpr (d.t >= 1) s_quarter(a1t[(d.t - 1) & 1], IC<d.a>{});
+        } else {
+            constexpr bool fin = d.phase == 2;
+            constexpr bool first = fin ? d.a == 0 : (d.t == 0 && d.a == 0);
+            f32x16& t0 = fin ? a3[2 * d.b] : a2[2 * d.b];
+            f32x16& t1 = fin ? a3[2 * d.b + 1] : a2[2 * d.b + 1];
+            const bf16x8 (&x)[3] = fin ? xpl[d.a & 7] : xp[d.a];
+            if constexpr (first) {
+                t0 = mfma_bf16(f[2], x[0], zero16); t1 = mfma_bf16(f[5], x[0], zero16);
+            } else {
+                t0 = mfma_bf16(f[2], x[0], t0); t1 = mfma_bf16(f[5], x[0], t1);  // (l,h)
+            }
+            t0 = mfma_bf16(f[0], x[2], t0); t1 = mfma_bf16(f[3], x[2], t1);  // (h,l)
+            t0 = mfma_bf16(f[1], x[1], t0); t1 = mfma_bf16(f[4], x[1], t1);  // (m,m)
+            t0 = mfma_bf16(f[1], x[0], t0); t1 = mfma_bf16(f[4], x[0], t1);  // (m,h)
+            t0 = mfma_bf16(f[0], x[1], t0); t1 = mfma_bf16(f[3], x[1], t1);  // (h,m)
+            t0 = mfma_bf16(f[0], x[0], t0); t1 = mfma_bf16(f[3], x[0], t1);  // (h,h)
+        }
+        if constexpr (ss == 1 && more) cp_store_a(par ^ 1);
+        if constexpr (ss == 5 && more) cp_store_b(par ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---------------- exposed steps
+        if constexpr (s == 179) {  // B_10 done: tile 11 -> planes (nothing left to hide it under)
+            s_quarter(a1t[1], IC<0>{}); s_quarter(a1t[1], IC<1>{}); s_quarter(a1t[1], IC<2>{}); s_quarter(a1t[1], IC<3>{});
+        }
+        // Layer-2 epilogue + split, one 128-channel block (= 8 final-layer k-steps) at a time, right before the final
+        // layer consumes it:  relu(a2 + b2) + x,  x = [e | n'_i | n'_j]  (layers.py:181), in accumulator layout, split
+        // while the values are in VGPRs into the plane registers the edge row used during layers 1-2.
+        if constexpr (s == 191 || s == 207 || s == 223) {
+            constexpr int pb = (s - 191) / 16;
+            if constexpr (pb == 0) row_load(erow);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const float4 bq = ldg4(s_vec + 128 * pb, 4 * t + rq, h);
+                    const f32x16& a = a2[4 * pb + t];
+                    const float x[4] = {fmaxf(a[4 * rq + 0] + bq.x, 0.f) + rs[16 * t + 4 * rq + 0],
+                                        fmaxf(a[4 * rq + 1] + bq.y, 0.f) + rs[16 * t + 4 * rq + 1],
+                                        fmaxf(a[4 * rq + 2] + bq.z, 0.f) + rs[16 * t + 4 * rq + 2],
+                                        fmaxf(a[4 * rq + 3] + bq.w, 0.f) + rs[16 * t + 4 * rq + 3]};
+                    split4(x, xpl[2 * t + (rq >> 1)][0], xpl[2 * t + (rq >> 1)][1], xpl[2 * t + (rq >> 1)][2], 4 * (rq & 1));
+                }
+            if constexpr (pb < 2) row_load(pb == 0 ? npi : npj);  // lands under the next 16 slots
+        }
+    });
+
+    PROBE(100);
+    // ---- + bf, LayerNorm(128) over the pair's channels (half here, half in lane^32), edge mask, store
+    const float em = mask ? mask[bi] * mask[bj] : 1.0f;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-            const float4 x = ldg4(bf, 4 * t + rq, h);
-            a3[t][4 * rq + 0] = x.x; a3[t][4 * rq + 1] = x.y; a3[t][4 * rq + 2] = x.z; a3[t][4 * rq + 3] = x.w;
+            const float4 bq = ldg4(s_vec + 384, 4 * t + rq, h);
+            a3[t][4 * rq + 0] += bq.x; a3[t][4 * rq + 1] += bq.y; a3[t][4 * rq + 2] += bq.z; a3[t][4 * rq + 3] += bq.w;
         }
-    const float* npi = node_p + bi * 128;
-    const float* npj = node_p + bj * 128;
-#pragma unroll
-    for (int part = 0; part < 3; ++part) {
-        const int base = 6 + 8 * part;  // stage number of this part's first layer-2 stage (even: buffer parity = s & 1)
-        f32x16 a2[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const float4 x = ldg4(b2 + 128 * part, 4 * t + rq, h);
-                a2[t][4 * rq + 0] = x.x; a2[t][4 * rq + 1] = x.y; a2[t][4 * rq + 2] = x.z; a2[t][4 * rq + 3] = x.w;
-            }
-#pragma unroll
-        for (int s = 0; s < 6; ++s)
-            run_stage(base + s, s & 1, a2, [&](int kk, float (&x)[8]) {
-                const int ks = 4 * s + kk, tp = ks >> 1, u = ks & 1;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = a1[tp][8 * u + j];
-            });
-        // ReLU, then the residual  h2 + x,  x = [e | n'_i | n'_j]: part p is exactly block p of x  (layers.py:181)
-        const float* rs = part == 0 ? erow : (part == 1 ? npi : npj);
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const float4 x = ldg4(rs, 4 * t + rq, h);
-                a2[t][4 * rq + 0] = fmaxf(a2[t][4 * rq + 0], 0.f) + x.x; a2[t][4 * rq + 1] = fmaxf(a2[t][4 * rq + 1], 0.f) + x.y;
-                a2[t][4 * rq + 2] = fmaxf(a2[t][4 * rq + 2], 0.f) + x.z; a2[t][4 * rq + 3] = fmaxf(a2[t][4 * rq + 3], 0.f) + x.w;
-            }
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-            run_stage(base + 6 + s, s & 1, a3, [&](int kk, float (&x)[8]) {
-                const int ksl = 4 * s + kk, tp = ksl >> 1, u = ksl & 1;  // hidden channels of this part
-#pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = a2[tp][8 * u + j];
-            });
-    }
-
-    // ---- LayerNorm(128) over the pair's channels (half here, half in lane^32), edge mask, store
-    const float em = mask ? mask[bi] * mask[bj] : 1.0f;
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -267,8 +329,8 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float d = a3[t][r] - mean;
-            var += d * d;
+            const float dd = a3[t][r] - mean;
+            var += dd * dd;
         }
     const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / 128) + ln_eps);
     float* orow = out + p * 128;
@@ -277,7 +339,7 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
             const int g = 4 * t + rq;
-            const float4 ga = ldg4(gamma, g, h), be = ldg4(beta, g, h);
+            const float4 ga = ldg4(s_vec + 512, g, h), be = ldg4(s_vec + 640, g, h);
             float4 o;
             o.x = ((a3[t][4 * rq + 0] - mean) * rstd * ga.x + be.x) * em;
             o.y = ((a3[t][4 * rq + 1] - mean) * rstd * ga.y + be.y) * em;
@@ -285,7 +347,14 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
             o.w = ((a3[t][4 * rq + 3] - mean) * rstd * ga.w + be.w) * em;
             if (valid) *reinterpret_cast<float4*>(orow + 8 * g + 4 * h) = o;
         }
+    PROBE(101);
 }
+
+#ifdef S2S_ET_PROBE
+extern "C" int s2s_debug_read_et_probe(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(s2s_et_probe), sizeof(s2s_et_probe));
+}
+#endif
 
 }  // namespace
 

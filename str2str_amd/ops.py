@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 _tables_loaded = False
@@ -178,13 +178,21 @@ def pack_bf16x3_layer(w: torch.Tensor, kind: str) -> torch.Tensor:
 
 
 def pack_bf16x3_stream(w1_edge: torch.Tensor, w2: torch.Tensor, wf: torch.Tensor) -> torch.Tensor:
-    """The 30-stage (48 KiB = 4 k-steps x 4 tiles x 3 planes) weight stream of s2s_edge_transition_bf16x6 as int16,
-    in the kernel's consumption order: layer 1 output parts 0..2 (4 tiles each, 8 k-steps); then for each part p:
-    layer-2 output tiles 4p..4p+3 over all 24 k-steps, followed by the final layer's k-steps 8p..8p+7 (all 4 tiles)."""
-    l1, l2, lf = pack_bf16x3_layer(w1_edge, "row"), pack_bf16x3_layer(w2, "chain"), pack_bf16x3_layer(wf, "chain")
-    pieces = [l1[:, 4 * p:4 * p + 4] for p in range(3)]
-    for p in range(3):
-        pieces += [l2[:, 4 * p:4 * p + 4], lf[8 * p:8 * p + 8]]
+    """The weight stream of s2s_edge_transition_bf16x6 as int16: 240 slots of 6 fragments (6 KiB; 8 slots = one 48 KiB
+    stage) in the kernel's consumption order (csrc/pair_mlp_bf16.hip):
+      A_t (4 slots): layer-1 output tile t, k-step pairs (2s, 2s+1), fragments [k-step][plane];
+      B_t (12 slots): layer-2 k-steps 2t + u (u = 0, 1) x output tile pairs 0..5, fragments [tile][plane];
+      F  (48 slots): final layer k-steps 0..23 x tile pairs 0..1;
+    order  A_0 A_1 | B_0 A_2 | B_1 A_3 | ... | B_9 A_11 | B_10 B_11 | F."""
+    l1 = pack_bf16x3_layer(w1_edge, "row")    # [8, 12, 3, 64, 8]
+    l2 = pack_bf16x3_layer(w2, "chain")       # [24, 12, 3, 64, 8]
+    lf = pack_bf16x3_layer(wf, "chain")       # [24, 4, 3, 64, 8]
+    A = lambda t: l1[:, t]                    # [8 k-steps, 3, 64, 8]
+    B = lambda t: l2[2 * t:2 * t + 2]         # [2 k-steps, 12 tiles, 3, 64, 8]
+    pieces = [A(0), A(1)]
+    for t in range(10):
+        pieces += [B(t), A(t + 2)]
+    pieces += [B(10), B(11), lf]
     blob = torch.cat([x.contiguous().reshape(-1) for x in pieces]).view(torch.int16).contiguous()
     assert blob.numel() * 2 == 30 * 48 * 1024, blob.numel()
     return blob
