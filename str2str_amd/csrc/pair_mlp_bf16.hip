@@ -128,19 +128,34 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     cp_load_a(0);
     cp_load_b(0);
 
-    const long long tile = (long long)blockIdx.x * 4 + wave;
-    long long p = tile * 32 + (lane & 31);
-    const bool valid = p < M;
-    if (!valid) p = M - 1;  // waves / lanes past the end run on the last pair and store nothing
+    // ---- persistent workgroup: tiles of 128 pairs (32 per wave) blockIdx.x, blockIdx.x + gridDim.x, ...
+    struct PairCtx {
+        const float *erow, *arow, *brow, *npi, *npj;
+        float* orow;
+        float em;
+        bool valid;
+    };
     const long long NN = (long long)N * N;
-    const long long bb = p / NN;
-    const long long rem = p - bb * NN;
-    const long long bi = bb * N + rem / N, bj = bb * N + rem % N;
-    const float* erow = edge + p * 128;
-    const float* arow = node_ab + bi * 768;        // A_i + b1, 384 channels
-    const float* brow = node_ab + bj * 768 + 384;  // B_j
-    const float* const npi = node_p + bi * 128;
-    const float* const npj = node_p + bj * 128;
+    auto setup = [&](long long wg_tile) -> PairCtx {
+        long long p = (wg_tile * 4 + wave) * 32 + (lane & 31);
+        PairCtx c;
+        c.valid = p < M;
+        if (!c.valid) p = M - 1;  // waves / lanes past the end run on the last pair and store nothing
+        const long long bb = p / NN;
+        const long long rem = p - bb * NN;
+        const long long bi = bb * N + rem / N, bj = bb * N + rem % N;
+        c.erow = edge + p * 128;
+        c.arow = node_ab + bi * 768;        // A_i + b1, 384 channels
+        c.brow = node_ab + bj * 768 + 384;  // B_j
+        c.npi = node_p + bi * 128;
+        c.npj = node_p + bj * 128;
+        c.orow = out + p * 128;
+        c.em = mask ? mask[bi] * mask[bj] : 1.0f;
+        return c;
+    };
+    const long long n_wt = (M + 127) / 128;
+    long long wt = blockIdx.x;
+    PairCtx cur = setup(wt);
 
     // ---- the pair's 128 edge channels, split once: xpl[ks][plane] = B operand of layer-1 k-step ks (channels 16ks + 8h + j)
     bf16x8 xpl[8][3];
@@ -157,7 +172,7 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     {
         float4 xv[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) xv[i] = *reinterpret_cast<const float4*>(erow + 16 * (i >> 1) + 8 * h + 4 * (i & 1));
+        for (int i = 0; i < 16; ++i) xv[i] = *reinterpret_cast<const float4*>(cur.erow + 16 * (i >> 1) + 8 * h + 4 * (i & 1));
         for (int i = threadIdx.x; i < 768; i += 256)
             s_vec[i] = i < 384 ? b2[i] : (i < 512 ? bf[i - 384] : (i < 640 ? gamma[i - 512] : beta[i - 640]));
         cp_store_a(0);
@@ -174,15 +189,15 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     f32x16 a2[12];     // layer-2 accumulators, then relu(.)+residual = the final layer's input
     f32x16 a3[4];
     float sa[16], sb[16];  // per-node seeds A_i(+b1), B_j of the a1 tile that is split next
-    auto seeds_load = [&](int t) {  // C layout of tile t: register 4rq + e = channel 32t + 8rq + 4h + e
+    auto seeds_load = [&](const PairCtx& c, int t) {  // C layout of tile t: register 4rq + e = channel 32t + 8rq + 4h + e
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-            const float4 x = ldg4(arow + 32 * t, rq, h), y = ldg4(brow + 32 * t, rq, h);
+            const float4 x = ldg4(c.arow + 32 * t, rq, h), y = ldg4(c.brow + 32 * t, rq, h);
             sa[4 * rq + 0] = x.x; sa[4 * rq + 1] = x.y; sa[4 * rq + 2] = x.z; sa[4 * rq + 3] = x.w;
             sb[4 * rq + 0] = y.x; sb[4 * rq + 1] = y.y; sb[4 * rq + 2] = y.z; sb[4 * rq + 3] = y.w;
         }
     };
-    seeds_load(0);
+    seeds_load(cur, 0);
 
     bf16x8 fr[2][6];  // A fragments of the current / next slot
     bf16x8 xp[2][3];  // layer 2: planes of k-steps 2t, 2t+1 of the current a1 tile; final layer: current / next k-step
@@ -215,11 +230,16 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     PROBE(2);
     fetch(0, 0, fr[0]);
 
+    for (;;) {
+    const long long wt_next = wt + gridDim.x;
+    const bool has_next = wt_next < n_wt;
+    PairCtx nxt = cur;  // next tile's context, edge row and planes: produced under the last 16 slots of this tile
+    float4 xv[16];
+    bf16x8 xpn[8][3];
     static_for<0, kSlots>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         constexpr SlotDesc d = slot_desc(s);
         constexpr int stage = s / 8, ss = s % 8, par = stage & 1;
-        constexpr bool more = stage + 1 < kStages;
 
         // ---------------- top of the slot: next slot's fragments, weight copy, loads that land under later slots
 #ifdef S2S_ET_PROBE_SLOTS
@@ -230,16 +250,23 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
         // predecessor used, which is free from that stage's barrier (top of its slot 7) on.
         if constexpr (ss < 7) {
             fetch(par, ss + 1, fr[(s + 1) & 1]);
-            if constexpr (ss == 0 && more) cp_load_b(stage + 1);
-            if constexpr (ss == 4 && stage + 2 < kStages) cp_load_a(stage + 2);
-        } else if constexpr (more) {
+            if constexpr (ss == 0) cp_load_b((stage + 1) % kStages);   // the pipe wraps into the next tile's stages 0, 1
+            if constexpr (ss == 4) cp_load_a((stage + 2) % kStages);
+        } else {
             PROBE(4 + 2 * stage);
             S2S_LDS_BARRIER();
             PROBE(5 + 2 * stage);
             fetch(par ^ 1, 0, fr[(s + 1) & 1]);
         }
+        // next tile: context + edge row at the start of the last final-layer block, seeds of its tile 0 near the end
+        if constexpr (s == 224) {
+            nxt = setup(has_next ? wt_next : wt);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xv[i] = *reinterpret_cast<const float4*>(nxt.erow + 16 * (i >> 1) + 8 * h + 4 * (i & 1));
+        }
+        if constexpr (s == 236) seeds_load(nxt, 0);
         // seeds of a1 tile t+1 are fetched late in B_t (they are consumed under A_{t+2}, or right after B_10 for tile 11)
-        if constexpr (d.phase == 1 && d.a == 1 && d.b == 3 && d.t + 1 < 12) seeds_load(d.t + 1);
+        if constexpr (d.phase == 1 && d.a == 1 && d.b == 3 && d.t + 1 < 12) seeds_load(cur, d.t + 1);
         __builtin_amdgcn_sched_barrier(0);
 
         // ---------------- the 12 MFMAs
@@ -278,8 +305,15 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
             t0 = mfma_bf16(f[0], x[1], t0); t1 = mfma_bf16(f[3], x[1], t1);  // (h,m)
             t0 = mfma_bf16(f[0], x[0], t0); t1 = mfma_bf16(f[3], x[0], t1);  // (h,h)
         }
-        if constexpr (ss == 1 && more) cp_store_a(par ^ 1);
-        if constexpr (ss == 5 && more) cp_store_b(par ^ 1);
+        if constexpr (s >= 228 && s < 236) {  // split of the next tile's edge row, one k-step per slot
+            constexpr int i = s - 228;
+            const float x0[4] = {xv[2 * i].x, xv[2 * i].y, xv[2 * i].z, xv[2 * i].w};
+            const float x1[4] = {xv[2 * i + 1].x, xv[2 * i + 1].y, xv[2 * i + 1].z, xv[2 * i + 1].w};
+            split4(x0, xpn[i][0], xpn[i][1], xpn[i][2], 0);
+            split4(x1, xpn[i][0], xpn[i][1], xpn[i][2], 4);
+        }
+        if constexpr (ss == 1) cp_store_a(par ^ 1);
+        if constexpr (ss == 5) cp_store_b(par ^ 1);
         __builtin_amdgcn_sched_barrier(0);
 
         // ---------------- exposed steps
@@ -291,7 +325,7 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
         // while the values are in VGPRs into the plane registers the edge row used during layers 1-2.
         if constexpr (s == 191 || s == 207 || s == 223) {
             constexpr int pb = (s - 191) / 16;
-            if constexpr (pb == 0) row_load(erow);
+            if constexpr (pb == 0) row_load(cur.erow);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -304,13 +338,13 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
                                         fmaxf(a[4 * rq + 3] + bq.w, 0.f) + rs[16 * t + 4 * rq + 3]};
                     split4(x, xpl[2 * t + (rq >> 1)][0], xpl[2 * t + (rq >> 1)][1], xpl[2 * t + (rq >> 1)][2], 4 * (rq & 1));
                 }
-            if constexpr (pb < 2) row_load(pb == 0 ? npi : npj);  // lands under the next 16 slots
+            if constexpr (pb < 2) row_load(pb == 0 ? cur.npi : cur.npj);  // lands under the next 16 slots
         }
     });
 
     PROBE(100);
     // ---- + bf, LayerNorm(128) over the pair's channels (half here, half in lane^32), edge mask, store
-    const float em = mask ? mask[bi] * mask[bj] : 1.0f;
+    const float em = cur.em;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -333,7 +367,7 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
             var += dd * dd;
         }
     const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / 128) + ln_eps);
-    float* orow = out + p * 128;
+    float* orow = cur.orow;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -345,9 +379,15 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
             o.y = ((a3[t][4 * rq + 1] - mean) * rstd * ga.y + be.y) * em;
             o.z = ((a3[t][4 * rq + 2] - mean) * rstd * ga.z + be.z) * em;
             o.w = ((a3[t][4 * rq + 3] - mean) * rstd * ga.w + be.w) * em;
-            if (valid) *reinterpret_cast<float4*>(orow + 8 * g + 4 * h) = o;
+            if (cur.valid) *reinterpret_cast<float4*>(orow + 8 * g + 4 * h) = o;
         }
     PROBE(101);
+    if (!has_next) break;
+    cur = nxt;
+    wt = wt_next;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { xpl[i][0] = xpn[i][0]; xpl[i][1] = xpn[i][1]; xpl[i][2] = xpn[i][2]; }
+    }  // persistent tile loop
 }
 
 #ifdef S2S_ET_PROBE
@@ -364,8 +404,15 @@ extern "C" int s2s_edge_transition_bf16x6(const float* edge, const float* node_a
                                           int n_samples, int n_res, float ln_eps, void* stream) {
     const long long M = (long long)n_samples * n_res * n_res;
     if (M <= 0) return 0;
-    const long long tiles = (M + 31) / 32;
-    hipLaunchKernelGGL(edge_transition_bf16_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+    const long long wg_tiles = (M + 127) / 128;
+    static int n_cu = 0;  // persistent workgroups: one per CU (99 KB LDS + 512 registers per lane => one workgroup fits)
+    if (n_cu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+            n_cu = 256;
+    }
+    const long long grid = wg_tiles < n_cu ? wg_tiles : n_cu;
+    hipLaunchKernelGGL(edge_transition_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
                        edge, node_ab, node_p, (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mask, out, M, n_res,
                        ln_eps);
     return (int)hipGetLastError();
