@@ -68,7 +68,7 @@ int s2s_edge_embed(const float* node_a, const float* node_b, const float* rel_ta
 
 /* linear_b and down_z of InvariantPointAttention (src/models/net/ipa.py:177, :253) in one pass over z.
  *   w_packed: [linear_b.weight (8 rows); down_z.weight (32 rows); 24 zero rows] (64x128) packed
- *   bias_cat64 [64]; attn_bias [B,N,N,8]; pair_z [B,N,N,32]. */
+ *   bias_cat64 [64]; attn_bias [B,8,N,N] (head-major: what s2s_ipa_attention streams per head); pair_z [B,N,N,32]. */
 int s2s_pair_project(const float* edge, const float* w_packed, const float* bias_cat64, float* attn_bias, float* pair_z,
                      int n_samples, int n_res, void* stream);
 
@@ -82,16 +82,25 @@ int s2s_ipa_prep_points(const float* rigids7, const float* q_pts_lin, const floa
                         float* v_pts, long long n_frames, int n_heads, int n_qk_points, int n_v_points, int v_pts_stride,
                         void* stream);
 
-/* Attention core of InvariantPointAttention.forward (src/models/net/ipa.py:183-257): logits
+/* Attention core of InvariantPointAttention.forward (src/models/net/ipa.py:183-252): logits
  * (scalar + pair bias + point distances + mask), softmax over keys, o / o_pt (inverse-transformed,
- * with norms) / o_pair, written in linear_out's concat order (ipa.py:259-266):
- *   out [B,N, H*C | H*Pv (x) | H*Pv (y) | H*Pv (z) | H*Pv (norm) | H*c_pair_z].
- *   q [B,N,H,C]; kv [B,N,H,2C]; head_w_scaled [H] = softplus(head_weights)*sqrt(1/(3*(Pq*9/2))).
+ * with norms), written in linear_out's concat order (ipa.py:259-266):
+ *   out [B,N, H*C | H*Pv (x) | H*Pv (y) | H*Pv (z) | H*Pv (norm) | H*c_pair_z]   (the o_pair columns are left to
+ *   s2s_ipa_opair).
+ *   q [B,N,H,C]; kv [B,N,H,2C]; attn_bias [B,H,N,N]; head_w_scaled [H] = softplus(head_weights)*sqrt(1/(3*(Pq*9/2))).
+ *   logits_out [B,H,N,N] (masked logits; may alias attn_bias), stats_out [B,H,N,2] (row maximum, sum of exp).
  * Supported shape: C=256, Pq=8, Pv=12, c_pair_z=32, H multiple of 4 (configs/model/diffusion.yaml:29-40). */
 int s2s_ipa_attention(const float* q, const float* kv, const float* q_pts, const float* k_pts, const float* v_pts64,
-                      const float* attn_bias, const float* pair_z, const float* mask, const float* rigids7,
+                      const float* attn_bias, float* logits_out, float* stats_out, const float* mask, const float* rigids7,
                       const float* head_w_scaled, float* out, int n_samples, int n_res, int n_heads, int c_hidden,
                       int n_qk_points, int n_v_points, int c_pair_z, float inf, float eps, void* stream);
+
+/* The pair term of InvariantPointAttention.forward (src/models/net/ipa.py:253-257):
+ *   o_pair[b,i,h,:] = sum_j softmax_j(logits[b,h,i,:])[j] * pair_z[b,i,j,:]
+ * from the logits / statistics s2s_ipa_attention stored, streaming pair_z [B,N,N,c_pair_z] once for all heads;
+ * written to out[(b*N+i)*out_row_stride + out_col_offset + h*c_pair_z + c]  (H = 8, c_pair_z = 32). */
+int s2s_ipa_opair(const float* logits, const float* stats, const float* pair_z, float* out, int n_samples, int n_res,
+                  int n_heads, int c_pair_z, int out_row_stride, int out_col_offset, void* stream);
 
 /* ---- Rigid frames ---- */
 

@@ -19,10 +19,13 @@
 // quads; V / value points row-major (ds_read_b32, 32 consecutive floats per half wave); key points and
 // mask are read as broadcasts.  The VALU work (point distances, o_pair) is written inside the MFMA loops so
 // it issues in the shadow of the matrix pipe.
+// The pair term  o_pair[i,h,:] = sum_j a_ij pair_z[i,j,:]  is NOT done here: its "value" depends on the query, so every
+// head would gather the same 128 B rows of pair_z per lane (8x the traffic, exposed HBM latency).  This kernel stores
+// the masked logits (same [B,H,N,N] layout as the bias it reads, may alias it) and the final softmax statistics;
+// ipa_opair_kernel below streams pair_z once and applies all heads at a time.
 // Point term  -1/2 * softplus(w_h)*c * sum_p |q_ip - k_jp|^2  is evaluated with explicit differences on
 // the VALU exactly as the reference forms it — not through the |q|^2+|k|^2-2q.k expansion, which loses
-// ~2 digits to cancellation.  o_pair[i,h,:] = sum_j a_ij pair_z[i,j,:] is not a GEMM (the "value"
-// depends on i): VALU too.  Output is written directly in linear_out's concat order (ipa.py:259-266):
+// ~2 digits to cancellation.  Output is written directly in linear_out's concat order (ipa.py:259-266):
 //   [ o (H*C) | o_pt.x (H*Pv) | o_pt.y | o_pt.z | |o_pt| (H*Pv) | o_pair (H*PZ) ]
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -38,14 +41,31 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 }
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// LDS read pointers made opaque at the point of use: hipcc otherwise hoists every LDS read of a key tile (all 16 rows of
+// key points, all K fragments) to the top of the loop body -- there is no store in between that it can see -- and the
+// 400+ live values push the accumulators out to scratch.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const float lds_cf;
+typedef __attribute__((address_space(3))) const f32x4 lds_cf4;
+__device__ __forceinline__ lds_cf* lds_pin(const float* p) {
+    lds_cf* q = (lds_cf*)p;
+    asm volatile("" : "+v"(q));
+    return q;
+}
+__device__ __forceinline__ float4 lds_ld4(lds_cf* p) {
+    const f32x4 v = *(lds_cf4*)p;
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 struct IpaArgs {
     const float* q;         // [B,N,H,C]
     const float* kv;        // [B,N,H,2C]  (k = first C, v = last C of every head; ipa.py:132-141)
     const float* q_pts;     // [B,N,H,PQ*3] global frame
     const float* k_pts;     // [B,N,H,PQ*3]
     const float* v_pts;     // [B,N,H,64]  (x,y,z,0) per point, zero padded
-    const float* attn_bias; // [B,N,N,H]   linear_b(z)
-    const float* pair_z;    // [B,N,N,PZ]  down_z(z)
+    const float* attn_bias; // [B,H,N,N]   linear_b(z), head-major
+    float* logits;          // [B,H,N,N]   out: masked logits (may alias attn_bias)
+    float* stats;           // [B,H,N,2]   out: running max, sum of exp of every query row
     const float* mask;      // [B,N]
     const float* rigids7;   // [B,N,7]     frames (scaled translation) for the inverse transform
     const float* head_w;    // [H]         softplus(head_weights) * sqrt(1/(3*(PQ*9/2)))
@@ -62,6 +82,14 @@ __device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// Timeline probe (tools/ipa_probe.py; only in -DS2S_IPA_PROBE=<block> builds)
+#ifdef S2S_IPA_PROBE
+__device__ unsigned long long s2s_ipa_probe[4][128];
+#define IPROBE(idx) do { if (blockIdx.x == S2S_IPA_PROBE) s2s_ipa_probe[threadIdx.x >> 6][idx] = __builtin_readcyclecounter(); } while (0)
+#else
+#define IPROBE(idx) do { } while (0)
+#endif
+
 template <int C, int PQ>
 struct KeyStage {
     static constexpr int KS = C + 4;  // padded K row stride (floats)
@@ -72,7 +100,8 @@ struct KeyStage {
     float km[32];
 };
 
-template <int C, int PQ, int PV, int PZ>
+// FULL: N is a multiple of 32 -> no ragged-tile code (and no control flow) inside the key loop
+template <int C, int PQ, int PV, int PZ, bool FULL>
 __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
     static_assert(C == 256 && PV <= 16 && PZ % 4 == 0 && (PQ * 3) % 4 == 0 && 32 * PQ * 3 <= 3 * 256, "shape");
     using Stage = KeyStage<C, PQ>;
@@ -128,9 +157,12 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
     // ---- this lane's query row (B operand of QK^T), points and mask
     // half of the query row lives in registers; the other half is re-read (L1/L2 hits) through a small
     // ring every key tile: 64 fewer live VGPRs is what keeps this kernel out of scratch
-    constexpr int QR = QG / 2;
+#ifndef S2S_IPA_QR
+#define S2S_IPA_QR 0
+#endif
+    constexpr int QR = S2S_IPA_QR == 0 ? 0 : QG / S2S_IPA_QR;
     const float* qrow = a.q + (row_i * H + head) * C + 4 * h;
-    float4 qreg[QR];
+    float4 qreg[QR > 0 ? QR : 1];
 #pragma unroll
     for (int g = 0; g < QR; ++g) qreg[g] = *reinterpret_cast<const float4*>(qrow + 8 * g);
     float qpt[PQ * 3];
@@ -149,9 +181,6 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
     for (int t = 0; t < OT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
-    float opair[PZ];
-#pragma unroll
-    for (int x = 0; x < PZ; ++x) opair[x] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -160,9 +189,32 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
     int cur = 0;
     for (int j0 = 0; j0 < N; j0 += 32, cur ^= 1) {
         const Stage& st = stage[cur];
-        if (j0 + 32 < N) load_tile(stage[cur ^ 1], j0 + 32);  // in flight during this tile's compute
+        IPROBE(8 * (j0 >> 5) + 0);
+        // this lane's 16 bias values (keys j0 + 8g + 4h + e): one 128 B line per (query, tile), issued a whole
+        // QK^T loop ahead of their use
+        float4 bias4[4];
+        const long long brow = (((long long)b * H + head) * N + ic) * N + j0 + 4 * h;
+        const bool full_tile = FULL || j0 + 32 <= N;  // wave-uniform
+        if (full_tile) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias4[g] = *reinterpret_cast<const float4*>(a.attn_bias + brow + 8 * g);
+        } else {  // ragged last tile: element by element, clamped
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int jg = j0 + 8 * g + 4 * h;
+                const float* bp = a.attn_bias + brow + 8 * g - jg;  // row start
+                bias4[g].x = bp[min(jg, N - 1)];
+                bias4[g].y = bp[min(jg + 1, N - 1)];
+                bias4[g].z = bp[min(jg + 2, N - 1)];
+                bias4[g].w = bp[min(jg + 3, N - 1)];
+            }
+        }
 
-        // ---------------- S^T = K . Q^T, with the point distances issued between the MFMAs
+        // ---------------- S^T = K . Q^T, with the point distances issued between the MFMAs.
+        // Explicit software pipeline, one scheduling region per 4-MFMA group (hipcc otherwise serialises the whole
+        // VALU point term behind the MFMAs and waits on every operand right where it is loaded): the K fragment of
+        // group g+1, the ring slot of Q four groups ahead and the key points of the next key row are fetched while
+        // group g's MFMAs run.
         f32x16 S;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[r] = 0.f;
@@ -171,9 +223,18 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
         float4 qring[QD];
 #pragma unroll
         for (int d = 0; d < QD; ++d) qring[d] = *reinterpret_cast<const float4*>(qrow + 8 * (QR + d));
+        float4 kf_next = lds_ld4(lds_pin(st.k + c * KS + 4 * h));
+        float4 kpv[PQ * 3 / 4];  // key points of the key row whose distance term is evaluated next
+        {
+            lds_cf* kp = lds_pin(st.kp + rowmap(0, h) * (PQ * 3));
+#pragma unroll
+            for (int x = 0; x < PQ * 3 / 4; ++x) kpv[x] = lds_ld4(kp + 4 * x);
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < QG; ++g) {
-            const float4 kf = *reinterpret_cast<const float4*>(st.k + c * KS + 8 * g + 4 * h);
+            const float4 kf = kf_next;
+            if (g + 1 < QG) kf_next = lds_ld4(lds_pin(st.k + c * KS + 8 * (g + 1) + 4 * h));
             float4 qf;
             if (g < QR) {
                 qf = qreg[g];
@@ -187,25 +248,39 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
             S = mfma32(kf.w, qf.w, S);
             if ((g & 1) == 0) {
                 const int r = g >> 1;
-                const float* kp = st.kp + rowmap(r, h) * (PQ * 3);
+                const float kpf[PQ * 3] = {kpv[0].x, kpv[0].y, kpv[0].z, kpv[0].w, kpv[1].x, kpv[1].y, kpv[1].z, kpv[1].w,
+                                           kpv[2].x, kpv[2].y, kpv[2].z, kpv[2].w, kpv[3].x, kpv[3].y, kpv[3].z, kpv[3].w,
+                                           kpv[4].x, kpv[4].y, kpv[4].z, kpv[4].w, kpv[5].x, kpv[5].y, kpv[5].z, kpv[5].w};
                 float acc = 0.f;
 #pragma unroll
                 for (int p = 0; p < PQ; ++p) {
-                    const float dx = qpt[p * 3 + 0] - kp[p * 3 + 0];
-                    const float dy = qpt[p * 3 + 1] - kp[p * 3 + 1];
-                    const float dz = qpt[p * 3 + 2] - kp[p * 3 + 2];
+                    const float dx = qpt[p * 3 + 0] - kpf[p * 3 + 0];
+                    const float dy = qpt[p * 3 + 1] - kpf[p * 3 + 1];
+                    const float dz = qpt[p * 3 + 2] - kpf[p * 3 + 2];
                     acc += (dx * dx + dy * dy + dz * dz) * hw;
                 }
+                asm volatile("" : "+v"(acc));  // evaluated HERE, under this group's MFMAs (not sunk behind the loop)
                 pt[r] = acc;
+            } else if (g + 1 < QG) {
+                lds_cf* kp = lds_pin(st.kp + rowmap((g + 1) >> 1, h) * (PQ * 3));
+#pragma unroll
+                for (int x = 0; x < PQ * 3 / 4; ++x) kpv[x] = lds_ld4(kp + 4 * x);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        IPROBE(8 * (j0 >> 5) + 1);
+        // VMEM loads return in order: the next tile's DMA is issued only now, behind the last load of this tile (bias, Q
+        // ring), so that nothing consumed during this tile has to wait for 77 KB of DMA; it lands under softmax + PV,
+        // which touch no global memory loads (and must stay free of scratch reloads for the same reason).
+        if (j0 + 32 < N) load_tile(stage[cur ^ 1], j0 + 32);
+        IPROBE(8 * (j0 >> 5) + 2);
         // ---------------- logits (ipa.py:183-214)
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = j0 + rowmap(r, h);
-            const int jc = min(j, N - 1);
-            const float bias = a.attn_bias[(row_i * N + jc) * H + head];
+            const float4 b4 = bias4[r >> 2];
+            const float bias = (r & 3) == 0 ? b4.x : ((r & 3) == 1 ? b4.y : ((r & 3) == 2 ? b4.z : b4.w));
             const float sq = a.inf * (mask_i * st.km[rowmap(r, h)] - 1.0f);
             float s = S[r] * c1 + c2 * bias;
             s = s + pt[r] * (-0.5f);
@@ -214,9 +289,25 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
             S[r] = s;
             tmax = fmaxf(tmax, s);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        IPROBE(64 + 4 * (j0 >> 5) + 0);
+        if (ivalid) {
+            if (full_tile) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(a.logits + brow + 8 * g) = make_float4(S[4 * g], S[4 * g + 1], S[4 * g + 2], S[4 * g + 3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (j0 + rowmap(r, h) < N) a.logits[brow - 4 * h + rowmap(r, h)] = S[r];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        IPROBE(64 + 4 * (j0 >> 5) + 1);
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = expf(m_run - m_new);
+        const float alpha = expf(m_run - m_new);  // 0 on the first tile, 1 once the maximum has settled
+        m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -225,51 +316,46 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
             psum += p;
         }
         l_run = l_run * alpha + psum;
-        m_run = m_new;
-        if (!__all(alpha == 1.0f)) {  // the running max settles after a few tiles: skip the rescale then
-#pragma unroll
-            for (int t = 0; t < OT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
-#pragma unroll
-            for (int x = 0; x < PZ; ++x) opair[x] *= alpha;
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        IPROBE(64 + 4 * (j0 >> 5) + 2);
 
-        // ---------------- O^T += V^T . P^T (+ value points), o_pair FMAs in the MFMA shadow (ipa.py:221-257)
-        float4 z[PZ / 4];
-        {
-            const float* pz = a.pair_z + (row_i * N + min(j0 + rowmap(0, h), N - 1)) * PZ;
+        IPROBE(8 * (j0 >> 5) + 3);
+        // ---------------- O^T += V^T . P^T (+ value points)  (ipa.py:221-252), one output tile at a time: 16 chained MFMAs
+        // over the key rows; the A operands of tile t+1 are fetched from LDS and its accumulator is rescaled by alpha
+        // (16 VALU multiplies, unconditionally: no branch, no 160-register burst) while the MFMAs of tile t run.
+        float va[16];
+        auto fetch_v = [&](int t, float (&dst)[16]) {
+            lds_cf* base = lds_pin(t < CT ? st.v + 32 * t + c + 4 * h * C : st.vp + 32 * (t - CT) + c + 4 * h * 64);
+            const int rs = t < CT ? C : 64;  // row stride; key row of register r = (r&3) + 8(r>>2) (+ 4h, in the base)
 #pragma unroll
-            for (int x = 0; x < PZ / 4; ++x) z[x] = *reinterpret_cast<const float4*>(pz + 4 * x);
-        }
+            for (int r = 0; r < 16; ++r) dst[r] = base[((r & 3) + 8 * (r >> 2)) * rs];
+        };
+        fetch_v(0, va);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int kr = rowmap(r, h);
-            const float p = S[r];
-            float4 zc[PZ / 4];
+        for (int r = 0; r < 16; ++r) O[0][r] *= alpha;
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int x = 0; x < PZ / 4; ++x) zc[x] = z[x];
-            if (r + 1 < 16) {
-                const float* pz = a.pair_z + (row_i * N + min(j0 + rowmap(r + 1, h), N - 1)) * PZ;
+        for (int t = 0; t < OT; ++t) {
+            float vc[16];
 #pragma unroll
-                for (int x = 0; x < PZ / 4; ++x) z[x] = *reinterpret_cast<const float4*>(pz + 4 * x);
-            }
-            const float* vrow = st.v + kr * C + c;
+            for (int r = 0; r < 16; ++r) vc[r] = va[r];
+            if (t + 1 < OT) fetch_v(t + 1, va);
 #pragma unroll
-            for (int t = 0; t < CT; ++t) O[t] = mfma32(vrow[32 * t], p, O[t]);
-            O[CT] = mfma32(st.vp[kr * 64 + c], p, O[CT]);
-            O[CT + 1] = mfma32(st.vp[kr * 64 + 32 + c], p, O[CT + 1]);
+            for (int r = 0; r < 16; ++r) O[t] = mfma32(vc[r], S[r], O[t]);
+            if (t + 1 < OT) {
 #pragma unroll
-            for (int x = 0; x < PZ / 4; ++x) {
-                opair[4 * x + 0] += p * zc[x].x; opair[4 * x + 1] += p * zc[x].y;
-                opair[4 * x + 2] += p * zc[x].z; opair[4 * x + 3] += p * zc[x].w;
+                for (int r = 0; r < 16; ++r) O[t + 1][r] *= alpha;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        IPROBE(8 * (j0 >> 5) + 4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next tile's DMA has landed
+        IPROBE(8 * (j0 >> 5) + 5);
         __syncthreads();                                   // ... and everyone is done reading this one
+        IPROBE(8 * (j0 >> 5) + 6);
     }
 
+    IPROBE(120);
     // ---------------- epilogue: normalise, inverse-transform points, write concat layout
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -313,32 +399,129 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
                 }
             }
     }
-    {
-        float* op = orow + H * (C + 4 * PV) + head * PZ;
+    IPROBE(121);
+    if (ivalid && h == 0) {
+        float* st2 = a.stats + ((((long long)b * H + head) * N) + i) * 2;
+        st2[0] = m_run;
+        st2[1] = l_tot;
+    }
+}
+
+// o_pair[b,i,h,:] = sum_j softmax_j(logits[b,h,i,:]) * pair_z[b,i,j,:]   (ipa.py:253-257), written into the concat row.
+// One wave per (b,i): the 8 x N probabilities go through LDS once, pair_z rows (128 B) are streamed exactly once from HBM
+// as float4 (8 lanes per row, 8 rows per instruction); lane (jsub = lane>>3, c4 = lane&7) accumulates 4 channels x 8 heads
+// over the rows j = jsub (mod 8) and the 8 partial sums meet in a xor-shuffle tree.
+template <int H, int PZ>
+__global__ void __launch_bounds__(256) ipa_opair_kernel(const float* __restrict__ logits, const float* __restrict__ stats,
+                                                        const float* __restrict__ pair_z, float* __restrict__ out, int B, int N,
+                                                        int feat, int col0) {
+    static_assert(H == 8 && PZ == 32, "shape");
+    constexpr int CH = 256;  // keys per chunk
+    __shared__ __attribute__((aligned(16))) float a_s[4][CH * H];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long row = (long long)blockIdx.x * 4 + wave;  // b*N + i
+    if (row >= (long long)B * N) return;                    // wave-uniform; no workgroup barriers below
+    const long long b = row / N, i = row - b * N;
+    float m[H], inv[H];
 #pragma unroll
-        for (int x = 0; x < PZ / 4; ++x) {
-            float4 v;
-            v.x = (opair[4 * x + 0] + __shfl_xor(opair[4 * x + 0], 32, 64)) * inv;
-            v.y = (opair[4 * x + 1] + __shfl_xor(opair[4 * x + 1], 32, 64)) * inv;
-            v.z = (opair[4 * x + 2] + __shfl_xor(opair[4 * x + 2], 32, 64)) * inv;
-            v.w = (opair[4 * x + 3] + __shfl_xor(opair[4 * x + 3], 32, 64)) * inv;
-            if (ivalid && h == 0) *reinterpret_cast<float4*>(op + 4 * x) = v;
+    for (int hd = 0; hd < H; ++hd) {
+        const float* st = stats + (((b * H + hd) * N) + i) * 2;
+        m[hd] = st[0];
+        inv[hd] = 1.0f / st[1];
+    }
+    float acc[H][4];
+#pragma unroll
+    for (int hd = 0; hd < H; ++hd)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[hd][e] = 0.f;
+    float* as = a_s[wave];
+    const int jsub = lane >> 3, c4 = lane & 7;
+    for (int j0 = 0; j0 < N; j0 += CH) {
+        // probabilities of this chunk -> LDS as [key][head]
+        const int jl = 4 * lane;  // this lane's 4 keys
+        float pr[H][4];
+#pragma unroll
+        for (int hd = 0; hd < H; ++hd) {
+            const float* lrow = logits + ((b * H + hd) * N + i) * N + j0 + jl;
+            float4 s4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            if (j0 + jl + 3 < N) s4 = *reinterpret_cast<const float4*>(lrow);
+            else {
+                if (j0 + jl < N) s4.x = lrow[0];
+                if (j0 + jl + 1 < N) s4.y = lrow[1];
+                if (j0 + jl + 2 < N) s4.z = lrow[2];
+            }
+            pr[hd][0] = expf(s4.x - m[hd]) * inv[hd]; pr[hd][1] = expf(s4.y - m[hd]) * inv[hd];
+            pr[hd][2] = expf(s4.z - m[hd]) * inv[hd]; pr[hd][3] = expf(s4.w - m[hd]) * inv[hd];
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            *reinterpret_cast<float4*>(as + (jl + e) * H) = make_float4(pr[0][e], pr[1][e], pr[2][e], pr[3][e]);
+            *reinterpret_cast<float4*>(as + (jl + e) * H + 4) = make_float4(pr[4][e], pr[5][e], pr[6][e], pr[7][e]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int jn = min(CH, N - j0);
+        const float* pz = pair_z + (row * N + j0) * PZ + 4 * c4;
+        for (int j = jsub; j < jn; j += 8) {
+            const float4 z = *reinterpret_cast<const float4*>(pz + (long long)j * PZ);
+            const float4 a0 = *reinterpret_cast<const float4*>(as + j * H), a1 = *reinterpret_cast<const float4*>(as + j * H + 4);
+            const float av[H] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int hd = 0; hd < H; ++hd) {
+                acc[hd][0] += av[hd] * z.x; acc[hd][1] += av[hd] * z.y; acc[hd][2] += av[hd] * z.z; acc[hd][3] += av[hd] * z.w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the chunk image is reused
+    }
+#pragma unroll
+    for (int hd = 0; hd < H; ++hd)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = acc[hd][e];
+            v += __shfl_xor(v, 8, 64);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            acc[hd][e] = v;
+        }
+    if (jsub == 0) {
+        float* o = out + row * feat + col0 + 4 * c4;
+#pragma unroll
+        for (int hd = 0; hd < H; ++hd)
+            *reinterpret_cast<float4*>(o + hd * PZ) = make_float4(acc[hd][0], acc[hd][1], acc[hd][2], acc[hd][3]);
     }
 }
 
 }  // namespace
 
+#ifdef S2S_IPA_PROBE
+extern "C" int s2s_debug_read_ipa_probe(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(s2s_ipa_probe), sizeof(s2s_ipa_probe));
+}
+#endif
+
+extern "C" int s2s_ipa_opair(const float* logits, const float* stats, const float* pair_z, float* out, int n_samples, int n_res,
+                             int n_heads, int c_pair_z, int out_row_stride, int out_col_offset, void* stream) {
+    if (n_samples <= 0 || n_res <= 0) return 0;
+    if (n_heads != 8 || c_pair_z != 32) return (int)hipErrorInvalidValue;
+    const long long rows = (long long)n_samples * n_res;
+    hipLaunchKernelGGL((ipa_opair_kernel<8, 32>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, stats,
+                       pair_z, out, n_samples, n_res, out_row_stride, out_col_offset);
+    return (int)hipGetLastError();
+}
+
 extern "C" int s2s_ipa_attention(const float* q, const float* kv, const float* q_pts, const float* k_pts, const float* v_pts64,
-                                 const float* attn_bias, const float* pair_z, const float* mask, const float* rigids7,
-                                 const float* head_w_scaled, float* out, int n_samples, int n_res, int n_heads, int c_hidden,
+                                 const float* attn_bias, float* logits_out, float* stats_out, const float* mask,
+                                 const float* rigids7, const float* head_w_scaled, float* out, int n_samples, int n_res, int n_heads, int c_hidden,
                                  int n_qk_points, int n_v_points, int c_pair_z, float inf, float eps, void* stream) {
     if (n_samples <= 0 || n_res <= 0) return 0;
     if (c_hidden != 256 || n_qk_points != 8 || n_v_points != 12 || c_pair_z != 32 || n_heads < 1)
         return (int)hipErrorInvalidValue;  // the reference configuration (configs/model/diffusion.yaml:29-40)
-    IpaArgs a{q, kv, q_pts, k_pts, v_pts64, attn_bias, pair_z, mask, rigids7, head_w_scaled, out, n_samples, n_res, n_heads, inf, eps};
+    IpaArgs a{q, kv, q_pts, k_pts, v_pts64, attn_bias, logits_out, stats_out, mask, rigids7, head_w_scaled, out, n_samples, n_res, n_heads, inf, eps};
     const int n_qb = (n_res + 127) / 128;
     const long long blocks = (long long)n_samples * n_heads * n_qb;
-    hipLaunchKernelGGL((ipa_attention_kernel<256, 8, 12, 32>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (n_res % 32 == 0)
+        hipLaunchKernelGGL((ipa_attention_kernel<256, 8, 12, 32, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((ipa_attention_kernel<256, 8, 12, 32, false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }

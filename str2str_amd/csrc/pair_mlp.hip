@@ -144,9 +144,20 @@ __device__ __forceinline__ void ln_store(f32x16 (&acc)[T], const float* __restri
 // Optional fused epilogue: the IPA pair projections of the NEXT block (linear_b + down_z, ipa.py:177,253) applied
 // to the pair vector this kernel has just produced and still holds in registers in B layout (acc after ln_store).
 // Same arithmetic as pair_project_kernel on the stored values (bit-identical), minus a 512 B/pair re-read of z.
+// attention bias, head-major [B, 8, N, N] (what s2s_ipa_attention streams per head): rows 4h..4h+3 of the projection
+// (boff = offset of head 0 of this pair = p + 7*b*NN)
+__device__ __forceinline__ void store_bias_headmajor(float* __restrict__ bias_out, long long boff, long long NN, int h,
+                                                     const f32x16& acc0) {
+    float* o = bias_out + boff + 4 * h * NN;
+    o[0] = acc0[0];
+    o[NN] = acc0[1];
+    o[2 * NN] = acc0[2];
+    o[3 * NN] = acc0[3];
+}
+
 __device__ __forceinline__ void project_store(f32x16 (&zacc)[4], const float4* __restrict__ wp, const float* __restrict__ bcat,
                                               float* __restrict__ bias_out, float* __restrict__ pairz_out, long long p,
-                                              int lane, int h, bool valid) {
+                                              long long boff, long long NN, int lane, int h, bool valid) {
     f32x16 acc[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -157,7 +168,7 @@ __device__ __forceinline__ void project_store(f32x16 (&zacc)[4], const float4* _
         }
     mlp_layer<2, 16>(acc, wp, lane, [&](int s4, int q) { return zacc[s4 >> 2][(s4 & 3) * 4 + q]; });
     if (!valid) return;
-    *reinterpret_cast<float4*>(bias_out + p * 8 + 4 * h) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+    store_bias_headmajor(bias_out, boff, NN, h, acc[0]);
 #pragma unroll
     for (int g = 1; g <= 4; ++g) {
         const int t = g >> 2, rq = g & 3;
@@ -178,6 +189,7 @@ struct PairIdx {
     long long p;   // clamped flat pair index
     long long bi;  // b*N + i
     long long bj;  // b*N + j
+    long long boff;  // offset of this pair's head-0 entry in a head-major [B,8,N,N] tensor
     bool valid;
 };
 
@@ -193,6 +205,7 @@ __device__ __forceinline__ PairIdx pair_index(long long tile, int lane, long lon
     const long long i = rem / N, j = rem - i * N;
     x.bi = b * N + i;
     x.bj = b * N + j;
+    x.boff = p + 7 * b * NN;
     return x;
 }
 
@@ -300,7 +313,7 @@ __global__ void __launch_bounds__(256) edge_transition_kernel(
     }
     const float em = mask ? mask[px.bi] * mask[px.bj] : 1.0f;
     ln_store<4>(a3, gamma, beta, ln_eps, em, out + px.p * 128, h, px.valid);
-    if (proj_wp) project_store(a3, proj_wp, proj_b, proj_bias_out, proj_pz_out, px.p, lane, h, px.valid);
+    if (proj_wp) project_store(a3, proj_wp, proj_b, proj_bias_out, proj_pz_out, px.p, px.boff, (long long)N * N, lane, h, px.valid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -310,7 +323,7 @@ __global__ void __launch_bounds__(256) edge_transition_kernel(
 //   bin_tab[k] = W[:, 98+k]  for the distogram bin k of |ca_i - ca_j| (strict > lower, < upper;
 //   geo_utils.py:44-56), none when the distance sits exactly on an edge or is 0.
 // then two 128x128 MFMA layers, LayerNorm, edge mask.
-__global__ void __launch_bounds__(256) edge_embed_kernel(
+__global__ void __launch_bounds__(256, 2) edge_embed_kernel(
     const float* __restrict__ node_a, const float* __restrict__ node_b, const float* __restrict__ rel_tab,
     const float* __restrict__ bin_tab, const float* __restrict__ bin_lower, const long long* __restrict__ residue_idx,
     const float* __restrict__ ca, const float4* __restrict__ w2p, const float4* __restrict__ w3p,
@@ -372,15 +385,15 @@ __global__ void __launch_bounds__(256) edge_embed_kernel(
     mlp_layer<4, 16>(a3, w3p, lane, [&](int s4, int q) { return a2[s4 >> 2][(s4 & 3) * 4 + q]; });
     const float em = mask ? mask[px.bi] * mask[px.bj] : 1.0f;
     ln_store<4>(a3, gamma, beta, ln_eps, em, out + px.p * 128, h, px.valid);
-    if (proj_wp) project_store(a3, proj_wp, proj_b, proj_bias_out, proj_pz_out, px.p, lane, h, px.valid);
+    if (proj_wp) project_store(a3, proj_wp, proj_b, proj_bias_out, proj_pz_out, px.p, px.boff, (long long)N * N, lane, h, px.valid);
 }
 
 // ------------------------------------------------------------------------------------------
 // IPA pair projections: out = Wcat . z + bcat with Wcat = [linear_b (H rows) ; down_z (c_z/4 rows)]
-// zero-padded to 64 rows.  Writes bias_out [M, H] and pairz_out [M, PZ] (H = 8, PZ = 32).
+// zero-padded to 64 rows.  Writes bias_out [B, H, N, N] (head-major) and pairz_out [M, PZ] (H = 8, PZ = 32).
 __global__ void __launch_bounds__(256) pair_project_kernel(const float* __restrict__ edge, const float4* __restrict__ wp,
                                                            const float* __restrict__ bcat, float* __restrict__ bias_out,
-                                                           float* __restrict__ pairz_out, long long M) {
+                                                           float* __restrict__ pairz_out, long long M, long long NN) {
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const long long tile = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (tile * 32 >= M) return;
@@ -402,7 +415,7 @@ __global__ void __launch_bounds__(256) pair_project_kernel(const float* __restri
     mlp_layer<2, 16>(acc, wp, lane, [&](int s4, int q) { return q == 0 ? e[s4].x : q == 1 ? e[s4].y : q == 2 ? e[s4].z : e[s4].w; });
     if (!valid) return;
     // rows 0..7 -> attention bias (rows 0..3 live in h=0 / rq=0, rows 4..7 in h=1 / rq=0)
-    *reinterpret_cast<float4*>(bias_out + p * 8 + 4 * h) = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+    store_bias_headmajor(bias_out, p + 7 * (p / NN) * NN, NN, h, acc[0]);
     // rows 8..39 -> pair_z channel c = row - 8 : group g = row/8 in 1..4, i.e. (t, rq) = (0,1..3), (1,0)
 #pragma unroll
     for (int g = 1; g <= 4; ++g) {
@@ -455,7 +468,7 @@ int s2s_pair_project(const float* edge, const float* w_packed, const float* bias
     const long long M = (long long)n_samples * n_res * n_res;
     if (M <= 0) return 0;
     hipLaunchKernelGGL(pair_project_kernel, dim3(tiles_grid(M, 4)), dim3(256), 0, (hipStream_t)stream, edge,
-                       (const float4*)w_packed, bias_cat64, attn_bias, pair_z, M);
+                       (const float4*)w_packed, bias_cat64, attn_bias, pair_z, M, (long long)n_res * n_res);
     return (int)hipGetLastError();
 }
 

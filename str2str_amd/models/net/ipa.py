@@ -78,7 +78,7 @@ class InvariantPointAttention(nn.Module):
         attn_bias, pair_z = _pair_proj if _pair_proj is not None else ops.pair_project(z.contiguous(), d["wp"], d["b64"])
         feats = ops.ipa_attention(q.contiguous(), kv.contiguous(), q_pts, k_pts, v_pts, attn_bias, pair_z, mask, r7,
                                   d["hw"], self.no_heads, self.c_hidden, self.no_qk_points, self.no_v_points,
-                                  self.c_z // 4, self.inf, self.eps)
+                                  self.c_z // 4, self.inf, self.eps, logits_inplace=True)
         return self.linear_out(feats)
 
 

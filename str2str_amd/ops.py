@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib = None
 _tables_loaded = False
@@ -30,7 +30,8 @@ _SIGNATURES = {
     "s2s_edge_embed": [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "s2s_pair_project": [_vp] * 5 + [_i, _i, _vp],
     "s2s_ipa_prep_points": [_vp] * 6 + [_ll, _i, _i, _i, _i, _vp],
-    "s2s_ipa_attention": [_vp] * 11 + [_i, _i, _i, _i, _i, _i, _i, _f, _f, _vp],
+    "s2s_ipa_attention": [_vp] * 12 + [_i, _i, _i, _i, _i, _i, _i, _f, _f, _vp],
+    "s2s_ipa_opair": [_vp] * 4 + [_i, _i, _i, _i, _i, _i, _vp],
     "s2s_rigid_compose_update": [_vp] * 4 + [_ll, _vp],
     "s2s_rigid_scale_trans": [_vp, _vp, _ll, _f, _i, _vp],
     "s2s_set_backbone_tables": [_vp] * 4,
@@ -227,7 +228,7 @@ def _proj_args(proj, B, N, dev):
         return None, None, None, None
     wp, b64 = proj
     _req(wp, name="proj.wp"); _req(b64, name="proj.b64")
-    return (wp, b64, torch.empty(B, N, N, 8, device=dev, dtype=torch.float32),
+    return (wp, b64, torch.empty(B, 8, N, N, device=dev, dtype=torch.float32),  # attention bias is head-major
             torch.empty(B, N, N, 32, device=dev, dtype=torch.float32))
 
 
@@ -281,7 +282,7 @@ def pair_project(edge, wp, bias64, attn_bias=None, pair_z=None):
     B, N = edge.shape[0], edge.shape[1]
     _req(edge, name="edge"); _req(wp, name="wp"); _req(bias64, name="bias64")
     if attn_bias is None:
-        attn_bias = torch.empty(B, N, N, 8, device=edge.device, dtype=torch.float32)
+        attn_bias = torch.empty(B, 8, N, N, device=edge.device, dtype=torch.float32)  # head-major [B,H,N,N]
     if pair_z is None:
         pair_z = torch.empty(B, N, N, 32, device=edge.device, dtype=torch.float32)
     _check(lib.s2s_pair_project(_p(edge), _p(wp), _p(bias64), _p(attn_bias), _p(pair_z), B, N, _stream()), "s2s_pair_project")
@@ -303,17 +304,33 @@ def ipa_prep_points(rigids7, q_pts_lin, kv_pts_lin, n_heads=8, n_qk=8, n_v=12):
 
 
 def ipa_attention(q, kv, q_pts, k_pts, v_pts, attn_bias, pair_z, mask, rigids7, head_w_scaled, n_heads=8, c_hidden=256,
-                  n_qk=8, n_v=12, c_pz=32, inf=1e5, eps=1e-8, out=None):
+                  n_qk=8, n_v=12, c_pz=32, inf=1e5, eps=1e-8, out=None, logits_inplace=False):
+    """Attention core + pair term.  ``attn_bias`` is head-major [B,H,N,N] (as ``pair_project`` writes it); with
+    ``logits_inplace`` the masked logits overwrite it (the model does not reuse the bias).  Two launches:
+    s2s_ipa_attention (o, o_pt, logits, row statistics) and s2s_ipa_opair (streams pair_z once for all heads)."""
     lib = load_library()
     B, N = mask.shape
     for n, t in (("q", q), ("kv", kv), ("q_pts", q_pts), ("k_pts", k_pts), ("v_pts", v_pts), ("attn_bias", attn_bias),
                  ("pair_z", pair_z), ("mask", mask), ("rigids7", rigids7), ("head_w", head_w_scaled)):
         _req(t, name=n)
+    if attn_bias.shape != (B, n_heads, N, N) or pair_z.shape != (B, N, N, c_pz):
+        raise HipLibraryError("ipa_attention: attn_bias must be [B,H,N,N] and pair_z [B,N,N,c_pz]")
+    feat = n_heads * (c_hidden + 4 * n_v + c_pz)
     if out is None:
-        out = torch.empty(B, N, n_heads * (c_hidden + 4 * n_v + c_pz), device=q.device, dtype=torch.float32)
-    _check(_timed("s2s_ipa_attention", lambda: lib.s2s_ipa_attention(
-        _p(q), _p(kv), _p(q_pts), _p(k_pts), _p(v_pts), _p(attn_bias), _p(pair_z), _p(mask), _p(rigids7),
-        _p(head_w_scaled), _p(out), B, N, n_heads, c_hidden, n_qk, n_v, c_pz, inf, eps, _stream())), "s2s_ipa_attention")
+        out = torch.empty(B, N, feat, device=q.device, dtype=torch.float32)
+    logits = attn_bias if logits_inplace else torch.empty_like(attn_bias)
+    stats = torch.empty(B, n_heads, N, 2, device=q.device, dtype=torch.float32)
+
+    def launch():
+        rc = lib.s2s_ipa_attention(_p(q), _p(kv), _p(q_pts), _p(k_pts), _p(v_pts), _p(attn_bias), _p(logits), _p(stats),
+                                   _p(mask), _p(rigids7), _p(head_w_scaled), _p(out), B, N, n_heads, c_hidden, n_qk, n_v,
+                                   c_pz, inf, eps, _stream())
+        if rc:
+            return rc
+        return lib.s2s_ipa_opair(_p(logits), _p(stats), _p(pair_z), _p(out), B, N, n_heads, c_pz, feat,
+                                 n_heads * (c_hidden + 4 * n_v), _stream())
+
+    _check(_timed("s2s_ipa_attention", launch), "s2s_ipa_attention/s2s_ipa_opair")
     return out
 
 

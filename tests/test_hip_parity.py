@@ -210,7 +210,9 @@ def test_pair_project_vs_linear(net_rough):
     z = torch.randn(2, 19, 19, 128, generator=g).to(DEV)
     d = ipa._derived()
     b, pz = ops.pair_project(z, d["wp"], d["b64"])
-    assert rel(b, ipa.linear_b(z)) < 1e-5 and rel(pz, ipa.down_z(z)) < 1e-5
+    # the attention bias is written head-major [B,H,N,N] (the layout s2s_ipa_attention streams per head)
+    assert b.shape == (2, 8, 19, 19)
+    assert rel(b, ipa.linear_b(z).permute(0, 3, 1, 2)) < 1e-5 and rel(pz, ipa.down_z(z)) < 1e-5
 
 
 def test_ipa_golden(net_rough):

@@ -1,6 +1,12 @@
 #!/bin/bash
-# tools/build_variant.sh <name> [extra hipcc flags]: library variant with a differently compiled pair_mlp_bf16 unit
+# tools/build_variant.sh <name> [extra hipcc flags]: library variant with one differently compiled unit
+# (UNIT=pair_mlp_bf16 by default; e.g. UNIT=ipa_attention tools/build_variant.sh qr0 -DS2S_IPA_QR=0)
 N=$1; shift
+U=${UNIT:-pair_mlp_bf16}
 D=str2str_amd/csrc/build
-hipcc -x hip -c str2str_amd/csrc/pair_mlp_bf16.hip -o $D/pair_mlp_bf16_$N.o -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I include -I str2str_amd/csrc -mllvm -pragma-unroll-threshold=10000000 "$@" || exit 1
-hipcc -shared -fPIC --offload-arch=gfx950 -o $D/lib_$N.so $D/abi.o $D/rigid_kernels.o $D/se3_step.o $D/pair_mlp.o $D/pair_mlp_bf16_$N.o $D/ipa_attention.o && echo $D/lib_$N.so
+hipcc -x hip -c str2str_amd/csrc/$U.hip -o $D/${U}_$N.o -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I include -I str2str_amd/csrc -mllvm -pragma-unroll-threshold=10000000 "$@" || exit 1
+OBJS=""
+for u in abi rigid_kernels se3_step pair_mlp pair_mlp_bf16 ipa_attention; do
+  if [ $u == $U ]; then OBJS="$OBJS $D/${U}_$N.o"; else OBJS="$OBJS $D/$u.o"; fi
+done
+hipcc -shared -fPIC --offload-arch=gfx950 -o $D/lib_$N.so $OBJS && echo $D/lib_$N.so
