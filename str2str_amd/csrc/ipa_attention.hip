@@ -215,9 +215,9 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
         // VALU point term behind the MFMAs and waits on every operand right where it is loaded): the K fragment of
         // group g+1, the ring slot of Q four groups ahead and the key points of the next key row are fetched while
         // group g's MFMAs run.
-        f32x16 S;
+        f32x16 S, S1;  // two accumulation chains (even / odd groups): a dependent fp32 MFMA issues only every ~83 cycles
 #pragma unroll
-        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+        for (int r = 0; r < 16; ++r) S[r] = 0.f, S1[r] = 0.f;
         float pt[16];
         constexpr int QD = 4;
         float4 qring[QD];
@@ -243,9 +243,9 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
                 if (g + QD < QG) qring[(g - QR) % QD] = *reinterpret_cast<const float4*>(qrow + 8 * (g + QD));
             }
             S = mfma32(kf.x, qf.x, S);
-            S = mfma32(kf.y, qf.y, S);
+            S1 = mfma32(kf.y, qf.y, S1);
             S = mfma32(kf.z, qf.z, S);
-            S = mfma32(kf.w, qf.w, S);
+            S1 = mfma32(kf.w, qf.w, S1);
             if ((g & 1) == 0) {
                 const int r = g >> 1;
                 const float kpf[PQ * 3] = {kpv[0].x, kpv[0].y, kpv[0].z, kpv[0].w, kpv[1].x, kpv[1].y, kpv[1].z, kpv[1].w,
@@ -282,7 +282,7 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
             const float4 b4 = bias4[r >> 2];
             const float bias = (r & 3) == 0 ? b4.x : ((r & 3) == 1 ? b4.y : ((r & 3) == 2 ? b4.z : b4.w));
             const float sq = a.inf * (mask_i * st.km[rowmap(r, h)] - 1.0f);
-            float s = S[r] * c1 + c2 * bias;
+            float s = (S[r] + S1[r]) * c1 + c2 * bias;
             s = s + pt[r] * (-0.5f);
             s = s + sq;
             s = (j < N) ? s : -INFINITY;
@@ -323,28 +323,36 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
         // ---------------- O^T += V^T . P^T (+ value points)  (ipa.py:221-252), one output tile at a time: 16 chained MFMAs
         // over the key rows; the A operands of tile t+1 are fetched from LDS and its accumulator is rescaled by alpha
         // (16 VALU multiplies, unconditionally: no branch, no 160-register burst) while the MFMAs of tile t run.
-        float va[16];
         auto fetch_v = [&](int t, float (&dst)[16]) {
             lds_cf* base = lds_pin(t < CT ? st.v + 32 * t + c + 4 * h * C : st.vp + 32 * (t - CT) + c + 4 * h * 64);
             const int rs = t < CT ? C : 64;  // row stride; key row of register r = (r&3) + 8(r>>2) (+ 4h, in the base)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dst[r] = base[((r & 3) + 8 * (r >> 2)) * rs];
         };
-        fetch_v(0, va);
+        static_assert(OT % 2 == 0, "tiles are processed in pairs");
+        float va[2][16];
+        fetch_v(0, va[0]);
+        fetch_v(1, va[1]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) O[0][r] *= alpha;
+        for (int r = 0; r < 16; ++r) O[0][r] *= alpha, O[1][r] *= alpha;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < OT; ++t) {
-            float vc[16];
+        for (int t = 0; t < OT; t += 2) {  // two tiles = two independent MFMA chains
+            float vc[2][16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) vc[r] = va[r];
-            if (t + 1 < OT) fetch_v(t + 1, va);
+            for (int r = 0; r < 16; ++r) vc[0][r] = va[0][r], vc[1][r] = va[1][r];
+            if (t + 2 < OT) {
+                fetch_v(t + 2, va[0]);
+                fetch_v(t + 3, va[1]);
+            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) O[t] = mfma32(vc[r], S[r], O[t]);
-            if (t + 1 < OT) {
+            for (int r = 0; r < 16; ++r) {
+                O[t] = mfma32(vc[0][r], S[r], O[t]);
+                O[t + 1] = mfma32(vc[1][r], S[r], O[t + 1]);
+            }
+            if (t + 2 < OT) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) O[t + 1][r] *= alpha;
+                for (int r = 0; r < 16; ++r) O[t + 2][r] *= alpha, O[t + 3][r] *= alpha;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -361,14 +369,26 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
     const float inv = 1.0f / l_tot;
     const int feat = H * (C + 4 * PV + PZ);
     float* orow = a.out + row_i * feat;
-    if (ivalid) {
-        float* oo = orow + head * C;
+    {
+        // o: transpose through LDS (the key stages are dead; the last tile's barrier has passed) so that every query row
+        // leaves as ONE coalesced 1 KiB store per wave instead of 32 scattered 16 B stores per lane (store-issue bound).
+        // Each wave owns 32 rows x (C + 4) floats of the stage memory.
+        float* tr = reinterpret_cast<float*>(&stage[0]) + wave * 32 * KS;
+        static_assert(4 * 32 * (C + 4) * 4 <= (int)sizeof(stage), "transpose buffer fits in the stages");
 #pragma unroll
         for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq)
-                *reinterpret_cast<float4*>(oo + 32 * t + 8 * rq + 4 * h) =
+                *reinterpret_cast<float4*>(tr + c * KS + 32 * t + 8 * rq + 4 * h) =
                     make_float4(O[t][4 * rq] * inv, O[t][4 * rq + 1] * inv, O[t][4 * rq + 2] * inv, O[t][4 * rq + 3] * inv);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int i0 = qb * 128 + wave * 32;
+        for (int qq = 0; qq < 32; ++qq) {
+            if (i0 + qq >= N) break;  // wave-uniform
+            const float4 v = *reinterpret_cast<const float4*>(tr + qq * KS + 4 * lane);
+            *reinterpret_cast<float4*>(a.out + ((long long)b * N + i0 + qq) * feat + head * C + 4 * lane) = v;
+        }
     }
     {
         // frame of residue i: R = quat_to_rot(q) (rigid_utils.py:187-207), o_pt = R^T (x - t) (:1122-1133)
