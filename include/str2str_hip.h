@@ -45,12 +45,16 @@ int s2s_edge_transition(const float* edge, const float* node_ab, const float* no
                         float* proj_attn_bias, float* proj_pair_z, void* stream);
 
 /* The same operator on split-bf16 MFMA ("bf16x6": every fp32 operand split exactly into three bf16 planes, six
- * plane-pair products per MFMA block, fp32 accumulation; error <= 2^-26 per product, i.e. fp32-equivalent) at
- * 2.67x the fp32-MFMA rate.  weight_stream: 30 stages x 48 KiB of bf16 A fragments in the kernel's
- * slot order (ops.pack_bf16x3_stream; the order is part of ABI v4). */
+ * plane-pair products per MFMA block, fp32 accumulation; the dropped products are below one fp32 rounding, i.e.
+ * fp32-equivalent) at 2.67x fewer matrix-core cycles.  weight_stream: 30 stages x 48 KiB of bf16 A fragments in the
+ * kernel's slot order (ops.pack_bf16x3_stream; the order is part of the ABI version).
+ *   Optional fused epilogue (proj_attn_bias != NULL): the NEXT IPA block's linear_b / down_z (see s2s_pair_project);
+ *   the stream then carries a 31st stage with the chain-packed 64x128 [linear_b; down_z; 0] matrix, proj_bias_cat64 [64];
+ *   outputs proj_attn_bias [B,8,N,N] (head-major) and proj_pair_z [B,N,N,32]. */
 int s2s_edge_transition_bf16x6(const float* edge, const float* node_ab, const float* node_p, const void* weight_stream,
                                const float* b2, const float* bf, const float* ln_gamma, const float* ln_beta,
-                               const float* mask, float* out, int n_samples, int n_res, float ln_eps, void* stream);
+                               const float* mask, float* out, int n_samples, int n_res, float ln_eps,
+                               const float* proj_bias_cat64, float* proj_attn_bias, float* proj_pair_z, void* stream);
 
 /* EmbeddingModule.forward, edge branch (src/models/net/denoising_ipa.py:137-158, calc_distogram
  * src/common/geo_utils.py:44-56) + edge-mask multiply (denoising_ipa.py:187).

@@ -34,8 +34,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kStageBytes = 48 * 1024;  // 8 slots x 6 fragments x 1 KiB
-constexpr int kStages = 30;
-constexpr int kSlots = 8 * kStages;
+constexpr int kStagesBase = 30;  // + 1 stage (8 slots) for the fused pair projection of the next IPA block
 
 __device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -68,7 +67,8 @@ constexpr SlotDesc slot_desc(int s) {
         const int tau = s - 168;
         return {1, 10 + tau / 12, (tau % 12) / 6, tau % 6};
     }
-    return {2, 0, (s - 192) / 2, (s - 192) % 2};
+    if (s < 240) return {2, 0, (s - 192) / 2, (s - 192) % 2};
+    return {3, 0, s - 240, 0};  // P: fused projection k-step s - 240 (both output tiles)
 }
 
 #define S2S_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -81,13 +81,20 @@ __device__ unsigned long long s2s_et_probe[4][512];
 #define PROBE(idx) do { } while (0)
 #endif
 
+// PROJ: also emit the NEXT IPA block's linear_b / down_z (ipa.py:177,253) of the pair vector just produced -- one more
+// weight stage (64 x 128 Wcat, chain-packed), 8 more slots on the LayerNorm output while it is still in registers,
+// attention bias written head-major [B,8,N,N], pair_z [B,N,N,32].  Saves the 512 B/pair re-read of z by s2s_pair_project.
+template <bool PROJ>
 __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     const float* __restrict__ edge, const float* __restrict__ node_ab, const float* __restrict__ node_p,
     const char* __restrict__ wblob, const float* __restrict__ b2, const float* __restrict__ bf,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask,
-    float* __restrict__ out, long long M, int N, float ln_eps) {
+    float* __restrict__ out, long long M, int N, float ln_eps, const float* __restrict__ proj_b,
+    float* __restrict__ proj_bias_out, float* __restrict__ proj_pz_out) {
+    constexpr int kStages = kStagesBase + (PROJ ? 1 : 0);
+    constexpr int kSlots = 8 * kStages;
     __shared__ __attribute__((aligned(16))) char s_w[2][kStageBytes];
-    __shared__ __attribute__((aligned(16))) float s_vec[768];  // b2 | bf | gamma | beta
+    __shared__ __attribute__((aligned(16))) float s_vec[768 + 64];  // b2 | bf | gamma | beta | projection bias
     const int lane = threadIdx.x & 63, h = lane >> 5, wave = threadIdx.x >> 6;
 
     // ---- weight pipe (see header).  Each wave moves one contiguous 12 KiB of every stage.
@@ -132,6 +139,7 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     struct PairCtx {
         const float *erow, *arow, *brow, *npi, *npj;
         float* orow;
+        long long p, boff;  // flat pair index; offset of head 0 of this pair in a head-major [B,8,N,N] tensor
         float em;
         bool valid;
     };
@@ -150,6 +158,8 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
         c.npi = node_p + bi * 128;
         c.npj = node_p + bj * 128;
         c.orow = out + p * 128;
+        c.p = p;
+        c.boff = p + 7 * bb * NN;
         c.em = mask ? mask[bi] * mask[bj] : 1.0f;
         return c;
     };
@@ -175,6 +185,7 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
         for (int i = 0; i < 16; ++i) xv[i] = *reinterpret_cast<const float4*>(cur.erow + 16 * (i >> 1) + 8 * h + 4 * (i & 1));
         for (int i = threadIdx.x; i < 768; i += 256)
             s_vec[i] = i < 384 ? b2[i] : (i < 512 ? bf[i - 384] : (i < 640 ? gamma[i - 512] : beta[i - 640]));
+        if (PROJ && threadIdx.x < 64) s_vec[768 + threadIdx.x] = proj_b[threadIdx.x];
         cp_store_a(0);
         cp_load_a(1);
         cp_store_b(0);
@@ -188,6 +199,7 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     f32x16 a1t[2];     // layer-1 tiles t (even / odd)
     f32x16 a2[12];     // layer-2 accumulators, then relu(.)+residual = the final layer's input
     f32x16 a3[4];
+    f32x16 pq[2];      // fused projection accumulators (64 padded output rows)
     float sa[16], sb[16];  // per-node seeds A_i(+b1), B_j of the a1 tile that is split next
     auto seeds_load = [&](const PairCtx& c, int t) {  // C layout of tile t: register 4rq + e = channel 32t + 8rq + 4h + e
 #pragma unroll
@@ -229,6 +241,48 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     S2S_LDS_BARRIER();  // stage 0 and s_vec are in LDS
     PROBE(2);
     fetch(0, 0, fr[0]);
+
+    auto ln_epilogue = [&]() {
+    // ---- + bf, LayerNorm(128) over the pair's channels (half here, half in lane^32), edge mask, store
+    const float em = cur.em;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const float4 bq = ldg4(s_vec + 384, 4 * t + rq, h);
+            a3[t][4 * rq + 0] += bq.x; a3[t][4 * rq + 1] += bq.y; a3[t][4 * rq + 2] += bq.z; a3[t][4 * rq + 3] += bq.w;
+        }
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += a3[t][r];
+    const float mean = xhalf_sum(sum) * (1.0f / 128);
+    float var = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float dd = a3[t][r] - mean;
+            var += dd * dd;
+        }
+    const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / 128) + ln_eps);
+    float* orow = cur.orow;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int g = 4 * t + rq;
+            const float4 ga = ldg4(s_vec + 512, g, h), be = ldg4(s_vec + 640, g, h);
+            float4 o;
+            o.x = ((a3[t][4 * rq + 0] - mean) * rstd * ga.x + be.x) * em;
+            o.y = ((a3[t][4 * rq + 1] - mean) * rstd * ga.y + be.y) * em;
+            o.z = ((a3[t][4 * rq + 2] - mean) * rstd * ga.z + be.z) * em;
+            o.w = ((a3[t][4 * rq + 3] - mean) * rstd * ga.w + be.w) * em;
+            if (cur.valid) *reinterpret_cast<float4*>(orow + 8 * g + 4 * h) = o;
+            a3[t][4 * rq + 0] = o.x; a3[t][4 * rq + 1] = o.y; a3[t][4 * rq + 2] = o.z; a3[t][4 * rq + 3] = o.w;  // projection input
+        }
+    };
 
     for (;;) {
     const long long wt_next = wt + gridDim.x;
@@ -288,6 +342,19 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
             acc = mfma_bf16(f[3], x1[0], acc);
             // under A_t: relu + seeds + split of tile t-1, a quarter per slot
             if constexpr (d.t >= 1) s_quarter(a1t[(d.t - 1) & 1], IC<d.a>{});
+        } else if constexpr (d.phase == 3) {
+            const bf16x8 (&x)[3] = xpl[d.a];
+            f32x16 &t0 = pq[0], &t1 = pq[1];
+            if constexpr (d.a == 0) {
+                t0 = mfma_bf16(f[2], x[0], zero16); t1 = mfma_bf16(f[5], x[0], zero16);
+            } else {
+                t0 = mfma_bf16(f[2], x[0], t0); t1 = mfma_bf16(f[5], x[0], t1);
+            }
+            t0 = mfma_bf16(f[0], x[2], t0); t1 = mfma_bf16(f[3], x[2], t1);
+            t0 = mfma_bf16(f[1], x[1], t0); t1 = mfma_bf16(f[4], x[1], t1);
+            t0 = mfma_bf16(f[1], x[0], t0); t1 = mfma_bf16(f[4], x[0], t1);
+            t0 = mfma_bf16(f[0], x[1], t0); t1 = mfma_bf16(f[3], x[1], t1);
+            t0 = mfma_bf16(f[0], x[0], t0); t1 = mfma_bf16(f[3], x[0], t1);
         } else {
             constexpr bool fin = d.phase == 2;
             constexpr bool first = fin ? d.a == 0 : (d.t == 0 && d.a == 0);
@@ -323,6 +390,17 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
         // Layer-2 epilogue + split, one 128-channel block (= 8 final-layer k-steps) at a time, right before the final
         // layer consumes it:  relu(a2 + b2) + x,  x = [e | n'_i | n'_j]  (layers.py:181), in accumulator layout, split
         // while the values are in VGPRs into the plane registers the edge row used during layers 1-2.
+        if constexpr (PROJ && s == 239) {
+            // LayerNorm output (stored, and kept in a3) -> planes of the 8 projection k-steps (chain order)
+            ln_epilogue();
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const float x[4] = {a3[t][4 * rq + 0], a3[t][4 * rq + 1], a3[t][4 * rq + 2], a3[t][4 * rq + 3]};
+                    split4(x, xpl[2 * t + (rq >> 1)][0], xpl[2 * t + (rq >> 1)][1], xpl[2 * t + (rq >> 1)][2], 4 * (rq & 1));
+                }
+        }
         if constexpr (s == 191 || s == 207 || s == 223) {
             constexpr int pb = (s - 191) / 16;
             if constexpr (pb == 0) row_load(cur.erow);
@@ -342,45 +420,25 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
         }
     });
 
-    PROBE(100);
-    // ---- + bf, LayerNorm(128) over the pair's channels (half here, half in lane^32), edge mask, store
-    const float em = cur.em;
+    if constexpr (!PROJ) ln_epilogue();
+    if constexpr (PROJ) {
+        // rows 0..7 (+ bias) -> attention bias, head-major; rows 8..39 -> pair_z channel row - 8 (same map as pair_mlp.hip)
+        if (cur.valid) {
+            const float4 b0 = ldg4(s_vec + 768, 0, h);
+            float* o = proj_bias_out + cur.boff + 4 * h * NN;
+            o[0] = pq[0][0] + b0.x;
+            o[NN] = pq[0][1] + b0.y;
+            o[2 * NN] = pq[0][2] + b0.z;
+            o[3 * NN] = pq[0][3] + b0.w;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const float4 bq = ldg4(s_vec + 384, 4 * t + rq, h);
-            a3[t][4 * rq + 0] += bq.x; a3[t][4 * rq + 1] += bq.y; a3[t][4 * rq + 2] += bq.z; a3[t][4 * rq + 3] += bq.w;
+            for (int g = 1; g <= 4; ++g) {
+                const int t = g >> 2, rq = g & 3;
+                const float4 bq = ldg4(s_vec + 768, g, h);
+                *reinterpret_cast<float4*>(proj_pz_out + cur.p * 32 + 8 * (g - 1) + 4 * h) =
+                    make_float4(pq[t][4 * rq + 0] + bq.x, pq[t][4 * rq + 1] + bq.y, pq[t][4 * rq + 2] + bq.z, pq[t][4 * rq + 3] + bq.w);
+            }
         }
-    float sum = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sum += a3[t][r];
-    const float mean = xhalf_sum(sum) * (1.0f / 128);
-    float var = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float dd = a3[t][r] - mean;
-            var += dd * dd;
-        }
-    const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / 128) + ln_eps);
-    float* orow = cur.orow;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const int g = 4 * t + rq;
-            const float4 ga = ldg4(s_vec + 512, g, h), be = ldg4(s_vec + 640, g, h);
-            float4 o;
-            o.x = ((a3[t][4 * rq + 0] - mean) * rstd * ga.x + be.x) * em;
-            o.y = ((a3[t][4 * rq + 1] - mean) * rstd * ga.y + be.y) * em;
-            o.z = ((a3[t][4 * rq + 2] - mean) * rstd * ga.z + be.z) * em;
-            o.w = ((a3[t][4 * rq + 3] - mean) * rstd * ga.w + be.w) * em;
-            if (cur.valid) *reinterpret_cast<float4*>(orow + 8 * g + 4 * h) = o;
-        }
+    }
     PROBE(101);
     if (!has_next) break;
     cur = nxt;
@@ -401,7 +459,8 @@ extern "C" int s2s_debug_read_et_probe(void* dst) {
 extern "C" int s2s_edge_transition_bf16x6(const float* edge, const float* node_ab, const float* node_p,
                                           const void* weight_stream, const float* b2, const float* bf,
                                           const float* ln_gamma, const float* ln_beta, const float* mask, float* out,
-                                          int n_samples, int n_res, float ln_eps, void* stream) {
+                                          int n_samples, int n_res, float ln_eps, const float* proj_bias_cat64,
+                                          float* proj_attn_bias, float* proj_pair_z, void* stream) {
     const long long M = (long long)n_samples * n_res * n_res;
     if (M <= 0) return 0;
     const long long wg_tiles = (M + 127) / 128;
@@ -412,8 +471,13 @@ extern "C" int s2s_edge_transition_bf16x6(const float* edge, const float* node_a
             n_cu = 256;
     }
     const long long grid = wg_tiles < n_cu ? wg_tiles : n_cu;
-    hipLaunchKernelGGL(edge_transition_bf16_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
-                       edge, node_ab, node_p, (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mask, out, M, n_res,
-                       ln_eps);
+    if (proj_attn_bias)
+        hipLaunchKernelGGL(edge_transition_bf16_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, edge, node_ab,
+                           node_p, (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mask, out, M, n_res, ln_eps,
+                           proj_bias_cat64, proj_attn_bias, proj_pair_z);
+    else
+        hipLaunchKernelGGL(edge_transition_bf16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, edge, node_ab,
+                           node_p, (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mask, out, M, n_res, ln_eps,
+                           (const float*)nullptr, (float*)nullptr, (float*)nullptr);
     return (int)hipGetLastError();
 }

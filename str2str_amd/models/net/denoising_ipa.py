@@ -138,7 +138,8 @@ class EmbeddingModule(nn.Module):
         mask = None if node_mask is None else node_mask.to(dev).float().contiguous()
         e2, e4, ln = self.edge_embed[2], self.edge_embed[4], self.edge_embed[5]
         edge_embed = ops.edge_embed(node_a, node_b, rel_tab, w["bin_tab"], w["bin_lower"], idx_dev, ca, w["w2p"],
-                                    w["w3p"], e2.bias, e4.bias, ln.weight, ln.bias, mask, span, ln.eps, proj=next_proj)
+                                    w["w3p"], e2.bias, e4.bias, ln.weight, ln.bias, mask, span, ln.eps,
+                                    proj=None if next_proj is None else next_proj[:2])
         if mask is not None:
             node_embed = node_embed * mask[..., None]
         if next_proj is not None:

@@ -47,16 +47,19 @@ class InvariantPointAttention(nn.Module):
             b64 = bcat.new_zeros(64)
             b64[: bcat.numel()] = bcat
             hw = F.softplus(self.head_weights.float()) * math.sqrt(1.0 / (3 * (self.no_qk_points * 9.0 / 2)))
-            return {"wp": ops.pack_weight(wcat), "b64": b64.contiguous(), "hw": hw.contiguous()}
+            wcat64 = wcat.new_zeros(64, wcat.shape[1])
+            wcat64[: wcat.shape[0]] = wcat
+            return {"wp": ops.pack_weight(wcat), "b64": b64.contiguous(), "hw": hw.contiguous(),
+                    "wp_bf16x3": ops.pack_bf16x3_layer(wcat64, "chain").reshape(-1).view(torch.int16).contiguous()}
 
         return self._cache.get([self.linear_b.weight, self.linear_b.bias, self.down_z.weight, self.down_z.bias,
                                 self.head_weights], build)
 
     def pair_proj_weights(self):
-        """(packed [linear_b; down_z] weight, bias64): what a pair-stream producer needs to emit this block's
-        attention bias / pair_z in its own epilogue."""
+        """(packed [linear_b; down_z] weight, bias64, the same matrix as one bf16x3 weight stage): what a pair-stream
+        producer needs to emit this block's attention bias / pair_z in its own epilogue."""
         d = self._derived()
-        return d["wp"], d["b64"]
+        return d["wp"], d["b64"], d["wp_bf16x3"]
 
     def forward(self, s: torch.Tensor, z: torch.Tensor, r, mask: torch.Tensor, _rigids7: Optional[torch.Tensor] = None,
                 _pair_proj=None):

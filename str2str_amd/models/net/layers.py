@@ -102,6 +102,7 @@ class EdgeTransition(nn.Module):
         self.layer_norm = nn.LayerNorm(edge_embed_out)
         self._shape = (edge_embed_in, bias_embed_size, hidden, edge_embed_out, num_layers)
         self._cache = ParamCache()
+        self._proj_cache = ParamCache()
         # "bf16x6" (default): exact 3-way bf16 split of both operands, six plane-pair products on the bf16 MFMA with
         # fp32 accumulation — error <= 2^-26 per product, i.e. fp32-equivalent (csrc/pair_mlp_bf16.hip), 1.36x faster.
         # "f32": v_mfma_f32_32x32x2_f32 (csrc/pair_mlp.hip).  Both pass the same parity suite.
@@ -138,13 +139,17 @@ class EdgeTransition(nn.Module):
         node_ab = F.linear(n_p, pk["w_ab"], pk["b_ab"]).contiguous()
         mask = None if edge_mask_1d is None else edge_mask_1d.type(torch.float32).contiguous()
         if self.mfma_mode == "bf16x6":
-            out = ops.edge_transition_bf16x6(edge_embed.contiguous(), node_ab, n_p, pk["wstream"], self.trunk[2].bias,
-                                             self.final_layer.bias, self.layer_norm.weight, self.layer_norm.bias, mask,
-                                             self.layer_norm.eps)
-            return out if next_proj is None else (out, *ops.pair_project(out, *next_proj))
+            proj = None
+            if next_proj is not None:  # 31-stage stream: this layer's 30 stages + the next block's projection stage
+                stream = self._proj_cache.get([pk["wstream"], next_proj[2]], lambda: torch.cat([pk["wstream"], next_proj[2]]))
+                proj = (stream, next_proj[1])
+            return ops.edge_transition_bf16x6(edge_embed.contiguous(), node_ab, n_p, pk["wstream"], self.trunk[2].bias,
+                                              self.final_layer.bias, self.layer_norm.weight, self.layer_norm.bias, mask,
+                                              self.layer_norm.eps, proj=proj)
         return ops.edge_transition(edge_embed.contiguous(), node_ab, n_p, pk["w1p"], pk["w2p"], pk["wfp"],
                                    self.trunk[2].bias, self.final_layer.bias, self.layer_norm.weight,
-                                   self.layer_norm.bias, mask, self.layer_norm.eps, proj=next_proj)
+                                   self.layer_norm.bias, mask, self.layer_norm.eps,
+                                   proj=None if next_proj is None else next_proj[:2])
 
 
 class TorsionAngleHead(nn.Module):

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib = None
 _tables_loaded = False
@@ -26,7 +26,7 @@ _vp, _i, _f, _d, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_d
 _SIGNATURES = {
     "s2s_abi_version": [],
     "s2s_edge_transition": [_vp] * 12 + [_i, _i, _f, _vp, _vp, _vp, _vp, _vp],
-    "s2s_edge_transition_bf16x6": [_vp] * 10 + [_i, _i, _f, _vp],
+    "s2s_edge_transition_bf16x6": [_vp] * 10 + [_i, _i, _f, _vp, _vp, _vp, _vp],
     "s2s_edge_embed": [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "s2s_pair_project": [_vp] * 5 + [_i, _i, _vp],
     "s2s_ipa_prep_points": [_vp] * 6 + [_ll, _i, _i, _i, _i, _vp],
@@ -200,8 +200,10 @@ def pack_bf16x3_stream(w1_edge: torch.Tensor, w2: torch.Tensor, wf: torch.Tensor
 
 
 # ------------------------------------------------------------------------------------------ ops
-def edge_transition_bf16x6(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps=1e-5, out=None):
-    """EdgeTransition on split-bf16 MFMA (fp32-equivalent accuracy); same contract as ``edge_transition``."""
+def edge_transition_bf16x6(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps=1e-5, out=None, proj=None):
+    """EdgeTransition on split-bf16 MFMA (fp32-equivalent accuracy); same contract as ``edge_transition``.
+    ``proj`` = (31-stage stream = this layer's 30 stages + the next IPA block's projection stage, bias64) also
+    returns that block's (attn_bias [B,8,N,N], pair_z [B,N,N,32])."""
     lib = load_library()
     B, N = edge.shape[0], edge.shape[1]
     _req(edge, name="edge")
@@ -209,7 +211,15 @@ def edge_transition_bf16x6(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, 
         raise HipLibraryError("edge_transition_bf16x6: bad shapes")
     for n, t in (("node_ab", node_ab), ("node_p", node_p), ("b2", b2), ("bf", bf), ("gamma", gamma), ("beta", beta)):
         _req(t, name=n)
+    pb = pbias = ppz = None
+    if proj is not None:
+        wstream, pb = proj
+        _req(pb, name="proj.b64")
+        pbias = torch.empty(B, 8, N, N, device=edge.device, dtype=torch.float32)
+        ppz = torch.empty(B, N, N, 32, device=edge.device, dtype=torch.float32)
     _req(wstream, torch.int16, "wstream")
+    if wstream.numel() * 2 != (31 if proj is not None else 30) * 48 * 1024:
+        raise HipLibraryError("edge_transition_bf16x6: weight stream has the wrong number of stages")
     if mask is not None:
         _req(mask, name="mask")
     if out is None:
@@ -218,8 +228,8 @@ def edge_transition_bf16x6(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, 
         raise HipLibraryError("edge_transition: out may not alias edge")
     _check(_timed("s2s_edge_transition", lambda: lib.s2s_edge_transition_bf16x6(
         _p(edge), _p(node_ab), _p(node_p), _p(wstream), _p(b2), _p(bf), _p(gamma), _p(beta), _p(mask), _p(out), B, N,
-        ln_eps, _stream())), "s2s_edge_transition_bf16x6")
-    return out
+        ln_eps, _p(pb), _p(pbias), _p(ppz), _stream())), "s2s_edge_transition_bf16x6")
+    return out if proj is None else (out, pbias, ppz)
 
 
 def _proj_args(proj, B, N, dev):
