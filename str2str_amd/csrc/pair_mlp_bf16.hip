@@ -167,7 +167,9 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     long long wt = blockIdx.x;
     PairCtx cur = setup(wt);
 
-    // ---- the pair's 128 edge channels, split once: xpl[ks][plane] = B operand of layer-1 k-step ks (channels 16ks + 8h + j)
+    // ---- the pair's 128 edge channels, split once: xpl[ks][plane] = B operand of layer-1 k-step ks.  Element j of k-step
+    //      2t+u is channel 32t + 8(2u + (j>>2)) + 4h + (j&3): the accumulator layout of a 128-channel block (register 8u+j of
+    //      tile t), so the exact sum of the three planes later serves as the residual row of block 0 without a second read.
     bf16x8 xpl[8][3];
     auto split4 = [&](const float (&x)[4], bf16x8& ph, bf16x8& pm, bf16x8& pl, int at) {
 #pragma unroll
@@ -182,7 +184,7 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     {
         float4 xv[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) xv[i] = *reinterpret_cast<const float4*>(cur.erow + 16 * (i >> 1) + 8 * h + 4 * (i & 1));
+        for (int i = 0; i < 16; ++i) xv[i] = ldg4(cur.erow, i, h);  // accumulator ("chain") channel order, see xpl
         for (int i = threadIdx.x; i < 768; i += 256)
             s_vec[i] = i < 384 ? b2[i] : (i < 512 ? bf[i - 384] : (i < 640 ? gamma[i - 512] : beta[i - 640]));
         if (PROJ && threadIdx.x < 64) s_vec[768 + threadIdx.x] = proj_b[threadIdx.x];
@@ -316,7 +318,7 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
         if constexpr (s == 224) {
             nxt = setup(has_next ? wt_next : wt);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) xv[i] = *reinterpret_cast<const float4*>(nxt.erow + 16 * (i >> 1) + 8 * h + 4 * (i & 1));
+            for (int i = 0; i < 16; ++i) xv[i] = ldg4(nxt.erow, i, h);
         }
         if constexpr (s == 236) seeds_load(nxt, 0);
         // seeds of a1 tile t+1 are fetched late in B_t (they are consumed under A_{t+2}, or right after B_10 for tile 11)
@@ -403,7 +405,13 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
         }
         if constexpr (s == 191 || s == 207 || s == 223) {
             constexpr int pb = (s - 191) / 16;
-            if constexpr (pb == 0) row_load(cur.erow);
+            if constexpr (pb == 0) {  // residual block 0 = the edge row itself = h + m + l of its planes (exact)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        rs[8 * ks + j] = ((float)xpl[ks][0][j] + (float)xpl[ks][1][j]) + (float)xpl[ks][2][j];
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll

@@ -185,7 +185,7 @@ def pack_bf16x3_stream(w1_edge: torch.Tensor, w2: torch.Tensor, wf: torch.Tensor
       B_t (12 slots): layer-2 k-steps 2t + u (u = 0, 1) x output tile pairs 0..5, fragments [tile][plane];
       F  (48 slots): final layer k-steps 0..23 x tile pairs 0..1;
     order  A_0 A_1 | B_0 A_2 | B_1 A_3 | ... | B_9 A_11 | B_10 B_11 | F."""
-    l1 = pack_bf16x3_layer(w1_edge, "row")    # [8, 12, 3, 64, 8]
+    l1 = pack_bf16x3_layer(w1_edge, "chain")  # [8, 12, 3, 64, 8]  (the kernel reads the edge row in accumulator order)
     l2 = pack_bf16x3_layer(w2, "chain")       # [24, 12, 3, 64, 8]
     lf = pack_bf16x3_layer(wf, "chain")       # [24, 4, 3, 64, 8]
     A = lambda t: l1[:, t]                    # [8 k-steps, 3, 64, 8]
