@@ -58,13 +58,14 @@ def cpu_baseline(n_res, steps_sampled=5, replicas=2):
                       f"{n_res}-residue workload = {dt:.1f} s on the host, scaled linearly to {DENOISE_STEPS}+1 evaluations"}
 
 
-def traffic_bytes(pairs):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, read side doubled per the gfx950 correction), scaled by
-    the pairs of this launch.  None if the file is absent."""
+def traffic_bytes(pairs, mode):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_hbm_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, read side doubled per the gfx950 correction; recipe
+    tools/pmc_hbm_traffic.sh), scaled by the pairs of this launch.  None if the file is absent."""
+    name, key = ("r01f_pmc_hbm_traffic.json", "edge_transition_bf16x6") if mode == "bf16x6" else ("r01_pmc_hbm_traffic.json", "edge_transition")
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-            return json.load(f)["kernels"]["edge_transition"]["bytes_per_pair_corrected"] * pairs
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)["kernels"][key]["bytes_per_pair_corrected"] * pairs
     except Exception:
         return None
 
@@ -163,7 +164,7 @@ def main():
                          "kernel": "s2s_edge_transition" + ("_bf16x6 (edge_transition_bf16_kernel)" if mode == "bf16x6"
                                                             else " (edge_transition_kernel)"),
                          "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": traffic_bytes(pairs), "launches_timed": et_n, "mean_launch_ms": et_ms,
+                         "traffic": traffic_bytes(pairs, mode), "launches_timed": et_n, "mean_launch_ms": et_ms,
                          "algorithmic_flops_per_launch": alg, "executed_mfma_flops_per_launch": executed,
                          "fp32_equivalent_tflops": alg / (et_ms * 1e-3) / 1e12,
                          "fp32_equivalent_vs_fp32_mfma_peak": alg / (et_ms * 1e-3) / MFMA_FP32_PEAK},
