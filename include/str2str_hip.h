@@ -70,6 +70,16 @@ int s2s_edge_embed(const float* node_a, const float* node_b, const float* rel_ta
                    float ln_eps, const float* proj_w_packed, const float* proj_bias_cat64, float* proj_attn_bias,
                    float* proj_pair_z, void* stream);
 
+/* The same operator on split-bf16 MFMA (fp32-equivalent, see s2s_edge_transition_bf16x6).  weight_stream: 4 stages x 48 KiB
+ * (W2 | W3, chain-packed bf16x3 fragments in slot order: ops.pack_bf16x3_embed_stream) + a 5th stage with the
+ * [linear_b; down_z; 0] matrix when the fused projection is requested (proj_attn_bias != NULL). */
+int s2s_edge_embed_bf16x6(const float* node_a, const float* node_b, const float* rel_table, const float* bin_table,
+                          const float* bin_lower, const long long* residue_idx, const float* ca_xyz,
+                          const void* weight_stream, const float* b2, const float* b3, const float* ln_gamma,
+                          const float* ln_beta, const float* mask, float* out, int n_samples, int n_res, int rel_offset,
+                          int n_rel, int n_bins, float ln_eps, const float* proj_bias_cat64, float* proj_attn_bias,
+                          float* proj_pair_z, void* stream);
+
 /* linear_b and down_z of InvariantPointAttention (src/models/net/ipa.py:177, :253) in one pass over z.
  *   w_packed: [linear_b.weight (8 rows); down_z.weight (32 rows); 24 zero rows] (64x128) packed
  *   bias_cat64 [64]; attn_bias [B,8,N,N] (head-major: what s2s_ipa_attention streams per head); pair_z [B,N,N,32]. */

@@ -456,6 +456,327 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     }  // persistent tile loop
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Edge embedding on split-bf16 MFMA: same operator and contract as s2s_edge_embed (csrc/pair_mlp.hip; reference
+// EmbeddingModule.forward edge branch, denoising_ipa.py:137-158).  The first Linear(120 -> 128) is a sum of four gathered
+// rows (+ ReLU); the two 128 x 128 layers, LayerNorm and (PROJ) the first IPA block's linear_b / down_z run as bf16x6 slots
+// exactly like the edge transition above: 5 weight stages (W2 | W3 | Wcat), 40 slots of 12 MFMAs per 32-pair tile,
+// persistent workgroups; the NEXT tile's rows are gathered and split under the current tile's MFMAs.
+template <bool PROJ>
+__global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
+    const float* __restrict__ node_a, const float* __restrict__ node_b, const float* __restrict__ rel_tab,
+    const float* __restrict__ bin_tab, const float* __restrict__ bin_lower, const long long* __restrict__ residue_idx,
+    const float* __restrict__ ca, const char* __restrict__ wblob, const float* __restrict__ b2, const float* __restrict__ b3,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask, float* __restrict__ out,
+    long long M, int N, int rel_off, int n_rel, int n_bins, float ln_eps, const float* __restrict__ proj_b,
+    float* __restrict__ proj_bias_out, float* __restrict__ proj_pz_out) {
+    constexpr int kStages = PROJ ? 5 : 4;
+    constexpr int kSlots = 8 * kStages;
+    __shared__ __attribute__((aligned(16))) char s_w[2][kStageBytes];
+    __shared__ __attribute__((aligned(16))) float s_vec[512 + 64];  // b2 | b3 | gamma | beta | projection bias
+    __shared__ float s_bins[64];                                     // distogram bin lower edges
+    const int lane = threadIdx.x & 63, h = lane >> 5, wave = threadIdx.x >> 6;
+
+    // ---- weight pipe (identical to the edge transition's)
+    const unsigned voff = wave * 12288 + lane * 16;
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* lds_image[2] = {(lds_char*)&s_w[0][lane * 16], (lds_char*)&s_w[1][lane * 16]};
+    asm volatile("" : "+v"(lds_image[0]), "+v"(lds_image[1]));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wblob, 0, kStages * kStageBytes, 0x00020000);
+    auto ldw = [&](unsigned vo, int so) -> f32x4 {
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, vo, so, 0);
+        return f32x4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+    };
+    f32x4 c0, c1, c2, c3, c4, c5, e0, e1, e2, e3, e4, e5;
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    auto cp_load_a = [&](int stage) {
+        const int so = stage * kStageBytes;
+        c0 = ldw(voff, so); c1 = ldw(voff + 1024, so); c2 = ldw(voff + 2048, so);
+        c3 = ldw(voff + 3072, so); c4 = ldw(voff + 1024, so + 3072); c5 = ldw(voff + 2048, so + 3072);
+    };
+    auto cp_load_b = [&](int stage) {
+        const int so = stage * kStageBytes + 6144;
+        e0 = ldw(voff, so); e1 = ldw(voff + 1024, so); e2 = ldw(voff + 2048, so);
+        e3 = ldw(voff + 3072, so); e4 = ldw(voff + 1024, so + 3072); e5 = ldw(voff + 2048, so + 3072);
+    };
+    auto cp_store_a = [&](int par) {
+        lds_char* d = lds_image[par] + wave * 12288;
+        *(lds_f4*)(d) = c0; *(lds_f4*)(d + 1024) = c1; *(lds_f4*)(d + 2048) = c2;
+        *(lds_f4*)(d + 3072) = c3; *(lds_f4*)(d + 4096) = c4; *(lds_f4*)(d + 5120) = c5;
+    };
+    auto cp_store_b = [&](int par) {
+        lds_char* d = lds_image[par] + (wave * 12288 + 6144);
+        *(lds_f4*)(d) = e0; *(lds_f4*)(d + 1024) = e1; *(lds_f4*)(d + 2048) = e2;
+        *(lds_f4*)(d + 3072) = e3; *(lds_f4*)(d + 4096) = e4; *(lds_f4*)(d + 5120) = e5;
+    };
+    cp_load_a(0);
+    cp_load_b(0);
+
+    // ---- per-tile context: the four first-layer rows of this lane's pair
+    struct Ctx {
+        const float *ra, *rb, *rr, *rk;
+        float kb;
+        float* orow;
+        long long p, boff;
+        float em;
+        bool valid;
+    };
+    const long long NN = (long long)N * N;
+    // setup in two halves so that the per-pair loads (CA coordinates, residue indices, masks) are in flight for a slot
+    // before they are consumed; the distogram edges sit in LDS (s_bins)
+    struct Raw {
+        long long p, bi, bj, bb;
+        float ax, ay, az, bx, by, bz;
+        long long ii, ij;
+        float mi, mj;
+        bool valid;
+    };
+    auto setup_a = [&](long long wg_tile) -> Raw {
+        long long p = (wg_tile * 4 + wave) * 32 + (lane & 31);
+        Raw r;
+        r.valid = p < M;
+        if (!r.valid) p = M - 1;
+        r.p = p;
+        r.bb = p / NN;
+        const long long rem = p - r.bb * NN;
+        r.bi = r.bb * N + rem / N;
+        r.bj = r.bb * N + rem % N;
+        r.ax = ca[r.bi * 3 + 0]; r.ay = ca[r.bi * 3 + 1]; r.az = ca[r.bi * 3 + 2];
+        r.bx = ca[r.bj * 3 + 0]; r.by = ca[r.bj * 3 + 1]; r.bz = ca[r.bj * 3 + 2];
+        r.ii = residue_idx[r.bi];
+        r.ij = residue_idx[r.bj];
+        r.mi = mask ? mask[r.bi] : 1.0f;
+        r.mj = mask ? mask[r.bj] : 1.0f;
+        return r;
+    };
+    auto setup_b = [&](const Raw& r) -> Ctx {
+        Ctx c;
+        c.valid = r.valid;
+        // distogram bin of this pair (no FMA contraction: mirrors torch.linalg.norm of the difference; geo_utils.py:44-56)
+        const float dx = r.ax - r.bx, dy = r.ay - r.by, dz = r.az - r.bz;
+        const float dist = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+        int bin = -1;
+        for (int k = 0; k < n_bins; ++k) {
+            const float lo = s_bins[k];
+            const float up = (k + 1 < n_bins) ? s_bins[k + 1] : 1e8f;
+            if (dist > lo && dist < up) bin = k;
+        }
+        long long d = r.ii - r.ij + rel_off;
+        d = d < 0 ? 0 : (d >= n_rel ? n_rel - 1 : d);
+        c.ra = node_a + r.bi * 128;
+        c.rb = node_b + r.bj * 128;
+        c.rr = rel_tab + d * 128;
+        c.rk = bin_tab + (long long)(bin < 0 ? 0 : bin) * 128;
+        c.kb = bin < 0 ? 0.f : 1.f;
+        c.orow = out + r.p * 128;
+        c.p = r.p;
+        c.boff = r.p + 7 * r.bb * NN;
+        c.em = r.mi * r.mj;
+        return c;
+    };
+    auto split4 = [&](const float (&x)[4], bf16x8& ph, bf16x8& pm, bf16x8& pl, int at) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const __bf16 a = (__bf16)x[j];
+            const float r1 = x[j] - (float)a;
+            const __bf16 b = (__bf16)r1;
+            const float r2 = r1 - (float)b;
+            ph[at + j] = a; pm[at + j] = b; pl[at + j] = (__bf16)r2;
+        }
+    };
+    // first-layer sum in accumulator layout: g1[4G + q] = channel 8G + 4h + q, built row by row (same association as the
+    // fp32 kernel: ((a + b) + r) + kb*k)
+    float g1[64];
+    auto row_set = [&](const float* r) {
+#pragma unroll
+        for (int G = 0; G < 16; ++G) {
+            const float4 v = ldg4(r, G, h);
+            g1[4 * G + 0] = v.x; g1[4 * G + 1] = v.y; g1[4 * G + 2] = v.z; g1[4 * G + 3] = v.w;
+        }
+    };
+    float tmp[64];
+    auto row_tmp = [&](const float* r) {
+#pragma unroll
+        for (int G = 0; G < 16; ++G) {
+            const float4 v = ldg4(r, G, h);
+            tmp[4 * G + 0] = v.x; tmp[4 * G + 1] = v.y; tmp[4 * G + 2] = v.z; tmp[4 * G + 3] = v.w;
+        }
+    };
+    auto row_add = [&](float scale) {
+#pragma unroll
+        for (int i = 0; i < 64; ++i) g1[i] += scale * tmp[i];
+    };
+    // ReLU + split of first-layer k-step ks (registers 8ks .. 8ks+7 of g1: chain order) into planes
+    auto g1_split = [&](bf16x8 (&dst)[3], int ks) {
+        const float x0[4] = {fmaxf(g1[8 * ks + 0], 0.f), fmaxf(g1[8 * ks + 1], 0.f), fmaxf(g1[8 * ks + 2], 0.f), fmaxf(g1[8 * ks + 3], 0.f)};
+        const float x1[4] = {fmaxf(g1[8 * ks + 4], 0.f), fmaxf(g1[8 * ks + 5], 0.f), fmaxf(g1[8 * ks + 6], 0.f), fmaxf(g1[8 * ks + 7], 0.f)};
+        split4(x0, dst[0], dst[1], dst[2], 0);
+        split4(x1, dst[0], dst[1], dst[2], 4);
+    };
+
+    const long long n_wt = (M + 127) / 128;
+    long long wt = blockIdx.x;
+    if (threadIdx.x < 64) s_bins[threadIdx.x] = threadIdx.x < n_bins ? bin_lower[threadIdx.x] : 3.0e38f;
+    __syncthreads();
+    Ctx cur = setup_b(setup_a(wt));
+    bf16x8 xp[8][3];  // planes of the current layer's input (8 k-steps of 16)
+    {
+        row_set(cur.ra);
+        for (int i = threadIdx.x; i < 512; i += 256)
+            s_vec[i] = i < 128 ? b2[i] : (i < 256 ? b3[i - 128] : (i < 384 ? gamma[i - 256] : beta[i - 384]));
+        if (PROJ && threadIdx.x < 64) s_vec[512 + threadIdx.x] = proj_b[threadIdx.x];
+        cp_store_a(0);
+        cp_load_a(1);
+        cp_store_b(0);
+        row_tmp(cur.rb); row_add(1.0f);
+        row_tmp(cur.rr); row_add(1.0f);
+        row_tmp(cur.rk); row_add(cur.kb);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) g1_split(xp[ks], ks);
+    }
+    f32x16 a2[4], a3[4], pq[2];
+    bf16x8 fr[2][6];
+    auto fetch = [&](int par, int slot_in_stage, bf16x8 (&f)[6]) {
+        typedef __attribute__((address_space(3))) bf16x8 lds_frag;
+        const lds_frag* s = (const lds_frag*)lds_image[par] + slot_in_stage * 6 * 64;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) f[k] = s[64 * k];
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    S2S_LDS_BARRIER();
+    fetch(0, 0, fr[0]);
+
+    for (;;) {
+    const long long wt_next = wt + gridDim.x;
+    const bool has_next = wt_next < n_wt;
+    Ctx nxt = cur;
+    Raw nraw;
+    bf16x8 xpn[8][3];
+    static_for<0, kSlots>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int stage = s / 8, ss = s % 8, par = stage & 1;
+        constexpr int layer = s / 16;             // 0: layer 2, 1: layer 3, 2: projection
+        constexpr int ks = layer < 2 ? (s % 16) / 2 : s - 32;
+        constexpr int pr = layer < 2 ? s % 2 : 0;
+        if constexpr (ss < 7) {
+            fetch(par, ss + 1, fr[(s + 1) & 1]);
+            if constexpr (ss == 0) cp_load_b((stage + 1) % kStages);
+            if constexpr (ss == 4) cp_load_a((stage + 2) % kStages);
+        } else {
+            S2S_LDS_BARRIER();
+            fetch(par ^ 1, 0, fr[(s + 1) & 1]);
+        }
+        // next tile: context at slot 2, its four rows under layers 2 and 3
+        if constexpr (s == 0) nraw = setup_a(has_next ? wt_next : wt);
+        if constexpr (s == 4) row_set(nxt.ra);
+        if constexpr (s == 8) row_tmp(nxt.rb);
+        if constexpr (s == 12) row_tmp(nxt.rr);
+        if constexpr (s == 17) row_tmp(nxt.rk);
+        __builtin_amdgcn_sched_barrier(0);
+
+        const bf16x8 (&f)[6] = fr[s & 1];
+        const bf16x8 (&x)[3] = xp[ks];
+        f32x16& t0 = layer == 0 ? a2[2 * pr] : (layer == 1 ? a3[2 * pr] : pq[0]);
+        f32x16& t1 = layer == 0 ? a2[2 * pr + 1] : (layer == 1 ? a3[2 * pr + 1] : pq[1]);
+        if constexpr (ks == 0) {
+            t0 = mfma_bf16(f[2], x[0], zero16); t1 = mfma_bf16(f[5], x[0], zero16);
+        } else {
+            t0 = mfma_bf16(f[2], x[0], t0); t1 = mfma_bf16(f[5], x[0], t1);
+        }
+        t0 = mfma_bf16(f[0], x[2], t0); t1 = mfma_bf16(f[3], x[2], t1);
+        t0 = mfma_bf16(f[1], x[1], t0); t1 = mfma_bf16(f[4], x[1], t1);
+        t0 = mfma_bf16(f[1], x[0], t0); t1 = mfma_bf16(f[4], x[0], t1);
+        t0 = mfma_bf16(f[0], x[1], t0); t1 = mfma_bf16(f[3], x[1], t1);
+        t0 = mfma_bf16(f[0], x[0], t0); t1 = mfma_bf16(f[3], x[0], t1);
+        if constexpr (s == 2) nxt = setup_b(nraw);
+        if constexpr (s == 10) row_add(1.0f);
+        if constexpr (s == 14) row_add(1.0f);
+        if constexpr (s == 19) row_add(nxt.kb);
+        if constexpr (s >= 22 && s < 30) g1_split(xpn[s - 22], s - 22);  // ReLU + split of the next tile's first layer
+        if constexpr (ss == 1) cp_store_a(par ^ 1);
+        if constexpr (ss == 5) cp_store_b(par ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---------------- exposed steps
+        if constexpr (s == 15) {  // layer-2 output: + b2, ReLU, split -> layer-3 input planes
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const float4 bq = ldg4(s_vec, 4 * t + rq, h);
+                    const float xx[4] = {fmaxf(a2[t][4 * rq + 0] + bq.x, 0.f), fmaxf(a2[t][4 * rq + 1] + bq.y, 0.f),
+                                         fmaxf(a2[t][4 * rq + 2] + bq.z, 0.f), fmaxf(a2[t][4 * rq + 3] + bq.w, 0.f)};
+                    split4(xx, xp[2 * t + (rq >> 1)][0], xp[2 * t + (rq >> 1)][1], xp[2 * t + (rq >> 1)][2], 4 * (rq & 1));
+                }
+        }
+        if constexpr (s == 31) {  // layer-3 output: + b3, LayerNorm, edge mask, store (+ planes for the projection)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const float4 bq = ldg4(s_vec + 128, 4 * t + rq, h);
+                    a3[t][4 * rq + 0] += bq.x; a3[t][4 * rq + 1] += bq.y; a3[t][4 * rq + 2] += bq.z; a3[t][4 * rq + 3] += bq.w;
+                }
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += a3[t][r];
+            const float mean = xhalf_sum(sum) * (1.0f / 128);
+            float var = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dd = a3[t][r] - mean;
+                    var += dd * dd;
+                }
+            const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / 128) + ln_eps);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int g = 4 * t + rq;
+                    const float4 ga = ldg4(s_vec + 256, g, h), be = ldg4(s_vec + 384, g, h);
+                    float4 o;
+                    o.x = ((a3[t][4 * rq + 0] - mean) * rstd * ga.x + be.x) * cur.em;
+                    o.y = ((a3[t][4 * rq + 1] - mean) * rstd * ga.y + be.y) * cur.em;
+                    o.z = ((a3[t][4 * rq + 2] - mean) * rstd * ga.z + be.z) * cur.em;
+                    o.w = ((a3[t][4 * rq + 3] - mean) * rstd * ga.w + be.w) * cur.em;
+                    if (cur.valid) *reinterpret_cast<float4*>(cur.orow + 8 * g + 4 * h) = o;
+                    if constexpr (PROJ) {
+                        const float xx[4] = {o.x, o.y, o.z, o.w};
+                        split4(xx, xp[2 * t + (rq >> 1)][0], xp[2 * t + (rq >> 1)][1], xp[2 * t + (rq >> 1)][2], 4 * (rq & 1));
+                    }
+                }
+        }
+    });
+    if constexpr (PROJ) {
+        if (cur.valid) {
+            const float4 b0 = ldg4(s_vec + 512, 0, h);
+            float* o = proj_bias_out + cur.boff + 4 * h * NN;
+            o[0] = pq[0][0] + b0.x;
+            o[NN] = pq[0][1] + b0.y;
+            o[2 * NN] = pq[0][2] + b0.z;
+            o[3 * NN] = pq[0][3] + b0.w;
+#pragma unroll
+            for (int g = 1; g <= 4; ++g) {
+                const int t = g >> 2, rq = g & 3;
+                const float4 bq = ldg4(s_vec + 512, g, h);
+                *reinterpret_cast<float4*>(proj_pz_out + cur.p * 32 + 8 * (g - 1) + 4 * h) =
+                    make_float4(pq[t][4 * rq + 0] + bq.x, pq[t][4 * rq + 1] + bq.y, pq[t][4 * rq + 2] + bq.z, pq[t][4 * rq + 3] + bq.w);
+            }
+        }
+    }
+    if (!has_next) break;
+    cur = nxt;
+    wt = wt_next;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { xp[i][0] = xpn[i][0]; xp[i][1] = xpn[i][1]; xp[i][2] = xpn[i][2]; }
+    }  // persistent tile loop
+}
+
 #ifdef S2S_ET_PROBE
 extern "C" int s2s_debug_read_et_probe(void* dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(s2s_et_probe), sizeof(s2s_et_probe));
@@ -487,5 +808,32 @@ extern "C" int s2s_edge_transition_bf16x6(const float* edge, const float* node_a
         hipLaunchKernelGGL(edge_transition_bf16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, edge, node_ab,
                            node_p, (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mask, out, M, n_res, ln_eps,
                            (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    return (int)hipGetLastError();
+}
+
+extern "C" int s2s_edge_embed_bf16x6(const float* node_a, const float* node_b, const float* rel_table, const float* bin_table,
+                                     const float* bin_lower, const long long* residue_idx, const float* ca_xyz,
+                                     const void* weight_stream, const float* b2, const float* b3, const float* ln_gamma,
+                                     const float* ln_beta, const float* mask, float* out, int n_samples, int n_res,
+                                     int rel_offset, int n_rel, int n_bins, float ln_eps, const float* proj_bias_cat64,
+                                     float* proj_attn_bias, float* proj_pair_z, void* stream) {
+    const long long M = (long long)n_samples * n_res * n_res;
+    if (M <= 0) return 0;
+    if (n_bins > 64) return (int)hipErrorInvalidValue;  // the distogram edges are staged in a 64-entry LDS table
+    const long long wg_tiles = (M + 127) / 128;
+    int n_cu = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        n_cu = 256;
+    const long long grid = wg_tiles < n_cu ? wg_tiles : n_cu;
+    if (proj_attn_bias)
+        hipLaunchKernelGGL(edge_embed_bf16_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, node_a, node_b,
+                           rel_table, bin_table, bin_lower, residue_idx, ca_xyz, (const char*)weight_stream, b2, b3, ln_gamma,
+                           ln_beta, mask, out, M, n_res, rel_offset, n_rel, n_bins, ln_eps, proj_bias_cat64, proj_attn_bias,
+                           proj_pair_z);
+    else
+        hipLaunchKernelGGL(edge_embed_bf16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, node_a, node_b,
+                           rel_table, bin_table, bin_lower, residue_idx, ca_xyz, (const char*)weight_stream, b2, b3, ln_gamma,
+                           ln_beta, mask, out, M, n_res, rel_offset, n_rel, n_bins, ln_eps, (const float*)nullptr,
+                           (float*)nullptr, (float*)nullptr);
     return (int)hipGetLastError();
 }

@@ -13,6 +13,8 @@ import math
 from functools import partial
 from typing import Optional
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -64,6 +66,9 @@ class EmbeddingModule(nn.Module):
         self.position_embed = partial(get_positional_embedding, embedding_dim=pos_embed_size)
         self._dims = (init_embed_size, num_bins, float(min_bin), float(max_bin), edge_embed_size)
         self._wcache = ParamCache()
+        self._proj_cache = ParamCache()
+        # pair-stream MLP arithmetic: "bf16x6" (split-bf16 MFMA, fp32-equivalent, default) or "f32" (exact fp32 MFMA)
+        self.mfma_mode = os.environ.get("S2S_EDGE_MFMA", "bf16x6")
         self._idx_key = None
         self._idx_val = None
 
@@ -87,6 +92,7 @@ class EmbeddingModule(nn.Module):
                 "wn_t": wn[:, :ie].contiguous(), "wn_f": wn[:, ie].contiguous(), "wn_pos": wn[:, t1:t1 + ie].contiguous(),
                 "bn0": n0.bias.float().contiguous(),
                 "w2p": ops.pack_weight(e2.weight.float()), "w3p": ops.pack_weight(e4.weight.float()),
+                "wstream": ops.pack_bf16x3_embed_stream(e2.weight.float(), e4.weight.float()),
             }
             if self.self_conditioning:
                 out["bin_tab"] = w0[:, 2 * t1 + ie:2 * t1 + ie + nb].t().contiguous()
@@ -137,9 +143,18 @@ class EmbeddingModule(nn.Module):
         ca = self_conditioning_ca.to(dev).float().contiguous() if self.self_conditioning else t_emb.new_zeros(B, L, 3)
         mask = None if node_mask is None else node_mask.to(dev).float().contiguous()
         e2, e4, ln = self.edge_embed[2], self.edge_embed[4], self.edge_embed[5]
-        edge_embed = ops.edge_embed(node_a, node_b, rel_tab, w["bin_tab"], w["bin_lower"], idx_dev, ca, w["w2p"],
-                                    w["w3p"], e2.bias, e4.bias, ln.weight, ln.bias, mask, span, ln.eps,
-                                    proj=None if next_proj is None else next_proj[:2])
+        if self.mfma_mode == "bf16x6":
+            proj = None
+            if next_proj is not None:  # 5-stage stream: W2 | W3 | the first IPA block's projection stage
+                stream = self._proj_cache.get([w["wstream"], next_proj[2]], lambda: torch.cat([w["wstream"], next_proj[2]]))
+                proj = (stream, next_proj[1])
+            edge_embed = ops.edge_embed_bf16x6(node_a, node_b, rel_tab, w["bin_tab"], w["bin_lower"], idx_dev, ca,
+                                               w["wstream"], e2.bias, e4.bias, ln.weight, ln.bias, mask, span, ln.eps,
+                                               proj=proj)
+        else:
+            edge_embed = ops.edge_embed(node_a, node_b, rel_tab, w["bin_tab"], w["bin_lower"], idx_dev, ca, w["w2p"],
+                                        w["w3p"], e2.bias, e4.bias, ln.weight, ln.bias, mask, span, ln.eps,
+                                        proj=None if next_proj is None else next_proj[:2])
         if mask is not None:
             node_embed = node_embed * mask[..., None]
         if next_proj is not None:

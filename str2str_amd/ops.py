@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib = None
 _tables_loaded = False
@@ -28,6 +28,7 @@ _SIGNATURES = {
     "s2s_edge_transition": [_vp] * 12 + [_i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "s2s_edge_transition_bf16x6": [_vp] * 10 + [_i, _i, _f, _vp, _vp, _vp, _vp],
     "s2s_edge_embed": [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
+    "s2s_edge_embed_bf16x6": [_vp] * 14 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "s2s_pair_project": [_vp] * 5 + [_i, _i, _vp],
     "s2s_ipa_prep_points": [_vp] * 6 + [_ll, _i, _i, _i, _i, _vp],
     "s2s_ipa_attention": [_vp] * 12 + [_i, _i, _i, _i, _i, _i, _i, _f, _f, _vp],
@@ -284,6 +285,45 @@ def edge_embed(node_a, node_b, rel_table, bin_table, bin_lower, residue_idx, ca,
                               _p(w2p), _p(w3p), _p(b2), _p(b3), _p(gamma), _p(beta), _p(mask), _p(out), B, N,
                               int(rel_offset), rel_table.shape[0], bin_table.shape[0], ln_eps, _p(pw), _p(pb), _p(pbias),
                               _p(ppz), _stream()), "s2s_edge_embed")
+    return out if proj is None else (out, pbias, ppz)
+
+
+def pack_bf16x3_embed_stream(w2: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
+    """The 4-stage weight stream of s2s_edge_embed_bf16x6 as int16: layer 2 then layer 3, each [8 k-steps][4 tiles][3 planes]
+    chain-packed = 16 slots of (k-step, tile pair).  A projection stage (``InvariantPointAttention._derived()['wp_bf16x3']``)
+    may be appended as the 5th."""
+    blob = torch.cat([pack_bf16x3_layer(w2, "chain").reshape(-1), pack_bf16x3_layer(w3, "chain").reshape(-1)])
+    blob = blob.view(torch.int16).contiguous()
+    assert blob.numel() * 2 == 4 * 48 * 1024
+    return blob
+
+
+def edge_embed_bf16x6(node_a, node_b, rel_table, bin_table, bin_lower, residue_idx, ca, wstream, b2, b3, gamma, beta, mask,
+                      rel_offset: int, ln_eps=1e-5, out=None, proj=None):
+    """Edge embedding on split-bf16 MFMA; ``proj`` = (5-stage stream, bias64) also returns (attn_bias, pair_z)."""
+    lib = load_library()
+    B, N = node_a.shape[0], node_a.shape[1]
+    for n, t in (("node_a", node_a), ("node_b", node_b), ("rel_table", rel_table), ("bin_table", bin_table),
+                 ("bin_lower", bin_lower), ("ca", ca), ("b2", b2), ("b3", b3), ("gamma", gamma), ("beta", beta)):
+        _req(t, name=n)
+    _req(residue_idx, torch.int64, "residue_idx")
+    pb = pbias = ppz = None
+    if proj is not None:
+        wstream, pb = proj
+        _req(pb, name="proj.b64")
+        pbias = torch.empty(B, 8, N, N, device=node_a.device, dtype=torch.float32)
+        ppz = torch.empty(B, N, N, 32, device=node_a.device, dtype=torch.float32)
+    _req(wstream, torch.int16, "wstream")
+    if wstream.numel() * 2 != (5 if proj is not None else 4) * 48 * 1024:
+        raise HipLibraryError("edge_embed_bf16x6: weight stream has the wrong number of stages")
+    if mask is not None:
+        _req(mask, name="mask")
+    if out is None:
+        out = torch.empty(B, N, N, 128, device=node_a.device, dtype=torch.float32)
+    _check(lib.s2s_edge_embed_bf16x6(_p(node_a), _p(node_b), _p(rel_table), _p(bin_table), _p(bin_lower), _p(residue_idx),
+                                     _p(ca), _p(wstream), _p(b2), _p(b3), _p(gamma), _p(beta), _p(mask), _p(out), B, N,
+                                     int(rel_offset), rel_table.shape[0], bin_table.shape[0], ln_eps, _p(pb), _p(pbias),
+                                     _p(ppz), _stream()), "s2s_edge_embed_bf16x6")
     return out if proj is None else (out, pbias, ppz)
 
 

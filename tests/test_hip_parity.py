@@ -190,10 +190,22 @@ def test_edge_transition_vs_oracle(net_rough, B, N):
     assert rel(out, ref) < 2e-5, rel(out, ref)
 
 
-def test_edge_embed_golden(net_rough):
+@pytest.mark.parametrize("mode", ["bf16x6", "f32"])
+def test_edge_embed_golden(net_rough, mode):
     g = golden("embedding.npz")
-    node, edge = net_rough.embedder(residue_idx=T(g["residue_idx"]), t=T(g["t"]), fixed_mask=T(g["fixed_mask"]).to(DEV),
-                                    self_conditioning_ca=T(g["sc_ca"]).to(DEV))
+    prev = _set_edge_mode(net_rough, mode)
+    try:
+        node, edge = net_rough.embedder(residue_idx=T(g["residue_idx"]), t=T(g["t"]), fixed_mask=T(g["fixed_mask"]).to(DEV),
+                                        self_conditioning_ca=T(g["sc_ca"]).to(DEV))
+        # with the first IPA block's projection fused into the producer (what the network does)
+        ipa0 = net_rough.translator.trunk["ipa_0"]
+        _, edge2, (bias, pz) = net_rough.embedder(residue_idx=T(g["residue_idx"]), t=T(g["t"]), fixed_mask=T(g["fixed_mask"]).to(DEV),
+                                                  self_conditioning_ca=T(g["sc_ca"]).to(DEV), next_proj=ipa0.pair_proj_weights())
+    finally:
+        for m, v in prev:
+            m.mfma_mode = v
+    assert torch.equal(edge, edge2)
+    assert rel(bias, ipa0.linear_b(edge).permute(0, 3, 1, 2)) < 2e-5 and rel(pz, ipa0.down_z(edge)) < 2e-5
     assert rel(node, g["node"]) < 2e-5, rel(node, g["node"])
     d = np.abs(edge.cpu().numpy() - g["edge"]).max(-1)
     # a pair whose CA distance sits within 1 ulp of a distogram edge may legitimately land in the
