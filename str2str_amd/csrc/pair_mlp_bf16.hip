@@ -453,6 +453,11 @@ __global__ void __launch_bounds__(256) edge_transition_bf16_kernel(
     wt = wt_next;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { xpl[i][0] = xpn[i][0]; xpl[i][1] = xpn[i][1]; xpl[i][2] = xpn[i][2]; }
+    if constexpr (kStages % 2 == 1) {  // odd stage count: the next tile's stage 0 sits in the other buffer
+        lds_char* sw = lds_image[0];
+        lds_image[0] = lds_image[1];
+        lds_image[1] = sw;
+    }
     }  // persistent tile loop
 }
 
@@ -774,6 +779,11 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
     wt = wt_next;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { xp[i][0] = xpn[i][0]; xp[i][1] = xpn[i][1]; xp[i][2] = xpn[i][2]; }
+    if constexpr (kStages % 2 == 1) {  // odd stage count: the next tile's stage 0 sits in the other buffer
+        lds_char* sw = lds_image[0];
+        lds_image[0] = lds_image[1];
+        lds_image[1] = sw;
+    }
     }  // persistent tile loop
 }
 

@@ -9,6 +9,7 @@ Tolerances (float32 path; the reference itself is float32):
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import T, backbone_rmsd, golden, igso3_f32_noise, maxdiff, synth_sd
 
@@ -389,6 +390,80 @@ def test_free_running_trajectory_rmsd_both_edge_kernels(net_smooth, diffuser, mo
     rmsd = backbone_rmsd(a37.cpu().numpy()[..., :5, :], g["atom37"])
     assert rmsd < 1e-4, (mode, rmsd)
 
+
+
+
+@pytest.mark.parametrize("mode", ["bf16x6", "f32"])
+def test_pair_kernels_many_tiles_per_workgroup(net_rough, mode):
+    """More 128-pair tiles than CUs (B*N*N/128 = 1024): every persistent workgroup of the split-bf16 kernels walks several
+    tiles, with and without the fused projection (odd / even number of weight stages).  Checked against a float64
+    evaluation of the reference formulas (layers.py:170-185, ipa.py:177,253)."""
+    et, ipa1 = net_rough.translator.trunk["edge_transition_0"], net_rough.translator.trunk["ipa_1"]
+    B, N = 2, 256
+    gen = torch.Generator().manual_seed(21)
+    node = torch.randn(B, N, 256, generator=gen).to(DEV)
+    edge = torch.randn(B, N, N, 128, generator=gen).to(DEV)
+    n = et.initial_embed(node).double()
+    x = torch.cat([edge.double(), n[:, :, None, :].expand(B, N, N, -1), n[:, None, :, :].expand(B, N, N, -1)], -1)
+    hcur = x
+    for lyr in et.trunk:
+        hcur = F.linear(hcur, lyr.weight.double(), lyr.bias.double()) if isinstance(lyr, torch.nn.Linear) else F.relu(hcur)
+    ref = F.layer_norm(F.linear(hcur + x, et.final_layer.weight.double(), et.final_layer.bias.double()), (128,),
+                       et.layer_norm.weight.double(), et.layer_norm.bias.double(), et.layer_norm.eps)
+    del x, hcur
+    prev = _set_edge_mode(net_rough, mode)
+    try:
+        plain = et(node, edge)
+        out, bias, pz = et(node, edge, next_proj=ipa1.pair_proj_weights())
+    finally:
+        for m, v in prev:
+            m.mfma_mode = v
+    assert (plain.double() - ref).abs().max() < 5e-5 and (out.double() - ref).abs().max() < 5e-5
+    assert rel(bias, ipa1.linear_b(out).permute(0, 3, 1, 2)) < 2e-5 and rel(pz, ipa1.down_z(out)) < 2e-5
+    # edge embedding: both kernels agree over many tiles (the fp32 kernel is one-shot per tile)
+    emb = net_rough.embedder
+    ridx = torch.arange(N)[None].repeat(B, 1)
+    args = dict(residue_idx=ridx, t=torch.full((B,), 0.4), fixed_mask=torch.zeros(B, N).to(DEV),
+                self_conditioning_ca=(torch.randn(B, N, 3, generator=gen) * 8).to(DEV))
+    res = {}
+    for md in ("bf16x6", "f32"):
+        prev = _set_edge_mode(net_rough, md)
+        try:
+            res[md] = emb(**args, next_proj=net_rough.translator.trunk["ipa_0"].pair_proj_weights())
+        finally:
+            for m, v in prev:
+                m.mfma_mode = v
+    d = (res["bf16x6"][1] - res["f32"][1]).abs().amax(-1)
+    assert (d > 5e-5).sum() <= 4, ((d > 5e-5).sum(), d.max())   # a distogram-edge pair may flip bins (see the golden test)
+    assert rel(res["bf16x6"][2][0], res["f32"][2][0]) < 2e-5 and rel(res["bf16x6"][2][1], res["f32"][2][1]) < 2e-5
+
+def test_cfg4_shape_n512_kernels_agree_and_shard(net_smooth, diffuser):
+    """BASELINE configs[3] shape (N = 512; the oracle is too slow there): size-independent properties instead.
+    The split-bf16 and the exact-fp32 pair kernels give the same conformations, replica sharding reproduces the
+    single-process result, everything finite; N = 512 exercises 4 query blocks per head and the persistent tile loops."""
+    from str2str_amd.common.rigid_utils import Rigid
+    from str2str_amd.sampler import forward_backward
+    from str2str_amd.synth import synth_chain
+
+    N, B, S = 512, 3, 3
+    feats = synth_chain(N)
+    rig0 = Rigid.from_tensor_4x4(feats["rigidgroups_gt_frames"][..., 0, :, :].repeat(B, 1, 1, 1))
+    outs = {}
+    for mode in ("bf16x6", "f32"):
+        prev = _set_edge_mode(net_smooth, mode)
+        try:
+            torch.manual_seed(5)
+            outs[mode] = forward_backward(net_smooth, diffuser, feats, rig0, 0.5, num_timesteps=2 * S, device=DEV).cpu().numpy()
+        finally:
+            for m, v in prev:
+                m.mfma_mode = v
+    assert np.isfinite(outs["bf16x6"]).all() and outs["bf16x6"].shape == (B, N, 37, 3)
+    assert backbone_rmsd(outs["bf16x6"][..., :5, :], outs["f32"][..., :5, :]) < 1e-4
+    parts = []
+    for r in range(2):
+        torch.manual_seed(5)
+        parts.append(forward_backward(net_smooth, diffuser, feats, rig0, 0.5, num_timesteps=2 * S, device=DEV, shard=(r, 2)).cpu().numpy())
+    assert backbone_rmsd(np.concatenate(parts)[..., :5, :], outs["bf16x6"][..., :5, :]) < 5e-5
 
 @pytest.mark.parametrize("tag", ["n16_s20", "n12_prior", "n24_delta", "cfg1_n64_s20"])
 def test_free_running_trajectory_rmsd(net_smooth, diffuser, tag):
