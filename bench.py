@@ -93,11 +93,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    # S2S_BENCH_BACKEND=gloo is a TEST hook: it lets the multi-rank control flow (rendezvous, barriers, max-over-ranks
+    # timing, gather, rank-0-only output) run with several ranks sharing one GPU; the measured configuration is nccl (RCCL).
+    backend = os.environ.get("S2S_BENCH_BACKEND", "nccl")
+    local = local % torch.cuda.device_count() if backend == "gloo" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
+        # the host part of a step (forward marginal on the host generator) is tiny: keep the ranks from oversubscribing
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     ops.load_library()
 
     N, B, S = a.n_res, a.replicas, a.denoise_steps
@@ -105,14 +114,15 @@ def main():
     net = build_synthetic_net(seed=0, sigma_final=0.002, device=dev)
     diff = build_diffuser(os.path.join("/tmp", f"str2str_cache_{rank}"))
     rig0 = Rigid.from_tensor_4x4(feats["rigidgroups_gt_frames"][..., 0, :, :].repeat(B, 1, 1, 1))
-    gathered = [torch.empty(B, N, 37, 3, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gdev = dev if backend == "nccl" else torch.device("cpu")
+    gathered = [torch.empty(B, N, 37, 3, device=gdev) for _ in range(world)] if (world > 1 and rank == 0) else None
 
     def one_step(seed):
         torch.manual_seed(seed * 1000 + rank)  # independent noise per rank and step
         atom37 = forward_backward(net, diff, feats, rig0, 1.0, num_timesteps=S, min_t=0.01, probability_flow=True,
                                   self_conditioning=True, device=dev, rng="device")
         if world > 1:
-            dist.gather(atom37, gathered, dst=0)
+            dist.gather(atom37.to(gdev), gathered, dst=0)
             out = torch.stack(gathered) if rank == 0 else atom37
         else:
             out = atom37
@@ -132,7 +142,7 @@ def main():
             res = one_step(100 + k)
         barrier()
         elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    el = torch.tensor([elapsed], device=gdev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
