@@ -61,41 +61,49 @@ __global__ void __launch_bounds__(256) scale_trans_kernel(const float* __restric
 //   q_pts [M, H, Pq*3], k_pts [M, H, Pq*3]  (point-major xyz)
 //   v_pts [M, H, VP]  with VP = 4*ceil16(Pv) laid out (x,y,z,0) per point, zero padded: the
 //   4-float groups keep one point inside one lane of the attention kernel's MFMA C-layout.
+// One thread per output point (q point, k point, or one of the VP/4 value-point slots incl. padding): the coordinate-major
+// linear outputs are read with unit stride across threads and the (x,y,z,0) value points leave as one float4 per thread.
 __global__ void __launch_bounds__(256) ipa_prep_points_kernel(const float* __restrict__ rig, const float* __restrict__ qp_lin,
                                                               const float* __restrict__ kvp_lin, float* __restrict__ q_pts,
                                                               float* __restrict__ k_pts, float* __restrict__ v_pts,
                                                               long long M, int H, int Pq, int Pv, int VP) {
+    const int per_frame = H * (2 * Pq + VP / 4);
     const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= M * H) return;
-    const long long r = id / H;
-    const int h = (int)(id % H);
+    if (id >= M * per_frame) return;
+    const long long r = id / per_frame;
+    int w = (int)(id - r * per_frame);
     Quat<float> q; Vec3<float> t;
     load7(rig + r * 7, q, t);
     const Mat3<float> R = quat_to_rot<float>(q);
     const int HPq = H * Pq, HPkv = H * (Pq + Pv);
-    const float* ql = qp_lin + r * 3 * HPq;
-    const float* kl = kvp_lin + r * 3 * HPkv;
-    float* qo = q_pts + (r * H + h) * Pq * 3;
-    float* ko = k_pts + (r * H + h) * Pq * 3;
-    float* vo = v_pts + (r * H + h) * VP;
-    for (int p = 0; p < Pq; ++p) {
-        const int c = h * Pq + p;
-        const Vec3<float> a{ql[c], ql[HPq + c], ql[2 * HPq + c]};
+    if (w < HPq) {  // query point c = h*Pq + p
+        const float* ql = qp_lin + r * 3 * HPq;
+        const Vec3<float> a{ql[w], ql[HPq + w], ql[2 * HPq + w]};
         const Vec3<float> g = rot_vec_mul<float>(R, a);
-        qo[p * 3 + 0] = g.x + t.x; qo[p * 3 + 1] = g.y + t.y; qo[p * 3 + 2] = g.z + t.z;
+        float* o = q_pts + (r * HPq + w) * 3;
+        o[0] = g.x + t.x; o[1] = g.y + t.y; o[2] = g.z + t.z;
+        return;
     }
-    for (int p = 0; p < Pq + Pv; ++p) {
-        const int c = h * (Pq + Pv) + p;
+    w -= HPq;
+    const float* kl = kvp_lin + r * 3 * HPkv;
+    if (w < HPq) {  // key point (h, p): column h*(Pq+Pv) + p of the kv-point projection
+        const int hh = w / Pq, p = w - hh * Pq, c = hh * (Pq + Pv) + p;
         const Vec3<float> a{kl[c], kl[HPkv + c], kl[2 * HPkv + c]};
         const Vec3<float> g = rot_vec_mul<float>(R, a);
-        if (p < Pq) {
-            ko[p * 3 + 0] = g.x + t.x; ko[p * 3 + 1] = g.y + t.y; ko[p * 3 + 2] = g.z + t.z;
-        } else {
-            float* d = vo + (p - Pq) * 4;
-            d[0] = g.x + t.x; d[1] = g.y + t.y; d[2] = g.z + t.z; d[3] = 0.f;
-        }
+        float* o = k_pts + (r * HPq + w) * 3;
+        o[0] = g.x + t.x; o[1] = g.y + t.y; o[2] = g.z + t.z;
+        return;
     }
-    for (int x = Pv * 4; x < VP; ++x) vo[x] = 0.f;
+    w -= HPq;  // value-point slot (h, p) with p < VP/4; slots >= Pv are zero padding
+    const int slots = VP / 4, hh = w / slots, p = w - hh * slots;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < Pv) {
+        const int c = hh * (Pq + Pv) + Pq + p;
+        const Vec3<float> a{kl[c], kl[HPkv + c], kl[2 * HPkv + c]};
+        const Vec3<float> g = rot_vec_mul<float>(R, a);
+        o = make_float4(g.x + t.x, g.y + t.y, g.z + t.z, 0.f);
+    }
+    *reinterpret_cast<float4*>(v_pts + ((r * H + hh) * slots + p) * 4) = o;
 }
 
 // Backbone projection.  tables: pos[21][5][3], amask[21][5], group3[21][5] (1 if atom sits in the psi
@@ -195,7 +203,9 @@ int s2s_ipa_prep_points(const float* rigids7, const float* q_pts_lin, const floa
                         void* stream) {
     if (n_frames <= 0) return 0;
     if (v_pts_stride < 4 * n_v_points) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(ipa_prep_points_kernel, dim3(grid_for(n_frames * n_heads, 256)), dim3(256), 0, (hipStream_t)stream,
+    if (v_pts_stride % 4) return (int)hipErrorInvalidValue;
+    const long long threads = n_frames * n_heads * (2 * n_qk_points + v_pts_stride / 4);
+    hipLaunchKernelGGL(ipa_prep_points_kernel, dim3(grid_for(threads, 256)), dim3(256), 0, (hipStream_t)stream,
                        rigids7, q_pts_lin, kv_pts_lin, q_pts, k_pts, v_pts, n_frames, n_heads, n_qk_points, n_v_points,
                        v_pts_stride);
     return (int)hipGetLastError();
