@@ -73,6 +73,44 @@ def test_pack_weight_layout():
         assert float(p[s4, t, lane, q]) == want
 
 
+def test_bf16x3_split_and_stream_layout():
+    """Host side of the split-bf16 kernels: the 3-way split is EXACT, fragments sit where the kernels' lanes read them,
+    and the streams follow the slot schedule documented in csrc/pair_mlp_bf16.hip (A_0 A_1 | B_0 A_2 | ... | B_10 B_11 | F)."""
+    from str2str_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(96, 64, generator=g) * torch.logspace(-6, 3, 64)  # wide dynamic range
+    h, m, l = ops.split_bf16x3(w)
+    assert h.dtype == torch.bfloat16 and torch.equal(h.double() + m.double() + l.double(), w.double())
+    assert (m.float().abs() <= h.float().abs() * 2 ** -7 + 1e-38).all()
+
+    # chain order: element j of lane (row m, k-group g) in k-step ks is W[32t + m][32t' + (r&3) + 8(r>>2) + 4g], t' = ks>>1, r = 8(ks&1)+j
+    wk = torch.arange(64 * 64, dtype=torch.float32).reshape(64, 64)
+    pk = ops.pack_bf16x3_layer(wk, "chain")  # [KS=4, T=2, 3, 64, 8]
+    assert pk.shape == (4, 2, 3, 64, 8)
+    for ks, t, lane, j in [(0, 0, 0, 0), (1, 1, 37, 5), (3, 0, 63, 7), (2, 1, 31, 3)]:
+        r = 8 * (ks & 1) + j
+        col = 32 * (ks >> 1) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+        want = wk[32 * t + (lane & 31), col]
+        got = pk[ks, t, :, lane, j].float().sum()
+        assert float(got) == float(want), (ks, t, lane, j)
+    prow = ops.pack_bf16x3_layer(wk, "row")
+    assert float(prow[1, 0, :, 40, 2].float().sum()) == float(wk[8, 16 + 8 + 2])
+
+    # edge-transition stream: 30 stages x 8 slots x 6 fragments x (64 lanes x 8 bf16)
+    w1, w2, wf = torch.randn(384, 128, generator=g), torch.randn(384, 384, generator=g), torch.randn(128, 384, generator=g)
+    st = ops.pack_bf16x3_stream(w1, w2, wf).view(torch.bfloat16).reshape(240, 6, 64, 8)
+    l1, l2, lf = ops.pack_bf16x3_layer(w1, "chain"), ops.pack_bf16x3_layer(w2, "chain"), ops.pack_bf16x3_layer(wf, "chain")
+    assert torch.equal(st[0], l1[0:2, 0].reshape(6, 64, 8))            # A_0 slot 0: k-steps 0,1 of tile 0, [k-step][plane]
+    assert torch.equal(st[4 + 3], l1[6:8, 1].reshape(6, 64, 8))        # A_1 slot 3
+    assert torch.equal(st[8 + 7], l2[1, 2:4].reshape(6, 64, 8))        # B_0 slot (u=1, pair 1): k-step 1, tiles 2,3
+    assert torch.equal(st[8 + 12 + 1], l1[2:4, 2].reshape(6, 64, 8))   # A_2 slot 1 follows B_0
+    assert torch.equal(st[168 + 12 + 6], l2[23, 0:2].reshape(6, 64, 8))  # B_11 (u=1, pair 0): k-step 2*11+1
+    assert torch.equal(st[192 + 2 * 5 + 1], lf[5, 2:4].reshape(6, 64, 8))  # final layer k-step 5, tiles 2,3
+    es = ops.pack_bf16x3_embed_stream(torch.randn(128, 128, generator=g), torch.randn(128, 128, generator=g))
+    assert es.numel() * 2 == 4 * 48 * 1024
+
+
 def test_rotation_and_rigid_host_types():
     from str2str_amd.common import rotation3d as R3
     from str2str_amd.common.rigid_utils import Rigid, Rotation, quat_multiply, quat_to_rot
