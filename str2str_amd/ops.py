@@ -475,7 +475,16 @@ def register_torch_ops():
         "edge_transition(Tensor edge, Tensor node_ab, Tensor node_p, Tensor w1p, Tensor w2p, Tensor wfp, Tensor b2, "
         "Tensor bf, Tensor gamma, Tensor beta, Tensor? mask, float ln_eps) -> Tensor":
             lambda *a: edge_transition(*a),
+        "edge_transition_bf16x6(Tensor edge, Tensor node_ab, Tensor node_p, Tensor wstream, Tensor b2, Tensor bf, "
+        "Tensor gamma, Tensor beta, Tensor? mask, float ln_eps) -> Tensor":
+            lambda *a: edge_transition_bf16x6(*a),
+        "edge_embed_bf16x6(Tensor node_a, Tensor node_b, Tensor rel_table, Tensor bin_table, Tensor bin_lower, "
+        "Tensor residue_idx, Tensor ca, Tensor wstream, Tensor b2, Tensor b3, Tensor gamma, Tensor beta, Tensor? mask, "
+        "int rel_offset, float ln_eps) -> Tensor":
+            lambda *a: edge_embed_bf16x6(*a),
         "pair_project(Tensor edge, Tensor wp, Tensor bias64) -> (Tensor, Tensor)": lambda *a: pair_project(*a),
+        "se3_step(Tensor x0_7, Tensor xt_7, Tensor mask, Tensor diffuse_mask, Tensor params8, float dt) -> Tensor":
+            lambda x0, xt, m, dm, p8, dt: se3_step(x0, xt, m, dm, p8, dt)[0],
         "ipa_attention(Tensor q, Tensor kv, Tensor q_pts, Tensor k_pts, Tensor v_pts, Tensor attn_bias, Tensor pair_z, "
         "Tensor mask, Tensor rigids7, Tensor head_w) -> Tensor": lambda *a: ipa_attention(*a),
         "rigid_compose_update(Tensor rigids7, Tensor update6, Tensor mask) -> Tensor": lambda *a: rigid_compose_update(*a),

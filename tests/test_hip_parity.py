@@ -437,6 +437,32 @@ def test_pair_kernels_many_tiles_per_workgroup(net_rough, mode):
     assert (d > 5e-5).sum() <= 4, ((d > 5e-5).sum(), d.max())   # a distogram-edge pair may flip bins (see the golden test)
     assert rel(res["bf16x6"][2][0], res["f32"][2][0]) < 2e-5 and rel(res["bf16x6"][2][1], res["f32"][2][1]) < 2e-5
 
+
+def test_torch_ops_registration(net_rough):
+    """The kernels are also reachable as torch.ops.str2str_amd.* (SURVEY 8b): same results as the ops module."""
+    from str2str_amd import ops
+
+    ops.register_torch_ops()
+    g = golden("prims.npz")
+    r7 = torch.cat([T(g["q"]), T(g["t"])], -1).to(DEV).contiguous()
+    upd, msk = T(g["upd"]).to(DEV).contiguous(), T(g["msk"])[:, 0].to(DEV).contiguous()
+    a = torch.ops.str2str_amd.rigid_compose_update(r7, upd, msk)
+    assert torch.equal(a, ops.rigid_compose_update(r7, upd, msk))
+    et = _edge_transition_module(net_rough)
+    pk = et._packed()
+    gen = torch.Generator().manual_seed(3)
+    node, edge = torch.randn(1, 9, 256, generator=gen).to(DEV), torch.randn(1, 9, 9, 128, generator=gen).to(DEV)
+    n_p = et.initial_embed(node).contiguous()
+    node_ab = F.linear(n_p, pk["w_ab"], pk["b_ab"]).contiguous()
+    o = torch.ops.str2str_amd.edge_transition_bf16x6(edge, node_ab, n_p, pk["wstream"], et.trunk[2].bias, et.final_layer.bias,
+                                                     et.layer_norm.weight, et.layer_norm.bias, None, et.layer_norm.eps)
+    prev = _set_edge_mode(net_rough, "bf16x6")
+    try:
+        assert torch.equal(o, et(node, edge))
+    finally:
+        for m, v in prev:
+            m.mfma_mode = v
+
 def test_cfg4_shape_n512_kernels_agree_and_shard(net_smooth, diffuser):
     """BASELINE configs[3] shape (N = 512; the oracle is too slow there): size-independent properties instead.
     The split-bf16 and the exact-fp32 pair kernels give the same conformations, replica sharding reproduces the
