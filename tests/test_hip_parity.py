@@ -238,7 +238,8 @@ def test_ipa_golden(net_rough):
     assert rel(out.cpu().numpy()[valid], g["out"][valid]) < 2e-5, rel(out.cpu().numpy()[valid], g["out"][valid])
 
 
-@pytest.mark.parametrize("B,N", [(1, 7), (2, 40), (1, 96)])
+# N = 256: full 32-key tiles, two query blocks per head; N = 300: ragged last tile, three query blocks, two chunks in s2s_ipa_opair
+@pytest.mark.parametrize("B,N", [(1, 7), (2, 40), (1, 96), (1, 256), (1, 300)])
 def test_ipa_vs_oracle(net_rough, B, N):
     from oracle import geometry as OG
     from oracle import net as ON
