@@ -13,15 +13,19 @@
 //   B_t  (12 slots) layer-2 k-steps 2t, 2t+1 (= the 32 channels of a1 tile t) into all 12 output tiles; the 192
 //                   layer-2 accumulators stay resident, a1 is never materialised beyond two tiles.
 //   order: A_0 A_1 | B_0 A_2 | B_1 A_3 | ... | B_9 A_11 | B_10 B_11 | final layer (48 slots, k-step major).
-//   The ReLU + per-node seeds + split of a1 tile t (VALU) runs under A_{t+1}; the final layer's splits run under its
-//   own MFMAs.  Every activation is split exactly once: ~1.2 VALU instructions per MFMA (microbenchmark
+//   The ReLU + per-node seeds + split of a1 tile t (VALU) runs under A_{t+1}; the final layer's input (ReLU + residual +
+//   split) is produced block-wise (8 k-steps) in three exposed steps -- hiding it under the final layer's own MFMAs
+//   (3.75 VALU per MFMA) measured slower.  Every activation is split exactly once: ~1.2 VALU instructions per MFMA (microbenchmark
 //   tools/ubench/mfma_fill.hip: at most 5 independent VALU issue slots hide under one 32-cycle MFMA, a dependent one
 //   or a v_accvgpr_read costs 8 cycles, one v_pk_add_f32 costs 18).
 //   C->B chaining as in pair_mlp.hip: element j of lane (pair, g) in k-step 2t'+u is accumulator register 8u+j of
 //   tile t' (row 32t' + (r&3) + 8(r>>2) + 4g); the host packs A fragments in that k order (ops.pack_bf16x3_stream).
 //   Weight pipe: this wave's quarter of the next stage travels global -> VGPR -> LDS in two halves, each loaded (buffer
-//   loads: SGPR base + constant lane offset) three slots before it is stored; the workgroup barrier sits at the top
+//   loads: SGPR base + constant lane offset) five slots before it is stored; the workgroup barrier sits at the top
 //   of the last slot of a stage, after which the next stage's first fragments are fetched one slot ahead.
+//   Workgroups are persistent (one per CU); the next tile's edge row, seeds and weight stages are prefetched under the
+//   last final-layer block.  With the fused projection (PROJ) the stream has a 31st stage and the two LDS buffers swap
+//   roles after every tile (odd stage count).
 #include <hip/hip_runtime.h>
 
 #include "str2str_hip.h"

@@ -104,7 +104,7 @@ class EdgeTransition(nn.Module):
         self._cache = ParamCache()
         self._proj_cache = ParamCache()
         # "bf16x6" (default): exact 3-way bf16 split of both operands, six plane-pair products on the bf16 MFMA with
-        # fp32 accumulation — error <= 2^-26 per product, i.e. fp32-equivalent (csrc/pair_mlp_bf16.hip), 1.36x faster.
+        # fp32 accumulation — dropped products below one fp32 rounding, i.e. fp32-equivalent (csrc/pair_mlp_bf16.hip), 1.7x faster.
         # "f32": v_mfma_f32_32x32x2_f32 (csrc/pair_mlp.hip).  Both pass the same parity suite.
         self.mfma_mode = os.environ.get("S2S_EDGE_MFMA", "bf16x6")
         if self.mfma_mode not in ("bf16x6", "f32"):
