@@ -8,7 +8,8 @@
 // workgroup straight into LDS by the LDS-DMA (global_load_lds, no VGPR round trip), double buffered,
 // one barrier per tile, so all four waves (and the other workgroup sharing the head through L2) reuse it.
 //
-// MFMA orientation (v_mfma_f32_32x32x2_f32, exact fp32):
+// MFMA orientation (QK^T: v_mfma_f32_32x32x2_f32, exact fp32; PV: v_mfma_f32_32x32x16_bf16 on the exact 3-way bf16 split of
+// both operands, six plane-pair products, fp32 accumulate = fp32-equivalent, see pair_mlp_bf16.hip):
 //   S^T[j, i] = K[j, :] . Q[i, :]      A = key tile (row j per lane), B = Q held in registers
 //   O^T[c, i] += V^T[c, j] . P^T[j, i] A = value columns (coalesced 128 B per half wave),
 //                                       B = the S^T accumulator itself (C layout == B layout,
@@ -36,6 +37,10 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_b16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -320,39 +325,64 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
         IPROBE(64 + 4 * (j0 >> 5) + 2);
 
         IPROBE(8 * (j0 >> 5) + 3);
-        // ---------------- O^T += V^T . P^T (+ value points)  (ipa.py:221-252), one output tile at a time: 16 chained MFMAs
-        // over the key rows; the A operands of tile t+1 are fetched from LDS and its accumulator is rescaled by alpha
-        // (16 VALU multiplies, unconditionally: no branch, no 160-register burst) while the MFMAs of tile t run.
+        // ---------------- O^T += V^T . P^T (+ value points)  (ipa.py:221-252), one output tile at a time; the A operands of
+        // tile t+1 are fetched from LDS and split, and its accumulator is rescaled by alpha (16 VALU multiplies,
+        // unconditionally: a wave-uniform branch around them brought scratch spills back and ran 10 % slower) while the
+        // MFMAs of tile t run.
         auto fetch_v = [&](int t, float (&dst)[16]) {
             lds_cf* base = lds_pin(t < CT ? st.v + 32 * t + c + 4 * h * C : st.vp + 32 * (t - CT) + c + 4 * h * 64);
             const int rs = t < CT ? C : 64;  // row stride; key row of register r = (r&3) + 8(r>>2) (+ 4h, in the base)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dst[r] = base[((r & 3) + 8 * (r >> 2)) * rs];
         };
-        static_assert(OT % 2 == 0, "tiles are processed in pairs");
-        float va[2][16];
-        fetch_v(0, va[0]);
-        fetch_v(1, va[1]);
+        // PV runs on the bf16 matrix cores with the exact 3-way split of pair_mlp_bf16.hip (fp32-equivalent: six plane-pair
+        // products, fp32 accumulate): 12 x 32-cycle MFMAs per output tile instead of 16 x ~82-cycle fp32 MFMAs.  The
+        // k order of a k-step u is the accumulator order, element j <-> key row of register 8u+j, for both operands; the
+        // split of the next tile's V^T fragments (88 VALU) rides under the current tile's MFMAs.
+        bf16x8 pp[2][3];   // P^T planes (B operand), k-steps u = 0, 1
+        auto split8 = [&](const float* v, bf16x8 (&d)[3]) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) O[0][r] *= alpha, O[1][r] *= alpha;
+            for (int j = 0; j < 8; ++j) {
+                const __bf16 a_ = (__bf16)v[j];
+                const float r1 = v[j] - (float)a_;
+                const __bf16 b_ = (__bf16)r1;
+                const float r2 = r1 - (float)b_;
+                d[0][j] = a_; d[1][j] = b_; d[2][j] = (__bf16)r2;
+            }
+        };
+        {
+            float pv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pv[r] = S[r];
+            split8(pv, pp[0]);
+            split8(pv + 8, pp[1]);
+        }
+        float va[16];
+        bf16x8 av[2][2][3];  // [buffer][k-step][plane] of V^T fragments (A operand)
+        fetch_v(0, va);
+        split8(va, av[0][0]);
+        split8(va + 8, av[0][1]);
+        fetch_v(1, va);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[0][r] *= alpha;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < OT; t += 2) {  // two tiles = two independent MFMA chains
-            float vc[2][16];
+        for (int t = 0; t < OT; ++t) {
+            const bf16x8 (&a0)[3] = av[t & 1][0], (&a1)[3] = av[t & 1][1];
+            f32x16 o = O[t];
+            o = mfma_b16(a0[2], pp[0][0], o); o = mfma_b16(a0[0], pp[0][2], o); o = mfma_b16(a0[1], pp[0][1], o);
+            o = mfma_b16(a0[1], pp[0][0], o); o = mfma_b16(a0[0], pp[0][1], o); o = mfma_b16(a0[0], pp[0][0], o);
+            o = mfma_b16(a1[2], pp[1][0], o); o = mfma_b16(a1[0], pp[1][2], o); o = mfma_b16(a1[1], pp[1][1], o);
+            o = mfma_b16(a1[1], pp[1][0], o); o = mfma_b16(a1[0], pp[1][1], o); o = mfma_b16(a1[0], pp[1][0], o);
+            O[t] = o;
+            if (t + 1 < OT) {
+                bf16x8 (&n0)[3] = av[(t + 1) & 1][0], (&n1)[3] = av[(t + 1) & 1][1];
+                split8(va, n0);
+                split8(va + 8, n1);
+                asm volatile("" : "+v"(n0[0]), "+v"(n0[1]), "+v"(n0[2]), "+v"(n1[0]), "+v"(n1[1]), "+v"(n1[2]));
+                if (t + 2 < OT) fetch_v(t + 2, va);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) vc[0][r] = va[0][r], vc[1][r] = va[1][r];
-            if (t + 2 < OT) {
-                fetch_v(t + 2, va[0]);
-                fetch_v(t + 3, va[1]);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                O[t] = mfma32(vc[0][r], S[r], O[t]);
-                O[t + 1] = mfma32(vc[1][r], S[r], O[t + 1]);
-            }
-            if (t + 2 < OT) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) O[t + 2][r] *= alpha, O[t + 3][r] *= alpha;
+                for (int r = 0; r < 16; ++r) O[t + 1][r] *= alpha;
             }
             __builtin_amdgcn_sched_barrier(0);
         }
