@@ -62,7 +62,7 @@ def traffic_bytes(pairs, mode):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_hbm_traffic.json:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, read side doubled per the gfx950 correction; recipe
     tools/pmc_hbm_traffic.sh), scaled by the pairs of this launch.  None if the file is absent."""
-    name, key = ("r01f_pmc_hbm_traffic.json", "edge_transition_bf16x6") if mode == "bf16x6" else ("r01_pmc_hbm_traffic.json", "edge_transition")
+    name, key = ("r01i_pmc_hbm_traffic.json", "edge_transition_bf16x6") if mode == "bf16x6" else ("r01_pmc_hbm_traffic.json", "edge_transition")
     try:
         with open(os.path.join(ROOT, "profiles", name)) as f:
             return json.load(f)["kernels"][key]["bytes_per_pair_corrected"] * pairs
