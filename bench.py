@@ -176,6 +176,9 @@ def main():
                          "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
                          "traffic": traffic_bytes(pairs, mode), "launches_timed": et_n, "mean_launch_ms": et_ms,
                          "algorithmic_flops_per_launch": alg, "executed_mfma_flops_per_launch": executed,
+                         # what a bare MFMA loop on random operands sustains under this part's 1400 W cap
+                         # (tools/ubench/mfma_shape_power.hip): context for `frac`, which uses the nominal peak
+                         "power_limited_mfma_rate_measured": 1800.0 if mode == "bf16x6" else None,
                          "fp32_equivalent_tflops": alg / (et_ms * 1e-3) / 1e12,
                          "fp32_equivalent_vs_fp32_mfma_peak": alg / (et_ms * 1e-3) / MFMA_FP32_PEAK},
             "ipa_kernel": {"bound": "hbm", "kernel": "s2s_ipa_attention", "mean_launch_ms": ipa_ms, "launches_timed": ipa_n,
