@@ -322,7 +322,7 @@ def _batch(g, dev):
 
 
 def test_denoising_net_golden(net_rough):
-    for tag in ("b1n10", "b2n16"):
+    for tag in ("b1n10", "b2n16", "b1n256"):  # b1n256: the bench shape (one reference evaluation at N = 256)
         g = golden(f"net_{tag}.npz")
         out = net_rough(_batch(g, DEV))
         assert maxdiff(out["rigids"].to_tensor_7().cpu(), g["rigids7"]) < 5e-4, tag
