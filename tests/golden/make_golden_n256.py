@@ -16,5 +16,27 @@ def main():
           atom37=out["atom37"][..., :5, :], atom14=out["atom14"][..., :5, :])
 
 
+def trajectory():
+    """Free-running reference trajectory at N = 256 (B = 2 -> 1024 tiles of 128 pairs: every persistent workgroup of the pair
+    kernels walks several tiles), 5 denoise steps, contractive weights -> tests/golden/traj_free_n256_s5.npz (~2 min)."""
+    from str2str_amd.synth import synth_chain
+
+    diff = G.build_diffuser()
+    net2, _ = G.build_net(seed=0, sigma_final=0.002)
+    N, B, S, td = 256, 2, 5, 1.0
+    feats = synth_chain(N)
+    rig0 = G.Rigid.from_tensor_4x4(feats["rigidgroups_gt_frames"][..., 0, :, :].clone().repeat(B, 1, 1, 1))
+    torch.manual_seed(42)
+    trace = []
+    atom37, ts, dt = G.ref_forward_backward(net2, diff, feats, rig0, td, num_timesteps=S, trace=trace)
+    G.npz("traj_free_n256_s5.npz", atom37=atom37[..., :5, :], ts=ts.copy(), dt=dt, seed=42, n_res=N, B=B, num_timesteps=S,
+          t_delta=td, first_rigids_t=trace[0]["rigids_t"], last_x0=trace[-1]["x0"])
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+
+    if "--trajectory" in sys.argv:
+        trajectory()
+    else:
+        main()

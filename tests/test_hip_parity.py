@@ -492,7 +492,7 @@ def test_cfg4_shape_n512_kernels_agree_and_shard(net_smooth, diffuser):
         parts.append(forward_backward(net_smooth, diffuser, feats, rig0, 0.5, num_timesteps=2 * S, device=DEV, shard=(r, 2)).cpu().numpy())
     assert backbone_rmsd(np.concatenate(parts)[..., :5, :], outs["bf16x6"][..., :5, :]) < 5e-5
 
-@pytest.mark.parametrize("tag", ["n16_s20", "n12_prior", "n24_delta", "cfg1_n64_s20"])
+@pytest.mark.parametrize("tag", ["n16_s20", "n12_prior", "n24_delta", "cfg1_n64_s20", "n256_s5"])
 def test_free_running_trajectory_rmsd(net_smooth, diffuser, tag):
     """Same input, same seed, contractive synthetic weights: backbone RMSD vs the reference <= 1e-4 A."""
     from str2str_amd.common.rigid_utils import Rigid
