@@ -120,7 +120,7 @@ class EmbeddingModule(nn.Module):
         return self._idx_val
 
     def forward(self, residue_idx, t, fixed_mask, self_conditioning_ca, node_mask: Optional[torch.Tensor] = None,
-                next_proj=None):
+                next_proj=None, t_emb: Optional[torch.Tensor] = None):
         """-> node_embed [B,N,D_node], edge_embed [B,N,N,D_edge] (reference :107-159).  ``t`` may live on
         the host (the sampler knows it there): its embedding is then computed on the host and uploaded.
         ``node_mask`` optionally fuses DenoisingNet's mask multiplies (reference :186-187); ``next_proj`` (packed
@@ -134,7 +134,13 @@ class EmbeddingModule(nn.Module):
         B, L = residue_idx.shape
         rel_tab, span, node_pos, idx_dev = self._index_tables(residue_idx, w["w_rel"], w["wn_pos"])
         fixed = fixed_mask.to(dev)[..., None].float()
-        t_emb = self.time_embed(t).to(dev)  # [B, 32]
+        # [B, 32]; evaluated once per DISTINCT t (a sampler chunk shares one t, and the host sin/cos of arguments up to 1e4 rad
+        # costs ~40 us per element): same values, row for row
+        if t_emb is not None:   # the sampler uploads the embeddings of the whole schedule once: no per-step H2D copy
+            t_emb = t_emb.to(dev).reshape(-1, t_emb.shape[-1]).expand(B, -1)   # (a host->device copy here would make the
+        else:                                                                  #  host wait for the GPU every evaluation)
+            t_u, t_inv = torch.unique(t.detach().reshape(-1), return_inverse=True)
+            t_emb = self.time_embed(t_u)[t_inv].to(dev)
         ne = self.node_embed
         h = F.relu(F.linear(t_emb, w["wn_t"], w["bn0"])[:, None, :] + fixed * w["wn_f"] + node_pos)
         node_embed = ne[5](ne[4](F.relu(ne[2](h))))
@@ -180,7 +186,7 @@ class DenoisingNet(nn.Module):
         fixed_mask = batch["fixed_mask"].to(dev).type(torch.float)
         fuse = getattr(self.translator, "fuse_pair_projection", False)
         emb = self.embedder(residue_idx=batch["residue_idx"], t=batch["t"], fixed_mask=fixed_mask,
-                            self_conditioning_ca=batch["sc_ca_t"], node_mask=node_mask,
+                            self_conditioning_ca=batch["sc_ca_t"], node_mask=node_mask, t_emb=batch.get("t_emb"),
                             next_proj=self.translator.trunk["ipa_0"].pair_proj_weights() if fuse else None)
         node_embed, edge_embed = emb[0], emb[1]
         tb = dict(batch)

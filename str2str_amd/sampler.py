@@ -56,6 +56,8 @@ def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: flo
     diffuse_mask = ((1 - feats["fixed_mask"].float()) * mask).contiguous()
     t_all = torch.as_tensor(np.ascontiguousarray(ts, dtype=np.float64)).float()  # fl32(t), as `t * torch.ones(B)` gives
     p8_all = diffuser.step_params(t_all).to(device)  # [n, 8]: t is uniform over the chunk
+    # timestep embeddings of the whole schedule, uploaded once (same host function the network would call per step)
+    temb_all = net.embedder.time_embed(t_all).to(device) if hasattr(getattr(net, "embedder", None), "time_embed") else None
     keep_bb = getattr(net, "backbone_in_forward", None)
     if keep_bb is not None:
         net.backbone_in_forward = False
@@ -64,10 +66,14 @@ def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: flo
         feats["sc_ca_t"] = torch.zeros(b, N, 3, device=device)
         if self_conditioning:
             feats["t"] = torch.full((b,), float(ts[0]), dtype=torch.float32)
+            if temb_all is not None:
+                feats["t_emb"] = temb_all[0]
             feats["sc_ca_t"] = net(feats, as_tensor_7=True)["rigids7"][..., 4:]
         final = None
         for k, t in enumerate(ts):
             feats["t"] = torch.full((b,), float(t), dtype=torch.float32)
+            if temb_all is not None:
+                feats["t_emb"] = temb_all[k]
             out = net(feats, as_tensor_7=False)
             x0_7 = out["rigids7"]
             if t == min_t:
