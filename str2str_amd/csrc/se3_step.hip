@@ -14,10 +14,13 @@
 // computed on the host once per trajectory with the reference's own float32 formulae and passed
 // in `params` (8 floats per sample): no np.digitize round trip inside the loop.
 //
-// IGSO(3) series: the argument omega*(l+1/2) is rounded to float32 exactly as the reference does,
-// sin/cos of that argument and the 1000-term sums are evaluated in float64 (the reference sums
-// float32 terms; ours is the better-conditioned evaluation of the same series).  Terms whose
-// float32 weight exp(-l(l+1)sigma^2/2) underflowed to 0 contribute exactly 0 and are skipped.
+// IGSO(3) series: omega (float32, from the reference's float32 conversion chain) and the float32 weights are promoted
+// and the 1000-term sums of so3.py:21-62 / :85-130 are evaluated entirely in float64 -- the exact value of the formula the
+// reference evaluates in float32.  Where that formula is well conditioned the two agree to float32 rounding; where it is
+// not (f << sum|terms|, or the O(omega^3) difference lo*dhi - hi*dlo at small omega) the reference's own float32 value is
+// rounding noise around this one.  Parity is judged against float64 anchors generated from the reference's own functions
+// (tests/golden/make_golden_score64.py): |ours - ref64| <= |ref32 - ref64| + 4e-5 |s| per residue.  Terms whose float32
+// weight exp(-l(l+1)sigma^2/2) underflowed to 0 contribute exactly 0 and are skipped.
 #include <hip/hip_runtime.h>
 
 #include "geom.h"
@@ -38,7 +41,7 @@ __global__ void __launch_bounds__(kThreads) se3_step_kernel(
     const double* __restrict__ trans_score_in, float* __restrict__ next7, double* __restrict__ rot_score_out,
     double* __restrict__ trans_score_out, int N, double dt, double coord_scale_d, int probability_flow, int center,
     double noise_scale) {
-    __shared__ float s_cw[kL];       // (2l+1) * exp(-l(l+1) sigma^2 / 2), float32 like the reference
+    __shared__ double s_cw[kL];      // (2l+1) * exp(-l(l+1) sigma^2 / 2) in float64 (sigma = the float32 bin value)
     __shared__ int s_leff;
     __shared__ double s_red[4][kThreads / 64];
     __shared__ double s_com[3];
@@ -54,13 +57,13 @@ __global__ void __launch_bounds__(kThreads) se3_step_kernel(
     if (tid == 0) s_leff = 0;
     __syncthreads();
     {
-        const float s2 = sigma * sigma;
+        const double s2 = (double)sigma * (double)sigma;
         int last = 0;
         for (int l = tid; l < kL; l += kThreads) {
-            const float a = -(float)(l * (l + 1));
-            const float w = expf(a * s2 / 2.0f);
-            s_cw[l] = (float)(2 * l + 1) * w;
-            if (w != 0.0f) last = l + 1;
+            const double a = -(double)(l * (l + 1));
+            const double w = exp(a * s2 / 2.0);
+            s_cw[l] = (double)(2 * l + 1) * w;
+            if ((float)w != 0.0f) last = l + 1;  // below the float32 underflow the reference's term is exactly 0
         }
         atomicMax(&s_leff, last);
     }
@@ -101,17 +104,17 @@ __global__ void __launch_bounds__(kThreads) se3_step_kernel(
         const Vec3<float> v = quaternion_to_axis_angle<float>(quat_multiply<float>(q0i, qtm));
         const float omega = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z) + 1e-6f;
 
-        const double lo = sin((double)(omega / 2.0f));
-        const double dlo = 0.5 * cos((double)(omega / 2.0f));
+        const double omd = (double)omega;
+        const double lo = sin(omd / 2.0);
+        const double dlo = 0.5 * cos(omd / 2.0);
         double f = 0.0, df = 0.0;
         for (int l = 0; l < leff; ++l) {
-            const float lh = (float)l + 0.5f;
-            const float arg = omega * lh;  // float32 product, as in the reference
+            const double lh = (double)l + 0.5;
             double hi, ch;
-            sincos((double)arg, &hi, &ch);
-            const double cw = (double)s_cw[l];
+            sincos(omd * lh, &hi, &ch);
+            const double cw = s_cw[l];
             f += cw * hi / lo;
-            df += cw * (lo * ((double)lh * ch) - hi * dlo) / (lo * lo);
+            df += cw * (lo * (lh * ch) - hi * dlo) / (lo * lo);
         }
         const float ff = (float)f;
         const float sc = (float)df / (ff + 1e-4f);

@@ -11,7 +11,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import T, backbone_rmsd, golden, igso3_f32_noise, maxdiff, synth_sd
+from conftest import T, backbone_rmsd, golden, maxdiff, record_margin, synth_sd
 
 pytestmark = pytest.mark.gpu
 
@@ -93,33 +93,25 @@ def test_frames_to_backbone_golden():
     assert (m37.cpu().numpy() == g["mask37"]).all()
 
 
-def _rotvec_0t(x0_7, xt_7):
-    """log(R0^T R_t) through the oracle's conversion chain (inputs: numpy / cpu tensors)."""
-    from oracle import geometry as OG
-
-    x0, xt = OG.Frames.from_tensor_7(T(x0_7)), OG.Frames.from_tensor_7(T(xt_7))
-    q0i = OG.matrix_to_quaternion(OG.Frames(x0.trans, quats=OG.invert_quat(x0.quats)).get_rot_mats())
-    return OG.quaternion_to_axis_angle(OG.quat_multiply(q0i, OG.matrix_to_quaternion(xt.get_rot_mats())))
-
-
-def _assert_rot_score_close(got, want, rotvec, sigma, what=""):
-    """|got - want| <= (4e-5 + 8 * float32-noise bound of the REFERENCE's own series) * |score|."""
-    relb, _ = igso3_f32_noise(rotvec, sigma)
-    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
-    mag = np.linalg.norm(want, axis=-1, keepdims=True) + 1e-6
-    err = np.abs(got - want) / mag
-    tol = 4e-5 + 8 * relb[..., None]
-    # where the bound exceeds 5 % the reference's own float32 value is rounding noise (f + 1e-4 can even
-    # change sign): nothing meaningful to compare there beyond finiteness
-    judged = relb < 0.05
+def _assert_rot_score_close(got, ref32, ref64, what=""):
+    """Float64-anchored bound (tests/golden/make_golden_score64.py): the reference's own functions evaluated in float64
+    on the same rotation vectors say how far the reference's float32 value is from the exact value of its formula.  Per
+    residue:   |ours - ref64| <= |ref32 - ref64| + 4e-5 |ref64|   (no fitted constants, nothing excluded).
+    Returns the mask of residues where the reference itself is well conditioned (|ref32 - ref64| <= 1e-5 |ref64|)."""
+    got, ref32, ref64 = (np.asarray(x, dtype=np.float64) for x in (got, ref32, ref64))
+    mag = np.linalg.norm(ref64, axis=-1)
+    e_hip = np.linalg.norm(got - ref64, axis=-1)
+    e_ref = np.linalg.norm(ref32 - ref64, axis=-1)
+    tol = e_ref + 4e-5 * mag
     assert np.isfinite(got).all()
-    assert (err[judged] <= np.broadcast_to(tol, err.shape)[judged]).all(), (
-        what, float((err / tol)[judged].max()), float(err[judged].max()))
-    # and the well-conditioned majority must agree to float32 accuracy
-    good = relb < 1e-5
-    if good.any():
-        assert float(err[good].max()) < 1e-4, (what, float(err[good].max()))
-    return relb
+    record_margin(f"rot_score[{what}]: max |ours-ref64| / (|ref32-ref64| + 4e-5|s|)", float((e_hip / np.maximum(tol, 1e-300)).max()), 1.0)
+    assert (e_hip <= tol).all(), (what, float((e_hip / np.maximum(tol, 1e-300)).max()))
+    good = (e_ref <= 1e-5 * mag) & (mag > 0)
+    if good.any():  # where the reference is float32-accurate, so are we -- against the reference's own value
+        rel32 = float((np.linalg.norm(got - ref32, axis=-1)[good] / mag[good]).max())
+        record_margin(f"rot_score[{what}]: max rel |ours-ref32| on well-conditioned residues", rel32, 4e-5)
+        assert rel32 < 4e-5, (what, rel32)
+    return good
 
 
 def _edge_transition_module(net):
@@ -269,8 +261,7 @@ def test_se3_step_golden(diffuser):
     sc = diffuser.score(Rigid.from_tensor_7(x0), Rigid.from_tensor_7(xt), t, mask.to(DEV))
     assert sc["rot_score"].dtype == torch.float64
     assert rel(sc["trans_score"], g["trans_score"]) < 1e-5
-    sigma = diffuser.step_params(t)[:, 0]
-    _assert_rot_score_close(sc["rot_score"].cpu().numpy(), g["rot_score"], _rotvec_0t(g["x0"], g["xt"]), sigma, "score")
+    _assert_rot_score_close(sc["rot_score"].cpu().numpy(), g["rot_score"], golden("score64.npz")["sr_score64"], "score_reverse")
     # reverse from the reference's own scores (probability-flow ODE)
     nxt = diffuser.reverse(Rigid.from_tensor_7(xt), T(g["rot_score"]).to(DEV), T(g["trans_score"]).to(DEV), t, float(g["dt"]),
                            mask.to(DEV), True, 1.0, True)
@@ -304,12 +295,8 @@ def test_so3_score_grid(diffuser):
     # compare on the unambiguous range
     ang = vec.norm(dim=-1).numpy()
     ok = ang < 1.5  # w > |xyz|: candidate 0 of matrix_to_quaternion, no 2*pi wrap
-    relb, _ = igso3_f32_noise(vec, p8[:, 0].cpu())
-    got, want = rs.cpu().numpy(), g["score"]
-    err = np.abs(got - want) / (np.linalg.norm(want, axis=-1, keepdims=True) + 1e-6)
-    tol = 4e-5 + 8 * relb[..., None]
-    assert (err[ok] <= tol[ok]).all(), float((err[ok] / tol[ok]).max())
-    assert (ok & (relb < 1e-5)).sum() > 20 and float(err[ok & (relb < 1e-5)].max()) < 1e-4
+    good = _assert_rot_score_close(rs.cpu().numpy()[ok], g["score"][ok], golden("score64.npz")["grid_score64"][ok], "omega grid")
+    assert good.sum() > 20
 
 
 def _batch(g, dev):
@@ -336,6 +323,7 @@ def test_teacher_forced_trajectory(net_rough, diffuser):
     from str2str_amd.synth import synth_chain
 
     g = golden("traj_teacher_n16.npz")
+    s64 = golden("score64.npz")
     B = int(g["B"])
     feats = synth_chain(int(g["n_res"]))
     f = {k: v.repeat(B, *(1,) * (v.ndim - 1)).to(DEV) for k, v in feats.items()
@@ -355,11 +343,9 @@ def test_teacher_forced_trajectory(net_rough, diffuser):
             p8 = diffuser.step_params(f["t"]).to(DEV)
             nxt, rs, tsc = diffuser.step(T(g["x0"][i]).to(DEV), f["rigids_t"].contiguous(), p8, dt, mask, mask,
                                          want_scores=True)
-            relb = _assert_rot_score_close(rs.cpu().numpy(), g["rot_score"][i], _rotvec_0t(g["x0"][i], g["rigids_t"][i]),
-                                           p8[:, 0].cpu(), f"step {i}")
+            good = _assert_rot_score_close(rs.cpu().numpy(), g["rot_score"][i], s64["tf_score64"][i], f"teacher-forced step {i}")
             assert rel(tsc, g["trans_score"][i]) < 1e-5
             # frames of residues whose rotation score is well conditioned in the reference's own float32
-            good = relb < 1e-5
             n_good += int(good.sum())
             if good.any():
                 worst_next = max(worst_next, maxdiff(nxt.cpu()[T(good)], g["next7"][i][good]))
@@ -509,9 +495,12 @@ def test_cfg4_shape_n512_kernels_agree_and_shard(net_smooth, diffuser):
         parts.append(forward_backward(net_smooth, diffuser, feats, rig0, 0.5, num_timesteps=2 * S, device=DEV, shard=(r, 2)).cpu().numpy())
     assert backbone_rmsd(np.concatenate(parts)[..., :5, :], outs["bf16x6"][..., :5, :]) < 5e-5
 
-@pytest.mark.parametrize("tag", ["n16_s20", "n12_prior", "n24_delta", "cfg1_n64_s20", "n256_s5"])
+@pytest.mark.parametrize("tag", ["n16_s20", "n12_prior", "n24_delta", "cfg1_n64_s20", "n256_s5", "n256_s100"])
 def test_free_running_trajectory_rmsd(net_smooth, diffuser, tag):
-    """Same input, same seed, contractive synthetic weights: backbone RMSD vs the reference <= 1e-4 A."""
+    """Same input, same seed, contractive synthetic weights: backbone RMSD vs the reference <= 1e-4 A.
+    n256_s100 is the HEADLINE workload as the reference itself runs it (BASELINE configs[1]: 256 residues, 100 denoise
+    steps + the self-conditioning evaluation, B = 2 replicas): final coordinates AND the frames entering steps 25 / 50 / 75 /
+    99 are compared, so a divergence would be located, not just detected."""
     from str2str_amd.common.rigid_utils import Rigid
     from str2str_amd.sampler import forward_backward
     from str2str_amd.synth import synth_chain
@@ -521,9 +510,19 @@ def test_free_running_trajectory_rmsd(net_smooth, diffuser, tag):
     feats = synth_chain(N)
     rig0 = Rigid.from_tensor_4x4(feats["rigidgroups_gt_frames"][..., 0, :, :].repeat(B, 1, 1, 1))
     torch.manual_seed(int(g["seed"]))
+    marks = sorted(int(k[len("rigids_t_step"):]) for k in g if k.startswith("rigids_t_step"))
+    trace = [] if marks else None
     a37 = forward_backward(net_smooth, diffuser, feats, rig0, float(g["t_delta"]), num_timesteps=int(g["num_timesteps"]),
-                           device=DEV)
+                           device=DEV, trace=trace)
+    for k in marks:  # translations in Angstrom, quaternions up to sign-free float32 agreement
+        want = g[f"rigids_t_step{k}"]
+        got = trace[k]["rigids_t"].cpu().numpy()
+        dq = np.minimum(np.abs(got[..., :4] - want[..., :4]).max(-1), np.abs(got[..., :4] + want[..., :4]).max(-1))  # q ~ -q
+        d = float(max(dq.max(), np.abs(got[..., 4:] - want[..., 4:]).max()))
+        record_margin(f"free-running {tag}: max |frames entering step {k} - reference|", d, 1e-4)
+        assert d < 1e-4, (tag, k, d)
     rmsd = backbone_rmsd(a37.cpu().numpy()[..., :5, :], g["atom37"])
+    record_margin(f"free-running {tag}: backbone RMSD vs reference (A)", rmsd, 1e-4)
     assert rmsd < 1e-4, (tag, rmsd)
 
 

@@ -80,9 +80,12 @@ def test_writers_byte_identical(tmp_path):
 
 
 def test_dataset_and_collate():
-    ds = SamplingPDBDataset(os.path.join(GOLDEN, "pdb"), transform=ProteinFeatureTransform(strip_missing_residues=False,
-                                                                                           recenter_and_scale=False))
+    ds = SamplingPDBDataset(os.path.join(GOLDEN, "pdb"), accession_code_fillter=["CLN025", "NuG2", "lambda"],
+                            transform=ProteinFeatureTransform(strip_missing_residues=False, recenter_and_scale=False))
     assert len(ds) == 3 and ds[0]["accession_code"] == "CLN025"
+    # the whole Science2011 fast-folder set (BASELINE configs[2]): 12 targets, lengths as SURVEY section 8 counted them
+    full = SamplingPDBDataset(os.path.join(GOLDEN, "pdb"), transform=ProteinFeatureTransform())
+    assert sorted(int(full[i]["aatype"].shape[0]) for i in range(len(full))) == [10, 20, 28, 35, 35, 39, 47, 47, 52, 56, 73, 80]
     dm = ProteinDataModule(ds, batch_size=1)
     batches = dm.test_dataloader()
     assert len(batches) == 3 and batches[1]["aatype"].shape == (1, 56) and batches[1]["accession_code"] == ["NuG2"]
