@@ -5,10 +5,13 @@
 configs/model/diffusion.yaml, one target per batch, replicas chunked by ``replica_per_batch``, one
 multi-MODEL PDB per t_delta under ``<output_dir>/<t_delta>/<accession>.pdb`` and the merged
 ``<output_dir>/all_delta/<accession>.pdb`` — while the loop body runs on the HIP kernels
-(str2str_amd/sampler.py).  New: when ``torch.distributed`` is initialised, every chunk's replicas are
-sharded over the ranks (independent trajectories) and gathered to rank 0 with ONE collective
-per chunk (RCCL on GPUs); rank-major concatenation reproduces the reference's MODEL order, and because the
-host noise of the whole chunk is drawn identically on every rank the files equal a single-GPU run.
+(str2str_amd/sampler.py).  New: when ``torch.distributed`` is initialised, the WHOLE ``n_replica`` range of a
+(target, t_delta) is sharded over the ranks (independent trajectories): rank r owns the contiguous
+replicas ``shard_range(n_replica, r, world)``, walks the reference's chunks of ``replica_per_batch`` and samples
+its intersection with each (a full 64-replica launch per rank once n_replica >= 64 x world, instead of 64/world),
+and ONE collective per t_delta (RCCL gather on GPUs) brings the coordinates to rank 0; rank-major concatenation
+reproduces the reference's MODEL order.  In the default ``rng_mode="host"`` every rank draws each chunk's host
+noise identically (also for chunks it does not sample), so the files equal a single-GPU run sample for sample.
 Training hooks are out of scope (inference-only north star).  Lightning is optional: with it installed
 the class is a LightningModule, without it a plain nn.Module with the same attributes.
 """
@@ -95,29 +98,38 @@ class DiffusionLitModule(_Base):
         device = next(self.net.parameters()).device
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         shard = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
+        if self.rng_mode == "device" and not getattr(self, "_device_rng_seeded", False):
+            # throughput mode draws on the device generator: decorrelate the ranks once (they all start from the same
+            # default seed otherwise and would share their Brownian increments)
+            torch.cuda.manual_seed(torch.initial_seed() + 7919 * shard[0])
+            self._device_rng_seeded = True
         accession_code = batch["accession_code"][0]
         extra = {k: batch[k][0].detach().cpu().numpy() for k in ("aatype", "chain_index", "residue_index")}
         kw = dict(num_timesteps=inf.num_timesteps, min_t=inf.min_t, noise_scale=inf.noise_scale,
-                  probability_flow=inf.probability_flow, self_conditioning=self_cond, device=device, shard=shard,
-                  rng=self.rng_mode)
+                  probability_flow=inf.probability_flow, self_conditioning=self_cond, device=device, rng=self.rng_mode)
+        my_lo, my_hi = shard_range(n_replica, *shard)
         saved = []
         for t_delta in delta_range:
             gt4 = batch["rigidgroups_gt_frames"][..., 0, :, :].clone()
             sizes = [replica_per_batch] * (n_replica // replica_per_batch)
             if n_replica % replica_per_batch > 0:
                 sizes.append(n_replica % replica_per_batch)
-            chunks = []
-            for bsz in sizes:
-                rig0 = Rigid.from_tensor_4x4(gt4.repeat(bsz, *(1,) * (gt4.ndim - 1)))
-                a37 = forward_backward(self.net, self.diffuser, batch, rig0, float(t_delta), **kw)
-                if distributed:
-                    a37 = gather_replicas(a37, bsz)
-                if a37 is not None:
-                    chunks.append(a37.cpu().numpy())
+            mine, c0 = [], 0
+            for bsz in sizes:  # the reference's chunks are the unit of its host noise stream
+                lo, hi = max(my_lo, c0) - c0, min(my_hi, c0 + bsz) - c0
+                lo, hi = (lo, hi) if hi > lo else (0, 0)
+                if hi > lo or self.rng_mode == "host":  # an empty slice still advances the host generator in lock-step
+                    rig0 = Rigid.from_tensor_4x4(gt4.repeat(bsz, *(1,) * (gt4.ndim - 1)))
+                    mine.append(forward_backward(self.net, self.diffuser, batch, rig0, float(t_delta),
+                                                 replica_slice=(lo, hi), **kw))
+                c0 += bsz
+            a37 = torch.cat(mine, dim=0) if mine else torch.zeros(0, gt4.shape[-3], 37, 3, device=device)
+            if distributed:
+                a37 = gather_replicas(a37, n_replica)   # ONE collective per (target, t_delta)
             if shard[0] == 0:
                 t_dir = os.path.join(output_dir, f"{t_delta}")
                 os.makedirs(t_dir, exist_ok=True)
-                saved.append(atom37_to_pdb(atom_positions=np.concatenate(chunks, axis=0),
+                saved.append(atom37_to_pdb(atom_positions=a37.cpu().numpy(),
                                            save_to=os.path.join(t_dir, f"{accession_code}.pdb"), **extra))
         all_dir = os.path.join(output_dir, "all_delta")
         if shard[0] == 0:

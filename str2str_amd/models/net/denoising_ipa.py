@@ -71,6 +71,7 @@ class EmbeddingModule(nn.Module):
         self.mfma_mode = os.environ.get("S2S_EDGE_MFMA", "bf16x6")
         self._idx_key = None
         self._idx_val = None
+        self._idx_src = None
 
     # ---- derived tensors
     def _weights(self):
@@ -108,7 +109,10 @@ class EmbeddingModule(nn.Module):
         table rel_tab[d + off] = W_rel . posemb(d).  Cached on the index tensor (one host sync per target)."""
         key = (residue_idx.data_ptr(), tuple(residue_idx.shape), residue_idx._version, w_rel.data_ptr(), w_rel._version,
                wn_pos.data_ptr(), wn_pos._version)
-        if key != self._idx_key:
+        # the key is the tensor's identity, so the tensor itself is kept alive with the cached tables: a later target
+        # can then never be allocated at the same (recycled) address and hit tables built for other residue numbering
+        if key != self._idx_key or self._idx_src is not residue_idx:
+            self._idx_src = residue_idx
             idx_cpu = residue_idx.detach().cpu()
             span = int(idx_cpu.max() - idx_cpu.min())
             d = torch.arange(-span, span + 1)

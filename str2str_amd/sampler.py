@@ -61,18 +61,46 @@ class _GraphedNet:
         return self.out
 
 
+_GRAPH_CACHE = {}   # (net id, parameter versions, b, N, feature bytes) -> _GraphedNet; a few entries (one per chunk shape)
+_GRAPH_CACHE_MAX = 4
+
+
+def _graph_key(net, feats, b, N):
+    import hashlib
+
+    h = hashlib.sha1()
+    for k in sorted(feats):
+        v = feats[k]
+        if k in ("rigids_t", "sc_ca_t", "t_emb", "t") or not torch.is_tensor(v):
+            continue  # per-step inputs are copied into the static buffers at every replay
+        h.update(k.encode()); h.update(str(tuple(v.shape)).encode()); h.update(v.detach().cpu().numpy().tobytes())
+    tr = getattr(net, "translator", None)
+    return (id(net), sum(p._version for p in net.parameters()), b, N, bool(getattr(tr, "exact_padding", False)),
+            h.hexdigest())
+
+
 def _maybe_graph(net, feats, b, N, trace, n_steps):
     mode = os.environ.get("S2S_HIP_GRAPH", "auto")
     if mode == "0" or trace is not None or ops.KernelTimer.active is not None or "t_emb" not in feats:
         return None
     if mode != "1" and (b * N * N > _GRAPH_MAX_PAIRS or n_steps < _GRAPH_MIN_STEPS):
         return None
+    key = _graph_key(net, feats, b, N)   # chunks / t_deltas of one target share the capture (same static features)
+    hit = _GRAPH_CACHE.get(key)
+    if hit is not None:
+        return hit
     try:
-        return _GraphedNet(net, feats)
-    except Exception as e:  # capture is an optimisation: fall back to eager launches
+        g = _GraphedNet(net, feats)
+    except ops.HipLibraryError:
+        raise                            # a kernel / ABI error is an error, not a capture problem
+    except RuntimeError as e:            # capture itself is an optimisation: fall back to eager launches
         _log.warning("HIP graph capture failed (%s); continuing with eager launches", repr(e)[:200])
         torch.cuda.synchronize()
         return None
+    if len(_GRAPH_CACHE) >= _GRAPH_CACHE_MAX:
+        _GRAPH_CACHE.pop(next(iter(_GRAPH_CACHE)))
+    _GRAPH_CACHE[key] = g
+    return g
 
 
 def schedule(t_delta: float, num_timesteps: int, min_t: float):
@@ -157,27 +185,50 @@ def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: flo
 def forward_backward(net, diffuser, batch: dict, rigids_0: Rigid, t_delta: float, *, num_timesteps: int,
                      min_t: float = 0.01, noise_scale: float = 1.0, probability_flow: bool = True,
                      self_conditioning: bool = True, device=None, shard: Tuple[int, int] = (0, 1),
-                     rng: str = "host", trace: Optional[list] = None, return_rigids: bool = False):
-    """-> atom37 [b, N, 37, 3] float32 DEVICE tensor for this rank's replica slice (b = hi - lo)."""
+                     replica_slice: Optional[Tuple[int, int]] = None, rng: str = "host", trace: Optional[list] = None,
+                     return_rigids: bool = False):
+    """-> atom37 [b, N, 37, 3] float32 DEVICE tensor for this rank's replica slice (b = hi - lo).
+
+    The chunk (``rigids_0.shape[0]`` replicas) is the unit of the reference's host noise stream.  ``replica_slice`` =
+    (lo, hi) selects the replicas of the chunk THIS process samples (``shard`` = (rank, world) is the ceil split of
+    the chunk); in ``rng="host"`` mode every process still draws the whole chunk's noise in the reference's order --
+    including a process whose slice is empty -- so the union over processes equals the single-process run sample for
+    sample and every generator stays in lock-step for later chunks.  ``rng="device"`` (throughput mode) draws the
+    forward-marginal and step noise on the device generator for the slice only."""
     device = torch.device(device) if device is not None else next(net.parameters()).device
     if device.type != "cuda":
         raise ops.HipLibraryError("the sampler needs the HIP device (MI355X); there is no CPU fallback")
     B_total = rigids_0.shape[0]
-    lo, hi = shard_range(B_total, *shard)
+    lo, hi = replica_slice if replica_slice is not None else shard_range(B_total, *shard)
+    if not (0 <= lo <= hi <= B_total):
+        raise ValueError(f"replica_slice {(lo, hi)} outside the chunk of {B_total} replicas")
     b = hi - lo
     T, n, dt, ts = schedule(t_delta, num_timesteps, min_t)
-
-    # ---- once per trajectory, on the host generator, for the WHOLE chunk (reference order)
-    if t_delta > 0:
-        rigids_t = diffuser.forward_marginal(rigids_0=rigids_0.to(device="cpu"), t=t_delta * torch.ones(B_total),
-                                             diffuse_mask=batch["residue_mask"].cpu().repeat(B_total, 1),
-                                             as_tensor_7=True)["rigids_t"]
-    else:
-        rigids_t = diffuser.sample_prior(shape=rigids_0.shape, device="cpu", as_tensor_7=True)["rigids_t"]
     N = rigids_0.shape[1]
-    if b == 0:
-        return torch.zeros(0, N, 37, 3, device=device)
-    rigids_t = rigids_t[lo:hi].to(device).float().contiguous()
+
+    if rng == "device":
+        # ---- throughput mode: noise for this slice only, drawn and applied on the device (s2s_forward_marginal)
+        if b == 0:
+            return torch.zeros(0, N, 37, 3, device=device)
+        r0_7 = rigids_0[lo:hi].to_tensor_7().to(device).float().contiguous()
+        dmask = batch["residue_mask"].to(device).float().reshape(1, N).expand(b, N).contiguous()
+        rigids_t = diffuser.forward_marginal_device(r0_7, t_delta if t_delta > 0 else None, dmask)
+    else:
+        # ---- once per trajectory, on the host generator, for the WHOLE chunk (reference order)
+        if t_delta > 0:
+            rigids_t = diffuser.forward_marginal(rigids_0=rigids_0.to(device="cpu"), t=t_delta * torch.ones(B_total),
+                                                 diffuse_mask=batch["residue_mask"].cpu().repeat(B_total, 1),
+                                                 as_tensor_7=True)["rigids_t"]
+        else:
+            rigids_t = diffuser.sample_prior(shape=rigids_0.shape, device="cpu", as_tensor_7=True)["rigids_t"]
+        if b == 0:
+            # nothing to sample here, but the reference's per-step draws (two float64 normals per step, see host_noise
+            # below) must still be consumed so that this process' generator matches every other process' afterwards
+            for _ in range(len(ts) - 1):
+                torch.randn(B_total, N, 3, dtype=torch.float64)
+                torch.randn(B_total, N, 3, dtype=torch.float64)
+            return torch.zeros(0, N, 37, 3, device=device)
+        rigids_t = rigids_t[lo:hi].to(device).float().contiguous()
     feats = {k: batch[k].to(device).repeat(b, *(1,) * (batch[k].ndim - 1)) for k in _REPEAT_KEYS if k in batch}
 
     def host_noise():

@@ -35,7 +35,15 @@ class Trainer:
             dist.init_process_group("nccl", device_id=dev)
         if ckpt_path is not None:  # Lightning-style .ckpt: {'state_dict': {'net.…': tensor}}
             sd = torch.load(ckpt_path, map_location="cpu")["state_dict"]
-            model.load_state_dict(sd, strict=False)
+            # the reference's Lightning Trainer restores strictly; here only `net.*` is part of the sampling path, so
+            # non-network entries (loss / metric buffers of a training checkpoint) may be absent from this module, but
+            # every network parameter must be found -- a silently unloaded key would sample from init weights
+            res = model.load_state_dict(sd, strict=False)
+            missing = [k for k in res.missing_keys if k.startswith("net.")]
+            unexpected = [k for k in res.unexpected_keys if k.startswith("net.")]
+            if missing or unexpected:
+                raise RuntimeError(f"checkpoint {ckpt_path} does not match the network: missing {missing[:5]} "
+                                   f"(+{max(0, len(missing) - 5)}), unexpected {unexpected[:5]} (+{max(0, len(unexpected) - 5)})")
         ops.load_library()
         model = model.to(dev).eval()
         out = []
