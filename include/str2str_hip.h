@@ -156,6 +156,42 @@ int s2s_se3_step(const float* x0_7, const float* xt_7, const float* mask, const 
                  double coordinate_scaling, int probability_flow, int center_trans, double noise_scale,
                  void* stream);
 
+/* ---- Forward process / prior, once per trajectory ---- */
+
+/* FrameDiffuser.forward_marginal (src/models/score/frame.py:36-107; so3.py:244-272, :315-331, :13-19; r3.py:49-74) or, with
+ * rigids0_4x4 == NULL, FrameDiffuser.sample_prior (frame.py:212-255), followed by Rigid.to_tensor_7.
+ *   rigids0_4x4 [B,N,4,4] starting frames (Angstrom) or NULL; noise drawn by the caller: z_axis [B,N,3] ~ N(0,1) (rotation
+ *   axis), u01 [B,N] ~ U[0,1) (inverse CDF of the IGSO(3) angle), z_trans [B,N,3] ~ N(0,1);
+ *   cdf_rows [R,n_omega] double (so3.py:185-187) and cdf_row_of_sample [B] (row per sample = sigma bin of its t),
+ *   omega_grid [n_omega] (SO3Diffuser.discrete_omega); params2 [B,2] = exp(-marginal_b_t/2), sqrt(1-exp(-marginal_b_t));
+ *   diffuse_mask [B,N] or NULL (= all ones); out rigids_t7 [B,N,7]. */
+int s2s_forward_marginal(const float* rigids0_4x4, const float* z_axis, const float* u01, const float* z_trans,
+                         const double* cdf_rows, const int* cdf_row_of_sample, const float* omega_grid, int n_omega,
+                         const float* params2, const float* diffuse_mask, float coordinate_scaling, float* rigids_t7,
+                         int n_samples, int n_res, void* stream);
+
+/* ---- PDB text at the exit of the path (HOST pointers, host code; byte-identical to the reference's writers) ---- */
+
+/* protein.to_pdb per model (src/common/protein.py:152-234) over atom37 [n_models, n_res, 37, 3] float32 HOST coordinates with
+ * the atom mask of pdb_utils.atom37_to_pdb (src/common/pdb_utils.py:233: sum |xyz| > 1e-7; GLY CB skipped).
+ *   aatype / residue_index / chain_index [n_res] int64 or NULL (defaults of protein_with_default_params, pdb_utils.py:175-203:
+ *   ALA, 1..n_res, chain 0); b_factors [n_res,37] double or NULL (zeros); MODEL numbers first_model_number + m;
+ *   add_end: 0 = none, 1 = an "END" line after every model (to_pdb(add_end=True)), 2 = one bare "END" without newline after
+ *   the last model (atom37_to_pdb).  Returns the number of bytes of text; writes them when out != NULL and they fit in
+ *   out_capacity (call with out = NULL to size the buffer).  < 0: -1 bad argument / aatype > 20, -2 more than 62 chains. */
+long long s2s_format_pdb_models(const float* atom37, int n_models, int n_res, const long long* aatype,
+                                const long long* residue_index, const long long* chain_index, const double* b_factors,
+                                int first_model_number, int add_end, char* out, long long out_capacity);
+
+/* The same text streamed to a file in bounded blocks of models (append != 0: append to an existing file).
+ * Returns bytes written, -3 cannot open, -4 write error. */
+long long s2s_write_pdb_models(const char* path, int append, const float* atom37, int n_models, int n_res,
+                               const long long* aatype, const long long* residue_index, const long long* chain_index,
+                               const double* b_factors, int first_model_number, int add_end);
+
+/* pdb_utils.merge_pdbfiles (src/common/pdb_utils.py:31-83): MODELs of the inputs, in order, renumbered from 1. */
+long long s2s_merge_pdb_files(const char* const* paths, int n_paths, const char* out_path);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,8 +25,10 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", os.path.
           "-Wno-unused-result"]
 UNITS = {
     "abi.hip": [],
+    "pdb_format.cpp": [],   # host-only C++ (PDB text writer / merger behind the C ABI)
     "rigid_kernels.hip": ["-ffp-contract=off"],
     "se3_step.hip": ["-ffp-contract=off"],
+    "forward_marginal.hip": ["-ffp-contract=off"],
     # the MFMA chains are fully unrolled on purpose (accumulator tiles must be statically indexed)
     "pair_mlp.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
     "pair_mlp_bf16.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
@@ -57,9 +59,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def compile_one(item):
         src, extra = item
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         if force or _stale(o, [s] + headers):
-            cmd = [cc, "-x", "hip", "-c", s, "-o", o] + COMMON + extra
+            if src.endswith(".cpp"):
+                cmd = [cc, "-x", "c++", "-c", s, "-o", o] + [c for c in COMMON if not c.startswith("--offload-arch")] + extra
+            else:
+                cmd = [cc, "-x", "hip", "-c", s, "-o", o] + COMMON + extra
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

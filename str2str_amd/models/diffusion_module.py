@@ -26,7 +26,7 @@ import torch
 
 from ..common.pdb_utils import atom37_to_pdb, merge_pdbfiles
 from ..common.rigid_utils import Rigid
-from ..sampler import forward_backward, shard_range
+from ..sampler import forward_backward, rank_chunk_slices, shard_range
 
 try:  # pragma: no cover - depends on the environment
     from lightning import LightningModule as _Base
@@ -107,22 +107,17 @@ class DiffusionLitModule(_Base):
         extra = {k: batch[k][0].detach().cpu().numpy() for k in ("aatype", "chain_index", "residue_index")}
         kw = dict(num_timesteps=inf.num_timesteps, min_t=inf.min_t, noise_scale=inf.noise_scale,
                   probability_flow=inf.probability_flow, self_conditioning=self_cond, device=device, rng=self.rng_mode)
-        my_lo, my_hi = shard_range(n_replica, *shard)
         saved = []
         for t_delta in delta_range:
             gt4 = batch["rigidgroups_gt_frames"][..., 0, :, :].clone()
-            sizes = [replica_per_batch] * (n_replica // replica_per_batch)
-            if n_replica % replica_per_batch > 0:
-                sizes.append(n_replica % replica_per_batch)
-            mine, c0 = [], 0
-            for bsz in sizes:  # the reference's chunks are the unit of its host noise stream
-                lo, hi = max(my_lo, c0) - c0, min(my_hi, c0 + bsz) - c0
-                lo, hi = (lo, hi) if hi > lo else (0, 0)
-                if hi > lo or self.rng_mode == "host":  # an empty slice still advances the host generator in lock-step
+            mine = []
+            for bsz, lo, hi in rank_chunk_slices(n_replica, replica_per_batch, *shard):
+                # the reference's chunks are the unit of its host noise stream: an empty slice still advances the host
+                # generator in lock-step with the ranks that sample the chunk
+                if hi > lo or self.rng_mode == "host":
                     rig0 = Rigid.from_tensor_4x4(gt4.repeat(bsz, *(1,) * (gt4.ndim - 1)))
                     mine.append(forward_backward(self.net, self.diffuser, batch, rig0, float(t_delta),
                                                  replica_slice=(lo, hi), **kw))
-                c0 += bsz
             a37 = torch.cat(mine, dim=0) if mine else torch.zeros(0, gt4.shape[-3], 37, 3, device=device)
             if distributed:
                 a37 = gather_replicas(a37, n_replica)   # ONE collective per (target, t_delta)

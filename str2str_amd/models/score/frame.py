@@ -10,6 +10,7 @@ from __future__ import annotations
 
 from typing import Optional
 
+import numpy as np
 import torch
 
 from ... import ops
@@ -64,6 +65,34 @@ class FrameDiffuser:
         trans = self.trans_diffuser.unscale(self.trans_diffuser.sample_prior(shape=shape + (3,)))
         rigids_t = assemble_rigid(rot, trans)
         return {"rigids_t": rigids_t.to_tensor_7().to(device) if as_tensor_7 else rigids_t.to(device=device)}
+
+    def forward_marginal_device(self, rigids0_4x4: Optional[torch.Tensor], t_delta: Optional[float], diffuse_mask=None,
+                                shape=None, noise=None) -> torch.Tensor:
+        """Throughput-mode forward marginal (``rigids0_4x4`` [B,N,4,4] on the device, ``t_delta`` > 0) or prior sample
+        (``rigids0_4x4=None``, ``shape=(B, N)``): the same arithmetic as ``forward_marginal`` / ``sample_prior``
+        (reference frame.py:36-107, :212-255) in ONE launch (``s2s_forward_marginal``) on noise drawn by the device
+        generator -- no per-replica host loop, no np.interp, no host->device copy.  ``noise`` = (z_axis [B,N,3], u [B,N],
+        z_trans [B,N,3]) overrides the draws (parity test against the host path).  -> rigids_t as tensor_7 [B,N,7]."""
+        prior = rigids0_4x4 is None
+        dev = torch.device("cuda", torch.cuda.current_device()) if prior else rigids0_4x4.device
+        B, N = tuple(shape) if prior else rigids0_4x4.shape[:2]
+        t = torch.full((B,), 1.0 if prior else float(t_delta), dtype=torch.float32)
+        sd = self.rot_diffuser
+        idx = sd.t_to_idx(t)
+        rows, inv = torch.unique(idx, return_inverse=True)
+        cdf = torch.as_tensor(np.stack([sd.cdf_row(int(i)) for i in rows]), dtype=torch.float64).to(dev).contiguous()
+        if noise is None:
+            noise = (torch.randn(B, N, 3, device=dev), torch.rand(B, N, device=dev), torch.randn(B, N, 3, device=dev))
+        z_axis, u, z_trans = (x.to(dev).float().contiguous() for x in noise)
+        p2 = None
+        if not prior:
+            mb = self.trans_diffuser.marginal_b_t(t)
+            p2 = torch.stack([torch.exp(-0.5 * mb), torch.sqrt(1 - torch.exp(-mb))], dim=-1).float().to(dev).contiguous()
+            rigids0_4x4 = rigids0_4x4.float().contiguous()
+        dm = None if diffuse_mask is None else diffuse_mask.to(dev).float().contiguous()
+        return ops.forward_marginal(rigids0_4x4, z_axis, u, z_trans, cdf, inv.to(torch.int32).to(dev).contiguous(),
+                                    sd.discrete_omega.float().to(dev).contiguous(), p2, dm,
+                                    self.trans_diffuser.coordinate_scaling)
 
     # ------------------------------------------------------------------ per step (HIP)
     def step_params(self, t: torch.Tensor) -> torch.Tensor:

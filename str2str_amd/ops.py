@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 _tables_loaded = False
@@ -38,7 +38,12 @@ _SIGNATURES = {
     "s2s_set_backbone_tables": [_vp] * 4,
     "s2s_frames_to_backbone": [_vp] * 5 + [_ll, _vp],
     "s2s_se3_step": [_vp] * 12 + [_i, _i, _d, _d, _i, _i, _d, _vp],
+    "s2s_forward_marginal": [_vp] * 7 + [_i, _vp, _vp, _f, _vp, _i, _i, _vp],
+    "s2s_format_pdb_models": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _ll],
+    "s2s_write_pdb_models": [ctypes.c_char_p, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i],
+    "s2s_merge_pdb_files": [_vp, _i, ctypes.c_char_p],
 }
+_LL_RETURN = ("s2s_format_pdb_models", "s2s_write_pdb_models", "s2s_merge_pdb_files")
 EXPORTS = tuple(_SIGNATURES)
 
 
@@ -96,7 +101,7 @@ def load_library(path: Optional[str] = None):
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI is incomplete
         fn.argtypes = args
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_longlong if name in _LL_RETURN else ctypes.c_int
     v = lib.s2s_abi_version()
     if v != ABI_VERSION:
         raise HipLibraryError(f"libstr2str_hip.so ABI {v} != expected {ABI_VERSION}; rebuild")
@@ -459,6 +464,95 @@ def se3_step(x0_7, xt_7, mask, diffuse_mask, params8, dt: float, coordinate_scal
                             _p(rs), _p(ts), B, N, float(dt), float(coordinate_scaling), int(bool(probability_flow)),
                             int(center), float(noise_scale), _stream()), "s2s_se3_step")
     return nxt, rs, ts
+
+
+def forward_marginal(rigids0_4x4, z_axis, u01, z_trans, cdf_rows, row_of_sample, omega_grid, params2, diffuse_mask=None,
+                     coordinate_scaling: float = 0.1):
+    """Forward marginal (``rigids0_4x4`` [B,N,4,4]) or prior sample (``None``) from caller-drawn noise -> rigids_t7 [B,N,7]."""
+    lib = load_library()
+    B, N = u01.shape
+    for n, t in (("z_axis", z_axis), ("u01", u01), ("z_trans", z_trans), ("omega_grid", omega_grid)):
+        _req(t, name=n)
+    _req(cdf_rows, torch.float64, "cdf_rows"); _req(row_of_sample, torch.int32, "row_of_sample")
+    if z_axis.shape != (B, N, 3) or z_trans.shape != (B, N, 3) or cdf_rows.ndim != 2 or cdf_rows.shape[1] != omega_grid.numel() \
+            or row_of_sample.shape != (B,):
+        raise HipLibraryError("forward_marginal: bad shapes")
+    if rigids0_4x4 is not None:
+        _req(rigids0_4x4, name="rigids0_4x4"); _req(params2, name="params2")
+        if rigids0_4x4.shape != (B, N, 4, 4) or params2.shape != (B, 2):
+            raise HipLibraryError("forward_marginal: rigids0_4x4 must be [B,N,4,4] and params2 [B,2]")
+    if diffuse_mask is not None:
+        _req(diffuse_mask, name="diffuse_mask")
+    out = torch.empty(B, N, 7, device=u01.device, dtype=torch.float32)
+    _check(lib.s2s_forward_marginal(_p(rigids0_4x4), _p(z_axis), _p(u01), _p(z_trans), _p(cdf_rows), _p(row_of_sample),
+                                    _p(omega_grid), omega_grid.numel(), _p(params2), _p(diffuse_mask), float(coordinate_scaling),
+                                    _p(out), B, N, _stream()), "s2s_forward_marginal")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ PDB text (host side of the ABI)
+def _np_or_none(x, dtype):
+    if x is None:
+        return None, None
+    a = np.ascontiguousarray(np.asarray(x), dtype=dtype)
+    return a, a.ctypes.data_as(_vp)
+
+
+def _pdb_args(atom37, aatype, residue_index, chain_index, b_factors):
+    pos = np.ascontiguousarray(np.asarray(atom37), dtype=np.float32)
+    if pos.ndim == 3:
+        pos = pos[None]
+    if pos.ndim != 4 or pos.shape[-2:] != (37, 3):
+        raise ValueError(f"Invalid positions shape {pos.shape}")
+    n = pos.shape[1]
+    sq = lambda x: None if x is None else (np.squeeze(np.asarray(x)) if np.asarray(x).shape[0] == 1 and np.asarray(x).ndim > 1 else np.asarray(x))  # noqa: E731
+    keep = [pos]
+    ptrs = [pos.ctypes.data_as(_vp), pos.shape[0], n]
+    for x, dt, want in ((aatype, np.int64, (n,)), (residue_index, np.int64, (n,)), (chain_index, np.int64, (n,)),
+                        (b_factors, np.float64, (n, 37))):
+        a, p = _np_or_none(sq(x), dt)
+        if a is not None and a.shape != want:
+            raise ValueError(f"expected shape {want}, got {a.shape}")
+        keep.append(a)
+        ptrs.append(p)
+    return keep, ptrs
+
+
+def _pdb_rc(rc, what):
+    if rc == -1:
+        raise ValueError("Invalid aatypes." if what != "merge" else "bad arguments")
+    if rc == -2:
+        raise ValueError("The PDB format supports at most 62 chains.")
+    if rc < 0:
+        raise OSError(f"{what}: I/O error {rc}")
+    return rc
+
+
+def format_pdb_models(atom37, aatype=None, residue_index=None, chain_index=None, b_factors=None, first_model: int = 1,
+                      add_end: int = 2) -> str:
+    """Text of ``atom37_to_pdb`` (add_end=2) / ``to_pdb`` per model (add_end=1 / 0) for atom37 [M,N,37,3] or [N,37,3]."""
+    lib = load_library()
+    keep, a = _pdb_args(atom37, aatype, residue_index, chain_index, b_factors)
+    need = _pdb_rc(lib.s2s_format_pdb_models(*a, int(first_model), int(add_end), None, 0), "format")
+    buf = ctypes.create_string_buffer(int(need) + 1)
+    got = _pdb_rc(lib.s2s_format_pdb_models(*a, int(first_model), int(add_end), ctypes.cast(buf, _vp), int(need)), "format")
+    assert got == need
+    return buf.raw[:need].decode("ascii")
+
+
+def write_pdb_models(path: str, atom37, aatype=None, residue_index=None, chain_index=None, b_factors=None,
+                     first_model: int = 1, add_end: int = 2, append: bool = False) -> int:
+    """Stream the same text to ``path`` (bounded memory); returns the number of bytes written."""
+    lib = load_library()
+    keep, a = _pdb_args(atom37, aatype, residue_index, chain_index, b_factors)
+    return _pdb_rc(lib.s2s_write_pdb_models(os.fsencode(path), int(bool(append)), *a, int(first_model), int(add_end)), "write")
+
+
+def merge_pdb_files(paths, out_path: str) -> int:
+    lib = load_library()
+    enc = [os.fsencode(p) for p in paths]
+    arr = (ctypes.c_char_p * len(enc))(*enc)
+    return _pdb_rc(lib.s2s_merge_pdb_files(ctypes.cast(arr, _vp), len(enc), os.fsencode(out_path)), "merge")
 
 
 _registered = False

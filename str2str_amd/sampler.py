@@ -116,6 +116,24 @@ def shard_range(total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, min(total, lo + per)
 
 
+def rank_chunk_slices(n_replica: int, replica_per_batch: int, rank: int, world: int):
+    """How ``rank`` walks the reference's replica chunks (diffusion_module.py:341-351: ``n_replica`` split into chunks of
+    ``replica_per_batch``, the unit of its host noise stream) when the WHOLE replica range is sharded over ``world`` ranks:
+    -> [(chunk_size, lo, hi)] per chunk, (lo, hi) = the part of that chunk inside this rank's contiguous range
+    ``shard_range(n_replica, rank, world)`` ((0, 0) when the chunk lies outside it).  Rank-major concatenation of the
+    sampled slices is the single-process replica order."""
+    my_lo, my_hi = shard_range(n_replica, rank, world)
+    sizes = [replica_per_batch] * (n_replica // replica_per_batch)
+    if n_replica % replica_per_batch > 0:
+        sizes.append(n_replica % replica_per_batch)
+    out, c0 = [], 0
+    for bsz in sizes:
+        lo, hi = max(my_lo, c0) - c0, min(my_hi, c0 + bsz) - c0
+        out.append((bsz, lo, hi) if hi > lo else (bsz, 0, 0))
+        c0 += bsz
+    return out
+
+
 @torch.no_grad()
 def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: float, *, min_t: float,
                  noise_scale: float = 1.0, probability_flow: bool = True, self_conditioning: bool = True,
@@ -210,9 +228,11 @@ def forward_backward(net, diffuser, batch: dict, rigids_0: Rigid, t_delta: float
         # ---- throughput mode: noise for this slice only, drawn and applied on the device (s2s_forward_marginal)
         if b == 0:
             return torch.zeros(0, N, 37, 3, device=device)
-        r0_7 = rigids_0[lo:hi].to_tensor_7().to(device).float().contiguous()
-        dmask = batch["residue_mask"].to(device).float().reshape(1, N).expand(b, N).contiguous()
-        rigids_t = diffuser.forward_marginal_device(r0_7, t_delta if t_delta > 0 else None, dmask)
+        if t_delta > 0:
+            dmask = batch["residue_mask"].to(device).float().reshape(1, N).expand(b, N).contiguous()
+            rigids_t = diffuser.forward_marginal_device(rigids_0[lo:hi].to_tensor_4x4().to(device), t_delta, dmask)
+        else:
+            rigids_t = diffuser.forward_marginal_device(None, None, shape=(b, N))
     else:
         # ---- once per trajectory, on the host generator, for the WHOLE chunk (reference order)
         if t_delta > 0:

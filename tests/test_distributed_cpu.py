@@ -1,8 +1,12 @@
-"""The N>1 path on CPU: world_size-2 gloo processes exercise the replica sharding + ONE gather per chunk
-that DiffusionLitModule.predict_step / bench.py use on RCCL (sampling itself needs the GPU)."""
+"""The N>1 path on CPU: world_size-2 (and 3) gloo processes exercise what DiffusionLitModule.predict_step / bench.py do on
+RCCL: the WHOLE replica range of a (target, t_delta) sharded over the ranks, the reference's chunks walked per rank with
+the host generator in lock-step (also through chunks a rank does not sample), ONE gather per t_delta, rank-major order ==
+single-process MODEL order.  The network itself needs the GPU, so ``forward_backward`` is replaced by a stand-in with the
+REAL function's generator behaviour (tests/test_hip_parity.py::test_sharded_* covers the real sampler on the GPU)."""
 import os
 import socket
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -14,35 +18,118 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, total, q):
+def test_rank_chunk_slices_partition_the_replica_range():
+    from str2str_amd.sampler import rank_chunk_slices
+
+    for n, rpb, world in [(1000, 64, 8), (1024, 128, 8), (64, 64, 8), (5, 2, 3), (3, 64, 8), (1, 1, 2), (130, 64, 4), (9, 4, 8)]:
+        seen, launches = [], []
+        for r in range(world):
+            c0 = 0
+            for bsz, lo, hi in rank_chunk_slices(n, rpb, r, world):
+                assert 0 <= lo <= hi <= bsz <= rpb
+                seen += list(range(c0 + lo, c0 + hi))
+                if hi > lo:
+                    launches.append(hi - lo)
+                c0 += bsz
+            assert c0 == n
+        assert seen == list(range(n)), (n, rpb, world)          # every replica exactly once, rank-major == replica order
+    # full-size launches once every rank owns at least one chunk (cfg4: 1024 replicas, 8 ranks, chunks of 128)
+    assert [hi - lo for _, lo, hi in rank_chunk_slices(1024, 128, 3, 8) if hi > lo] == [128]
+    assert sorted(hi - lo for _, lo, hi in rank_chunk_slices(1000, 64, 0, 8) if hi > lo) == [61, 64]
+
+
+def _fake_forward_backward(net, diffuser, batch, rigids_0, t_delta, *, replica_slice, num_timesteps, **kw):
+    """Generator behaviour of sampler.forward_backward in rng='host' mode: the WHOLE chunk's forward-marginal noise and two
+    float64 normal draws per step are consumed whatever the slice; returns, per replica of the slice, its forward-marginal
+    noise value (so a wrong slice / a generator out of lock-step shows up in the gathered file)."""
+    B, N = rigids_0.shape
+    z = torch.randn(B, N, 3)              # stands for the chunk's forward-marginal draws
+    for _ in range(num_timesteps - 1):
+        torch.randn(B, N, 3, dtype=torch.float64); torch.randn(B, N, 3, dtype=torch.float64)
+    lo, hi = replica_slice
+    out = torch.zeros(hi - lo, N, 37, 3)
+    out[:, :, 1, :] = z[lo:hi]
+    return out
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(1))
+        self.embedder = type("E", (), {"self_conditioning": True})()
+
+
+def _predict(rank, world, port, n_replica, rpb, out_dir, q):
+    if world > 1:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ["S2S_PDB_WRITER"] = "python"
+    from str2str_amd.models import diffusion_module as DM
+    from str2str_amd.synth import synth_chain
+
+    DM.forward_backward = _fake_forward_backward
+    inf = dict(n_replica=n_replica, replica_per_batch=rpb, delta_min=0.5, delta_max=0.6, delta_step=0.1, num_timesteps=4,
+               noise_scale=1.0, probability_flow=True, self_conditioning=True, min_t=0.01, output_dir=out_dir, backward_only=False)
+    model = DM.DiffusionLitModule(net=_Net(), diffuser=None, inference=inf)
+    batch = synth_chain(6)
+    batch["residue_index"] = batch["residue_index"] + 1
+    torch.manual_seed(3)
+    model.predict_step(batch, 0)
+    if rank == 0:
+        q.put("done")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _run_predict(world, n_replica, rpb, out_dir):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_predict, args=(r, world, port, n_replica, rpb, out_dir, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    assert q.get(timeout=180) == "done"
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    return {d: open(os.path.join(out_dir, d, "synth6.pdb")).read() for d in ("0.5", "0.6", "all_delta")}
+
+
+def test_predict_step_multi_rank_files_equal_single_process(tmp_path):
+    """Whole-n_replica sharding, uneven splits (5 replicas in chunks of 2 over 2 and 3 ranks) and more ranks than replicas
+    (1 replica, 2 ranks: one rank samples nothing in any chunk and must still stay in generator lock-step across the two
+    t_deltas): the files rank 0 writes are byte-identical to a single-process run with the same seed."""
+    for n_replica, rpb in [(5, 2), (1, 1)]:
+        single = _run_predict(1, n_replica, rpb, str(tmp_path / f"w1_{n_replica}"))
+        assert single["0.5"].count("MODEL ") == n_replica and single["all_delta"].count("MODEL ") == 2 * n_replica
+        for world in (2, 3):
+            multi = _run_predict(world, n_replica, rpb, str(tmp_path / f"w{world}_{n_replica}"))
+            assert multi == single, (n_replica, rpb, world)
+
+
+def _gather_worker(rank, world, port, total, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from str2str_amd.models.diffusion_module import gather_replicas
     from str2str_amd.sampler import shard_range
 
     lo, hi = shard_range(total, rank, world)
-    # stand-in for this rank's sampled coordinates: replica r is filled with the value r
     mine = torch.arange(lo, hi, dtype=torch.float32)[:, None, None, None].expand(hi - lo, 4, 37, 3).contiguous()
     out = gather_replicas(mine, total)
     if rank == 0:
         q.put(out[:, 0, 0, 0].tolist())
     else:
         assert out is None
-    # identical host noise on every rank (same seed) -> slices of one stream
-    torch.manual_seed(7)
-    z = torch.randn(total, 3)
-    gathered = [torch.empty_like(z) for _ in range(world)]
-    dist.all_gather(gathered, z)
-    assert all(torch.equal(g, z) for g in gathered)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def _run(total):
+def _run_gather(total, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, total, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = q.get(timeout=120)
@@ -52,9 +139,7 @@ def _run(total):
     return got
 
 
-def test_gather_keeps_replica_order_even_split():
-    assert _run(6) == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
-
-
-def test_gather_keeps_replica_order_uneven_split():
-    assert _run(5) == [0.0, 1.0, 2.0, 3.0, 4.0]
+def test_gather_keeps_replica_order():
+    assert _run_gather(6) == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
+    assert _run_gather(5) == [0.0, 1.0, 2.0, 3.0, 4.0]           # uneven split
+    assert _run_gather(2, world=3) == [0.0, 1.0]                 # a rank with an empty slice

@@ -670,3 +670,106 @@ def test_mixed_length_padded_batch_equals_unpadded_runs(net_smooth, diffuser):
         assert got.shape == alone.shape
         rmsd = backbone_rmsd(got.cpu().numpy()[..., :5, :], alone.cpu().numpy()[..., :5, :])
         assert rmsd < 1e-4, (tg["aatype"].shape, rmsd)
+
+
+def _q_sign_free(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    dq = np.minimum(np.abs(a[..., :4] - b[..., :4]).max(-1), np.abs(a[..., :4] + b[..., :4]).max(-1))
+    return float(max(dq.max(), np.abs(a[..., 4:] - b[..., 4:]).max()))
+
+
+def test_forward_marginal_device_reproduces_reference_draws(diffuser):
+    """the device forward marginal / prior (s2s_forward_marginal) is the reference's arithmetic
+    (frame.py:36-107, :212-255) as a pure function of the noise: fed the draws the REFERENCE made for the committed fixture
+    (same host generator state, same order: axis normals, inverse-CDF uniforms, translation normals) it returns the
+    reference's frames."""
+    from str2str_amd.common.rigid_utils import Rigid
+
+    g = golden("forward_marginal.npz")
+    gt4, mask = T(g["gt4"]), T(g["mask"])
+    B, N = mask.shape
+    torch.manual_seed(int(g["seed_fm"]))
+    noise = (torch.randn(B, N, 3), torch.rand(B, N), torch.randn(B, N, 3))
+    got = diffuser.forward_marginal_device(gt4.to(DEV), float(g["t_delta"]), mask.to(DEV), noise=noise)
+    check("forward marginal (device) vs reference frames", _q_sign_free(got.cpu().numpy(), g["rigids_t"]), 2e-5)
+    torch.manual_seed(int(g["seed_prior"]))
+    noise = (torch.randn(B, N, 3), torch.rand(B, N), torch.randn(B, N, 3))
+    got = diffuser.forward_marginal_device(None, None, shape=(B, N), noise=noise)
+    check("prior sample (device) vs reference frames", _q_sign_free(got.cpu().numpy(), g["prior"]), 2e-5)
+    # host path of this build on fresh draws == device path on the same draws (larger sample, all four t regimes)
+    rig0 = Rigid.from_tensor_4x4(gt4[:1].repeat(64, 1, 1, 1))
+    for td in (0.05, 0.35, 1.0):
+        torch.manual_seed(5)
+        host = diffuser.forward_marginal(rig0, td * torch.ones(64), torch.ones(64, N))["rigids_t"]
+        torch.manual_seed(5)
+        noise = (torch.randn(64, N, 3), torch.rand(64, N), torch.randn(64, N, 3))
+        dev = diffuser.forward_marginal_device(rig0.to_tensor_4x4().to(DEV), td, noise=noise)
+        check(f"forward marginal device vs host, t={td}", _q_sign_free(dev.cpu().numpy(), host.numpy()), 2e-5)
+
+
+def test_forward_marginal_device_distribution(diffuser):
+    """Throughput mode draws on the device generator (Philox): the rotation-angle and translation distributions must be the
+    host sampler's (two-sample Kolmogorov-Smirnov, 20k draws each)."""
+    from scipy.stats import ks_2samp
+
+    from str2str_amd.common import rotation3d
+    from str2str_amd.common.rigid_utils import Rigid
+
+    B, N, td = 200, 100, 0.35
+    eye = torch.eye(4)[None, None].repeat(B, N, 1, 1)
+    torch.manual_seed(1)
+    host = diffuser.forward_marginal(Rigid.from_tensor_4x4(eye), td * torch.ones(B), torch.ones(B, N))["rigids_t"]
+    torch.cuda.manual_seed(2)
+    dev = diffuser.forward_marginal_device(eye.to(DEV), td).cpu()
+
+    def angle(r7):
+        return rotation3d.quaternion_to_axis_angle(r7[..., :4]).norm(dim=-1).reshape(-1).numpy()
+
+    ah, ad = np.minimum(angle(host), 2 * np.pi - angle(host)), np.minimum(angle(dev), 2 * np.pi - angle(dev))
+    p_ang = ks_2samp(ah, ad).pvalue
+    p_tr = ks_2samp(host[..., 4:].reshape(-1).numpy(), dev[..., 4:].reshape(-1).numpy()).pvalue
+    record_margin("forward marginal device vs host: KS p-value rotation angle (must exceed 1e-3)", 1 - p_ang, 1 - 1e-3)
+    assert p_ang > 1e-3 and p_tr > 1e-3, (p_ang, p_tr)
+    # and a rank-seeded throughput-mode trajectory runs end to end with no host noise
+
+
+def test_empty_replica_slice_keeps_host_generator_in_lockstep(net_smooth, diffuser):
+    """A rank whose slice of a chunk is empty (more ranks than replicas, remainder chunks) must consume the chunk's host draws
+    exactly like a rank that samples it, or every later chunk / t_delta / target would see a different noise stream."""
+    from str2str_amd.common.rigid_utils import Rigid
+    from str2str_amd.sampler import forward_backward
+    from str2str_amd.synth import synth_chain
+
+    feats = synth_chain(10)
+    rig0 = Rigid.from_tensor_4x4(feats["rigidgroups_gt_frames"][..., 0, :, :].repeat(3, 1, 1, 1))
+    states = []
+    for sl in ((0, 3), (0, 0), (1, 2)):
+        for pf in (True, False):
+            torch.manual_seed(9)
+            out = forward_backward(net_smooth, diffuser, feats, rig0, 0.5, num_timesteps=8, device=DEV, replica_slice=sl,
+                                   probability_flow=pf)
+            assert out.shape[0] == sl[1] - sl[0]
+            states.append(torch.get_rng_state())
+    assert all(torch.equal(states[0], s) for s in states[1:])
+
+
+def test_throughput_mode_runs_without_host_noise(net_smooth, diffuser):
+    """rng='device': forward marginal and step noise on the device generator; finite, replica-distinct, seed-reproducible."""
+    from str2str_amd.common.rigid_utils import Rigid
+    from str2str_amd.sampler import forward_backward
+    from str2str_amd.synth import synth_chain
+
+    feats = synth_chain(16)
+    rig0 = Rigid.from_tensor_4x4(feats["rigidgroups_gt_frames"][..., 0, :, :].repeat(4, 1, 1, 1))
+    outs = []
+    for pf in (True, False):
+        for rep in range(2):
+            torch.cuda.manual_seed(77)
+            host_state = torch.get_rng_state()
+            outs.append(forward_backward(net_smooth, diffuser, feats, rig0, 0.7, num_timesteps=6, device=DEV, rng="device",
+                                         probability_flow=pf).cpu())
+            assert torch.equal(host_state, torch.get_rng_state())   # the host generator is not touched
+        assert torch.isfinite(outs[-1]).all() and torch.equal(outs[-1], outs[-2])
+        assert float((outs[-1][0] - outs[-1][1]).abs().max()) > 1e-2
+    prior = forward_backward(net_smooth, diffuser, feats, rig0, -1.0, num_timesteps=6, device=DEV, rng="device")
+    assert torch.isfinite(prior).all()

@@ -123,3 +123,54 @@ def test_eval_cli_plumbing(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "eval.py"), "task_name=inference", "ckpt_path=null", "trainer=cpu"],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+def test_native_writer_byte_identical_to_reference_text(tmp_path, monkeypatch):
+    """The native formatter behind the C ABI (csrc/pdb_format.cpp; host code, no GPU needed) against the texts the
+    REFERENCE's writers produced: to_pdb of the three bundled targets, the two-model atom37 file, the merged file — and
+    against the Python restatement on awkward values (ties at the third decimal, -0.0, |x| >= 1000, 5-digit atom serials,
+    multiple chains, unknown residues, non-zero B factors)."""
+    from str2str_amd import ops
+
+    for code in CODES:
+        prot = protein.from_pdb_string(_read(f"pdb/{code}.pdb"))
+        pos = (prot.atom_positions * prot.atom_mask[..., None]).astype(np.float32)  # masked atoms are exactly zero
+        txt = ops.format_pdb_models(pos, aatype=prot.aatype, residue_index=prot.residue_index, chain_index=prot.chain_index,
+                                    b_factors=prot.b_factors, add_end=1)
+        assert txt == _read(f"io_{code}_to_pdb.txt"), code
+    g = golden("io_writer_inputs.npz")
+    kw = dict(aatype=g["aatype"], chain_index=g["chain_index"], residue_index=g["residue_index"])
+    for writer in ("native", "python"):
+        monkeypatch.setenv("S2S_PDB_WRITER", writer)
+        d = tmp_path / writer
+        os.makedirs(d / "0.25"); os.makedirs(d / "0.3")
+        p1 = pdb_utils.atom37_to_pdb(save_to=str(d / "0.25" / "x.pdb"), atom_positions=g["pos"], **kw)
+        p2 = pdb_utils.atom37_to_pdb(save_to=str(d / "0.3" / "x.pdb"), atom_positions=g["pos"][:1] + 1.0, **kw)
+        assert open(p1).read() == _read("io_atom37_two_models.pdb.txt"), writer
+        pdb_utils.merge_pdbfiles([p1, p2], str(d / "all_delta" / "x.pdb"), verbose=False)
+        assert open(d / "all_delta" / "x.pdb").read() == _read("io_merged.pdb.txt"), writer
+    # awkward values: native == Python restatement (which is pinned to the reference above)
+    rng = np.random.default_rng(0)
+    n = 2300  # > 9999 atoms in one model -> 5-digit serials; residue numbers > 999
+    pos = np.zeros((2, n, 37, 3), dtype=np.float32)
+    pos[:, :, :5] = rng.normal(0, 40, size=(2, n, 5, 3)).astype(np.float32)
+    pos[0, 0, 0] = [0.0625, -0.0625, 0.1875]      # exact ties at the third decimal (round half to even)
+    pos[0, 1, 1] = [-0.0004, 1234.5675, -999.9995]
+    pos[0, 2, 2] = [2.5e-8, 2.5e-8, 2.5e-8]       # below the 1e-7 mask threshold -> no line
+    pos[0, 3, 4] = [-0.0, 0.0, 1e-6]
+    aat = rng.integers(0, 21, size=n)
+    chain = np.repeat(np.arange(4), n // 4 + 1)[:n]
+    resi = np.arange(n) * 3 + 5
+    bf = np.zeros((n, 37)); bf[:, 1] = rng.uniform(0, 99, size=n)
+    kw = dict(aatype=aat, chain_index=chain, residue_index=resi, b_factors=bf)
+    monkeypatch.setenv("S2S_PDB_WRITER", "python")
+    want = open(pdb_utils.atom37_to_pdb(save_to=str(tmp_path / "py.pdb"), atom_positions=pos, **kw)).read()
+    monkeypatch.setenv("S2S_PDB_WRITER", "native")
+    got = open(pdb_utils.atom37_to_pdb(save_to=str(tmp_path / "na.pdb"), atom_positions=pos, **kw)).read()
+    assert got == want and "  0.062  -0.062   0.188" in got and got.count("MODEL") == 2
+    assert ops.format_pdb_models(pos, **kw) == want
+    try:
+        ops.format_pdb_models(pos, aatype=aat + 5)
+        assert False
+    except ValueError as e:
+        assert "Invalid aatypes" in str(e)
