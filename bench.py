@@ -1,20 +1,25 @@
 """Headline benchmark: sampled conformations / second, 256-residue chain, 100 denoise steps.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W] [--config cfg2|cfg3|cfg4|cfg5]   (N > 1: torch.distributed.run)
 
-One "step" = one replica chunk sampled end to end on every GPU: forward marginal (host noise),
-1 self-conditioning forward + 100 x (score-network forward + fused SE(3) step), backbone projection,
-RCCL gather of the coordinates to rank 0 and copy to the host.  Replicas are independent, so the
-work is sharded with no data-path collective except that final gather (weak scaling: 128 replicas
-per GPU).  Prints ONE JSON line (see README "bench contract"); adds
-  roofline     the dominant kernel (s2s_edge_transition, fp32 MFMA bound) timed per launch with
-               HIP events on the launch stream inside the timed region
-  cpu_baseline the CPU oracle (a port of the reference path, bit-equal to it on CPU) timed on this
-               box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
+One "step" = one replica chunk sampled end to end on every GPU: forward marginal, 1 self-conditioning forward +
+S x (score-network forward + fused SE(3) step), backbone projection, RCCL gather of the coordinates to rank 0 and
+copy to the host.  Replicas are independent, so the work is sharded with no data-path collective except that final
+gather (weak scaling: the same replicas per GPU at every N).  Prints ONE JSON line (see README "bench contract"); adds
+  roofline     the dominant kernel (s2s_edge_transition, MFMA bound) timed per launch with HIP events on the launch
+               stream inside the timed region (+ `ipa_kernel`: the HBM-bound IPA core the north star names)
+  cpu_baseline the CPU oracle (a port of the reference path, bit-equal to it on CPU) timed on this box's host cores on
+               a bounded sample of the same workload (rank 0, N=1 only)
+--config selects the BASELINE.json workload (default cfg2 = configs[1], the one the metric is quoted on):
+  cfg3  configs[2]: the 12 Science2011 fast folders (tests/golden/pdb), 1000 replicas each, PDB text written natively
+  cfg4  configs[3]: 512-residue chain, 128 replicas per GPU (1024 over 8), 200 steps
+  cfg5  configs[4]: 32 chains U[64,384] (seed 5) x 256 replicas, FLOP-weighted length-bucketed plan; at --gpus N < 8 each
+        rank runs its share of the 8-rank plan (weak scaling: 1/8 of the job per GPU)
 """
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -24,15 +29,26 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_RES, REPLICAS, DENOISE_STEPS = 256, 128, 100
 FLOPS_PER_PAIR_ET = 491520          # 2*(128*384 + 384*384 + 384*128) fp32 multiply-adds x2
 MFMA_FP32_PEAK = 157.3e12           # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
 MFMA_BF16_PEAK = 2500e12            # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
+HBM_PEAK = 8e12
+METRIC = "sampled conformations/sec (whole node), 256-res chain, 100 denoise steps"
 
 
-def cpu_baseline(n_res, steps_sampled=5, replicas=2):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(n_res, denoise_steps, steps_sampled=5, replicas=2):
     """Oracle on the host cores: (1 self-conditioning forward + `steps_sampled` denoise steps) for
-    `replicas` replicas of the same synthetic chain, extrapolated linearly to DENOISE_STEPS steps."""
+    `replicas` replicas of the same synthetic chain, extrapolated linearly to `denoise_steps` steps."""
     from oracle import diffuser as OD
     from oracle import geometry as OG
     from oracle import net as ON
@@ -52,22 +68,25 @@ def cpu_baseline(n_res, steps_sampled=5, replicas=2):
     OD.forward_backward(lambda b: ON.denoising_net(sd, b), d, f, rig0, 1.0, num_timesteps=steps_sampled)
     dt = time.perf_counter() - t0
     per_forward = dt / (steps_sampled + 1)
-    conf_per_s = replicas / (per_forward * (DENOISE_STEPS + 1))
+    conf_per_s = replicas / (per_forward * (denoise_steps + 1))
     return {"value": conf_per_s, "unit": "conformations/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": cpu_model(), "nproc": os.cpu_count(),
             "sample": f"{replicas} replica x (1 self-conditioning + {steps_sampled} denoise) network evaluations of the "
-                      f"{n_res}-residue workload = {dt:.1f} s on the host, scaled linearly to {DENOISE_STEPS}+1 evaluations"}
+                      f"{n_res}-residue workload = {dt:.1f} s on the host, scaled linearly to {denoise_steps}+1 evaluations"}
 
 
-def traffic_bytes(pairs, mode):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/*_pmc_hbm_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, read side doubled per the gfx950 correction; recipe
-    tools/pmc_hbm_traffic.sh), scaled by the pairs of this launch.  None if the file is absent."""
-    name, key = ("r01i_pmc_hbm_traffic.json", "edge_transition_bf16x6") if mode == "bf16x6" else ("r01_pmc_hbm_traffic.json", "edge_transition")
-    try:
-        with open(os.path.join(ROOT, "profiles", name)) as f:
-            return json.load(f)["kernels"][key]["bytes_per_pair_corrected"] * pairs
-    except Exception:
-        return None
+def traffic_from_profiles(pairs, mode):
+    """HBM bytes per launch of the dominant kernel.  NOT measured in this run: PMC counters need rocprofv3 around the
+    process (separate --pmc passes, tools/pmc_hbm_traffic.sh), so the committed pass at B = 16, N = 256 is scaled by the
+    pairs of this launch and labelled as such.  (None, None) if the file is absent."""
+    for name in ("r02_pmc_hbm_traffic.json", "r01i_pmc_hbm_traffic.json"):
+        key = "edge_transition_bf16x6" if mode == "bf16x6" else "edge_transition"
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["kernels"][key]["bytes_per_pair_corrected"] * pairs, f"profiles/{name} (PMC pass at B=16, N=256, scaled per pair)"
+        except Exception:
+            continue
+    return None, None
 
 
 def main():
@@ -75,9 +94,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n-res", type=int, default=N_RES)
-    ap.add_argument("--replicas", type=int, default=REPLICAS, help="replicas per GPU per step")
-    ap.add_argument("--denoise-steps", type=int, default=DENOISE_STEPS)
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--n-res", type=int, default=None)
+    ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU per step")
+    ap.add_argument("--denoise-steps", type=int, default=None)
+    ap.add_argument("--rng", default="device", choices=["device", "host"], help="noise source (host = reference-order parity mode)")
+    ap.add_argument("--cpu-steps", type=int, default=5, help="denoise steps of the CPU-oracle sample (2 replicas)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -86,7 +108,7 @@ def main():
     from str2str_amd import ops
     from str2str_amd.common.rigid_utils import Rigid
     from str2str_amd.factory import build_diffuser, build_synthetic_net
-    from str2str_amd.sampler import forward_backward
+    from str2str_amd.sampler import forward_backward, plan_mixed_work, sample_mixed_lengths
     from str2str_amd.synth import synth_chain
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,28 +127,108 @@ def main():
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
         else:
             dist.init_process_group(backend)
-        # the host part of a step (forward marginal on the host generator) is tiny: keep the ranks from oversubscribing
+        # the host part of a step is tiny: keep the ranks from oversubscribing the cores
         torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     ops.load_library()
 
-    N, B, S = a.n_res, a.replicas, a.denoise_steps
-    feats = synth_chain(N)
+    defaults = {"cfg2": (256, 128, 100), "cfg3": (None, 1000, 100), "cfg4": (512, 128, 200), "cfg5": (None, 256, 100)}[a.config]
+    N = a.n_res if a.n_res is not None else defaults[0]
+    B = a.replicas if a.replicas is not None else defaults[1]
+    S = a.denoise_steps if a.denoise_steps is not None else defaults[2]
     net = build_synthetic_net(seed=0, sigma_final=0.002, device=dev)
     diff = build_diffuser(os.path.join("/tmp", f"str2str_cache_{rank}"))
-    rig0 = Rigid.from_tensor_4x4(feats["rigidgroups_gt_frames"][..., 0, :, :].repeat(B, 1, 1, 1))
     gdev = dev if backend == "nccl" else torch.device("cpu")
-    gathered = [torch.empty(B, N, 37, 3, device=gdev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    extra = {}
 
-    def one_step(seed):
-        torch.manual_seed(seed * 1000 + rank)  # independent noise per rank and step
-        atom37 = forward_backward(net, diff, feats, rig0, 1.0, num_timesteps=S, min_t=0.01, probability_flow=True,
-                                  self_conditioning=True, device=dev, rng="device")
-        if world > 1:
-            dist.gather(atom37.to(gdev), gathered, dst=0)
-            out = torch.stack(gathered) if rank == 0 else atom37
-        else:
-            out = atom37
-        return out.cpu() if rank == 0 else None  # coordinates on the host of rank 0 = end of the job
+    # ---------------------------------------------------------------- the workload of one step on this rank
+    if a.config in ("cfg2", "cfg4"):
+        feats = synth_chain(N)
+        rig0 = Rigid.from_tensor_4x4(feats["rigidgroups_gt_frames"][..., 0, :, :].repeat(B, 1, 1, 1))
+        gathered = [torch.empty(B, N, 37, 3, device=gdev) for _ in range(world)] if (world > 1 and rank == 0) else None
+        per_rank = B
+        workload = (f"configs[{1 if a.config == 'cfg2' else 3}]: single {N}-residue synthetic chain, {B} replicas per GPU x {S} "
+                    f"denoise steps (+1 self-conditioning forward), probability-flow ODE, seeded synthetic weights")
+        pairs_main = B * N * N
+
+        def one_step(seed):
+            torch.manual_seed(seed * 1000 + rank)
+            torch.cuda.manual_seed(seed * 1000 + rank)  # independent noise per rank and step
+            atom37 = forward_backward(net, diff, feats, rig0, 1.0, num_timesteps=S, min_t=0.01, probability_flow=True,
+                                      self_conditioning=True, device=dev, rng=a.rng)
+            if world > 1:
+                dist.gather(atom37.to(gdev), gathered, dst=0)
+                out = torch.stack(gathered) if rank == 0 else atom37
+            else:
+                out = atom37
+            return out.cpu() if rank == 0 else None  # coordinates on the host of rank 0 = end of the job
+    elif a.config == "cfg3":
+        from str2str_amd.common import protein
+        from str2str_amd.data.components.dataset import ProteinFeatureTransform
+
+        pdb_dir = os.path.join(ROOT, "tests", "golden", "pdb")
+        tf = ProteinFeatureTransform()
+        targets = []
+        for fn in sorted(os.listdir(pdb_dir)):
+            f = tf(protein.from_pdb_string(open(os.path.join(pdb_dir, fn)).read()).to_dict())
+            targets.append({k: (v[None] if torch.is_tensor(v) else v) for k, v in f.items()})
+        lens = [int(t["aatype"].shape[1]) for t in targets]
+        per_rank = B * len(targets)
+        workload = (f"configs[2]: Science2011 fast-folder set ({len(targets)} targets, N = {sorted(lens)}), {B} replicas each per GPU "
+                    f"x {S} denoise steps, one chunk per target, multi-MODEL PDB text written by the native writer")
+        pairs_main = B * max(lens) ** 2
+        out_dir = f"/tmp/s2s_bench_cfg3_{rank}"
+        os.makedirs(out_dir, exist_ok=True)
+        extra["pdb_write_s"] = 0.0
+
+        def one_step(seed):
+            torch.manual_seed(seed * 1000 + rank)
+            torch.cuda.manual_seed(seed * 1000 + rank)
+            res = None
+            for ti, tg in enumerate(targets):
+                rig0 = Rigid.from_tensor_4x4(tg["rigidgroups_gt_frames"][..., 0, :, :].repeat(B, 1, 1, 1))
+                a37 = forward_backward(net, diff, tg, rig0, 1.0, num_timesteps=S, min_t=0.01, probability_flow=True,
+                                       self_conditioning=True, device=dev, rng=a.rng)
+                if world > 1:
+                    bufs = [torch.empty_like(a37, device=gdev) for _ in range(world)] if rank == 0 else None
+                    dist.gather(a37.to(gdev), bufs, dst=0)
+                    a37 = torch.cat(bufs) if rank == 0 else a37
+                if rank == 0:
+                    res = a37.cpu()
+                    t0 = time.perf_counter()  # reported separately; inside the timed region all the same
+                    ops.write_pdb_models(os.path.join(out_dir, f"t{ti}.pdb"), res.numpy(), aatype=tg["aatype"][0].numpy(),
+                                         residue_index=tg["residue_index"].numpy(), chain_index=tg["chain_index"].numpy())
+                    extra["pdb_write_s"] += time.perf_counter() - t0
+            return res
+    else:  # cfg5
+        lens = [int(x) for x in np.random.default_rng(5).integers(64, 385, size=32)]
+        targets = [synth_chain(n, frame_seed=3 + n, aatype_seed=4 + n) for n in lens]
+        plan_world = max(8, world)
+        plan = plan_mixed_work(lens, B, plan_world)
+        my = rank % plan_world
+        per_rank = sum(hi - lo for b in plan[my] for _, lo, hi in b["items"])
+        workload = (f"configs[4]: 32 synthetic chains N ~ U[64,384] (seed 5) x {B} replicas x {S} denoise steps, FLOP-weighted "
+                    f"length-bucketed plan over {plan_world} ranks; every GPU runs one rank's share "
+                    f"({per_rank} (chain, replica) items in {len(plan[my])} padded batches)")
+        pairs_main = max(sum(hi - lo for _, lo, hi in b["items"]) * b["n_pad"] ** 2 for b in plan[my])
+
+        def one_step(seed):
+            torch.manual_seed(seed * 1000 + rank)
+            torch.cuda.manual_seed(seed * 1000 + rank)
+            pieces = sample_mixed_lengths(net, diff, targets, B, 1.0, num_timesteps=S, device=dev, rng="device",
+                                          shard=(my, plan_world), plan=plan)
+            # compact backbone [.,5,3] per piece, flattened: ONE gather of a padded flat buffer per step
+            flat = torch.cat([p[..., :5, :].reshape(-1) for ps in pieces for _, p in ps]) if per_rank else torch.zeros(0, device=dev)
+            if world > 1:
+                size = torch.tensor([flat.numel()], device=gdev)
+                sizes = [torch.zeros_like(size) for _ in range(world)]
+                dist.all_gather(sizes, size)
+                mx = int(max(int(x) for x in sizes))
+                pad = torch.zeros(mx, device=gdev)
+                pad[: flat.numel()] = flat.to(gdev)
+                bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+                dist.gather(pad, bufs, dst=0)
+                flat = torch.cat([b[: int(n)] for b, n in zip(bufs, sizes)]) if rank == 0 else flat
+            return flat.cpu() if rank == 0 else None
 
     def barrier():
         if world > 1:
@@ -135,58 +237,65 @@ def main():
 
     for w in range(a.warmup):
         one_step(w)
+    extra = {k: 0.0 for k in extra}
     barrier()
     t0 = time.perf_counter()
-    with ops.KernelTimer("s2s_edge_transition", "s2s_ipa_attention") as kt:
+    timed = ("s2s_edge_transition", "s2s_ipa_attention") if a.config in ("cfg2", "cfg4") else ()  # (timers disable HIP graphs)
+    with ops.KernelTimer(*timed) as kt:
         for k in range(a.steps):
             res = one_step(100 + k)
+        my_elapsed = time.perf_counter() - t0   # this rank's own time (before the closing barrier)
         barrier()
         elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], device=gdev, dtype=torch.float64)
+    mine = torch.tensor([my_elapsed], device=gdev, dtype=torch.float64)
+    per_rank_s = [mine.clone() for _ in range(world)]
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_gather(per_rank_s, mine)
     elapsed = float(el.item())
-    et_ms, et_n = kt.mean_ms("s2s_edge_transition")
-    ipa_ms, ipa_n = kt.mean_ms("s2s_ipa_attention")
+    et_ms, et_n = kt.mean_ms("s2s_edge_transition") if timed else (float("nan"), 0)
+    ipa_ms, ipa_n = kt.mean_ms("s2s_ipa_attention") if timed else (float("nan"), 0)
 
     if rank == 0:
         assert res is not None and torch.isfinite(res).all()
-        total = a.steps * B * world
-        pairs = B * N * N
+        total = a.steps * per_rank * world
         mode = net.translator.trunk["edge_transition_0"].mfma_mode
-        alg = pairs * FLOPS_PER_PAIR_ET                       # fp32 multiply-add flops the operator needs
-        executed = alg * (6 if mode == "bf16x6" else 1)       # bf16x6: six bf16 plane-pair products per fp32 product
-        peak = MFMA_BF16_PEAK if mode == "bf16x6" else MFMA_FP32_PEAK
-        ach = executed / (et_ms * 1e-3)
-        ipa_bytes = B * 4 * (9512 * N + 40 * N * N)
         line = {
-            "metric": "sampled conformations/sec (whole node), 256-res chain, 100 denoise steps",
+            "metric": METRIC if a.config == "cfg2" else f"sampled conformations/sec (whole node), BASELINE {a.config}",
             "value": total / elapsed, "unit": "conformations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if mode == "f32" else "f32 (pair MLP on exact 3-way bf16 split MFMA, fp32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": f"configs[1]: single {N}-residue synthetic chain, {B} replicas per GPU x {S} denoise "
-                                   f"steps (+1 self-conditioning forward), probability-flow ODE, seeded synthetic weights",
-                       "n_res": N, "replicas_per_gpu": B, "denoise_steps": S, "parallelism": f"replica-shard x{world}",
-                       "edge_mfma_mode": mode,
-                       "step_definition": "one replica chunk sampled end to end incl. gather + D2H"},
-            "roofline": {"bound": "mfma",
-                         "kernel": "s2s_edge_transition" + ("_bf16x6 (edge_transition_bf16_kernel)" if mode == "bf16x6"
-                                                            else " (edge_transition_kernel)"),
-                         "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
-                         "traffic": traffic_bytes(pairs, mode), "launches_timed": et_n, "mean_launch_ms": et_ms,
-                         "algorithmic_flops_per_launch": alg, "executed_mfma_flops_per_launch": executed,
-                         # what a bare MFMA loop on random operands sustains under this part's 1400 W cap
-                         # (tools/ubench/mfma_shape_power.hip): context for `frac`, which uses the nominal peak
-                         "power_limited_mfma_rate_measured": 1800.0 if mode == "bf16x6" else None,
-                         "fp32_equivalent_tflops": alg / (et_ms * 1e-3) / 1e12,
-                         "fp32_equivalent_vs_fp32_mfma_peak": alg / (et_ms * 1e-3) / MFMA_FP32_PEAK},
-            "ipa_kernel": {"bound": "hbm", "kernel": "s2s_ipa_attention", "mean_launch_ms": ipa_ms, "launches_timed": ipa_n,
-                           "achieved": ipa_bytes / (ipa_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                           "frac": ipa_bytes / (ipa_ms * 1e-3) / 8e12},
+            "config": {"workload": workload, "n_res": N, "replicas_per_gpu": B, "denoise_steps": S,
+                       "parallelism": f"replica-shard x{world}", "edge_mfma_mode": mode, "rng": a.rng,
+                       "step_definition": "one replica chunk (cfg3: all 12 targets; cfg5: the rank's plan) sampled end to end incl. gather + D2H"},
+            "distributed": {"backend": (dist.get_backend() if world > 1 else None), "world_size": world,
+                            "per_rank_conformations_per_s": [a.steps * per_rank / float(x.item()) for x in per_rank_s]},
         }
-        if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(N)
+        line["config"].update(extra)
+        if a.config in ("cfg2", "cfg4") and et_n:
+            pairs = pairs_main
+            alg = pairs * FLOPS_PER_PAIR_ET                       # fp32 multiply-add flops the operator needs
+            executed = alg * (6 if mode == "bf16x6" else 1)       # bf16x6: six bf16 plane-pair products per fp32 product
+            peak = MFMA_BF16_PEAK if mode == "bf16x6" else MFMA_FP32_PEAK
+            ach = executed / (et_ms * 1e-3)
+            traffic, traffic_src = traffic_from_profiles(pairs, mode)
+            ipa_bytes = B * 4 * (9512 * N + 40 * N * N)
+            line["roofline"] = {
+                "bound": "mfma",
+                "kernel": "s2s_edge_transition" + ("_bf16x6 (edge_transition_bf16_kernel)" if mode == "bf16x6" else " (edge_transition_kernel)"),
+                "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
+                "traffic": traffic, "traffic_source": traffic_src, "launches_timed": et_n, "mean_launch_ms": et_ms,
+                "algorithmic_flops_per_launch": alg, "executed_mfma_flops_per_launch": executed,
+                "fp32_equivalent_tflops": alg / (et_ms * 1e-3) / 1e12,
+                "fp32_equivalent_vs_fp32_mfma_peak": alg / (et_ms * 1e-3) / MFMA_FP32_PEAK}
+            line["ipa_kernel"] = {"bound": "hbm", "kernel": "s2s_ipa_attention (+ s2s_ipa_opair)", "mean_launch_ms": ipa_ms,
+                                  "launches_timed": ipa_n, "achieved": ipa_bytes / (ipa_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
+                                  "unit": "GB/s", "frac": ipa_bytes / (ipa_ms * 1e-3) / HBM_PEAK,
+                                  "algorithmic_bytes_per_launch": ipa_bytes}
+        if world == 1 and not a.no_cpu_baseline and a.config == "cfg2":
+            line["cpu_baseline"] = cpu_baseline(N, S, steps_sampled=a.cpu_steps)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -62,7 +62,7 @@ class KernelTimer:
         self.events = {n: [] for n in names}
 
     def __enter__(self):
-        KernelTimer.active = self
+        KernelTimer.active = self if self.names else None   # no names: a no-op context (HIP graphs stay enabled)
         return self
 
     def __exit__(self, *exc):

@@ -268,54 +268,126 @@ def forward_backward(net, diffuser, batch: dict, rigids_0: Rigid, t_delta: float
     return atom37
 
 
+def forward_flops(n_res: int) -> float:
+    """Algorithmic FLOPs of one network evaluation per replica: F(N) = 2,251,264 N^2 + 3.24e7 N."""
+    return 2251264.0 * n_res * n_res + 3.24e7 * n_res
+
+
+def plan_mixed_work(lengths, replicas: int, world: int = 1, *, max_pairs: int = 24 << 20, ms_per_mpair: float = 10.7,
+                    launch_floor_ms: float = 4.0):
+    """Work distribution for many chains of different length (BASELINE configs[4]): flatten to (chain,
+    replica block) items, balance them over the ranks by FLOP weight, bucket each rank's items by padded length.
+
+      1. every chain's replicas are ceil-split into ``world`` blocks (``shard_range``); the non-empty blocks are the items,
+         weight = (replicas in the block) x F(N);
+      2. longest-processing-time-first: items in decreasing weight go to the currently least loaded rank (even splits give
+         every rank the same set of lengths; remainders and replicas < world are what the weights are for);
+      3. per rank, items in decreasing length are packed into padded batches (n_pad = the longest chain of the batch; the
+         kernels take ragged N, so there is no tile rounding).  An item joins the open batch when that is cheaper than a
+         batch of its own (within 5 %) under  cost(batch) = max(launch_floor_ms, ms_per_mpair x padded Mpairs)  per network evaluation
+         -- one evaluation is ~330 launches, so small batches are launch-bound and padding them into a neighbour is free,
+         while large ones pay for every padded pair (measured: 10.7 ms per 2^20 pairs at cfg2) -- and the batch stays
+         below ``max_pairs`` (device memory: ~1.3 KB per pair).
+    -> plan[rank] = [ {"n_pad": int, "items": [(chain, replica_lo, replica_hi), ...]}, ... ]"""
+    lengths = [int(x) for x in lengths]
+    items = []
+    for k, L in enumerate(lengths):
+        for r in range(world):
+            lo, hi = shard_range(replicas, r, world)
+            if hi > lo:
+                items.append((forward_flops(L) * (hi - lo), k, lo, hi))
+    items.sort(key=lambda it: (-it[0], it[1], it[2]))
+    load = [0.0] * world
+    mine = [[] for _ in range(world)]
+    for w, k, lo, hi in items:
+        r = min(range(world), key=lambda q: (load[q], q))
+        load[r] += w
+        mine[r].append((k, lo, hi))
+    plan = []
+    for r in range(world):
+        cost = lambda pairs: max(launch_floor_ms, ms_per_mpair * pairs / float(1 << 20))  # noqa: E731
+        batches, cur, cur_b, n_pad = [], [], 0, 0
+        for k, lo, hi in sorted(mine[r], key=lambda it: (-lengths[it[0]], it[0], it[1])):
+            L, b = lengths[k], hi - lo
+            if cur:
+                merged = (cur_b + b) * n_pad * n_pad
+                if merged > max_pairs or cost(merged) > 1.05 * (cost(cur_b * n_pad * n_pad) + cost(b * L * L)):
+                    batches.append({"n_pad": n_pad, "items": cur})
+                    cur, cur_b = [], 0
+            if not cur:
+                n_pad = L
+            cur.append((k, lo, hi)); cur_b += b
+        if cur:
+            batches.append({"n_pad": n_pad, "items": cur})
+        plan.append(batches)
+    return plan
+
+
 @torch.no_grad()
 def sample_mixed_lengths(net, diffuser, targets, replicas: int, t_delta: float, *, num_timesteps: int,
                          min_t: float = 0.01, noise_scale: float = 1.0, probability_flow: bool = True,
-                         self_conditioning: bool = True, device=None, rigids_t_init=None):
-    """BASELINE configs[4]: several chains of different length in ONE padded batch (``replicas`` each).
+                         self_conditioning: bool = True, device=None, rigids_t_init=None, shard: Tuple[int, int] = (0, 1),
+                         rng: str = "host", max_pairs: int = 24 << 20, plan=None):
+    """BASELINE configs[4]: many chains of different length, ``replicas`` each, in padded batches.
 
     The reference cannot do this (`assert batch size == 1`, diffusion_module.py:249) and its padding semantics
     would be wrong for it (float key-padding mask added to the transformer logits, centre of mass over padded
     residues).  Here padding is exact: padded keys are removed from both attentions, pair rows/cols are
-    masked, the centre of mass runs over real residues only — so every chain reproduces its own un-padded run.
-    ``targets``: list of single-target feature dicts (batch dim 1).  -> list of atom37 [replicas, N_k, 37, 3]."""
+    masked, the centre of mass runs over real residues only -- so every chain reproduces its own un-padded run.
+    Work is distributed by ``plan_mixed_work`` (FLOP-weighted over ``shard`` = (rank, world), bucketed by length).
+    ``targets``: list of single-target feature dicts (batch dim 1).  ``rng="device"`` draws the forward-marginal / step
+    noise on the device; "host" on the host generator per (chain, block) in plan order; ``rigids_t_init[k]`` [replicas,
+    N_k, 7] overrides the starting frames.
+    -> list over chains of (replica_lo, atom37 [b, N_k, 37, 3]) pieces this rank sampled, in replica order."""
     device = torch.device(device) if device is not None else next(net.parameters()).device
-    n_max = max(int(t["aatype"].shape[1]) for t in targets)
+    lengths = [int(t["aatype"].shape[1]) for t in targets]
+    rank, world = shard
+    if plan is None:
+        plan = plan_mixed_work(lengths, replicas, world, max_pairs=max_pairs)
     T, n, dt, ts = schedule(t_delta, num_timesteps, min_t)
-    rows, r_t = {k: [] for k in _REPEAT_KEYS}, []
-    for ti, tg in enumerate(targets):
-        L = int(tg["aatype"].shape[1])
-        for k in _REPEAT_KEYS:
-            v = tg[k]
-            pad = torch.zeros((1, n_max - L) + tuple(v.shape[2:]), dtype=v.dtype)
-            if k == "residue_idx" and L < n_max:  # keep padded indices inside the real range (table lookups stay in bounds)
-                pad = pad + v[:, -1:]
-            rows[k].append(torch.cat([v.cpu(), pad], dim=1).repeat(replicas, *(1,) * (v.ndim - 1)))
-        if rigids_t_init is not None:
-            rt = rigids_t_init[ti].cpu()
-        else:
-            gt4 = tg["rigidgroups_gt_frames"][..., 0, :, :].cpu()
-            rig0 = Rigid.from_tensor_4x4(gt4.repeat(replicas, 1, 1, 1))
-            if t_delta > 0:
-                rt = diffuser.forward_marginal(rig0, t_delta * torch.ones(replicas), tg["residue_mask"].cpu().repeat(replicas, 1))["rigids_t"]
-            else:
-                rt = diffuser.sample_prior(shape=rig0.shape, device="cpu", as_tensor_7=True)["rigids_t"]
-        ident = torch.zeros(replicas, n_max - L, 7)
-        ident[..., 0] = 1.0  # identity frames on the padding: finite everywhere, masked out of every result
-        r_t.append(torch.cat([rt.float(), ident], dim=1))
-    feats = {k: torch.cat(v, dim=0).to(device) for k, v in rows.items()}
-    rigids_t = torch.cat(r_t, dim=0).to(device).contiguous()
+    pieces = [[] for _ in targets]
     tr = net.translator
     keep = tr.exact_padding
     tr.exact_padding = True
     try:
-        atom37, _, _ = denoise_loop(net, diffuser, feats, rigids_t, ts, dt, min_t=min_t, noise_scale=noise_scale,
-                                    probability_flow=probability_flow, self_conditioning=self_conditioning, center_mode=2)
+        for batch in plan[rank]:
+            n_pad = batch["n_pad"]
+            rows, r_t = {k: [] for k in _REPEAT_KEYS}, []
+            for ti, lo, hi in batch["items"]:
+                tg, L, b = targets[ti], lengths[ti], hi - lo
+                for k in _REPEAT_KEYS:
+                    v = tg[k]
+                    pad = torch.zeros((1, n_pad - L) + tuple(v.shape[2:]), dtype=v.dtype)
+                    if k == "residue_idx" and L < n_pad:  # keep padded indices inside the real range (table lookups stay in bounds)
+                        pad = pad + v[:, -1:]
+                    rows[k].append(torch.cat([v.cpu(), pad], dim=1).repeat(b, *(1,) * (v.ndim - 1)))
+                gt4 = tg["rigidgroups_gt_frames"][..., 0, :, :]
+                if rigids_t_init is not None:
+                    rt = rigids_t_init[ti][lo:hi].to(device).float()
+                elif rng == "device":
+                    if t_delta > 0:
+                        rt = diffuser.forward_marginal_device(gt4.to(device).float().repeat(b, 1, 1, 1), t_delta,
+                                                              tg["residue_mask"].to(device).float().repeat(b, 1))
+                    else:
+                        rt = diffuser.forward_marginal_device(None, None, shape=(b, L))
+                else:
+                    rig0 = Rigid.from_tensor_4x4(gt4.cpu().repeat(b, 1, 1, 1))
+                    if t_delta > 0:
+                        rt = diffuser.forward_marginal(rig0, t_delta * torch.ones(b), tg["residue_mask"].cpu().repeat(b, 1))["rigids_t"]
+                    else:
+                        rt = diffuser.sample_prior(shape=rig0.shape, device="cpu", as_tensor_7=True)["rigids_t"]
+                    rt = rt.to(device).float()
+                ident = torch.zeros(b, n_pad - L, 7, device=device)
+                ident[..., 0] = 1.0  # identity frames on the padding: finite everywhere, masked out of every result
+                r_t.append(torch.cat([rt, ident], dim=1))
+            feats = {k: torch.cat(v, dim=0).to(device) for k, v in rows.items()}
+            rigids_t = torch.cat(r_t, dim=0).contiguous()
+            atom37, _, _ = denoise_loop(net, diffuser, feats, rigids_t, ts, dt, min_t=min_t, noise_scale=noise_scale,
+                                        probability_flow=probability_flow, self_conditioning=self_conditioning, center_mode=2)
+            o = 0
+            for ti, lo, hi in batch["items"]:
+                pieces[ti].append((lo, atom37[o:o + hi - lo, :lengths[ti]].clone()))
+                o += hi - lo
     finally:
         tr.exact_padding = keep
-    out, o = [], 0
-    for tg in targets:
-        L = int(tg["aatype"].shape[1])
-        out.append(atom37[o:o + replicas, :L])
-        o += replicas
-    return out
+    return [sorted(p, key=lambda x: x[0]) for p in pieces]

@@ -647,29 +647,40 @@ def test_predict_step_entry_writes_reference_layout(tmp_path, monkeypatch):
 
 
 def test_mixed_length_padded_batch_equals_unpadded_runs(net_smooth, diffuser):
-    """BASELINE configs[4] semantics: chains of different length in one padded batch; every chain must equal its
-    own un-padded single-chain run (same initial noised frames)."""
+    """BASELINE configs[4] semantics: chains of different length in padded batches; every chain must equal its own un-padded
+    single-chain run (same initial noised frames).  Lengths drawn like the cfg5 workload (U[64, 384], seed 5) plus two short
+    ones, 2 replicas each, through the FLOP-weighted planner: as one process and as 2 'ranks' run back to back."""
     from str2str_amd.common.rigid_utils import Rigid
-    from str2str_amd.sampler import denoise_loop, sample_mixed_lengths, schedule
+    from str2str_amd.sampler import denoise_loop, plan_mixed_work, sample_mixed_lengths, schedule
     from str2str_amd.synth import synth_chain
 
-    lens, R, S = (12, 33, 20), 2, 5
+    lens = [12, 33] + [int(x) for x in np.random.default_rng(5).integers(64, 385, size=32)[:6]]
+    R, S = 2, 4
     targets = [synth_chain(n, frame_seed=3 + n, aatype_seed=4 + n) for n in lens]
     torch.manual_seed(3)
     inits = []
     for tg in targets:
         rig0 = Rigid.from_tensor_4x4(tg["rigidgroups_gt_frames"][..., 0, :, :].repeat(R, 1, 1, 1))
         inits.append(diffuser.forward_marginal(rig0, 1.0 * torch.ones(R), tg["residue_mask"].repeat(R, 1))["rigids_t"])
-    mixed = sample_mixed_lengths(net_smooth, diffuser, targets, R, 1.0, num_timesteps=S, device=DEV, rigids_t_init=inits)
+    plan = plan_mixed_work(lens, R, 1, launch_floor_ms=1e9)   # force everything into as few padded batches as memory allows
+    assert len(plan[0]) == 1 and plan[0][0]["n_pad"] == max(lens)
+    mixed = sample_mixed_lengths(net_smooth, diffuser, targets, R, 1.0, num_timesteps=S, device=DEV, rigids_t_init=inits, plan=plan)
+    halves = [sample_mixed_lengths(net_smooth, diffuser, targets, R, 1.0, num_timesteps=S, device=DEV, rigids_t_init=inits,
+                                   shard=(r, 2)) for r in range(2)]
     T, n, dt, ts = schedule(1.0, S, 0.01)
-    for tg, init, got in zip(targets, inits, mixed):
-        f = {k: tg[k].to(DEV).repeat(R, *(1,) * (tg[k].ndim - 1)) for k in
+    for k, (tg, init) in enumerate(zip(targets, inits)):
+        f = {kk: tg[kk].to(DEV).repeat(R, *(1,) * (tg[kk].ndim - 1)) for kk in
              ("aatype", "residue_mask", "fixed_mask", "residue_idx", "torsion_angles_sin_cos")}
         f["residue_idx"] = tg["residue_idx"].repeat(R, 1)
         alone, _, _ = denoise_loop(net_smooth, diffuser, f, init.to(DEV).float().contiguous(), ts, dt, min_t=0.01)
-        assert got.shape == alone.shape
-        rmsd = backbone_rmsd(got.cpu().numpy()[..., :5, :], alone.cpu().numpy()[..., :5, :])
-        assert rmsd < 1e-4, (tg["aatype"].shape, rmsd)
+        alone = alone.cpu().numpy()[..., :5, :]
+        (lo, got), = mixed[k]
+        assert lo == 0 and got.shape == (R, lens[k], 37, 3)
+        check(f"mixed-length padded batch vs un-padded run, N={lens[k]} (RMSD, A)", backbone_rmsd(got.cpu().numpy()[..., :5, :], alone), 1e-4)
+        parts = sorted(halves[0][k] + halves[1][k], key=lambda x: x[0])
+        both = torch.cat([p for _, p in parts]).cpu().numpy()[..., :5, :]
+        assert [lo for lo, _ in parts] == [0, 1] and both.shape[0] == R
+        check(f"mixed-length 2-rank plan vs un-padded run, N={lens[k]} (RMSD, A)", backbone_rmsd(both, alone), 1e-4)
 
 
 def _q_sign_free(a, b):

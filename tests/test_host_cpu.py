@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(built_library):
     from str2str_amd import ops
 
     hdr = open(os.path.join(ROOT, "include", "str2str_hip.h")).read()
-    declared = sorted(set(re.findall(r"^int\s+(s2s_\w+)\s*\(", hdr, flags=re.M)))
+    declared = sorted(set(re.findall(r"^(?:int|long long)\s+(s2s_\w+)\s*\(", hdr, flags=re.M)))
     assert declared and set(declared) == set(ops.EXPORTS), (declared, ops.EXPORTS)
     lib = ops.load_library()  # dlopen + symbol lookup for every entry point; raises if one is missing
     for name in declared:
@@ -181,3 +181,31 @@ def test_schedule_and_step_params(tmp_path):
     sd = golden("so3_score.npz")
     for row, idx in zip(sd["cdf_rows"], sd["cdf_row_idx"]):
         assert np.abs(d.rot_diffuser.cdf_row(int(idx)) - row).max() < 1e-12
+
+
+def test_mixed_length_plan_covers_every_replica_once_and_balances():
+    """cfg5 work distribution: 32 chains U[64,384] (seed 5) x 256 replicas over 1, 8 and 3 ranks, plus awkward
+    cases (fewer replicas than ranks): every (chain, replica) exactly once, FLOP load balanced, batches inside the memory cap."""
+    import numpy as np
+
+    from str2str_amd.sampler import forward_flops, plan_mixed_work
+
+    lens = [int(x) for x in np.random.default_rng(5).integers(64, 385, size=32)]
+    for replicas, world in [(256, 1), (256, 8), (256, 3), (3, 8), (1, 4)]:
+        plan = plan_mixed_work(lens, replicas, world)
+        seen = {}
+        loads = []
+        for r in range(world):
+            load = 0.0
+            for b in plan[r]:
+                assert b["n_pad"] == max(lens[k] for k, _, _ in b["items"])
+                assert sum(hi - lo for _, lo, hi in b["items"]) * b["n_pad"] ** 2 <= 24 << 20 or len(b["items"]) == 1
+                for k, lo, hi in b["items"]:
+                    for q in range(lo, hi):
+                        assert (k, q) not in seen
+                        seen[(k, q)] = r
+                    load += forward_flops(lens[k]) * (hi - lo)
+            loads.append(load)
+        assert len(seen) == len(lens) * replicas
+        if replicas >= world:
+            assert max(loads) <= 1.12 * sum(loads) / world, (replicas, world, loads)
