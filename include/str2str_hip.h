@@ -156,6 +156,30 @@ int s2s_se3_step(const float* x0_7, const float* xt_7, const float* mask, const 
                  double coordinate_scaling, int probability_flow, int center_trans, double noise_scale,
                  void* stream);
 
+/* ---- Per-node dense layers (split-bf16 MFMA, fp32-equivalent) ----
+ * Activations travel between these layers as PACKED PLANES ("XP"): for X [M, K],
+ *   XP[rt = row/32][ks = K/16][plane 3][lane 64][8] bf16, lane = 32 g + (row & 31),
+ *   element j = plane of X[row][32 (ks>>1) + (r&3) + 8 (r>>2) + 4 g], r = 8 (ks&1) + j   (exact 3-way bf16 split h, m, l);
+ * rows past M inside the last row tile are zero. */
+
+/* fp32 row-major x [n_rows, ld], columns col0 .. col0 + n_cols (n_cols % 32 == 0), optionally scaled per row, -> k-steps
+ * xp_kstep0 .. of an XP buffer holding xp_ksteps k-steps (concatenation along K = k-step ranges). */
+int s2s_pack_planes(const float* x, long long n_rows, int ld, int col0, int n_cols, void* xp, int xp_ksteps, int xp_kstep0,
+                    const float* row_scale, void* stream);
+
+/* One nn.Linear of the node stream with its surrounding elementwise ops (reference: Linear src/models/net/layers.py:64-124;
+ * call sites ipa.py:131-171 (q/kv/points), :259-266 (linear_out), :343-366 (LayerNorm, skip, transformer, linear, transitions),
+ * layers.py:128-145,176,188-241; torch.nn.TransformerEncoderLayer's projections and feed-forward):
+ *     v = acc * pre_scale[row] + bias;  relu;  v *= pre_mask[row];  v += residual[row, col];  LayerNorm(v) over the n_out
+ *     columns (gamma/beta given; needs n_out == 32 * tiles_per_block);  v *= post_mask[row]
+ *   xp: packed planes of the input [n_rows, k_in]; w_packed: ops.pack_node_weight(W [n_out, k_in], tiles_per_block);
+ *   outputs: out_f32[row * out_ld + out_col0 + col] and/or the packed planes of the result as k-steps out_xp_kstep0 .. of an XP
+ *   buffer with out_xp_ksteps k-steps (the input format of the next layer).  Any pointer may be NULL to skip that step. */
+int s2s_node_linear(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
+                    int tiles_per_block, const float* pre_scale, int relu, const float* pre_mask, const float* residual,
+                    int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_mask,
+                    float* out_f32, int out_ld, int out_col0, void* out_xp, int out_xp_ksteps, int out_xp_kstep0, void* stream);
+
 /* ---- Forward process / prior, once per trajectory ---- */
 
 /* FrameDiffuser.forward_marginal (src/models/score/frame.py:36-107; so3.py:244-272, :315-331, :13-19; r3.py:49-74) or, with

@@ -33,6 +33,7 @@ UNITS = {
     "pair_mlp.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
     "pair_mlp_bf16.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
     "ipa_attention.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
+    "node_gemm.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
 }
 
 

@@ -1,0 +1,366 @@
+// Per-node dense layers on split-bf16 MFMA ("bf16x6", fp32-equivalent; see pair_mlp_bf16.hip): every nn.Linear of the trunk that acts
+// on the [B*N, c] node stream -- linear_q / linear_kv / point projections, linear_out, skip_embed, the transformer's in/out
+// projections and feed-forward, trunk.linear_b, NodeTransition, BackboneUpdate, EdgeTransition.initial_embed and the per-node
+// halves of its first layer, TorsionAngleHead (reference src/models/net/ipa.py:131-171,259-266,312-317,357-366;
+// layers.py:128-145,188-241) -- with bias / ReLU / mask / residual / LayerNorm fused into the epilogue.
+//
+// Formulation (the edge kernel's, transposed):  Y^T[out, row] = W . X^T.   A operand = weight fragment (shared by the 4 waves
+// of a workgroup through LDS, double buffered), B operand = activation fragment of the wave's own 32 rows.  In that
+// orientation the accumulator layout of a layer IS the B-operand layout of the next one, so activations travel between
+// layers as PACKED PLANES ("XP"): for X [M, K]
+//     XP[rt = row/32][ks = K/16][plane 3][lane 64][8] bf16,  lane = 32 g + (row & 31),
+//     element j = plane of X[row][32 (ks>>1) + (r&3) + 8 (r>>2) + 4 g],  r = 8 (ks&1) + j        ("chain" order)
+// i.e. exactly the 1 KiB a wave's B-fragment load wants: every global access of this kernel is lane-linear (16 B per lane,
+// 1 KiB per instruction), there is no LDS staging, no swizzle and no split VALU on the input side -- a value is split into
+// its three planes ONCE, in the epilogue of the kernel that produced it (or by s2s_pack_planes for fp32 inputs).
+// Weights are packed on the host in the same chain order (ops.pack_node_weight): [col block][k-step][tile][plane 3][lane][8].
+//
+// Per workgroup: 4 waves x 32 rows, TG output tiles of 32 columns (TG x 16 accumulator registers per lane), one weight stage
+// (one k-step: TG tiles x 3 planes = 3 TG KiB) per barrier, two workgroups per CU.  Per (k-step, tile): 3 ds_read_b128 + 6
+// MFMAs (plane pairs lh, hl, mm, mh, hm, hh).  The weight stage of the NEXT k-step travels global -> VGPR during a stage and
+// VGPR -> LDS at its end, the wave's own activation fragments are fetched one k-step ahead.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "str2str_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+// exact 3-way split of 8 fp32 values into bf16 planes (round-to-nearest residues)
+__device__ __forceinline__ void split8(const float* v, bf16x8& ph, bf16x8& pm, bf16x8& pl) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 a = (__bf16)v[j];
+        const float r1 = v[j] - (float)a;
+        const __bf16 b = (__bf16)r1;
+        const float r2 = r1 - (float)b;
+        ph[j] = a; pm[j] = b; pl[j] = (__bf16)r2;
+    }
+}
+
+struct GemmArgs {
+    const bf16x8* xp;        // packed activation planes [RT][KS][3][64] fragments
+    const char* wpk;         // packed weights [n_col_blocks][KS][TG][3][64][8] bf16
+    const float* bias;       // [Nout] or NULL
+    const float* pre_scale;  // [M] or NULL: acc *= pre_scale[row] before the bias (input rows were to be scaled)
+    const float* pre_mask;   // [M] or NULL: (acc + bias) *= pre_mask[row]
+    const float* residual;   // [M, res_ld] fp32 or NULL (added after relu / pre_mask)
+    const float* ln_gamma;   // LayerNorm over the Nout columns (requires one column block) or NULL
+    const float* ln_beta;
+    const float* post_mask;  // [M] or NULL: applied last
+    float* out_f32;          // [M, out_ld] (columns out_col0 + ...) or NULL
+    bf16x8* out_xp;          // packed planes of the output as a K' = 16 * xp_KS wide activation, at k-step offset xp_ks0, or NULL
+    long long M;
+    int KS;                  // K / 16 (even)
+    int n_col_blocks;
+    int res_ld, out_ld, out_col0, xp_KS, xp_ks0;
+    int relu;
+    float ln_eps;
+};
+
+template <int TG, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
+    // One weight stage = ONE k-step (TG tiles x 3 planes = 3 TG KiB), double buffered: 6 TG KiB of LDS and <= 256 registers, so
+    // two workgroups share a CU (two waves per SIMD): one's barrier / LDS latency hides under the other's MFMAs.
+    // (Measured and dropped: LDS-DMA for the weight copy, 2-wave workgroups for single-column-block shapes, and persistent
+    // workgroups walking several column blocks with one continuous weight stream -- each slower than this plain form.)
+    constexpr int kStage = 3 * TG * 1024;
+    constexpr int kFrags = 3 * TG;                          // 1 KiB pieces per stage
+    constexpr int kPieces = (kFrags + WAVES - 1) / WAVES;   // per wave
+    extern __shared__ __attribute__((aligned(16))) char s_w[];  // 2 stages
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar branches below
+    const long long rt = (long long)blockIdx.x * WAVES + wave;
+    const long long n_rt = (a.M + 31) / 32;
+    const long long rtc = rt < n_rt ? rt : n_rt - 1;  // waves past the end redo the last row tile and store nothing
+    const int KS = a.KS;                               // even
+
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    typedef __attribute__((address_space(3))) bf16x8 lds_frag;
+
+    // weight copy global -> VGPR -> LDS (an LDS-DMA copy costs ~100 issue cycles per 1 KiB piece on the wave that issues it,
+    // measured slower here as in the edge kernel): piece k of this wave = KiB number WAVES k + wave of the stage
+    f32x4 wst[kPieces];
+    const char* wsrc = a.wpk + (long long)blockIdx.y * KS * kStage + lane * 16;
+    auto w_load = [&](int ks) {  // clamped to the last k-step (the extra loads are never stored)
+        ks = ks < KS ? ks : KS - 1;
+        const char* src = wsrc + (long long)ks * kStage;
+#pragma unroll
+        for (int k = 0; k < kPieces; ++k) {
+            if (WAVES * k + WAVES - 1 < kFrags || WAVES * k + wave < kFrags)
+                wst[k] = *reinterpret_cast<const f32x4*>(src + (WAVES * k + wave) * 1024);
+        }
+    };
+    auto w_store = [&](int par) {
+        lds_char* dst = (lds_char*)s_w + par * kStage + lane * 16;
+#pragma unroll
+        for (int k = 0; k < kPieces; ++k) {
+            if (WAVES * k + WAVES - 1 < kFrags || WAVES * k + wave < kFrags) *(lds_f4*)(dst + (WAVES * k + wave) * 1024) = wst[k];
+        }
+    };
+    const bf16x8* xsrc = a.xp + (rtc * KS) * 3 * 64 + lane;
+    bf16x8 xa[3], xb[3];  // activation fragments (planes) of the current / next k-step
+    auto x_load = [&](int ks, bf16x8 (&x)[3]) {
+        ks = ks < KS ? ks : KS - 1;
+        const bf16x8* p = xsrc + (long long)ks * 3 * 64;
+        x[0] = p[0]; x[1] = p[64]; x[2] = p[128];
+    };
+
+    f32x16 acc[TG];
+
+    w_load(0);
+    x_load(0, xa);
+    w_store(0);
+    w_load(1);
+    __syncthreads();
+
+    // tiles in pairs (two interleaved accumulators); the fragments of the next pair are fetched before the current pair's MFMAs
+    constexpr int NP = (TG + 1) / 2;
+    auto compute = [&](int par, const bf16x8 (&x)[3]) {
+        const lds_frag* wl = (const lds_frag*)((lds_char*)s_w + par * kStage) + lane;
+        bf16x8 f[2][6];
+        auto fetch = [&](int p, bf16x8 (&d)[6]) {
+            const lds_frag* q = wl + (2 * p) * 3 * 64;
+            d[0] = q[0]; d[1] = q[64]; d[2] = q[128];
+            if (2 * p + 1 < TG) { d[3] = q[192]; d[4] = q[256]; d[5] = q[320]; }
+        };
+        fetch(0, f[0]);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (p + 1 < NP) fetch(p + 1, f[(p + 1) & 1]);
+            const bf16x8 (&w)[6] = f[p & 1];
+            if (2 * p + 1 < TG) {
+                f32x16 c = acc[2 * p], d = acc[2 * p + 1];
+                c = mfma_bf16(w[2], x[0], c); d = mfma_bf16(w[5], x[0], d);  // (l,h)
+                c = mfma_bf16(w[0], x[2], c); d = mfma_bf16(w[3], x[2], d);  // (h,l)
+                c = mfma_bf16(w[1], x[1], c); d = mfma_bf16(w[4], x[1], d);  // (m,m)
+                c = mfma_bf16(w[1], x[0], c); d = mfma_bf16(w[4], x[0], d);  // (m,h)
+                c = mfma_bf16(w[0], x[1], c); d = mfma_bf16(w[3], x[1], d);  // (h,m)
+                c = mfma_bf16(w[0], x[0], c); d = mfma_bf16(w[3], x[0], d);  // (h,h)
+                acc[2 * p] = c; acc[2 * p + 1] = d;
+            } else {
+                f32x16 c = acc[2 * p];
+                c = mfma_bf16(w[2], x[0], c);
+                c = mfma_bf16(w[0], x[2], c);
+                c = mfma_bf16(w[1], x[1], c);
+                c = mfma_bf16(w[1], x[0], c);
+                c = mfma_bf16(w[0], x[1], c);
+                c = mfma_bf16(w[0], x[0], c);
+                acc[2 * p] = c;
+            }
+        }
+    };
+
+    const long long row = rt * 32 + (lane & 31);
+    const bool valid = rt < n_rt && row < a.M;
+    const long long rowc = valid ? row : a.M - 1;
+    const float ps = a.pre_scale ? a.pre_scale[rowc] : 1.0f;
+    const float pm = a.pre_mask ? a.pre_mask[rowc] : 1.0f;
+
+    const int cb = blockIdx.y;
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // k-steps in pairs (buffer parity is static: KS is even); loads past the end of the stream are clamped and never consumed
+    for (int ks = 0; ks < KS; ks += 2) {
+        x_load(ks + 1, xb);
+        compute(0, xa);
+        w_store(1);                 // k-step ks + 1 (loaded one stage ago) -> buffer 1 (last read two barriers ago)
+        w_load(ks + 2);
+        __syncthreads();
+        x_load(ks + 2, xa);
+        compute(1, xb);
+        w_store(0);
+        w_load(ks + 3);
+        __syncthreads();
+    }
+
+    // ---------------- epilogue.  Lane (row m = lane & 31, half h): register r of tile t = column 32 t + (r&3) + 8 (r>>2) + 4 h
+    const int col_base = cb * TG * 32;
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int c0 = col_base + 32 * t + 8 * rq + 4 * h;
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + c0);
+            float v[4] = {acc[t][4 * rq + 0] * ps + b.x, acc[t][4 * rq + 1] * ps + b.y, acc[t][4 * rq + 2] * ps + b.z,
+                          acc[t][4 * rq + 3] * ps + b.w};
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= pm;
+            if (a.residual) {
+                const float4 rr = *reinterpret_cast<const float4*>(a.residual + rowc * a.res_ld + c0);
+                v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][4 * rq + e] = v[e];
+        }
+    if (a.ln_gamma) {  // LayerNorm over the TG*32 columns of the row (half here, half in lane ^ 32)
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[t][r];
+        const float mean = xhalf_sum(sum) * (1.0f / (TG * 32));
+        float var = 0.f;
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = acc[t][r] - mean;
+                var += d * d;
+            }
+        const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / (TG * 32)) + a.ln_eps);
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int c0 = col_base + 32 * t + 8 * rq + 4 * h;
+                const float4 g = *reinterpret_cast<const float4*>(a.ln_gamma + c0), be = *reinterpret_cast<const float4*>(a.ln_beta + c0);
+                acc[t][4 * rq + 0] = (acc[t][4 * rq + 0] - mean) * rstd * g.x + be.x;
+                acc[t][4 * rq + 1] = (acc[t][4 * rq + 1] - mean) * rstd * g.y + be.y;
+                acc[t][4 * rq + 2] = (acc[t][4 * rq + 2] - mean) * rstd * g.z + be.z;
+                acc[t][4 * rq + 3] = (acc[t][4 * rq + 3] - mean) * rstd * g.w + be.w;
+            }
+    }
+    if (a.post_mask) {
+        const float q = a.post_mask[rowc];
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] *= q;
+    }
+    if (a.out_f32 && valid) {
+        float* o = a.out_f32 + row * a.out_ld + a.out_col0 + col_base;
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                *reinterpret_cast<float4*>(o + 32 * t + 8 * rq + 4 * h) =
+                    make_float4(acc[t][4 * rq + 0], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]);
+    }
+    if (a.out_xp && rt < n_rt) {
+        // the accumulator layout is the next layer's B-operand layout: k-step 2 (cb TG + t) + u = registers 8u .. 8u+7 of tile t.
+        // Rows past M inside the last row tile are written as zeros (they are read, never stored, by the consumer).
+        bf16x8* o = a.out_xp + ((rt * a.xp_KS + a.xp_ks0 + 2 * (cb * TG)) * 3) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = valid ? acc[t][8 * u + j] : 0.f;
+                bf16x8 ph, pmid, pl;
+                split8(v, ph, pmid, pl);
+                bf16x8* q = o + ((2 * t + u) * 3) * 64;
+                q[0] = ph; q[64] = pmid; q[128] = pl;
+            }
+    }
+}
+
+// fp32 row-major [M, ld] (columns col0 .. col0 + 16 KS) -> packed planes at k-step offset ks0 of an XP buffer with xp_KS k-steps.
+// One wave per (row tile, k-step): lane (row m, half g) gathers its 8 chain-ordered channels (two float4), splits, stores 3 x 16 B.
+__global__ void __launch_bounds__(256) pack_planes_kernel(const float* __restrict__ x, long long M, int ld, int col0, int KS,
+                                                          bf16x8* __restrict__ xp, int xp_KS, int ks0, const float* __restrict__ row_scale) {
+    const int lane = threadIdx.x & 63, g = lane >> 5;
+    const long long unit = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long n_rt = (M + 31) / 32;
+    if (unit >= n_rt * KS) return;
+    const long long rt = unit / KS;
+    const int ks = (int)(unit - rt * KS);
+    const long long row = rt * 32 + (lane & 31);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (row < M) {
+        // element j: channel 32 (ks>>1) + (r&3) + 8 (r>>2) + 4 g, r = 8 (ks&1) + j  ->  two runs of 4 consecutive channels
+        const float* p = x + row * ld + col0 + 32 * (ks >> 1) + 16 * (ks & 1) + 4 * g;
+        const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 8);
+        const float sc = row_scale ? row_scale[row] : 1.0f;
+        v[0] = lo.x * sc; v[1] = lo.y * sc; v[2] = lo.z * sc; v[3] = lo.w * sc;
+        v[4] = hi.x * sc; v[5] = hi.y * sc; v[6] = hi.z * sc; v[7] = hi.w * sc;
+    }
+    bf16x8 ph, pm, pl;
+    split8(v, ph, pm, pl);
+    bf16x8* o = xp + ((rt * xp_KS + ks0 + ks) * 3) * 64 + lane;
+    o[0] = ph; o[64] = pm; o[128] = pl;
+}
+
+template <int TG, int WAVES>
+int launch_gemm_w(const GemmArgs& a, hipStream_t stream) {
+    constexpr int lds = 2 * 3 * TG * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&node_gemm_kernel<TG, WAVES>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const long long n_rt = (a.M + 31) / 32;
+    const long long row_blocks = (n_rt + WAVES - 1) / WAVES;
+    hipLaunchKernelGGL((node_gemm_kernel<TG, WAVES>), dim3((unsigned)row_blocks, (unsigned)a.n_col_blocks), dim3(64 * WAVES), lds, stream, a);
+    return (int)hipGetLastError();
+}
+
+template <int TG>
+int launch_gemm(const GemmArgs& a, hipStream_t stream) {
+    return launch_gemm_w<TG, 4>(a, stream);  // 4 waves (128 rows) per workgroup share a weight stage
+}
+
+}  // namespace
+
+extern "C" int s2s_pack_planes(const float* x, long long n_rows, int ld, int col0, int n_cols, void* xp, int xp_ksteps,
+                               int xp_kstep0, const float* row_scale, void* stream) {
+    if (n_rows <= 0) return 0;
+    if (!x || !xp || n_cols <= 0 || n_cols % 32 || ld % 4 || col0 % 4 || xp_kstep0 < 0 || xp_kstep0 + n_cols / 16 > xp_ksteps)
+        return (int)hipErrorInvalidValue;
+    const int KS = n_cols / 16;
+    const long long units = ((n_rows + 31) / 32) * KS;
+    hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n_rows, ld, col0, KS,
+                       (bf16x8*)xp, xp_ksteps, xp_kstep0, row_scale);
+    return (int)hipGetLastError();
+}
+
+extern "C" int s2s_node_linear(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
+                               int tiles_per_block, const float* pre_scale, int relu, const float* pre_mask, const float* residual,
+                               int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_mask,
+                               float* out_f32, int out_ld, int out_col0, void* out_xp, int out_xp_ksteps, int out_xp_kstep0,
+                               void* stream) {
+    if (n_rows <= 0) return 0;
+    const int TG = tiles_per_block;
+    if (!xp || !w_packed || k_in <= 0 || k_in % 32 || n_out <= 0 || n_out % (32 * TG) || (!out_f32 && !out_xp))
+        return (int)hipErrorInvalidValue;
+    const int ncb = n_out / (32 * TG);
+    if ((ln_gamma != nullptr) != (ln_beta != nullptr) || (ln_gamma && ncb != 1)) return (int)hipErrorInvalidValue;
+    if (out_f32 && (out_ld % 4 || out_col0 % 4)) return (int)hipErrorInvalidValue;
+    if (residual && residual_ld % 4) return (int)hipErrorInvalidValue;
+    if (out_xp && (out_xp_kstep0 < 0 || out_xp_kstep0 % 2 || out_xp_kstep0 + n_out / 16 > out_xp_ksteps)) return (int)hipErrorInvalidValue;
+    GemmArgs a{(const bf16x8*)xp, (const char*)w_packed, bias, pre_scale, pre_mask, residual, ln_gamma, ln_beta, post_mask, out_f32,
+               (bf16x8*)out_xp, n_rows, k_in / 16, ncb, residual_ld, out_ld, out_col0, out_xp_ksteps, out_xp_kstep0, relu, ln_eps};
+    hipStream_t st = (hipStream_t)stream;
+    switch (TG) {
+        case 1: return launch_gemm<1>(a, st);
+        case 2: return launch_gemm<2>(a, st);
+        case 4: return launch_gemm<4>(a, st);
+        case 5: return launch_gemm<5>(a, st);
+        case 6: return launch_gemm<6>(a, st);
+        case 8: return launch_gemm<8>(a, st);
+        case 10: return launch_gemm<10>(a, st);
+        default: return (int)hipErrorInvalidValue;
+    }
+}

@@ -39,6 +39,8 @@ _SIGNATURES = {
     "s2s_frames_to_backbone": [_vp] * 5 + [_ll, _vp],
     "s2s_se3_step": [_vp] * 12 + [_i, _i, _d, _d, _i, _i, _d, _vp],
     "s2s_forward_marginal": [_vp] * 7 + [_i, _vp, _vp, _f, _vp, _i, _i, _vp],
+    "s2s_pack_planes": [_vp, _ll, _i, _i, _i, _vp, _i, _i, _vp, _vp],
+    "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
     "s2s_format_pdb_models": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _ll],
     "s2s_write_pdb_models": [ctypes.c_char_p, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i],
     "s2s_merge_pdb_files": [_vp, _i, ctypes.c_char_p],
@@ -488,6 +490,108 @@ def forward_marginal(rigids0_4x4, z_axis, u01, z_trans, cdf_rows, row_of_sample,
                                     _p(omega_grid), omega_grid.numel(), _p(params2), _p(diffuse_mask), float(coordinate_scaling),
                                     _p(out), B, N, _stream()), "s2s_forward_marginal")
     return out
+
+
+# ------------------------------------------------------------------------------------------ per-node dense layers
+NODE_TG = (10, 8, 6, 5, 4, 2, 1)   # tiles of 32 output columns per workgroup the kernel is instantiated for
+
+
+def node_tiles(n_out: int, whole_row: bool = False) -> int:
+    """Tiles per column block for an ``n_out``-wide layer (``whole_row``: one block must hold the row, e.g. for LayerNorm)."""
+    if n_out % 32:
+        raise ValueError("n_out must be a multiple of 32 (pad the weight)")
+    t = n_out // 32
+    if whole_row:
+        if t not in NODE_TG:
+            raise HipLibraryError(f"no node_linear instantiation holds a whole row of {n_out} columns")
+        return t
+    return next(g for g in NODE_TG if t % g == 0)
+
+
+def pack_node_weight(w: torch.Tensor, tiles_per_block: int) -> torch.Tensor:
+    """[n_out, k_in] fp32 -> int16 blob [n_out/(32 TG)][k_in/16][TG][3][64][8] of chain-ordered bf16x3 A fragments
+    (s2s_node_linear).  n_out is zero-padded to a multiple of 32 first."""
+    n_out, k = w.shape
+    pad = (-n_out) % 32
+    if pad:
+        w = torch.cat([w, w.new_zeros(pad, k)], dim=0)
+    if k % 32 or (w.shape[0] // 32) % tiles_per_block:
+        raise ValueError("k_in must be a multiple of 32 and n_out/32 of tiles_per_block")
+    fr = pack_bf16x3_layer(w.float(), "chain")                      # [KS, T, 3, 64, 8]
+    KS, T = fr.shape[:2]
+    fr = fr.reshape(KS, T // tiles_per_block, tiles_per_block, 3, 64, 8).permute(1, 0, 2, 3, 4, 5)
+    return fr.contiguous().view(torch.int16).reshape(-1)
+
+
+def xp_alloc(n_rows: int, k: int, device) -> torch.Tensor:
+    """Packed-plane activation buffer for [n_rows, k] (int16 storage of bf16; see include/str2str_hip.h)."""
+    return torch.empty(((n_rows + 31) // 32) * (k // 16) * 3 * 64 * 8, dtype=torch.int16, device=device)
+
+
+def pack_planes(x2d: torch.Tensor, col0: int = 0, n_cols: Optional[int] = None, out=None, out_k: Optional[int] = None,
+                k0: int = 0, row_scale=None):
+    """fp32 [M, ld] (columns col0 .. col0 + n_cols) -> XP planes, optionally into columns k0.. of a wider XP buffer."""
+    lib = load_library()
+    _req(x2d, name="x")
+    M, ld = x2d.shape
+    n_cols = ld - col0 if n_cols is None else n_cols
+    out_k = n_cols if out_k is None else out_k
+    if out is None:
+        out = xp_alloc(M, out_k, x2d.device)
+    if row_scale is not None:
+        _req(row_scale, name="row_scale")
+    _check(lib.s2s_pack_planes(_p(x2d), M, ld, col0, n_cols, _p(out), out_k // 16, k0 // 16, _p(row_scale), _stream()),
+           "s2s_pack_planes")
+    return out
+
+
+def node_linear(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles: int, *, pre_scale=None, relu=False, pre_mask=None,
+                residual=None, ln=None, post_mask=None, out_f32=None, out_col0: int = 0, want_f32=True, out_xp=None,
+                out_xp_k: Optional[int] = None, out_xp_k0: int = 0, want_xp=False):
+    """One fused per-node layer (s2s_node_linear).  ``residual`` [n_rows, ld] fp32 (its leading n_out columns are added);
+    ``ln`` = (gamma, beta, eps); ``out_f32`` a preallocated [n_rows, ld] buffer written at ``out_col0`` (allocated
+    [n_rows, n_out] when ``want_f32``); ``out_xp`` likewise for the packed planes.  -> (out_f32 or None, out_xp or None)."""
+    lib = load_library()
+    _req(xp, torch.int16, "xp"); _req(wpk, torch.int16, "w_packed")
+    dev = xp.device
+    for n, t in (("bias", bias), ("pre_scale", pre_scale), ("pre_mask", pre_mask), ("residual", residual), ("post_mask", post_mask)):
+        if t is not None:
+            _req(t, name=n)
+    if xp.numel() != ((n_rows + 31) // 32) * (k_in // 16) * 1536 or wpk.numel() != n_out * k_in * 3:
+        raise HipLibraryError(f"node_linear: operand sizes do not match M={n_rows} K={k_in} N={n_out}")
+    if out_f32 is None and want_f32:
+        out_f32 = torch.empty(n_rows, n_out, device=dev, dtype=torch.float32)
+    if out_f32 is not None:
+        _req(out_f32, name="out_f32")
+    if out_xp is None and want_xp:
+        out_xp_k = n_out if out_xp_k is None else out_xp_k
+        out_xp = xp_alloc(n_rows, out_xp_k, dev)
+    if out_xp is not None:
+        out_xp_k = n_out if out_xp_k is None else out_xp_k
+        _req(out_xp, torch.int16, "out_xp")
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    if ln is not None:
+        _req(g, name="ln.gamma"); _req(b, name="ln.beta")
+    _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear(
+        _p(xp), _p(wpk), _p(bias), n_rows, k_in, n_out, tiles, _p(pre_scale), int(bool(relu)), _p(pre_mask), _p(residual),
+        residual.shape[-1] if residual is not None else 0, _p(g), _p(b), float(eps), _p(post_mask), _p(out_f32),
+        out_f32.shape[-1] if out_f32 is not None else 0, out_col0, _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16,
+        _stream())), "s2s_node_linear")
+    return out_f32, out_xp
+
+
+def unpack_planes(xp: torch.Tensor, n_rows: int, k: int) -> torch.Tensor:
+    """XP -> fp32 [n_rows, k] (sum of the three planes; for tests and debugging)."""
+    KS = k // 16
+    fr = xp.view(torch.bfloat16).reshape(-1, KS, 3, 2, 32, 8).float().sum(2)    # [RT, KS, g, m, j]
+    ks = torch.arange(KS)[:, None, None]
+    g = torch.arange(2)[None, :, None]
+    j = torch.arange(8)[None, None, :]
+    r = 8 * (ks & 1) + j
+    chan = (32 * (ks >> 1) + (r & 3) + 8 * (r >> 2) + 4 * g).to(xp.device)     # [KS, 2, 8]
+    out = torch.zeros(fr.shape[0], 32, k, device=xp.device)
+    out[:, :, chan.reshape(-1)] = fr.permute(0, 3, 1, 2, 4).reshape(fr.shape[0], 32, -1)
+    return out.reshape(-1, k)[:n_rows]
 
 
 # ------------------------------------------------------------------------------------------ PDB text (host side of the ABI)

@@ -784,3 +784,43 @@ def test_throughput_mode_runs_without_host_noise(net_smooth, diffuser):
         assert float((outs[-1][0] - outs[-1][1]).abs().max()) > 1e-2
     prior = forward_backward(net_smooth, diffuser, feats, rig0, -1.0, num_timesteps=6, device=DEV, rng="device")
     assert torch.isfinite(prior).all()
+
+
+@pytest.mark.parametrize("M,K,N", [(70, 256, 256), (128, 320, 960), (33, 2688, 256), (257, 256, 192), (64, 128, 768), (40, 256, 6)])
+def test_node_linear_vs_float64(M, K, N):
+    """s2s_node_linear (split-bf16 MFMA, packed-plane activations) against a float64 evaluation of
+    LayerNorm(residual + mask * relu(scale * x W^T + b)) * mask -- every epilogue stage on -- for the trunk's layer shapes
+    (ragged row counts, K = 2688 of linear_out, a 6-wide head padded to 32); the packed-plane output must decode to the
+    fp32 output bit for bit (the planes are an exact split)."""
+    from str2str_amd import ops
+
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    n_pad = -(-N // 32) * 32
+    whole = n_pad // 32 in ops.NODE_TG
+    tg = ops.node_tiles(n_pad, whole_row=whole)
+    wpk = ops.pack_node_weight(w, tg)
+    bias = torch.zeros(n_pad, device=DEV); bias[:N] = b
+    xp = ops.pack_planes(x)
+    assert torch.equal(ops.unpack_planes(xp, M, K), x)           # exact 3-way split
+    y, yxp = ops.node_linear(xp, wpk, bias, M, K, n_pad, tg, want_xp=True)
+    ref = (x.double() @ w.double().t() + b.double())
+    check(f"node_linear plain M{M} K{K} N{N}", rel(y[:, :N], ref), 2e-6)
+    assert float(y[:, N:].abs().max()) == 0 if n_pad > N else True
+    assert torch.equal(ops.unpack_planes(yxp, M, n_pad), y)
+    if whole:
+        scale = (torch.rand(M, generator=g) + 0.5).to(DEV)
+        mask = (torch.rand(M, generator=g) > 0.3).float().to(DEV)
+        res = torch.randn(M, n_pad + 32, generator=g).to(DEV)    # wider leading dimension on purpose
+        ga, be = (1 + 0.1 * torch.randn(n_pad, generator=g)).to(DEV), (0.1 * torch.randn(n_pad, generator=g)).to(DEV)
+        out = torch.full((M, n_pad + 64), -7.0, device=DEV)
+        y, yxp = ops.node_linear(xp, wpk, bias, M, K, n_pad, tg, pre_scale=scale, relu=True, pre_mask=mask, residual=res,
+                                 ln=(ga, be, 1e-5), post_mask=mask, out_f32=out, out_col0=32, want_xp=True, out_xp_k=n_pad + 64,
+                                 out_xp_k0=64)
+        wz = torch.zeros(n_pad, K, device=DEV, dtype=torch.float64); wz[:N] = w.double()
+        v = torch.relu((x.double() * scale.double()[:, None]) @ wz.t() + bias.double()) * mask.double()[:, None] + res[:, :n_pad].double()
+        ref = F.layer_norm(v, (n_pad,), ga.double(), be.double(), 1e-5) * mask.double()[:, None]
+        check(f"node_linear fused epilogue M{M} K{K} N{N}", rel(out[:, 32:32 + n_pad], ref), 5e-6)
+        assert float((out[:, :32] + 7).abs().max()) == 0 and float((out[:, 32 + n_pad:] + 7).abs().max()) == 0
