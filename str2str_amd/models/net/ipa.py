@@ -1,14 +1,19 @@
 """Invariant Point Attention and the ``TranslationIPA`` trunk on the HIP kernels.
 
 Interface, constructor arguments and ``state_dict`` keys follow the reference's
-``src/models/net/ipa.py`` (InvariantPointAttention :34-268, TranslationIPA :271-387).  The input
-projections and ``linear_out`` are dense fp32 GEMMs; everything between them — point frames,
-pair projections (linear_b / down_z), logits, softmax, o / o_pt / o_pair — is three HIP launches:
-``s2s_ipa_prep_points``, ``s2s_pair_project`` and ``s2s_ipa_attention``.
+``src/models/net/ipa.py`` (InvariantPointAttention :34-268, TranslationIPA :271-387).  Point frames,
+pair projections (linear_b / down_z), logits, softmax, o / o_pt / o_pair are the HIP launches
+``s2s_ipa_prep_points``, ``s2s_pair_project`` (normally fused into the producer of z) and ``s2s_ipa_attention``.
+Every dense layer of the node stream (q / kv / point projections, linear_out, skip_embed, the transformer's
+projections and feed-forward, trunk.linear, NodeTransition, BackboneUpdate, the per-node parts of EdgeTransition, the
+torsion head) runs on ``s2s_node_linear`` (csrc/node_gemm.hip: split-bf16 MFMA, activations travelling as packed bf16x3
+planes) with bias / ReLU / mask / residual / LayerNorm fused into its epilogue -- ``TranslationIPA._forward_fused``.
+``S2S_NODE_PATH=blas`` keeps the layer-by-layer torch evaluation (same parameters) for A/B measurements.
 """
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -110,6 +115,17 @@ def encoder_forward(enc: nn.TransformerEncoder, x: torch.Tensor, key_padding_flo
     return x
 
 
+def encoder_attention(qkv: torch.Tensor, key_padding_float: torch.Tensor, exact_padding: bool = False) -> torch.Tensor:
+    """Self-attention core of one encoder layer on the projected [B,N,3,h,dh] tensor -> [B,N,h*dh] (same mask semantics as
+    ``encoder_forward``)."""
+    B, N = qkv.shape[:2]
+    if exact_padding:
+        key_padding_float = torch.where(key_padding_float > 0, float("-inf"), 0.0).to(qkv.dtype)
+    q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
+    bias = key_padding_float[:, None, None, :].expand(B, q.shape[1], N, N)
+    return F.scaled_dot_product_attention(q, k, v, attn_mask=bias).transpose(1, 2).reshape(B, N, -1).contiguous()
+
+
 class TranslationIPA(nn.Module):
     def __init__(self, c_s: int, c_z: int, coordinate_scaling: float, no_ipa_blocks: int, skip_embed_size: int,
                  transformer_num_heads: int = 4, transformer_num_layers: int = 2, c_hidden: int = 256, no_heads: int = 8,
@@ -137,13 +153,143 @@ class TranslationIPA(nn.Module):
                 self.trunk[f"edge_transition_{b}"] = EdgeTransition(node_embed_size=c_s, edge_embed_in=c_z,
                                                                     edge_embed_out=c_z)
         self.torsion_pred = TorsionAngleHead(c_s, 1)
+        self._wcache = ParamCache()
         self.exact_padding = False  # see encoder_forward; set by the mixed-length sampler
         self.fuse_pair_projection = True  # producers of z also emit the next IPA block's linear_b / down_z
+
+    # ------------------------------------------------------------------ packed weights of the fused node path
+    def _node_weights(self):
+        def build():
+            T = self.trunk
+            pk = lambda lin, whole=False: self._pack(lin.weight, lin.bias, whole)  # noqa: E731
+            out = {}
+            for b in range(self.num_blocks):
+                ipa = T[f"ipa_{b}"]
+                d = {"q": pk(ipa.linear_q), "kv": pk(ipa.linear_kv), "qp": pk(ipa.linear_q_points),
+                     "kvp": pk(ipa.linear_kv_points), "out": pk(ipa.linear_out, True), "skip": pk(T[f"skip_embed_{b}"]),
+                     "lin": pk(T[f"linear_{b}"], True), "bb": pk(T[f"bb_update_{b}"].linear)}
+                nt = T[f"node_transition_{b}"]
+                d["nt1"], d["nt2"], d["nt3"] = pk(nt.linear_1, True), pk(nt.linear_2, True), pk(nt.linear_3, True)
+                d["layers"] = []
+                for layer in T[f"transformer_{b}"].layers:
+                    att = layer.self_attn
+                    d["layers"].append({"in": self._pack(att.in_proj_weight, att.in_proj_bias), "o": pk(att.out_proj, True),
+                                        "l1": pk(layer.linear1, True), "l2": pk(layer.linear2, True)})
+                if b < self.num_blocks - 1:
+                    et = T[f"edge_transition_{b}"]
+                    ep = et._packed()
+                    d["et_init"] = pk(et.initial_embed)
+                    d["et_ab"] = self._pack(ep["w_ab"], ep["b_ab"])
+                out[b] = d
+            tp = self.torsion_pred
+            out["tor"] = {"l1": pk(tp.linear_1, True), "l2": pk(tp.linear_2, True), "fin": pk(tp.linear_final)}
+            return out
+
+        return self._wcache.get(list(self.parameters()), build)
+
+    @staticmethod
+    def _pack(w, bias, whole_row=False):
+        n_out, k = w.shape
+        n_pad = -(-n_out // 32) * 32
+        tg = ops.node_tiles(n_pad, whole_row=whole_row)
+        b = w.new_zeros(n_pad, dtype=torch.float32)
+        if bias is not None:
+            b[:n_out] = bias.float()
+        return {"w": ops.pack_node_weight(w.float(), tg), "b": b.contiguous(), "n": n_pad, "k": k, "tg": tg}
 
     def forward(self, node_embed: torch.Tensor, edge_embed: torch.Tensor, batch: dict, _first_proj=None) -> dict:
         """reference :331-387.  Frames travel as one [B,N,7] tensor between the fused kernels."""
         if not node_embed.is_cuda:
             raise ops.HipLibraryError("TranslationIPA runs on the HIP device only (no CPU fallback)")
+        if os.environ.get("S2S_NODE_PATH", "fused") == "blas":
+            return self._forward_blas(node_embed, edge_embed, batch, _first_proj)
+        return self._forward_fused(node_embed, edge_embed, batch, _first_proj)
+
+    def _forward_fused(self, node_embed, edge_embed, batch, _first_proj=None) -> dict:
+        T, W = self.trunk, self._node_weights()
+        B, N, C = node_embed.shape
+        M = B * N
+        dev = node_embed.device
+        node_mask = batch["residue_mask"].type(torch.float).contiguous()
+        diffuse_mask = ((1 - batch["fixed_mask"].type(torch.float)) * node_mask).contiguous()
+        nm, dm = node_mask.reshape(M), diffuse_mask.reshape(M)
+        init7 = batch["rigids_t"].type(torch.float).contiguous()
+        curr7 = ops.rigid_scale_trans(init7, self.coordinate_scaling, divide=False)
+        pad = 1.0 - node_mask
+        proj = _first_proj
+
+        def lin(xp, w, **kw):
+            return ops.node_linear(xp, w["w"], w["b"], M, w["k"], w["n"], w["tg"], **kw)
+
+        s_f32 = node_embed.reshape(M, C).float().contiguous()
+        init_xp = ops.pack_planes(s_f32)          # skip_embed reads the embedder's output in every block
+        s_xp = init_xp
+        D = C + T["skip_embed_0"].out_features     # transformer width (320)
+        for b in range(self.num_blocks):
+            w, ipa = W[b], T[f"ipa_{b}"]
+            d = ipa._derived()
+            # ---- InvariantPointAttention (:100-268): projections -> points -> attention core -> linear_out (+mask, +residual, LN)
+            q, _ = lin(s_xp, w["q"])
+            kv, _ = lin(s_xp, w["kv"])
+            qp, _ = lin(s_xp, w["qp"])
+            kvp, _ = lin(s_xp, w["kvp"])
+            q_pts, k_pts, v_pts = ops.ipa_prep_points(curr7, qp.view(B, N, -1), kvp.view(B, N, -1), ipa.no_heads, ipa.no_qk_points,
+                                                      ipa.no_v_points)
+            attn_bias, pair_z = proj if proj is not None else ops.pair_project(edge_embed.contiguous(), d["wp"], d["b64"])
+            proj = None
+            feats = ops.ipa_attention(q.view(B, N, ipa.no_heads, -1), kv.view(B, N, ipa.no_heads, -1), q_pts, k_pts, v_pts, attn_bias,
+                                      pair_z, node_mask, curr7, d["hw"], ipa.no_heads, ipa.c_hidden, ipa.no_qk_points, ipa.no_v_points,
+                                      ipa.c_z // 4, ipa.inf, ipa.eps, logits_inplace=True)
+            feats_xp = ops.pack_planes(feats.view(M, -1))
+            ln = T[f"ipa_ln_{b}"]
+            x_f32 = torch.empty(M, D, device=dev, dtype=torch.float32)     # [node_embed | skip_embed(init)] (:356)
+            x_xp = ops.xp_alloc(M, D, dev)
+            lin(feats_xp, w["out"], pre_mask=nm, residual=s_f32, ln=(ln.weight, ln.bias, ln.eps), out_f32=x_f32, out_xp=x_xp, out_xp_k=D)
+            lin(init_xp, w["skip"], out_f32=x_f32, out_col0=C, out_xp=x_xp, out_xp_k=D, out_xp_k0=C)
+            # ---- 2 x post-norm TransformerEncoderLayer (:312-317,357)
+            xf, xx = x_f32, x_xp
+            for layer, lw in zip(T[f"transformer_{b}"].layers, w["layers"]):
+                qkv, _ = lin(xx, lw["in"])
+                sa = encoder_attention(qkv.view(B, N, 3, layer.self_attn.num_heads, -1), pad, self.exact_padding)
+                sa_xp = ops.pack_planes(sa.view(M, D))
+                x1, x1x = lin(sa_xp, lw["o"], residual=xf, ln=(layer.norm1.weight, layer.norm1.bias, layer.norm1.eps), want_xp=True)
+                _, hx = lin(x1x, lw["l1"], relu=True, want_f32=False, want_xp=True)
+                xf, xx = lin(hx, lw["l2"], residual=x1, ln=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), want_xp=True)
+            # ---- node_embed + linear(tr) (:358), NodeTransition (:359, layers.py:128-145), mask (:360)
+            n_f32, n_xp = lin(xx, w["lin"], residual=x_f32, want_xp=True)
+            _, h1 = lin(n_xp, w["nt1"], relu=True, want_f32=False, want_xp=True)
+            _, h2 = lin(h1, w["nt2"], relu=True, want_f32=False, want_xp=True)
+            nt = T[f"node_transition_{b}"]
+            s_f32, s_xp = lin(h2, w["nt3"], residual=n_f32, ln=(nt.ln.weight, nt.ln.bias, nt.ln.eps), post_mask=nm, want_xp=True)
+            # ---- backbone update (:361-365)
+            upd, _ = lin(s_xp, w["bb"], pre_scale=dm)
+            curr7 = ops.rigid_compose_update(curr7, upd[:, :6].contiguous().view(B, N, 6), diffuse_mask)
+            # ---- EdgeTransition (:367-372): per-node parts here, the pair MLP in its own kernel
+            if b < self.num_blocks - 1:
+                et = T[f"edge_transition_{b}"]
+                n_p, n_pxp = lin(s_xp, w["et_init"], want_xp=True)
+                node_ab, _ = lin(n_pxp, w["et_ab"])
+                nxt = T[f"ipa_{b + 1}"].pair_proj_weights() if self.fuse_pair_projection else None
+                res = et.pair_mlp(edge_embed, node_ab.view(B, N, -1), n_p.view(B, N, -1), node_mask, nxt)
+                if nxt is not None:
+                    edge_embed, *proj = res
+                else:
+                    edge_embed = res
+        wt = W["tor"]
+        _, t1 = lin(s_xp, wt["l1"], relu=True, want_f32=False, want_xp=True)
+        _, t2 = lin(t1, wt["l2"], residual=s_f32, want_f32=False, want_xp=True)
+        u = lin(t2, wt["fin"])[0][:, :2].reshape(B, N, 2)
+        psi = u / torch.sqrt(torch.clamp(torch.sum(u**2, dim=-1, keepdim=True), min=self.torsion_pred.eps))
+        out7 = ops.rigid_scale_trans(curr7, self.coordinate_scaling, divide=True)
+        return {
+            "in_rigids": Rigid.from_tensor_7(init7),
+            "out_rigids": Rigid(Rotation(quats=out7[..., :4], normalize_quats=False), out7[..., 4:]),
+            "out_rigids7": out7,
+            "psi": psi,
+        }
+
+    def _forward_blas(self, node_embed: torch.Tensor, edge_embed: torch.Tensor, batch: dict, _first_proj=None) -> dict:
+        """Layer-by-layer evaluation with torch's dense ops (rocBLAS fp32) on the same parameters: the A/B baseline."""
         T = self.trunk
         node_mask = batch["residue_mask"].type(torch.float).contiguous()
         diffuse_mask = ((1 - batch["fixed_mask"].type(torch.float)) * node_mask).contiguous()

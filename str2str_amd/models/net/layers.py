@@ -132,11 +132,16 @@ class EdgeTransition(nn.Module):
         """edge_embed [B,N,N,c_z] -> [B,N,N,c_z].  ``edge_mask_1d`` (node mask [B,N]) optionally fuses
         the caller's ``* edge_mask[..., None]`` (reference ipa.py:372) into the kernel epilogue; ``next_proj``
         = (packed [linear_b; down_z], bias64) of the NEXT IPA block additionally returns its (attn_bias, pair_z)."""
+        n_p = self.initial_embed(node_embed).contiguous()
+        node_ab = F.linear(n_p, self._packed()["w_ab"], self._packed()["b_ab"]).contiguous()
+        return self.pair_mlp(edge_embed, node_ab, n_p, edge_mask_1d, next_proj)
+
+    def pair_mlp(self, edge_embed, node_ab, n_p, edge_mask_1d=None, next_proj=None):
+        """The N x N part given the per-node vectors n' = initial_embed(node) [B,N,128] and
+        node_ab = [W1[:,128:256] n' + b1 | W1[:,256:] n'] [B,N,768] (computed by the fused node path or by ``forward``)."""
         if self._shape != (128, 128, 384, 128, 2):
             raise ops.HipLibraryError(f"EdgeTransition kernel is built for c_z=128, c_s=256 (got {self._shape})")
         pk = self._packed()
-        n_p = self.initial_embed(node_embed).contiguous()
-        node_ab = F.linear(n_p, pk["w_ab"], pk["b_ab"]).contiguous()
         mask = None if edge_mask_1d is None else edge_mask_1d.type(torch.float32).contiguous()
         if self.mfma_mode == "bf16x6":
             proj = None
