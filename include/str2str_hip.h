@@ -180,6 +180,13 @@ int s2s_node_linear(const void* xp, const void* w_packed, const float* bias, lon
                     int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_mask,
                     float* out_f32, int out_ld, int out_col0, void* out_xp, int out_xp_ksteps, int out_xp_kstep0, void* stream);
 
+/* Self-attention core of the trunk's TransformerEncoderLayer (src/models/net/ipa.py:312-317,357; torch.nn.MultiheadAttention with
+ * d_model = n_heads * head_dim, head_dim = 80): softmax(q k^T / sqrt(head_dim) + key_bias[j]) v per (sample, head), exact fp32 MFMA.
+ *   qkv [B*N, 3*D] fp32 = in_proj output (q | k | v); key_bias [B,N] or NULL: added to the logits of key j (PyTorch's float
+ *   key-padding-mask semantics; -inf removes a key); out_f32 [B*N, D] and/or out_xp = packed planes of it (see above). */
+int s2s_encoder_attention(const float* qkv, const float* key_bias, float* out_f32, void* out_xp, int n_samples, int n_res,
+                          int n_heads, int head_dim, void* stream);
+
 /* ---- Forward process / prior, once per trajectory ---- */
 
 /* FrameDiffuser.forward_marginal (src/models/score/frame.py:36-107; so3.py:244-272, :315-331, :13-19; r3.py:49-74) or, with

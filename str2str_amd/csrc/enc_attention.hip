@@ -1,0 +1,201 @@
+// Self-attention core of the trunk's nn.TransformerEncoderLayer (reference src/models/net/ipa.py:312-317,357: d_model 320,
+// 4 heads of 80 channels, sequence = the N residues of one sample) on exact fp32 MFMA, flash style: softmax(q k^T / sqrt(dh)
+// + key bias) v  per (sample, head) without materialising the [N, N] matrix.
+//
+// Input: the in_proj output qkv [B*N, 3*D] fp32 (q | k | v, each [heads, dh]); key_bias [B, N] is ADDED to the logits of key j
+// -- PyTorch's semantics for a FLOAT key-padding mask (1 - mask: a no-op for the all-ones masks of every reference run);
+// exact-padding mode (mixed-length batches) passes -inf there.  Output: the head-concatenated attention result as PACKED
+// PLANES (the input format of s2s_node_linear, csrc/node_gemm.hip) and/or fp32 [B*N, D].
+//
+// A workgroup = 4 waves x 32 queries of one (sample, head); 32-key tiles of K and V (32 x 80 floats each) are double buffered in
+// LDS (global -> VGPR before the tile's MFMAs, VGPR -> LDS after them).  Orientation as in ipa_attention.hip:
+//   S^T[j, i] = K[j, :] . Q[i, :]   (A = key rows from LDS, B = the lane's query row in 40 registers; v_mfma_f32_32x32x2_f32)
+//   O^T[c, i] += V^T[c, j] P^T[j, i] (A = value columns from LDS, B = the S^T accumulator itself, C layout == B layout)
+// so a lane owns one query: max / sum / rescale are per-lane scalars (+ one cross-half exchange), and the accumulator registers
+// 8u .. 8u+7 of output tile t are exactly fragment k-step 5 head + 2t + u of the packed-plane row (dh = 80 = 5 k-steps).
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "str2str_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+template <int DH>
+__global__ void __launch_bounds__(256) enc_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ key_bias,
+                                                            float* __restrict__ out_f32, bf16x8* __restrict__ out_xp, int B, int N,
+                                                            int heads, float scale) {
+    static_assert(DH == 80, "built for the reference configuration (d_model 320, 4 heads)");
+    constexpr int KSd = DH + 4;          // padded LDS row stride (floats): conflict-free ds_read_b128 of the key rows
+    constexpr int CT = (DH + 31) / 32;   // output tiles of 32 channels (the last one is partly padding)
+    constexpr int HALF = DH / 2;         // channels per k-group of the QK^T contraction
+    __shared__ __attribute__((aligned(16))) float s_k[2][32 * KSd];
+    __shared__ __attribute__((aligned(16))) float s_v[2][32 * 96];   // rows padded to 96 channels (3 tiles)
+    __shared__ float s_b[2][32];
+    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31, wave = threadIdx.x >> 6;
+    const int n_qb = (N + 127) / 128;
+    int bid = blockIdx.x;
+    const int qb = bid % n_qb; bid /= n_qb;
+    const int head = bid % heads;
+    const int b = bid / heads;
+    const int D = heads * DH;
+    const int i = qb * 128 + wave * 32 + c;
+    const bool ivalid = i < N;
+    const long long row_i = (long long)b * N + (ivalid ? i : N - 1);
+    const float* base = qkv + (long long)b * N * 3 * D + head * DH;
+
+    // ---- tile staging: 32 keys x (K 80 + V 80) floats = 1280 float4, 5 per thread
+    float4 st[5];
+    auto tile_load = [&](int j0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int idx = threadIdx.x + 256 * k;           // 0 .. 1279
+            const int which = idx / 640, rem = idx % 640, r = rem / 20, c4 = rem % 20;
+            const int j = min(j0 + r, N - 1);
+            st[k] = *reinterpret_cast<const float4*>(base + (long long)j * 3 * D + D * (1 + which) + 4 * c4);
+        }
+    };
+    auto tile_store = [&](int par, int j0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int idx = threadIdx.x + 256 * k;
+            const int which = idx / 640, rem = idx % 640, r = rem / 20, c4 = rem % 20;
+            float* dst = which ? &s_v[par][r * 96 + 4 * c4] : &s_k[par][r * KSd + 4 * c4];
+            *reinterpret_cast<float4*>(dst) = st[k];
+        }
+        if (threadIdx.x < 32) {
+            const int j = j0 + threadIdx.x;
+            s_b[par][threadIdx.x] = j < N ? (key_bias ? key_bias[(long long)b * N + j] : 0.f) : -INFINITY;
+        }
+    };
+    // the padding channels 80..95 of the value rows are multiplied into output columns that are never stored: keep them finite
+    for (int idx = threadIdx.x; idx < 2 * 32 * 16; idx += 256) s_v[idx / 512][((idx % 512) / 16) * 96 + 80 + idx % 16] = 0.f;
+
+    tile_load(0);
+    // ---- this lane's query row: channels HALF h + s, s = 0 .. HALF-1 (B operand of k-step s), pre-scaled like PyTorch (q * dh^-1/2)
+    float qreg[HALF];
+    {
+        const float* qrow = qkv + row_i * 3 * D + head * DH + HALF * h;
+#pragma unroll
+        for (int s4 = 0; s4 < HALF / 4; ++s4) {
+            const float4 v = *reinterpret_cast<const float4*>(qrow + 4 * s4);
+            qreg[4 * s4 + 0] = v.x * scale; qreg[4 * s4 + 1] = v.y * scale; qreg[4 * s4 + 2] = v.z * scale; qreg[4 * s4 + 3] = v.w * scale;
+        }
+    }
+    f32x16 O[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    tile_store(0, 0);
+    __syncthreads();
+
+    int cur = 0;
+    for (int j0 = 0; j0 < N; j0 += 32, cur ^= 1) {
+        const bool more = j0 + 32 < N;
+        if (more) tile_load(j0 + 32);
+        // ---- S^T = K . Q^T : two accumulation chains (a dependent fp32 MFMA issues only every ~64 cycles)
+        f32x16 S, S1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f, S1[r] = 0.f;
+        const float* krow = &s_k[cur][c * KSd + HALF * h];
+#pragma unroll
+        for (int s4 = 0; s4 < HALF / 4; ++s4) {
+            const float4 kf = *reinterpret_cast<const float4*>(krow + 4 * s4);
+            S = mfma32(kf.x, qreg[4 * s4 + 0], S);
+            S1 = mfma32(kf.y, qreg[4 * s4 + 1], S1);
+            S = mfma32(kf.z, qreg[4 * s4 + 2], S);
+            S1 = mfma32(kf.w, qreg[4 * s4 + 3], S1);
+        }
+        float tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float s = (S[r] + S1[r]) + s_b[cur][rowmap(r, h)];
+            S[r] = s;
+            tmax = fmaxf(tmax, s);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(m_run, tmax);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;   // a fully masked prefix: exp(-inf - 0) = 0, no NaN
+        const float alpha = expf(m_run - m_use);
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = expf(S[r] - m_use);
+            S[r] = p;
+            psum += p;
+        }
+        l_run = l_run * alpha + psum;
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            f32x16 o = O[t];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+            const float* vcol = &s_v[cur][32 * t + c + 4 * h * 96];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) o = mfma32(vcol[((s & 3) + 8 * (s >> 2)) * 96], S[s], o);
+            O[t] = o;
+        }
+        if (more) tile_store(cur ^ 1, j0 + 32);
+        __syncthreads();
+    }
+
+    // ---- epilogue: register r of tile t = channel 32 t + (r&3) + 8 (r>>2) + 4 h of this lane's query
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (!ivalid) return;
+    const long long row = (long long)b * N + i;
+    if (out_f32) {
+        float* o = out_f32 + row * D + head * DH;
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int c0 = 32 * t + 8 * rq + 4 * h;
+                if (c0 < DH)
+                    *reinterpret_cast<float4*>(o + c0) = make_float4(O[t][4 * rq] * inv, O[t][4 * rq + 1] * inv, O[t][4 * rq + 2] * inv, O[t][4 * rq + 3] * inv);
+            }
+    }
+    if (out_xp) {
+        // packed planes of the [B*N, D] result: fragment (row tile, k-step 5 head + 2t + u, plane, lane 32 h + row % 32)
+        const int KS = D / 16;
+        bf16x8* o = out_xp + (((row >> 5) * KS + (DH / 16) * head) * 3) * 64 + 32 * h + (int)(row & 31);
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (2 * t + u >= DH / 16) continue;
+                bf16x8 ph, pm, pl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float v = O[t][8 * u + j] * inv;
+                    const __bf16 a_ = (__bf16)v;
+                    const float r1 = v - (float)a_;
+                    const __bf16 b_ = (__bf16)r1;
+                    ph[j] = a_; pm[j] = b_; pl[j] = (__bf16)(r1 - (float)b_);
+                }
+                bf16x8* q = o + ((2 * t + u) * 3) * 64;
+                q[0] = ph; q[64] = pm; q[128] = pl;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int s2s_encoder_attention(const float* qkv, const float* key_bias, float* out_f32, void* out_xp, int n_samples, int n_res,
+                                     int n_heads, int head_dim, void* stream) {
+    if (n_samples <= 0 || n_res <= 0) return 0;
+    if (!qkv || (!out_f32 && !out_xp) || head_dim != 80 || n_heads < 1 || (n_heads * head_dim) % 32) return (int)hipErrorInvalidValue;
+    const long long blocks = (long long)n_samples * n_heads * ((n_res + 127) / 128);
+    hipLaunchKernelGGL((enc_attention_kernel<80>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, qkv, key_bias, out_f32,
+                       (bf16x8*)out_xp, n_samples, n_res, n_heads, 1.0f / sqrtf((float)head_dim));
+    return (int)hipGetLastError();
+}

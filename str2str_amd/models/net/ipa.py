@@ -216,6 +216,9 @@ class TranslationIPA(nn.Module):
         init7 = batch["rigids_t"].type(torch.float).contiguous()
         curr7 = ops.rigid_scale_trans(init7, self.coordinate_scaling, divide=False)
         pad = 1.0 - node_mask
+        # float key-padding mask of the encoder layers: ADDED to the logits (PyTorch semantics, a no-op for all-ones masks);
+        # exact-padding mode removes padded keys instead
+        key_bias = (torch.where(pad > 0, float("-inf"), 0.0) if self.exact_padding else pad).float().contiguous()
         proj = _first_proj
 
         def lin(xp, w, **kw):
@@ -250,8 +253,7 @@ class TranslationIPA(nn.Module):
             xf, xx = x_f32, x_xp
             for layer, lw in zip(T[f"transformer_{b}"].layers, w["layers"]):
                 qkv, _ = lin(xx, lw["in"])
-                sa = encoder_attention(qkv.view(B, N, 3, layer.self_attn.num_heads, -1), pad, self.exact_padding)
-                sa_xp = ops.pack_planes(sa.view(M, D))
+                _, sa_xp = ops.encoder_attention(qkv, key_bias, B, N, layer.self_attn.num_heads)
                 x1, x1x = lin(sa_xp, lw["o"], residual=xf, ln=(layer.norm1.weight, layer.norm1.bias, layer.norm1.eps), want_xp=True)
                 _, hx = lin(x1x, lw["l1"], relu=True, want_f32=False, want_xp=True)
                 xf, xx = lin(hx, lw["l2"], residual=x1, ln=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), want_xp=True)

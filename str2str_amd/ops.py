@@ -41,6 +41,7 @@ _SIGNATURES = {
     "s2s_forward_marginal": [_vp] * 7 + [_i, _vp, _vp, _f, _vp, _i, _i, _vp],
     "s2s_pack_planes": [_vp, _ll, _i, _i, _i, _vp, _i, _i, _vp, _vp],
     "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
+    "s2s_encoder_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "s2s_format_pdb_models": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _ll],
     "s2s_write_pdb_models": [ctypes.c_char_p, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i],
     "s2s_merge_pdb_files": [_vp, _i, ctypes.c_char_p],
@@ -578,6 +579,25 @@ def node_linear(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles: int, *
         out_f32.shape[-1] if out_f32 is not None else 0, out_col0, _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16,
         _stream())), "s2s_node_linear")
     return out_f32, out_xp
+
+
+def encoder_attention(qkv: torch.Tensor, key_bias: Optional[torch.Tensor], n_samples: int, n_res: int, n_heads: int = 4,
+                      want_f32: bool = False, want_xp: bool = True):
+    """Self-attention core of one encoder layer on the in_proj output qkv [B*N, 3*D] -> (fp32 [B*N, D] or None, packed planes or
+    None).  ``key_bias`` [B,N] is added to the logits of key j (None = zeros)."""
+    lib = load_library()
+    _req(qkv, name="qkv")
+    M, D3 = qkv.shape
+    D = D3 // 3
+    if M != n_samples * n_res or D % n_heads:
+        raise HipLibraryError("encoder_attention: bad shapes")
+    if key_bias is not None:
+        _req(key_bias, name="key_bias")
+    out = torch.empty(M, D, device=qkv.device, dtype=torch.float32) if want_f32 else None
+    oxp = xp_alloc(M, D, qkv.device) if want_xp else None
+    _check(_timed("s2s_encoder_attention", lambda: lib.s2s_encoder_attention(_p(qkv), _p(key_bias), _p(out), _p(oxp), n_samples, n_res,
+                                                                             n_heads, D // n_heads, _stream())), "s2s_encoder_attention")
+    return out, oxp
 
 
 def unpack_planes(xp: torch.Tensor, n_rows: int, k: int) -> torch.Tensor:

@@ -824,3 +824,45 @@ def test_node_linear_vs_float64(M, K, N):
         ref = F.layer_norm(v, (n_pad,), ga.double(), be.double(), 1e-5) * mask.double()[:, None]
         check(f"node_linear fused epilogue M{M} K{K} N{N}", rel(out[:, 32:32 + n_pad], ref), 5e-6)
         assert float((out[:, :32] + 7).abs().max()) == 0 and float((out[:, 32 + n_pad:] + 7).abs().max()) == 0
+
+
+@pytest.mark.parametrize("B,N", [(2, 37), (1, 256), (3, 130)])
+def test_encoder_attention_vs_torch(net_rough, B, N):
+    """s2s_encoder_attention against torch's own nn.TransformerEncoder (the module the reference calls, ipa.py:357) in float64
+    on the same parameters: full 2-layer encoder through the fused node kernels (in_proj -> attention -> out_proj + LN ->
+    feed-forward + LN) with a partial FLOAT key-padding mask (added to the logits), and the exact-padding variant (-inf)."""
+    import copy
+
+    from str2str_amd import ops
+
+    tr = net_rough.translator
+    enc = tr.trunk["transformer_1"]
+    W = tr._node_weights()[1]["layers"]
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    x = torch.randn(B, N, 320, generator=g).to(DEV)
+    mask = torch.ones(B, N); mask[-1, -5:] = 0
+    pad = (1.0 - mask).to(DEV)
+    ref_enc = copy.deepcopy(enc).double()
+    M = B * N
+
+    def run(key_bias):
+        xf = x.reshape(M, 320).contiguous()
+        xx = ops.pack_planes(xf)
+        for layer, lw in zip(enc.layers, W):
+            lin = lambda xp, w, **kw: ops.node_linear(xp, w["w"], w["b"], M, w["k"], w["n"], w["tg"], **kw)  # noqa: E731
+            qkv, _ = lin(xx, lw["in"])
+            sa32, sa_xp = ops.encoder_attention(qkv, key_bias, B, N, 4, want_f32=True)
+            assert torch.equal(ops.unpack_planes(sa_xp, M, 320), sa32)
+            x1, x1x = lin(sa_xp, lw["o"], residual=xf, ln=(layer.norm1.weight, layer.norm1.bias, layer.norm1.eps), want_xp=True)
+            _, hx = lin(x1x, lw["l1"], relu=True, want_f32=False, want_xp=True)
+            xf, xx = lin(hx, lw["l2"], residual=x1, ln=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), want_xp=True)
+        return xf.view(B, N, 320)
+
+    # float mask: added to the logits (what the reference's call does with src_key_padding_mask = 1 - mask)
+    ref = ref_enc(x.double().transpose(0, 1), src_key_padding_mask=pad.double()).transpose(0, 1)
+    check(f"encoder (float mask) B{B} N{N}", rel(run(pad.contiguous()), ref), 5e-6)
+    # exact padding: padded keys removed (bool mask in torch)
+    ref = ref_enc(x.double().transpose(0, 1), src_key_padding_mask=pad.bool()).transpose(0, 1)
+    got = run(torch.where(pad > 0, float("-inf"), 0.0).contiguous())
+    valid = mask.bool().numpy()
+    check(f"encoder (exact padding) B{B} N{N}", rel(got.cpu().numpy()[valid], ref.cpu().numpy()[valid]), 5e-6)
