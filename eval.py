@@ -1,8 +1,9 @@
 """Entry point with the reference's CLI:  python eval.py task_name=inference [ckpt_path=…] [target_dir=null]
 (reference: src/eval.py:102-173).  Composes configs/eval.yaml (hydra if installed, otherwise the built-in
 composer), instantiates datamodule / model / trainer from their `_target_`s, loads the checkpoint with the
-reference's key contract and runs ``trainer.predict``.  Metrics evaluation (src/eval.py:47-99) is out of
-scope and skipped with a log line."""
+reference's key contract and runs ``trainer.predict``; when ``target_dir`` holds reference ensembles the samples are then
+scored (src/eval.py:47-99) with the device metrics of str2str_amd/metrics (validity, bonding validity, JS-PwD, JS-Rg; JS-TICA
+needs deeptime and is skipped without it) into the reference's tab-separated ``metrics_<tag>_<mmdd-HH-MM>.csv``."""
 import logging
 import os
 import sys
@@ -41,11 +42,50 @@ def load_model_checkpoint(model, ckpt_path):
     raise ValueError(f"ckpt_path {ckpt_path} is not a valid checkpoint file.")
 
 
+def evaluate_prediction(pred_dir: str, target_dir: str = None, tag: str = None):
+    """reference src/eval.py:47-99: one row per target, one column per metric, plus the mean row."""
+    from time import strftime
+
+    import numpy as np
+    import pandas as pd
+
+    from str2str_amd.common.pdb_utils import extract_backbone_coords
+    from str2str_amd.metrics import metrics
+
+    if target_dir is None or not os.path.isdir(target_dir):
+        log.warning(f"target_dir {target_dir} does not exist. Skip evaluation.")
+        return {}
+    assert os.path.isdir(pred_dir), f"pred_dir {pred_dir} is not a directory."
+    targets = [d.replace(".pdb", "") for d in os.listdir(target_dir)]
+    output_dir = os.path.dirname(os.path.dirname(os.path.abspath(pred_dir)))
+    tag = tag if tag is not None else "dev"
+    fns = {"val_clash": metrics.validity, "val_bond": metrics.bonding_validity, "js_pwd": metrics.js_pwd, "js_rg": metrics.js_rg}
+    try:
+        import deeptime  # noqa: F401
+
+        fns["js_tica"] = metrics.js_tica
+    except ImportError:
+        log.warning("deeptime is not installed: js_tica is skipped")
+    eval_res = {k: {} for k in fns}
+    for target in targets:
+        pred_file = os.path.join(pred_dir, f"{target}.pdb")
+        if not os.path.isfile(pred_file):
+            continue
+        ca = {"target": extract_backbone_coords(os.path.join(target_dir, f"{target}.pdb")), "pred": extract_backbone_coords(pred_file)}
+        for name, fn in fns.items():
+            res = fn(ca, ref_key="target") if name.startswith("js_") else fn(ca)
+            eval_res[name][target] = res[0]["pred"] if name == "js_tica" else res["pred"]
+    df = pd.DataFrame.from_dict(eval_res)
+    df.loc["mean"] = np.around(df.mean(), decimals=4)
+    df.to_csv(os.path.join(output_dir, f"metrics_{tag}_{strftime('%m%d-%H-%M')}.csv"), index=True, sep="\t")
+    return df.loc["mean"]
+
+
 def evaluate(cfg):
     pred_dir = cfg.get("pred_dir")
     if pred_dir and os.path.isdir(pred_dir):
-        log.info("pred_dir given: metric evaluation is outside this build's scope (use the reference's eval).")
-        return pred_dir
+        log.info(f"Found pre-computed prediction directory {pred_dir}.")
+        return evaluate_prediction(pred_dir, target_dir=cfg.get("target_dir"), tag=cfg.get("task_name"))
     log.info(f"Instantiating datamodule <{cfg.data['_target_']}>")
     datamodule = C.instantiate(cfg.data)
     log.info(f"Instantiating model <{cfg.model['_target_']}>")
@@ -68,7 +108,9 @@ def evaluate(cfg):
         return None
     log.info("Starting predictions.")
     pred_dir = trainer.predict(model=model, dataloaders=dataloaders, ckpt_path=ckpt_path)[-1]
-    log.info(f"Samples written under {pred_dir} (metric evaluation is out of scope of this build).")
+    log.info(f"Samples written under {pred_dir}.")
+    if int(os.environ.get("RANK", "0")) == 0 and cfg.get("target_dir"):
+        log.info(f"metrics: {dict(evaluate_prediction(pred_dir, target_dir=cfg.get('target_dir'), tag=cfg.get('task_name')))}")
     return pred_dir
 
 

@@ -201,6 +201,19 @@ int s2s_forward_marginal(const float* rigids0_4x4, const float* z_axis, const fl
                          const float* params2, const float* diffuse_mask, float coordinate_scaling, float* rigids_t7,
                          int n_samples, int n_res, void* stream);
 
+/* ---- Ensemble metrics on the device (src/metrics/metrics.py) over CA coordinates [n, L, 3] float32 ---- */
+
+/* Per sample: CA pairs (|i-j| > k_exclusion) closer than clash_bar (metrics.py:80-105), the largest adjacent CA-CA distance
+ * (:12-23; bonding_validity :124-137 compares it with the reference ensemble's), the radius of gyration (:53-77, float64). */
+int s2s_ca_sample_stats(const float* ca, int n_samples, int n_res, float clash_bar, int k_exclusion, int* n_clash,
+                        float* adjacent_max, double* radius_of_gyration, void* stream);
+
+/* js_pwd (metrics.py:140-166): per pair channel (i, j >= i + offset; np.triu_indices order) the Jensen-Shannon distance between
+ * the n_bins-bin histograms (range = the reference ensemble's [min, max], numpy's float32 bin arithmetic, + pseudo_count) of the
+ * predicted and the reference ensemble -> js_per_channel [(L-offset)(L-offset+1)/2] float64 (the metric is their mean). */
+int s2s_ca_pwd_js(const float* ref_ca, int n_ref, const float* pred_ca, int n_pred, int n_res, int offset, int n_bins,
+                  double pseudo_count, double* js_per_channel, void* stream);
+
 /* ---- PDB text at the exit of the path (HOST pointers, host code; byte-identical to the reference's writers) ---- */
 
 /* protein.to_pdb per model (src/common/protein.py:152-234) over atom37 [n_models, n_res, 37, 3] float32 HOST coordinates with

@@ -29,6 +29,7 @@ UNITS = {
     "rigid_kernels.hip": ["-ffp-contract=off"],
     "se3_step.hip": ["-ffp-contract=off"],
     "forward_marginal.hip": ["-ffp-contract=off"],
+    "ensemble_metrics.hip": ["-ffp-contract=off"],
     # the MFMA chains are fully unrolled on purpose (accumulator tiles must be statically indexed)
     "pair_mlp.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
     "pair_mlp_bf16.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],

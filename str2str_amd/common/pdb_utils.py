@@ -95,3 +95,30 @@ def merge_pdbfiles(input, output_file: str, verbose: bool = True) -> None:
         fo.write("\n".join(x.ljust(80) for x in out) + "\n")
     if verbose:
         print(f"Merged {len(files)} PDB files into {output_file} with {model_number} models.")
+
+
+def extract_backbone_coords(input_path: str, max_n_model: Optional[int] = None) -> np.ndarray:
+    """CA coordinates [n_models, L, 3] float32 of a (multi-MODEL) PDB file, a .npy file or a directory of PDB files
+    (reference pdb_utils.py:255-317, which goes through biotite; here a fixed-column scan of the ATOM records)."""
+    assert os.path.exists(input_path), f"File {input_path} does not exist."
+    if input_path.endswith(".npy"):
+        coords = np.load(input_path)
+    elif os.path.isdir(input_path):
+        coords = np.concatenate([extract_backbone_coords(os.path.join(input_path, f)) for f in os.listdir(input_path)
+                                 if f.endswith(".pdb")], axis=0)
+    elif input_path.endswith(".pdb"):
+        models, cur = [], []
+        with open(input_path) as fh:
+            for ln in fh:
+                if ln.startswith("ATOM") and ln[12:16].strip() == "CA":
+                    cur.append((float(ln[30:38]), float(ln[38:46]), float(ln[46:54])))
+                elif ln.startswith("ENDMDL"):
+                    models.append(cur); cur = []
+        if cur:
+            models.append(cur)
+        coords = np.asarray(models, dtype=np.float32)
+    else:
+        raise ValueError(f"Unrecognized input path {input_path}.")
+    if max_n_model is not None and len(coords) > max_n_model > 0:
+        coords = coords[:max_n_model]
+    return coords

@@ -42,6 +42,8 @@ _SIGNATURES = {
     "s2s_pack_planes": [_vp, _ll, _i, _i, _i, _vp, _i, _i, _vp, _vp],
     "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
     "s2s_encoder_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "s2s_ca_sample_stats": [_vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
+    "s2s_ca_pwd_js": [_vp, _i, _vp, _i, _i, _i, _i, _d, _vp, _vp],
     "s2s_format_pdb_models": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _ll],
     "s2s_write_pdb_models": [ctypes.c_char_p, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i],
     "s2s_merge_pdb_files": [_vp, _i, ctypes.c_char_p],
@@ -598,6 +600,31 @@ def encoder_attention(qkv: torch.Tensor, key_bias: Optional[torch.Tensor], n_sam
     _check(_timed("s2s_encoder_attention", lambda: lib.s2s_encoder_attention(_p(qkv), _p(key_bias), _p(out), _p(oxp), n_samples, n_res,
                                                                              n_heads, D // n_heads, _stream())), "s2s_encoder_attention")
     return out, oxp
+
+
+def ca_sample_stats(ca: torch.Tensor, clash_bar: float = 3.0, k_exclusion: int = 0):
+    """CA [R, L, 3] fp32 device tensor -> (n_clash [R] int32, adjacent_max [R] fp32, radius_of_gyration [R] fp64)."""
+    lib = load_library()
+    _req(ca, name="ca")
+    R, L = ca.shape[:2]
+    nc = torch.empty(R, dtype=torch.int32, device=ca.device)
+    am = torch.empty(R, dtype=torch.float32, device=ca.device)
+    rg = torch.empty(R, dtype=torch.float64, device=ca.device)
+    _check(lib.s2s_ca_sample_stats(_p(ca), R, L, float(clash_bar), int(k_exclusion), _p(nc), _p(am), _p(rg), _stream()), "s2s_ca_sample_stats")
+    return nc, am, rg
+
+
+def ca_pwd_js(ref_ca: torch.Tensor, pred_ca: torch.Tensor, offset: int = 3, n_bins: int = 50, pseudo: float = 1e-6) -> torch.Tensor:
+    """Per pair channel Jensen-Shannon distance between the distance histograms of two CA ensembles -> [D] fp64."""
+    lib = load_library()
+    _req(ref_ca, name="ref_ca"); _req(pred_ca, name="pred_ca")
+    L = ref_ca.shape[1]
+    if pred_ca.shape[1] != L:
+        raise HipLibraryError("ca_pwd_js: the ensembles have different lengths")
+    out = torch.empty((L - offset) * (L - offset + 1) // 2, dtype=torch.float64, device=ref_ca.device)
+    _check(lib.s2s_ca_pwd_js(_p(ref_ca), ref_ca.shape[0], _p(pred_ca), pred_ca.shape[0], L, int(offset), int(n_bins), float(pseudo),
+                             _p(out), _stream()), "s2s_ca_pwd_js")
+    return out
 
 
 def unpack_planes(xp: torch.Tensor, n_rows: int, k: int) -> torch.Tensor:

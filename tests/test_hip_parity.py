@@ -645,6 +645,16 @@ def test_predict_step_entry_writes_reference_layout(tmp_path, monkeypatch):
     want = np.array(want)
     assert got.shape == want.shape and np.abs(got - want).max() < 2e-3, np.abs(got - want).max()
 
+    # evaluation step (src/eval.py:47-99) on the samples just written: device metrics -> the reference's tab-separated csv
+    import glob
+
+    mean = entry.evaluate_prediction(all_dir, os.path.join(GOLDEN, "pdb"), tag="t")
+    files = glob.glob(os.path.join(os.path.dirname(os.path.dirname(all_dir)), "metrics_t_*.csv"))
+    assert len(files) == 1
+    rows = [ln.rstrip("\n").split("\t") for ln in open(files[0])]
+    assert rows[0] == ["", "val_clash", "val_bond", "js_pwd", "js_rg"] and [r[0] for r in rows[1:]] == ["CLN025", "mean"]
+    assert 0.0 <= float(mean["val_clash"]) <= 1.0 and 0.0 <= float(mean["js_pwd"]) <= 1.0
+
 
 def test_mixed_length_padded_batch_equals_unpadded_runs(net_smooth, diffuser):
     """BASELINE configs[4] semantics: chains of different length in padded batches; every chain must equal its own un-padded
@@ -866,3 +876,23 @@ def test_encoder_attention_vs_torch(net_rough, B, N):
     got = run(torch.where(pad > 0, float("-inf"), 0.0).contiguous())
     valid = mask.bool().numpy()
     check(f"encoder (exact padding) B{B} N{N}", rel(got.cpu().numpy()[valid], ref.cpu().numpy()[valid]), 5e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_ensemble_metrics_match_reference(tag):
+    """validity / bonding validity / js_pwd / js_rg on the device against the values the REFERENCE's
+    src/metrics/metrics.py returned for the same float32 CA ensembles (tests/golden/make_golden_metrics.py; case c has a
+    single-structure target: numpy's degenerate-range rule).  The per-channel js_pwd values are checked un-rounded: the
+    histogram counts must be numpy's."""
+    from str2str_amd import ops
+    from str2str_amd.metrics import metrics as M
+
+    g = golden("metrics.npz")
+    d = {"target": g[f"{tag}_target"], "pred": g[f"{tag}_pred"]}
+    v, b = M.validity(d), M.bonding_validity(d)
+    assert [v["target"], v["pred"]] == list(g[f"{tag}_validity"]) and [b["target"], b["pred"]] == list(g[f"{tag}_bonding"])
+    ch = ops.ca_pwd_js(torch.as_tensor(d["target"]).to(DEV), torch.as_tensor(d["pred"]).to(DEV)).cpu().numpy()
+    check(f"js_pwd per-channel vs reference [{tag}]", float(np.abs(ch - g[f"{tag}_js_pwd_channels"]).max()), 1e-12)
+    assert M.js_pwd(d)["pred"] == float(g[f"{tag}_js_pwd"]) and M.js_pwd(d)["target"] == 0.0
+    check(f"radius of gyration vs reference [{tag}]", float(np.abs(M.radius_of_gyration(d["pred"]) - g[f"{tag}_rg_pred"]).max()), 2e-5)
+    check(f"js_rg vs reference [{tag}]", abs(M.js_rg(d)["pred"] - float(g[f"{tag}_js_rg"])), 2.1e-3)
