@@ -30,6 +30,7 @@
 //   [ o (H*C) | o_pt.x (H*Pv) | o_pt.y | o_pt.z | |o_pt| (H*Pv) | o_pair (H*PZ) ]
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "str2str_hip.h"
 
@@ -77,6 +78,7 @@ struct IpaArgs {
     float* out;             // [B,N,H*(C+4*PV+PZ)]
     int B, N, H;
     float inf, eps;
+    int xcd_remap;  // 1: give every XCD (private L2) a contiguous range of (sample, head, query block) ids
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -121,6 +123,10 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
     const int N = a.N, H = a.H;
     const int n_qb = (N + 127) / 128;
     int bid = blockIdx.x;
+    // Workgroup b runs on XCD b % 8 (observed dispatch order; a speed assumption only).  The query blocks of one (sample, head)
+    // read the same K / V / point tiles: with consecutive LOGICAL ids on one XCD they run side by side there and the second
+    // reader hits that XCD's L2 instead of fetching the tiles from HBM again.
+    if (a.xcd_remap) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
     const int qb = bid % n_qb; bid /= n_qb;
     const int head = bid % H;
     const int b = bid / H;
@@ -566,9 +572,11 @@ extern "C" int s2s_ipa_attention(const float* q, const float* kv, const float* q
     if (n_samples <= 0 || n_res <= 0) return 0;
     if (c_hidden != 256 || n_qk_points != 8 || n_v_points != 12 || c_pair_z != 32 || n_heads < 1)
         return (int)hipErrorInvalidValue;  // the reference configuration (configs/model/diffusion.yaml:29-40)
-    IpaArgs a{q, kv, q_pts, k_pts, v_pts64, attn_bias, logits_out, stats_out, mask, rigids7, head_w_scaled, out, n_samples, n_res, n_heads, inf, eps};
     const int n_qb = (n_res + 127) / 128;
     const long long blocks = (long long)n_samples * n_heads * n_qb;
+    static const int remap_env = getenv("S2S_IPA_XCD") ? atoi(getenv("S2S_IPA_XCD")) : 1;
+    IpaArgs a{q, kv, q_pts, k_pts, v_pts64, attn_bias, logits_out, stats_out, mask, rigids7, head_w_scaled, out, n_samples, n_res, n_heads, inf, eps,
+              (remap_env && blocks % 8 == 0 && n_qb > 1) ? 1 : 0};
     if (n_res % 32 == 0)
         hipLaunchKernelGGL((ipa_attention_kernel<256, 8, 12, 32, true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else
