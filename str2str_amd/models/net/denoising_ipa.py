@@ -44,6 +44,13 @@ def get_timestep_embedding(timesteps: torch.Tensor, embedding_dim: int, max_len:
     return emb
 
 
+def _pack_node(lin: nn.Linear) -> dict:
+    """A whole-row nn.Linear in the layout of s2s_node_linear (csrc/node_gemm.hip)."""
+    n, k = lin.weight.shape
+    tg = ops.node_tiles(n, whole_row=True)
+    return {"w": ops.pack_node_weight(lin.weight.float(), tg), "b": lin.bias.float().contiguous(), "n": n, "k": k, "tg": tg}
+
+
 class EmbeddingModule(nn.Module):
     def __init__(self, init_embed_size: int, node_embed_size: int, edge_embed_size: int, num_bins: int = 22,
                  min_bin: float = 1e-5, max_bin: float = 20.0, self_conditioning: bool = True):
@@ -72,6 +79,7 @@ class EmbeddingModule(nn.Module):
         self._idx_key = None
         self._idx_val = None
         self._idx_src = None
+        self.node_embed_xp = None   # packed planes of the last node embedding (read by the trunk instead of re-packing)
 
     # ---- derived tensors
     def _weights(self):
@@ -93,6 +101,7 @@ class EmbeddingModule(nn.Module):
                 "wn_t": wn[:, :ie].contiguous(), "wn_f": wn[:, ie].contiguous(), "wn_pos": wn[:, t1:t1 + ie].contiguous(),
                 "bn0": n0.bias.float().contiguous(),
                 "w2p": ops.pack_weight(e2.weight.float()), "w3p": ops.pack_weight(e4.weight.float()),
+                "node_mlp": [_pack_node(self.node_embed[2]), _pack_node(self.node_embed[4])],
                 "wstream": ops.pack_bf16x3_embed_stream(e2.weight.float(), e4.weight.float()),
             }
             if self.self_conditioning:
@@ -102,7 +111,9 @@ class EmbeddingModule(nn.Module):
             out["bin_lower"] = torch.linspace(self._dims[2], self._dims[3], nb).to(w0.device)
             return out
 
-        return self._wcache.get([e0.weight, e0.bias, e2.weight, e4.weight, self.node_embed[0].weight, self.node_embed[0].bias], build)
+        ne = self.node_embed
+        return self._wcache.get([e0.weight, e0.bias, e2.weight, e4.weight, ne[0].weight, ne[0].bias, ne[2].weight, ne[2].bias,
+                                 ne[4].weight, ne[4].bias], build)
 
     def _index_tables(self, residue_idx: torch.Tensor, w_rel: torch.Tensor, wn_pos: torch.Tensor):
         """Per-target constants: first-layer image of the node positional features and the relative-position
@@ -141,17 +152,32 @@ class EmbeddingModule(nn.Module):
         # [B, 32]; evaluated once per DISTINCT t (a sampler chunk shares one t, and the host sin/cos of arguments up to 1e4 rad
         # costs ~40 us per element): same values, row for row
         if t_emb is not None:   # the sampler uploads the embeddings of the whole schedule once: no per-step H2D copy
-            t_emb = t_emb.to(dev).reshape(-1, t_emb.shape[-1]).expand(B, -1)   # (a host->device copy here would make the
+            t_emb = t_emb.to(dev).reshape(-1, t_emb.shape[-1])                 # (a host->device copy here would make the
         else:                                                                  #  host wait for the GPU every evaluation)
             t_u, t_inv = torch.unique(t.detach().reshape(-1), return_inverse=True)
             t_emb = self.time_embed(t_u)[t_inv].to(dev)
+        if t_emb.shape[0] == 1:
+            # one timestep for the whole chunk (every sampler call): the three [*, 32] first-layer images are one row each --
+            # a 32-term dot product per output channel, evaluated elementwise
+            tl = lambda wt, b=None: ((wt * t_emb).sum(-1) + (b if b is not None else 0.0))[None, :]  # noqa: E731
+        else:
+            tl = lambda wt, b=None: F.linear(t_emb, wt, b)  # noqa: E731
         ne = self.node_embed
-        h = F.relu(F.linear(t_emb, w["wn_t"], w["bn0"])[:, None, :] + fixed * w["wn_f"] + node_pos)
-        node_embed = ne[5](ne[4](F.relu(ne[2](h))))
-        node_a = (F.linear(t_emb, w["w_row_t"], w["b0"])[:, None, :] + fixed * w["w_row_f"]).contiguous()
-        node_b = (F.linear(t_emb, w["w_col_t"])[:, None, :] + fixed * w["w_col_f"]).contiguous()
-        ca = self_conditioning_ca.to(dev).float().contiguous() if self.self_conditioning else t_emb.new_zeros(B, L, 3)
         mask = None if node_mask is None else node_mask.to(dev).float().contiguous()
+        h = F.relu(tl(w["wn_t"], w["bn0"])[:, None, :] + fixed * w["wn_f"] + node_pos)
+        # layers 2, 3 + LayerNorm (+ DenoisingNet's node mask) on the fused node kernels; the packed planes of the result are
+        # what the trunk's first projections and every skip_embed read
+        M = B * L
+        nw = w["node_mlp"]
+        _, h2 = ops.node_linear(ops.pack_planes(h.reshape(M, -1).contiguous()), nw[0]["w"], nw[0]["b"], M, nw[0]["k"], nw[0]["n"],
+                                nw[0]["tg"], relu=True, want_f32=False, want_xp=True)
+        node_embed, self.node_embed_xp = ops.node_linear(h2, nw[1]["w"], nw[1]["b"], M, nw[1]["k"], nw[1]["n"], nw[1]["tg"],
+                                                         ln=(ne[5].weight, ne[5].bias, ne[5].eps),
+                                                         post_mask=None if mask is None else mask.reshape(M), want_xp=True)
+        node_embed = node_embed.view(B, L, -1)
+        node_a = (tl(w["w_row_t"], w["b0"])[:, None, :] + fixed * w["w_row_f"]).expand(B, L, -1).contiguous()
+        node_b = (tl(w["w_col_t"])[:, None, :] + fixed * w["w_col_f"]).expand(B, L, -1).contiguous()
+        ca = self_conditioning_ca.to(dev).float().contiguous() if self.self_conditioning else t_emb.new_zeros(B, L, 3)
         e2, e4, ln = self.edge_embed[2], self.edge_embed[4], self.edge_embed[5]
         if self.mfma_mode == "bf16x6":
             proj = None
@@ -165,8 +191,6 @@ class EmbeddingModule(nn.Module):
             edge_embed = ops.edge_embed(node_a, node_b, rel_tab, w["bin_tab"], w["bin_lower"], idx_dev, ca, w["w2p"],
                                         w["w3p"], e2.bias, e4.bias, ln.weight, ln.bias, mask, span, ln.eps,
                                         proj=None if next_proj is None else next_proj[:2])
-        if mask is not None:
-            node_embed = node_embed * mask[..., None]
         if next_proj is not None:
             edge_embed, *proj = edge_embed
             return node_embed, edge_embed, tuple(proj)
@@ -196,6 +220,7 @@ class DenoisingNet(nn.Module):
         tb = dict(batch)
         tb["residue_mask"], tb["fixed_mask"] = node_mask, fixed_mask
         tb["rigids_t"] = batch["rigids_t"].to(dev)
+        tb["_node_embed_xp"] = getattr(self.embedder, "node_embed_xp", None)
         model_out = self.translator(node_embed, edge_embed, tb, **({"_first_proj": emb[2]} if fuse else {}))
         gt_psi = batch["torsion_angles_sin_cos"].to(dev)[..., 2, :]
         psi_pred = gt_psi * fixed_mask[..., None] + model_out["psi"] * (1 - fixed_mask[..., None])

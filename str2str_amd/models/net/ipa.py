@@ -225,7 +225,9 @@ class TranslationIPA(nn.Module):
             return ops.node_linear(xp, w["w"], w["b"], M, w["k"], w["n"], w["tg"], **kw)
 
         s_f32 = node_embed.reshape(M, C).float().contiguous()
-        init_xp = ops.pack_planes(s_f32)          # skip_embed reads the embedder's output in every block
+        init_xp = batch.get("_node_embed_xp")     # skip_embed reads the embedder's output in every block
+        if init_xp is None:
+            init_xp = ops.pack_planes(s_f32)
         s_xp = init_xp
         D = C + T["skip_embed_0"].out_features     # transformer width (320)
         for b in range(self.num_blocks):
