@@ -180,6 +180,14 @@ int s2s_node_linear(const void* xp, const void* w_packed, const float* bias, lon
                     int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_mask,
                     float* out_f32, int out_ld, int out_col0, void* out_xp, int out_xp_ksteps, int out_xp_kstep0, void* stream);
 
+/* The same GEMM with the operands swapped, for a projection whose output is consumed as the A operand of a later product over
+ * its ROWS (the value projection of InvariantPointAttention, ipa.py:132-141, consumed by the PV step): the result (+ bias) is
+ * stored as bf16x3 MFMA A fragments  out_vf[row tile (32 rows)][head][column tile (32 cols) in head][k-step u (16 rows)][plane]
+ * [lane 64][8], element j of lane (column c, half h) = row (r&3) + 8 (r>>2) + 4 h, r = 8 u + j, of the tile.  w_packed as for
+ * s2s_node_linear with tiles_per_block = 8. */
+int s2s_node_linear_vfrag(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
+                          int tiles_per_head, void* out_vf, void* stream);
+
 /* Self-attention core of the trunk's TransformerEncoderLayer (src/models/net/ipa.py:312-317,357; torch.nn.MultiheadAttention with
  * d_model = n_heads * head_dim, head_dim = 80): softmax(q k^T / sqrt(head_dim) + key_bias[j]) v per (sample, head), exact fp32 MFMA.
  *   qkv [B*N, 3*D] fp32 = in_proj output (q | k | v); key_bias [B,N] or NULL: added to the logits of key j (PyTorch's float

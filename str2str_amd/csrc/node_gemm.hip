@@ -61,6 +61,8 @@ struct GemmArgs {
     const float* post_mask;  // [M] or NULL: applied last
     float* out_f32;          // [M, out_ld] (columns out_col0 + ...) or NULL
     bf16x8* out_xp;          // packed planes of the output as a K' = 16 * xp_KS wide activation, at k-step offset xp_ks0, or NULL
+    bf16x8* out_vf;          // VF kernels only: the output as A fragments of a [32 rows x 32 columns] x 2 k-step tiling (see below)
+    int vf_tiles_per_head;   // column tiles (of 32) per head
     long long M;
     int KS;                  // K / 16 (even)
     int n_col_blocks;
@@ -69,7 +71,12 @@ struct GemmArgs {
     float ln_eps;
 };
 
-template <int TG, int WAVES>
+// VF: operands swapped -- Y[row, col] = X . W^T with A = the activation fragment, B = the weight fragment -- so that a lane owns
+// one OUTPUT COLUMN and 16 rows (accumulator register r <-> row (r&3) + 8 (r>>2) + 4 h of the 32-row tile): registers 8u .. 8u+7
+// are then exactly the A fragment (k-step u) of a later  Z^T[col, i] += Y^T[col, row] P^T[row, i]  product over the rows, i.e. of
+// the attention's PV step with rows = keys (csrc/ipa_attention.hip).  The epilogue adds the bias, splits and stores them as
+//   out_vf[row tile][head][column tile in head][k-step u][plane 3][lane 64][8]   (bf16; 1 KiB per (u, plane), lane-linear)
+template <int TG, int WAVES, bool VF>
 __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
     // One weight stage = ONE k-step (TG tiles x 3 planes = 3 TG KiB), double buffered: 6 TG KiB of LDS and <= 256 registers, so
     // two workgroups share a CU (two waves per SIMD): one's barrier / LDS latency hides under the other's MFMAs.
@@ -141,23 +148,24 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
         for (int p = 0; p < NP; ++p) {
             if (p + 1 < NP) fetch(p + 1, f[(p + 1) & 1]);
             const bf16x8 (&w)[6] = f[p & 1];
+            auto mm = [&](const bf16x8& wf, const bf16x8& xf, f32x16 c) { return VF ? mfma_bf16(xf, wf, c) : mfma_bf16(wf, xf, c); };
             if (2 * p + 1 < TG) {
                 f32x16 c = acc[2 * p], d = acc[2 * p + 1];
-                c = mfma_bf16(w[2], x[0], c); d = mfma_bf16(w[5], x[0], d);  // (l,h)
-                c = mfma_bf16(w[0], x[2], c); d = mfma_bf16(w[3], x[2], d);  // (h,l)
-                c = mfma_bf16(w[1], x[1], c); d = mfma_bf16(w[4], x[1], d);  // (m,m)
-                c = mfma_bf16(w[1], x[0], c); d = mfma_bf16(w[4], x[0], d);  // (m,h)
-                c = mfma_bf16(w[0], x[1], c); d = mfma_bf16(w[3], x[1], d);  // (h,m)
-                c = mfma_bf16(w[0], x[0], c); d = mfma_bf16(w[3], x[0], d);  // (h,h)
+                c = mm(w[2], x[0], c); d = mm(w[5], x[0], d);  // (l,h)
+                c = mm(w[0], x[2], c); d = mm(w[3], x[2], d);  // (h,l)
+                c = mm(w[1], x[1], c); d = mm(w[4], x[1], d);  // (m,m)
+                c = mm(w[1], x[0], c); d = mm(w[4], x[0], d);  // (m,h)
+                c = mm(w[0], x[1], c); d = mm(w[3], x[1], d);  // (h,m)
+                c = mm(w[0], x[0], c); d = mm(w[3], x[0], d);  // (h,h)
                 acc[2 * p] = c; acc[2 * p + 1] = d;
             } else {
                 f32x16 c = acc[2 * p];
-                c = mfma_bf16(w[2], x[0], c);
-                c = mfma_bf16(w[0], x[2], c);
-                c = mfma_bf16(w[1], x[1], c);
-                c = mfma_bf16(w[1], x[0], c);
-                c = mfma_bf16(w[0], x[1], c);
-                c = mfma_bf16(w[0], x[0], c);
+                c = mm(w[2], x[0], c);
+                c = mm(w[0], x[2], c);
+                c = mm(w[1], x[1], c);
+                c = mm(w[1], x[0], c);
+                c = mm(w[0], x[1], c);
+                c = mm(w[0], x[0], c);
                 acc[2 * p] = c;
             }
         }
@@ -188,8 +196,33 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
         __syncthreads();
     }
 
-    // ---------------- epilogue.  Lane (row m = lane & 31, half h): register r of tile t = column 32 t + (r&3) + 8 (r>>2) + 4 h
     const int col_base = cb * TG * 32;
+    if constexpr (VF) {
+        // lane (column c = lane & 31 of tile t, half h): register r = row (r&3) + 8 (r>>2) + 4 h of the wave's row tile
+        if (rt < n_rt) {
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                const int T = cb * TG + t;
+                const float bv = a.bias ? a.bias[32 * T + (lane & 31)] : 0.f;
+                bf16x8* o = a.out_vf + ((((rt * (a.n_col_blocks * TG / a.vf_tiles_per_head) + T / a.vf_tiles_per_head) * a.vf_tiles_per_head +
+                                          T % a.vf_tiles_per_head) * 2) * 3) * 64 + lane;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int r = 8 * u + j;
+                        v[j] = (rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < a.M) ? acc[t][r] + bv : 0.f;
+                    }
+                    bf16x8 ph, pmid, pl;
+                    split8(v, ph, pmid, pl);
+                    o[(u * 3) * 64] = ph; o[(u * 3 + 1) * 64] = pmid; o[(u * 3 + 2) * 64] = pl;
+                }
+            }
+        }
+        return;
+    }
+    // ---------------- epilogue.  Lane (row m = lane & 31, half h): register r of tile t = column 32 t + (r&3) + 8 (r>>2) + 4 h
 #pragma unroll
     for (int t = 0; t < TG; ++t)
 #pragma unroll
@@ -301,19 +334,19 @@ __global__ void __launch_bounds__(256) pack_planes_kernel(const float* __restric
     o[0] = ph; o[64] = pm; o[128] = pl;
 }
 
-template <int TG, int WAVES>
+template <int TG, int WAVES, bool VF = false>
 int launch_gemm_w(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = 2 * 3 * TG * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&node_gemm_kernel<TG, WAVES>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&node_gemm_kernel<TG, WAVES, VF>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     const long long n_rt = (a.M + 31) / 32;
     const long long row_blocks = (n_rt + WAVES - 1) / WAVES;
-    hipLaunchKernelGGL((node_gemm_kernel<TG, WAVES>), dim3((unsigned)row_blocks, (unsigned)a.n_col_blocks), dim3(64 * WAVES), lds, stream, a);
+    hipLaunchKernelGGL((node_gemm_kernel<TG, WAVES, VF>), dim3((unsigned)row_blocks, (unsigned)a.n_col_blocks), dim3(64 * WAVES), lds, stream, a);
     return (int)hipGetLastError();
 }
 
@@ -351,7 +384,7 @@ extern "C" int s2s_node_linear(const void* xp, const void* w_packed, const float
     if (residual && residual_ld % 4) return (int)hipErrorInvalidValue;
     if (out_xp && (out_xp_kstep0 < 0 || out_xp_kstep0 % 2 || out_xp_kstep0 + n_out / 16 > out_xp_ksteps)) return (int)hipErrorInvalidValue;
     GemmArgs a{(const bf16x8*)xp, (const char*)w_packed, bias, pre_scale, pre_mask, residual, ln_gamma, ln_beta, post_mask, out_f32,
-               (bf16x8*)out_xp, n_rows, k_in / 16, ncb, residual_ld, out_ld, out_col0, out_xp_ksteps, out_xp_kstep0, relu, ln_eps};
+               (bf16x8*)out_xp, nullptr, 0, n_rows, k_in / 16, ncb, residual_ld, out_ld, out_col0, out_xp_ksteps, out_xp_kstep0, relu, ln_eps};
     hipStream_t st = (hipStream_t)stream;
     switch (TG) {
         case 1: return launch_gemm<1>(a, st);
@@ -363,4 +396,16 @@ extern "C" int s2s_node_linear(const void* xp, const void* w_packed, const float
         case 10: return launch_gemm<10>(a, st);
         default: return (int)hipErrorInvalidValue;
     }
+}
+
+extern "C" int s2s_node_linear_vfrag(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
+                                     int tiles_per_head, void* out_vf, void* stream) {
+    if (n_rows <= 0) return 0;
+    constexpr int TG = 8;
+    if (!xp || !w_packed || !out_vf || k_in <= 0 || k_in % 32 || n_out <= 0 || n_out % (32 * TG) || tiles_per_head <= 0 ||
+        (n_out / 32) % tiles_per_head)
+        return (int)hipErrorInvalidValue;
+    GemmArgs a{(const bf16x8*)xp, (const char*)w_packed, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+               (bf16x8*)out_vf, tiles_per_head, n_rows, k_in / 16, n_out / (32 * TG), 0, 0, 0, 0, 0, 0, 0.f};
+    return launch_gemm_w<TG, 4, true>(a, (hipStream_t)stream);
 }

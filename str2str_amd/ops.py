@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _lib = None
 _tables_loaded = False
@@ -41,6 +41,7 @@ _SIGNATURES = {
     "s2s_forward_marginal": [_vp] * 7 + [_i, _vp, _vp, _f, _vp, _i, _i, _vp],
     "s2s_pack_planes": [_vp, _ll, _i, _i, _i, _vp, _i, _i, _vp, _vp],
     "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
+    "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _vp],
     "s2s_encoder_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "s2s_ca_sample_stats": [_vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
     "s2s_ca_pwd_js": [_vp, _i, _vp, _i, _i, _i, _i, _d, _vp, _vp],
@@ -581,6 +582,22 @@ def node_linear(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles: int, *
         out_f32.shape[-1] if out_f32 is not None else 0, out_col0, _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16,
         _stream())), "s2s_node_linear")
     return out_f32, out_xp
+
+
+def node_linear_vfrag(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles_per_head: int = 8, out=None):
+    """Projection stored as bf16x3 A fragments over 32-row tiles (s2s_node_linear_vfrag; the value projection of the IPA).
+    -> int16 buffer [row tiles][heads][tiles_per_head][2][3][64][8]."""
+    lib = load_library()
+    _req(xp, torch.int16, "xp"); _req(wpk, torch.int16, "w_packed")
+    if bias is not None:
+        _req(bias, name="bias")
+    n_el = ((n_rows + 31) // 32) * (n_out // 32) * 2 * 3 * 64 * 8
+    if out is None:
+        out = torch.empty(n_el, dtype=torch.int16, device=xp.device)
+    _req(out, torch.int16, "out_vf")
+    _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_vfrag(_p(xp), _p(wpk), _p(bias), n_rows, k_in, n_out, tiles_per_head,
+                                                                       _p(out), _stream())), "s2s_node_linear_vfrag")
+    return out
 
 
 def encoder_attention(qkv: torch.Tensor, key_bias: Optional[torch.Tensor], n_samples: int, n_res: int, n_heads: int = 4,

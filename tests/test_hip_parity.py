@@ -836,6 +836,37 @@ def test_node_linear_vs_float64(M, K, N):
         assert float((out[:, :32] + 7).abs().max()) == 0 and float((out[:, 32 + n_pad:] + 7).abs().max()) == 0
 
 
+@pytest.mark.parametrize("M", [256, 77])
+def test_node_linear_vfrag_equals_plain_output(M):
+    """The operand-swapped GEMM (s2s_node_linear_vfrag: result stored as bf16x3 A fragments over 32-row tiles, the value operand
+    of the IPA's PV product) decodes to the plain s2s_node_linear output: same products, same accumulation order per element
+    up to the MFMA's internal order -> compared against float64 like the plain kernel, and the split itself is exact."""
+    from str2str_amd import ops
+
+    K, N, tph = 256, 2048, 8
+    g = torch.Generator().manual_seed(M)
+    x = torch.randn(M, K, generator=g).to(DEV)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    wpk = ops.pack_node_weight(w, 8)
+    xp = ops.pack_planes(x)
+    vf = ops.node_linear_vfrag(xp, wpk, b, M, K, N, tph)
+    RT = (M + 31) // 32
+    fr = vf.view(torch.bfloat16).reshape(RT, N // 32 // tph, tph, 2, 3, 2, 32, 8).float().sum(4)   # [RT, H, ct, u, h, c, j]
+    u = torch.arange(2)[:, None, None]; h = torch.arange(2)[None, :, None]; j = torch.arange(8)[None, None, :]
+    r = 8 * u + j
+    row = ((r & 3) + 8 * (r >> 2) + 4 * h).to(DEV)                                                  # [u, h, j]
+    y = torch.zeros(RT, 32, N, device=DEV)
+    cols = fr.permute(0, 3, 4, 6, 1, 2, 5).reshape(RT, 2, 2, 8, N)                                  # [RT, u, h, j, col]
+    y[:, row.reshape(-1)] = cols.reshape(RT, 32, N)
+    y = y.reshape(-1, N)
+    ref = x.double() @ w.double().t() + b.double()
+    check(f"node_linear_vfrag M{M}", rel(y[:M], ref), 2e-6)
+    assert float(y[M:].abs().max()) == 0 if RT * 32 > M else True
+    y_plain, _ = ops.node_linear(xp, wpk, b, M, K, N, 8)
+    check(f"node_linear_vfrag vs plain M{M}", rel(y[:M], y_plain.double()), 1e-6)
+
+
 @pytest.mark.parametrize("B,N", [(2, 37), (1, 256), (3, 130)])
 def test_encoder_attention_vs_torch(net_rough, B, N):
     """s2s_encoder_attention against torch's own nn.TransformerEncoder (the module the reference calls, ipa.py:357) in float64
