@@ -109,6 +109,25 @@ int s2s_ipa_attention(const float* q, const float* kv, const float* q_pts, const
                       const float* head_w_scaled, float* out, int n_samples, int n_res, int n_heads, int c_hidden,
                       int n_qk_points, int n_v_points, int c_pair_z, float inf, float eps, void* stream);
 
+/* The same two operators for n_res % 32 == 0 on operands that are ALREADY exact bf16x3 splits in MFMA fragment order
+ * (csrc/ipa_attention_planes.hip): q_xp / k_xp = packed planes [M/32][16 H][3][64][8] of the q and k projections (out_xp of
+ * s2s_node_linear with linear_q and the k rows of linear_kv), v_vf = s2s_node_linear_vfrag of the v rows of linear_kv.
+ * s2s_ipa_prep_points_planes (ipa.py:144-171) writes the global-frame points as fragments: qp_xp [M/32][H][2][3][64][8] (query
+ * points x head_w_scaled[h] / sqrt(1/(3 c_hidden))), kp_xp (key points), vp_vf [M/32][H][2][2][3][64][8] (value points as
+ * (x,y,z,0) groups), and q2 / k2 [M/32][H][32] = -1/2 head_w_scaled[h] |points|^2: the point term of the logits (ipa.py:191-205)
+ * is evaluated as  w q.k - w/2 |q|^2 - w/2 |k|^2  with the cross term on the matrix cores.
+ * s2s_ipa_attention_planes: out [B,N,feat] receives only the o_pt columns (H*c_hidden ..); the o columns are written as packed
+ * planes (k-steps 16 h .. 16 h + 15 of an activation with out_xp_ksteps k-steps per row: the input of linear_out);
+ * logits_out / stats_out as s2s_ipa_attention (consumed by s2s_ipa_opair). */
+int s2s_ipa_prep_points_planes(const float* rigids7, const float* q_pts_lin, const float* kv_pts_lin, const float* head_w_scaled,
+                               void* qp_xp, void* kp_xp, void* vp_vf, float* q2, float* k2, long long n_frames, int n_heads,
+                               int n_qk_points, int n_v_points, int c_hidden, void* stream);
+int s2s_ipa_attention_planes(const void* q_xp, const void* k_xp, const void* v_vf, const void* qp_xp, const void* kp_xp,
+                             const void* vp_vf, const float* q2, const float* k2, const float* attn_bias, float* logits_out,
+                             float* stats_out, const float* mask, const float* rigids7, float* out, void* out_xp,
+                             int out_xp_ksteps, int n_samples, int n_res, int n_heads, int c_hidden, int n_qk_points,
+                             int n_v_points, int c_pair_z, float inf, float eps, void* stream);
+
 /* The pair term of InvariantPointAttention.forward (src/models/net/ipa.py:253-257):
  *   o_pair[b,i,h,:] = sum_j softmax_j(logits[b,h,i,:])[j] * pair_z[b,i,j,:]
  * from the logits / statistics s2s_ipa_attention stored, streaming pair_z [B,N,N,c_pair_z] once for all heads;

@@ -1,0 +1,652 @@
+// Invariant Point Attention core on packed bf16x3 planes (gfx950) -- the fast path for n_res % 32 == 0.
+// Reference: InvariantPointAttention.forward, src/models/net/ipa.py:183-257 (same operator as csrc/ipa_attention.hip, which
+// remains the path for ragged lengths and documents the flash schedule, the MFMA orientation and the pair-term split).
+//
+// What differs from ipa_attention.hip: every matrix operand arrives ALREADY as exact 3-way bf16 splits in MFMA fragment order,
+// written by the epilogues of the producing GEMMs (csrc/node_gemm.hip) and by the point kernel below, so the attention kernel
+// contains no operand split except the 16 probabilities of a key tile, and all three products run on v_mfma_f32_32x32x16_bf16
+// (six plane-pair products, fp32 accumulate = fp32-equivalent):
+//   S^T[j, i]  = K[j, :] . Q[i, :]  + K'pts[j, :] . Q'pts[i, :]     18 k-steps: 16 of the head's channels + 2 of point coordinates
+//   O^T[c, i] += V^T[c, j] P^T[j, i]                                10 output tiles: 8 of channels + 2 of (x, y, z, 0) value points
+// The point term  -1/2 w_h sum_p |q_ip - k_jp|^2  =  w_h q.k  - 1/2 w_h |q_i|^2 - 1/2 w_h |k_j|^2 : the cross term rides in the
+// QK^T accumulator (the query points are pre-scaled by w_h / c1, c1 = sqrt(1/(3C)) the scalar-logit scale), the two squared
+// norms are per-residue fp32 scalars from the point kernel.  (ipa_attention.hip forms explicit differences on the VALU; the
+// expansion costs ~1e-6 absolute in a logit at protein coordinates / 10 -- see DESIGN.md -- and removes 900 VALU
+// instructions per key tile.)
+//   q_xp, k_xp : packed planes [row tile][16 H k-steps][3][64][8] of the q / k projections (s2s_node_linear out_xp)
+//   v_vf       : [row tile][H][8 col tiles][2][3][64][8] A fragments of the v projection (s2s_node_linear_vfrag)
+//   qp_xp, kp_xp [row tile][H][2][3][64][8], vp_vf [row tile][H][2][2][3][64][8], q2 / k2 [row tile][H][32]: the point kernel
+// A key tile's K image (54 KiB) and V image (60 KiB) are contiguous in HBM and go to LDS by LDS-DMA, single buffered and
+// staggered: K(t+1) is fetched under softmax(t) + PV(t), V(t+1) under QK(t+1); two workgroup barriers per key tile.
+// The head output leaves as packed planes of linear_out's input (the accumulator registers ARE its fragments).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "geom.h"
+#include "str2str_hip.h"
+
+namespace {
+
+using namespace s2s;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma_b16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ void load7(const float* __restrict__ p, Quat<float>& q, Vec3<float>& t) {
+    q.w = p[0]; q.x = p[1]; q.y = p[2]; q.z = p[3];
+    t.x = p[4]; t.y = p[5]; t.z = p[6];
+}
+
+// e^x for x <= ~0 in 6 VALU instructions: v_exp_f32 (2^t, 1 ulp) on t = fl(x log2 e), corrected to first order for the rounding
+// of the product and of the constant (exact residual by FMA), so the argument error does not grow with |x|.  Relative error
+// ~2 ulp; expf() expands to ~12 instructions with many temporaries (the softmax section was the register-pressure peak).
+__device__ __forceinline__ float exp_neg(float x) {
+    const float L2E = 1.44269504088896341f, L2E_LO = 1.92596299112661746e-8f, LN2 = 0.693147180559945309f;
+    const float t = x * L2E;
+    float e = __builtin_fmaf(x, L2E, -t);
+    e = __builtin_fmaf(x, L2E_LO, e);
+    const float r = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(r, e * LN2, r);
+}
+
+__device__ __forceinline__ void split8(const float* v, bf16x8& ph, bf16x8& pm, bf16x8& pl) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 a_ = (__bf16)v[j];
+        const float r1 = v[j] - (float)a_;
+        const __bf16 b_ = (__bf16)r1;
+        ph[j] = a_; pm[j] = b_; pl[j] = (__bf16)(r1 - (float)b_);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Point generation (ipa.py:144-171, rigid_utils.py:1107-1120) straight into MFMA fragments.  One workgroup per (row tile of 32
+// residues, head): the 8 + 8 + 12 global-frame points of every residue go through LDS, then 512 (fragment, lane) items are
+// split and stored.  Coordinate k of a point row = 3 p + d (24 of the 32 columns of two k-steps; the rest zero).
+constexpr int PQ = 8, PV = 12;
+
+__global__ void __launch_bounds__(256) ipa_prep_planes_kernel(const float* __restrict__ rig, const float* __restrict__ qp_lin,
+                                                              const float* __restrict__ kvp_lin, const float* __restrict__ head_w,
+                                                              float q_scale_c1, bf16x8* __restrict__ qp_xp, bf16x8* __restrict__ kp_xp,
+                                                              bf16x8* __restrict__ vp_vf, float* __restrict__ q2, float* __restrict__ k2,
+                                                              int H) {
+    __shared__ float sq[32][33], sk[32][33], sv[32][65];
+    const int tid = threadIdx.x;
+    const int head = blockIdx.x % H;
+    const long long rt = blockIdx.x / H;
+    const float hw = head_w[head];
+    {
+        const int row = tid >> 3, p = tid & 7;
+        const long long r = rt * 32 + row;
+        Quat<float> q; Vec3<float> t;
+        load7(rig + r * 7, q, t);
+        const Mat3<float> R = quat_to_rot<float>(q);
+        const int HPq = H * PQ, HPkv = H * (PQ + PV);
+        const float* ql = qp_lin + r * 3 * HPq;
+        const float* kl = kvp_lin + r * 3 * HPkv;
+        {
+            const int w = head * PQ + p;
+            const Vec3<float> g = rot_vec_mul<float>(R, Vec3<float>{ql[w], ql[HPq + w], ql[2 * HPq + w]});
+            sq[row][3 * p] = g.x + t.x; sq[row][3 * p + 1] = g.y + t.y; sq[row][3 * p + 2] = g.z + t.z;
+            sq[row][24 + p] = 0.f;
+        }
+        {
+            const int c = head * (PQ + PV) + p;
+            const Vec3<float> g = rot_vec_mul<float>(R, Vec3<float>{kl[c], kl[HPkv + c], kl[2 * HPkv + c]});
+            sk[row][3 * p] = g.x + t.x; sk[row][3 * p + 1] = g.y + t.y; sk[row][3 * p + 2] = g.z + t.z;
+            sk[row][24 + p] = 0.f;
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int pv = p + 8 * x;  // value-point slot 0..15; slots >= PV are zero padding
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pv < PV) {
+                const int c = head * (PQ + PV) + PQ + pv;
+                const Vec3<float> g = rot_vec_mul<float>(R, Vec3<float>{kl[c], kl[HPkv + c], kl[2 * HPkv + c]});
+                o = make_float4(g.x + t.x, g.y + t.y, g.z + t.z, 0.f);
+            }
+            sv[row][4 * pv] = o.x; sv[row][4 * pv + 1] = o.y; sv[row][4 * pv + 2] = o.z; sv[row][4 * pv + 3] = o.w;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {  // squared norms, fixed summation order
+        const int row = tid & 31;
+        const float (*s)[33] = tid < 32 ? sq : sk;
+        float acc = 0.f;
+#pragma unroll
+        for (int x = 0; x < 24; ++x) acc += s[row][x] * s[row][x];
+        (tid < 32 ? q2 : k2)[(rt * H + head) * 32 + row] = -0.5f * hw * acc;
+    }
+    const float qs = hw / q_scale_c1;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int item = tid + 256 * it;  // 0..127 q, 128..255 k, 256..511 value points
+        const int lane = item & 63, g = lane >> 5, c = lane & 31;
+        float v[8];
+        bf16x8* dst;
+        if (item < 256) {
+            const int ks = (item >> 6) & 1;
+            const bool isq = item < 128;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = isq ? sq[c][16 * ks + 8 * g + j] * qs : sk[c][16 * ks + 8 * g + j];
+            dst = (isq ? qp_xp : kp_xp) + (((rt * H + head) * 2 + ks) * 3) * 64 + lane;
+        } else {
+            const int f = (item - 256) >> 6, ct = f >> 1, u = f & 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = sv[rowmap(8 * u + j, g)][32 * ct + c];
+            dst = vp_vf + ((((rt * H + head) * 2 + ct) * 2 + u) * 3) * 64 + lane;
+        }
+        bf16x8 ph, pm, pl;
+        split8(v, ph, pm, pl);
+        dst[0] = ph; dst[64] = pm; dst[128] = pl;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+struct PlaneArgs {
+    const bf16x8* q_xp; const bf16x8* k_xp; const bf16x8* v_vf;
+    const bf16x8* qp_xp; const bf16x8* kp_xp; const bf16x8* vp_vf;
+    const float* q2; const float* k2;
+    const float* attn_bias;  // [B,H,N,N]
+    float* logits;           // [B,H,N,N] (may alias attn_bias)
+    float* stats;            // [B,H,N,2]
+    const float* mask;       // [B,N]
+    const float* rigids7;    // [B,N,7]
+    float* out;              // [B,N,feat] fp32: only the o_pt columns are written here
+    bf16x8* out_xp;          // packed planes of the [B*N, 16*xp_ksteps] linear_out input: the o columns (k-steps 16 head ..)
+    int xp_ksteps;
+    int B, N, H;
+    float inf, eps;
+    int xcd_remap;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+__device__ __forceinline__ void dma_kib(const bf16x8* src_piece, bf16x8* lds_piece, int lane) {
+    // one 1 KiB fragment: 16 B per lane, destination = wave-uniform base + lane * 16 (LDS-DMA semantics)
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_piece + lane), (lds_ptr_t)lds_piece, 16, 0, 0);
+}
+
+typedef __attribute__((address_space(3))) const bf16x8 lds_frag;
+__device__ __forceinline__ lds_frag* frag_pin(const bf16x8* p) {
+    lds_frag* q = (lds_frag*)p;
+    asm volatile("" : "+v"(q));
+    return q;
+}
+
+// Timeline probe (tools/ipa_planes_probe.py; only in -DS2S_IPA_PROBE=<block> builds)
+#ifdef S2S_IPA_PROBE
+__device__ unsigned long long s2s_ipa6_probe[4][128];
+#define IPROBE(idx) do { if (blockIdx.x == S2S_IPA_PROBE) s2s_ipa6_probe[threadIdx.x >> 6][idx] = __builtin_readcyclecounter(); } while (0)
+#else
+#define IPROBE(idx) do { } while (0)
+#endif
+
+constexpr int KQ = 18;   // k-steps of QK^T: 16 channels + 2 point coordinates
+constexpr int KH = KQ / 2;   // ... per wave of a pair
+constexpr int OT = 10;   // output tiles of PV: 8 channels + 2 value points
+constexpr int OH = OT / 2;   // ... per wave of a pair
+constexpr int CT = 8;
+
+// A workgroup = 4 waves = 2 query tiles (32 residues each) x 2 "halves".  The B operands must sit in VGPRs (hipcc allocates
+// MFMA sources there only), and the 18 x 3 query fragments of a tile are 216 of them: a PAIR of waves shares a query tile.
+// Half x holds the query fragments of k-steps 9x .. 9x+8 (108 VGPRs) and computes its half of the contraction of S^T; the
+// halves meet through LDS (added in the same order by both, so both waves see bit-identical logits and maxima); in the second
+// phase half x owns the accumulators of output tiles 5x .. 5x+4 (80 AGPRs).
+//
+// Two phases per workgroup instead of an online softmax:
+//   phase 1, key tiles 0 .. NT-1:  S^T -> masked logits -> global (the [B,H,N,N] buffer s2s_ipa_opair reads anyway), row maximum
+//   phase 2, key tiles 0 .. NT-1:  logits back from L2, p = exp(s - max), row sum, O^T += V^T P^T
+// The accumulators are never rescaled (a VALU pass over 80 matrix-core registers per tile, which also dragged the whole
+// register allocation into accvgpr copies), the query fragments are dead in phase 2, and the K images (phase 1) and V images
+// (phase 2) do not coexist in LDS: one stream of 2 NT images through two 60 KiB buffers, image g in buffer g & 1, fetched by
+// LDS-DMA a whole step ahead, a few 1 KiB pieces at a time between MFMA groups (a burst of 15 stalls the issuing wave for
+// ~3 k cycles: the LDS-DMA path takes one piece per ~37 cycles per CU).  One workgroup barrier per key tile and phase.
+struct PlaneStage {
+    bf16x8 img[2][OT * 2 * 3 * 64];   // 2 x 60 KiB: K image [k-step 18][plane][lane] (54 KiB) or V image [tile 10][u][plane][lane]
+    float4 xs[2][4][4][64];           // 32 KiB: partial S^T, [tile parity][wave][r / 4][lane]
+    __attribute__((aligned(16))) float k2[4][32];                  // per-key scalars of key tile t in slot t % 4 (written two tiles ahead, read one tile late)
+    __attribute__((aligned(16))) float km[4][32];
+};
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// 16 B load that bypasses the (non-coherent) vector L1 (cache policy sc0 | sc1): the logits were stored by the partner wave, to
+// lines this CU read as attention bias a moment ago.
+__device__ __forceinline__ f32x4v load_l2(__amdgpu_buffer_rsrc_t rsrc, int byte_offset) {
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_offset, 0, 17);
+    return __builtin_bit_cast(f32x4v, r);
+}
+
+__global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) {
+    __shared__ __attribute__((aligned(16))) PlaneStage st;
+    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    const int wave = threadIdx.x >> 6, half = wave & 1;
+    const int N = a.N, H = a.H;
+    const int NT = N / 32;                        // key tiles = row tiles per sample
+    const int n_qb = (NT + 1) / 2;
+    int bid = blockIdx.x;
+    if (a.xcd_remap) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
+    const int qb = bid % n_qb; bid /= n_qb;
+    const int head = bid % H;
+    const int b = bid / H;
+    const int qt = qb * 2 + (wave >> 1);          // this pair's query tile within the sample
+    const bool wvalid = qt < NT;                  // odd tile count: the last workgroup has an idle pair (it still copies and syncs)
+    const int qtc = wvalid ? qt : NT - 1;
+    const long long rt_q = (long long)b * NT + qtc;
+    const int i = qtc * 32 + c;
+    const long long row_i = (long long)b * N + i;
+
+    // ---- the image stream: g < NT: K image of key tile g (48 pieces of k_xp + 6 of kp_xp); else V image of tile g - NT (48 + 12)
+    const long long k_tile_stride = (long long)16 * H * 3 * 64, p_tile_stride = (long long)H * 6 * 64;
+    const long long v_tile_stride = (long long)H * 48 * 64, vp_tile_stride = (long long)H * 12 * 64;
+    const bf16x8* k_src0 = a.k_xp + (((long long)b * NT * (16 * H) + 16 * head) * 3) * 64 + wave * 64 + lane;
+    const bf16x8* kp_src0 = a.kp_xp + (((long long)b * NT * H + head) * 6) * 64 + wave * 64 + lane;
+    const bf16x8* v_src0 = a.v_vf + (((long long)b * NT * H + head) * 48) * 64 + wave * 64 + lane;
+    const bf16x8* vp_src0 = a.vp_vf + (((long long)b * NT * H + head) * 12) * 64 + wave * 64 + lane;
+    // Image g goes global -> VGPR (stage_load, one step before it is written) -> LDS (stage_store, one step before it is read):
+    // 14 / 15 pieces of 1 KiB per wave.  (LDS-DMA -- global_load_lds_dwordx4 -- would need no registers, but costs the issuing wave
+    // ~150 cycles per piece on this part: 2.3 k cycles per key tile, as much as the tile's MFMAs; only image 0 uses it.)
+    bf16x8 stg[15];
+    auto piece_src = [&](int g, int p) -> const bf16x8* {
+        if (g < NT) return p < 12 ? k_src0 + g * k_tile_stride + p * 256 : kp_src0 + g * p_tile_stride + (p - 12) * 256;
+        return p < 12 ? v_src0 + (g - NT) * v_tile_stride + p * 256 : vp_src0 + (g - NT) * vp_tile_stride + (p - 12) * 256;
+    };
+    auto piece_ok = [&](int g, int p) -> bool {   // wave-uniform: K images have 54 pieces (piece 13 only for waves 0, 1; no piece 14)
+        return g < 2 * NT && (g >= NT || p < 13 || (p == 13 && wave < 2));
+    };
+    // Every VMEM operation of the steady-state loops is UNCONDITIONAL (a piece that does not exist is replaced by a re-load of
+    // piece 12 / the last image): vmcnt counts in order, and a load that is only issued on one side of a branch makes hipcc
+    // fall back to s_waitcnt vmcnt(0) at every use of an older one -- each copy slot then waited for the load issued in the
+    // previous slot.
+    auto stage_load = [&](int g, int p) {
+        const int gc = min(g, 2 * NT - 1);
+        stg[p] = *piece_src(gc, piece_ok(gc, p) ? p : 12);
+    };
+    // one copy slot: piece p of image g_store leaves its register for LDS, the same register is refilled with piece p of the image
+    // after it.  15 slots spread evenly over a step keep the texture path (64 B / clock / CU, shared by the four waves) from
+    // backing up into the issuing wave -- a burst of 8 loads per wave costs it ~1 k cycles.
+    auto stage_slot = [&](int g_store, int p) {
+        if (p < 15) {
+            if (piece_ok(g_store, p)) st.img[g_store & 1][(p < 12 ? wave + 4 * p : 48 + wave + 4 * (p - 12)) * 64 + lane] = stg[p];
+            stage_load(g_store + 1, p);
+        }
+    };
+    auto small = [&](int t) {  // per-key scalars of key tile t (wave 3: k2, wave 2: mask)
+        if (t < NT) {
+            if (wave == 3 && lane < 32) st.k2[t & 3][lane] = a.k2[(((long long)b * NT + t) * H + head) * 32 + lane];
+            if (wave == 2 && lane < 32) st.km[t & 3][lane] = a.mask[(long long)b * N + t * 32 + lane];
+        }
+    };
+
+    IPROBE(126);
+#pragma unroll
+    for (int p = 0; p < 14; ++p)   // image 0 straight into LDS
+        if (piece_ok(0, p))
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)piece_src(0, p), (lds_ptr_t)(st.img[0] + (p < 12 ? wave + 4 * p : 48 + wave + 4 * (p - 12)) * 64), 16, 0, 0);
+#pragma unroll
+    for (int p = 0; p < 15; ++p) stage_load(1, p);
+    small(0);
+    small(1);
+
+    // ---- this wave's query fragments (B operands): k-steps 9 half .. 9 half + 8 of [16 of q_xp | 2 of qp_xp], three planes each
+    bf16x8 qf[KH][3];
+    {
+        const bf16x8* qs = a.q_xp + ((rt_q * (16 * H) + 16 * head) * 3) * 64 + lane;
+        const bf16x8* ps = a.qp_xp + ((rt_q * H + head) * 6) * 64 + lane;
+#pragma unroll
+        for (int x = 0; x < KH; ++x) {
+            const int ks = KH * half + x;   // wave-uniform
+#pragma unroll
+            for (int p = 0; p < 3; ++p) qf[x][p] = ks < 16 ? qs[(ks * 3 + p) * 64] : ps[((ks - 16) * 3 + p) * 64];
+        }
+    }
+    const float q2_i = a.q2[(rt_q * H + head) * 32 + c];
+    const float mask_i = a.mask[row_i];
+    const float c1 = sqrtf(1.0f / (3 * 256));
+    const float c2 = sqrtf(1.0f / 3);
+    const long long brow0 = (((long long)b * H + head) * N + i) * N + 4 * h;
+    float m_run = -INFINITY;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    IPROBE(127);
+
+    // =========================================================== phase 1: logits and row maxima
+    // Software pipeline: the logit arithmetic of tile t-1 (VALU + LDS reads) is issued between the MFMAs of tile t, one element
+    // per two MFMAs, so it runs in the shadow of the matrix pipe (one wave per SIMD: nothing else would fill it).
+    float4 bias_cur[4], bias_prev[4];
+    float tmax = -INFINITY;
+    float4 k2g, kmg;   // per-key scalars of the 4 keys 8g + 4h .. of the element group being evaluated
+    auto logit_elem = [&](int tp, int r, const float4 (&xa)[4], const float4 (&xb)[4], float (&sl)[16]) {
+        const int g = r >> 2, e = r & 3;
+        if (e == 0) {
+            k2g = *reinterpret_cast<const float4*>(&st.k2[tp & 3][8 * g + 4 * h]);
+            kmg = *reinterpret_cast<const float4*>(&st.km[tp & 3][8 * g + 4 * h]);
+        }
+        const float sa = e == 0 ? xa[g].x : (e == 1 ? xa[g].y : (e == 2 ? xa[g].z : xa[g].w));
+        const float sb = e == 0 ? xb[g].x : (e == 1 ? xb[g].y : (e == 2 ? xb[g].z : xb[g].w));
+        const float bv = e == 0 ? bias_prev[g].x : (e == 1 ? bias_prev[g].y : (e == 2 ? bias_prev[g].z : bias_prev[g].w));
+        const float k2v = e == 0 ? k2g.x : (e == 1 ? k2g.y : (e == 2 ? k2g.z : k2g.w));
+        const float kmv = e == 0 ? kmg.x : (e == 1 ? kmg.y : (e == 2 ? kmg.z : kmg.w));
+        float x = (sa + sb) * c1 + c2 * bv;
+        x = x + (q2_i + k2v);
+        x = x + a.inf * (mask_i * kmv - 1.0f);
+        sl[r] = x;
+        tmax = fmaxf(tmax, x);
+        if (r == 15) {   // both waves of a pair hold the same 16 logits: half 0 stores keys 8g + .. of g = 0, 1, half 1 those of g = 2, 3
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+                *reinterpret_cast<float4*>(a.logits + brow0 + tp * 32 + 16 * half + 8 * k) =
+                    make_float4(half ? sl[8 + 4 * k] : sl[4 * k], half ? sl[9 + 4 * k] : sl[4 * k + 1], half ? sl[10 + 4 * k] : sl[4 * k + 2],
+                                half ? sl[11 + 4 * k] : sl[4 * k + 3]);
+        }
+    };
+    auto step1 = [&](int t, auto have_c, auto prev_c) {
+        constexpr bool have = decltype(have_c)::value, prev = decltype(prev_c)::value;
+        const int par = t & 1;
+        IPROBE(6 * t + 0);
+        // partial sums of tile t-1 (both halves, added in the order half 0 + half 1 by both waves)
+        float4 xa[4], xb[4];
+        if constexpr (prev) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { xa[g] = st.xs[par ^ 1][wave & 2][g][lane]; xb[g] = st.xs[par ^ 1][wave | 1][g][lane]; }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias_prev[g] = bias_cur[g];
+        }
+        // this lane's 16 bias values of tile t (keys 32 t + 8 g + 4 h + e): one 128 B line per (query, tile)
+        if constexpr (have) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias_cur[g] = *reinterpret_cast<const float4*>(a.attn_bias + brow0 + t * 32 + 8 * g);
+        }
+        float sl[16];
+        f32x16 S0, S1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S0[r] = 0.f, S1[r] = 0.f;
+        if constexpr (have) {
+            // ---------------- this wave's half of S^T = K . Q^T (+ point cross term): 54 MFMAs on two accumulation chains
+            const bf16x8* k_half = st.img[par] + KH * half * 192 + lane;
+            bf16x8 kf[2][3];
+            lds_frag* kp = frag_pin(k_half);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) kf[0][p] = kp[p * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int x = 0; x < KH; ++x) {
+                if (x + 1 < KH) {
+                    lds_frag* kn = frag_pin(k_half + (x + 1) * 192);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) kf[(x + 1) & 1][p] = kn[p * 64];
+                }
+                const bf16x8 (&k)[3] = kf[x & 1];
+                const bf16x8 (&q)[3] = qf[x];
+                // copy slots 2x, 2x+1: image t + 1 -> LDS (its buffer was released by the barrier of tile t - 1), image t + 2 -> registers
+                S0 = mfma_b16(k[2], q[0], S0); S1 = mfma_b16(k[0], q[2], S1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (prev && 2 * x < 16) logit_elem(t - 1, 2 * x, xa, xb, sl);
+                stage_slot(t + 1, 2 * x);
+                __builtin_amdgcn_sched_barrier(0);
+                S0 = mfma_b16(k[1], q[1], S0); S1 = mfma_b16(k[1], q[0], S1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (prev && 2 * x + 1 < 16) logit_elem(t - 1, 2 * x + 1, xa, xb, sl);
+                stage_slot(t + 1, 2 * x + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                S0 = mfma_b16(k[0], q[1], S0); S1 = mfma_b16(k[0], q[0], S1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            IPROBE(6 * t + 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                st.xs[par][wave][g][lane] = make_float4(S0[4 * g] + S1[4 * g], S0[4 * g + 1] + S1[4 * g + 1],
+                                                        S0[4 * g + 2] + S1[4 * g + 2], S0[4 * g + 3] + S1[4 * g + 3]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < 15; ++p) stage_slot(t + 1, p);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) logit_elem(t - 1, r, xa, xb, sl);   // the last tile's logits: nothing left to hide them under
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and they must have reached L2 before phase 2 reads them back
+        }
+        IPROBE(6 * t + 2);
+        __syncthreads();                                   // partial sums and image t + 1 visible; buffer t & 1 released
+        IPROBE(6 * t + 3);
+        if constexpr (have) small(t + 2);
+        IPROBE(6 * t + 4);
+    };
+    step1(0, std::true_type{}, std::false_type{});
+    for (int t = 1; t < NT; ++t) step1(t, std::true_type{}, std::true_type{});
+    step1(NT, std::false_type{}, std::true_type{});
+    m_run = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    // images NT (= V(0)) and NT + 1 are in flight; the last tile's logits have reached L2 (vmcnt(0) + barrier above)
+    IPROBE(120);
+
+    // =========================================================== phase 2: probabilities and value aggregation
+    // Software pipeline again: exp + split of tile t+1 between the MFMAs of tile t.
+    f32x16 O[OH];
+#pragma unroll
+    for (int t = 0; t < OH; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
+    float l_run = 0.f;
+    // this (sample, head)'s [N, N] logit slab as a buffer resource: 32-bit offsets, cache policy on the instruction
+    const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.logits + ((long long)b * H + head) * N * N), 0,
+                                                                           N * N * 4, 0x00020000);
+    const int loff0 = (i * N + 4 * h) * 4;
+    f32x4v lg[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) lg[g] = load_l2(lrsrc, loff0 + 32 * g);
+    bf16x8 pc[2][3], pn[2][3];   // P^T planes of the current / next tile: [k-step u][plane]
+    float pe[16];
+    auto p_elem = [&](int r) {   // probability of element r of the tile whose logits sit in lg
+        const int g = r >> 2, e = r & 3;
+        pe[r] = exp_neg(lg[g][e] - m_run);
+        l_run += pe[r];
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p_elem(r);
+    split8(pe, pc[0][0], pc[0][1], pc[0][2]);
+    split8(pe + 8, pc[1][0], pc[1][1], pc[1][2]);
+    if (NT > 1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) lg[g] = load_l2(lrsrc, loff0 + 128 + 32 * g);
+    }
+    auto step2 = [&](int t, auto more_c, auto first_c) {
+        constexpr bool more = decltype(more_c)::value, first = decltype(first_c)::value;
+        IPROBE(60 + 6 * t + 0);
+        if constexpr (!first) __syncthreads();             // V(t) visible; every wave is done with V(t - 1)
+        IPROBE(60 + 6 * t + 1);
+        // ---------------- O^T += V^T . P^T for this wave's five output tiles
+        const bf16x8* v_half = st.img[(NT + t) & 1] + OH * half * 384 + lane;
+        auto load_v = [&](int x, bf16x8 (&d)[2][3]) {
+            lds_frag* pa = frag_pin(v_half + x * 384);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) d[u][p] = pa[(u * 3 + p) * 64];
+        };
+        bf16x8 vf[5][2][3];   // all five tiles' fragments: tile x + 2 is fetched while tiles x, x + 1 multiply
+        load_v(0, vf[0]);
+        load_v(1, vf[1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int xp = 0; xp < 2; ++xp) {   // tiles (0, 1), (2, 3): two independent accumulators back to back
+            if (xp == 0) { load_v(2, vf[2]); load_v(3, vf[3]); } else { load_v(4, vf[4]); }
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 (&va)[2][3] = vf[2 * xp], (&vb)[2][3] = vf[2 * xp + 1];
+            f32x16 oa = O[2 * xp], ob = O[2 * xp + 1];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int q4 = 4 * (2 * xp + u);   // elements q4 .. q4+3 of the next tile's probabilities ride here
+                oa = mfma_b16(va[u][2], pc[u][0], oa); ob = mfma_b16(vb[u][2], pc[u][0], ob);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (more) p_elem(q4);
+                if constexpr (!first) stage_slot(NT + t + 1, 3 * (2 * xp + u) + 0);
+                __builtin_amdgcn_sched_barrier(0);
+                oa = mfma_b16(va[u][0], pc[u][2], oa); ob = mfma_b16(vb[u][0], pc[u][2], ob);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (more) p_elem(q4 + 1);
+                if constexpr (!first) stage_slot(NT + t + 1, 3 * (2 * xp + u) + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                oa = mfma_b16(va[u][1], pc[u][1], oa); ob = mfma_b16(vb[u][1], pc[u][1], ob);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (more) p_elem(q4 + 2);
+                if constexpr (!first) stage_slot(NT + t + 1, 3 * (2 * xp + u) + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                oa = mfma_b16(va[u][1], pc[u][0], oa); ob = mfma_b16(vb[u][1], pc[u][0], ob);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (more) p_elem(q4 + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                oa = mfma_b16(va[u][0], pc[u][1], oa); ob = mfma_b16(vb[u][0], pc[u][1], ob);
+                oa = mfma_b16(va[u][0], pc[u][0], oa); ob = mfma_b16(vb[u][0], pc[u][0], ob);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            O[2 * xp] = oa; O[2 * xp + 1] = ob;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            // the fifth tile is one dependent chain (an MFMA every ~64 cycles): the split of the next tile's probabilities fills it
+            f32x16 o = O[4];
+            const bf16x8 (&va)[2][3] = vf[4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                o = mfma_b16(va[u][2], pc[u][0], o); o = mfma_b16(va[u][0], pc[u][2], o); o = mfma_b16(va[u][1], pc[u][1], o);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (more) split8(pe + 8 * u, pn[u][0], pn[u][1], pn[u][2]);
+                if constexpr (!first) { stage_slot(NT + t + 1, 12 + 2 * u); stage_slot(NT + t + 1, 13 + 2 * u); }
+                __builtin_amdgcn_sched_barrier(0);
+                o = mfma_b16(va[u][1], pc[u][0], o); o = mfma_b16(va[u][0], pc[u][1], o); o = mfma_b16(va[u][0], pc[u][0], o);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            O[4] = o;
+        }
+        if constexpr (more) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) lg[g] = load_l2(lrsrc, loff0 + min(t + 2, NT - 1) * 128 + 32 * g);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) pc[u][p] = pn[u][p];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        IPROBE(60 + 6 * t + 3);
+    };
+    if (NT > 1) {
+        step2(0, std::true_type{}, std::true_type{});
+        for (int t = 1; t + 1 < NT; ++t) step2(t, std::true_type{}, std::false_type{});
+        step2(NT - 1, std::false_type{}, std::false_type{});
+    } else {
+        step2(0, std::false_type{}, std::true_type{});
+    }
+    IPROBE(121);
+
+    // ---------------- epilogue
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (!wvalid) return;
+    {
+        // o: accumulator registers 8u .. 8u+7 of channel tile T = fragment k-step 16 head + 2T + u of this row tile (chain order)
+        bf16x8* o = a.out_xp + ((rt_q * a.xp_ksteps + 16 * head) * 3) * 64 + lane;
+#pragma unroll
+        for (int x = 0; x < OH; ++x) {
+            const int T = OH * half + x;   // wave-uniform
+            if (T >= CT) continue;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = O[x][8 * u + j] * inv;
+                bf16x8 ph, pm, pl;
+                split8(v, ph, pm, pl);
+                bf16x8* q = o + ((2 * T + u) * 3) * 64;
+                q[0] = ph; q[64] = pm; q[128] = pl;
+            }
+        }
+    }
+    if (half == 1) {
+        // frame of residue i: R = quat_to_rot(q) (rigid_utils.py:187-207), o_pt = R^T (x - t) (:1122-1133)
+        const int feat = H * (256 + 4 * PV + 32);
+        const float* f = a.rigids7 + row_i * 7;
+        const float qa = f[0], qb_ = f[1], qc = f[2], qd = f[3];
+        const float tx = f[4], ty = f[5], tz = f[6];
+        const float r00 = qa * qa + qb_ * qb_ - qc * qc - qd * qd, r01 = 2 * qb_ * qc - 2 * qa * qd, r02 = 2 * qb_ * qd + 2 * qa * qc;
+        const float r10 = 2 * qb_ * qc + 2 * qa * qd, r11 = qa * qa - qb_ * qb_ + qc * qc - qd * qd, r12 = 2 * qc * qd - 2 * qa * qb_;
+        const float r20 = 2 * qb_ * qd - 2 * qa * qc, r21 = 2 * qc * qd + 2 * qa * qb_, r22 = qa * qa - qb_ * qb_ - qc * qc + qd * qd;
+        float* ox = a.out + row_i * feat + H * 256 + head * PV;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int pt_idx = 8 * t + 2 * rq + h;  // point whose (x,y,z,0) group this lane holds
+                const f32x16& ov = O[CT - OH + t];      // output tiles 8, 9 = local 3, 4 of half 1
+                const float dx = ov[4 * rq + 0] * inv - tx;
+                const float dy = ov[4 * rq + 1] * inv - ty;
+                const float dz = ov[4 * rq + 2] * inv - tz;
+                const float lx = r00 * dx + r10 * dy + r20 * dz;
+                const float ly = r01 * dx + r11 * dy + r21 * dz;
+                const float lz = r02 * dx + r12 * dy + r22 * dz;
+                const float nr = sqrtf(lx * lx + ly * ly + lz * lz + a.eps);
+                if (pt_idx < PV) {
+                    ox[pt_idx] = lx;
+                    ox[H * PV + pt_idx] = ly;
+                    ox[2 * H * PV + pt_idx] = lz;
+                    ox[3 * H * PV + pt_idx] = nr;
+                }
+            }
+    } else if (h == 0) {
+        float* st2 = a.stats + ((((long long)b * H + head) * N) + i) * 2;
+        st2[0] = m_run;
+        st2[1] = l_tot;
+    }
+    IPROBE(122);
+}
+
+}  // namespace
+
+#ifdef S2S_IPA_PROBE
+extern "C" int s2s_debug_read_ipa6_probe(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(s2s_ipa6_probe), sizeof(s2s_ipa6_probe));
+}
+#endif
+
+extern "C" int s2s_ipa_prep_points_planes(const float* rigids7, const float* q_pts_lin, const float* kv_pts_lin,
+                                          const float* head_w_scaled, void* qp_xp, void* kp_xp, void* vp_vf, float* q2, float* k2,
+                                          long long n_frames, int n_heads, int n_qk_points, int n_v_points, int c_hidden, void* stream) {
+    if (n_frames <= 0) return 0;
+    if (n_frames % 32 || n_qk_points != PQ || n_v_points != PV || c_hidden != 256 || n_heads < 1) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(ipa_prep_planes_kernel, dim3((unsigned)(n_frames / 32 * n_heads)), dim3(256), 0, (hipStream_t)stream, rigids7,
+                       q_pts_lin, kv_pts_lin, head_w_scaled, sqrtf(1.0f / (3 * c_hidden)), (bf16x8*)qp_xp, (bf16x8*)kp_xp,
+                       (bf16x8*)vp_vf, q2, k2, n_heads);
+    return (int)hipGetLastError();
+}
+
+extern "C" int s2s_ipa_attention_planes(const void* q_xp, const void* k_xp, const void* v_vf, const void* qp_xp, const void* kp_xp,
+                                        const void* vp_vf, const float* q2, const float* k2, const float* attn_bias,
+                                        float* logits_out, float* stats_out, const float* mask, const float* rigids7, float* out,
+                                        void* out_xp, int out_xp_ksteps, int n_samples, int n_res, int n_heads, int c_hidden,
+                                        int n_qk_points, int n_v_points, int c_pair_z, float inf, float eps, void* stream) {
+    if (n_samples <= 0 || n_res <= 0) return 0;
+    if (c_hidden != 256 || n_qk_points != PQ || n_v_points != PV || c_pair_z != 32 || n_heads < 1 || n_res % 32 ||
+        out_xp_ksteps < 16 * n_heads || !out_xp)
+        return (int)hipErrorInvalidValue;
+    const int n_qb = (n_res + 63) / 64;
+    const long long blocks = (long long)n_samples * n_heads * n_qb;
+    static const int remap_env = getenv("S2S_IPA_XCD") ? atoi(getenv("S2S_IPA_XCD")) : 1;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ipa_attention_planes_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 0);
+        (void)e;
+        attr_set = true;
+    }
+    PlaneArgs a{(const bf16x8*)q_xp, (const bf16x8*)k_xp, (const bf16x8*)v_vf, (const bf16x8*)qp_xp, (const bf16x8*)kp_xp,
+                (const bf16x8*)vp_vf, q2, k2, attn_bias, logits_out, stats_out, mask, rigids7, out, (bf16x8*)out_xp, out_xp_ksteps,
+                n_samples, n_res, n_heads, inf, eps, (remap_env && blocks % 8 == 0 && n_qb > 1) ? 1 : 0};
+    hipLaunchKernelGGL(ipa_attention_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}

@@ -44,6 +44,7 @@ class InvariantPointAttention(nn.Module):
         self.softmax = nn.Softmax(dim=-1)
         self.softplus = nn.Softplus()
         self._cache = ParamCache()
+        self._packs = ParamCache()
 
     def _derived(self):
         def build():
@@ -59,6 +60,52 @@ class InvariantPointAttention(nn.Module):
 
         return self._cache.get([self.linear_b.weight, self.linear_b.bias, self.down_z.weight, self.down_z.bias,
                                 self.head_weights], build)
+
+    def node_packs(self):
+        """Packed bf16x3 weights of this block's node projections for s2s_node_linear (k and v rows of linear_kv separately:
+        the planes kernel consumes k as packed planes and v as A fragments)."""
+        def build():
+            H, C = self.no_heads, self.c_hidden
+            pk = TranslationIPA._pack
+            wkv = self.linear_kv.weight.view(H, 2, C, -1)
+            bkv = self.linear_kv.bias.view(H, 2, C)
+            d = {"q": pk(self.linear_q.weight, self.linear_q.bias), "kv": pk(self.linear_kv.weight, self.linear_kv.bias),
+                 "k": pk(wkv[:, 0].reshape(H * C, -1), bkv[:, 0].reshape(-1)),
+                 "v": pk(wkv[:, 1].reshape(H * C, -1), bkv[:, 1].reshape(-1)),
+                 "qp": pk(self.linear_q_points.weight, self.linear_q_points.bias),
+                 "kvp": pk(self.linear_kv_points.weight, self.linear_kv_points.bias),
+                 "out": pk(self.linear_out.weight, self.linear_out.bias, True)}
+            if d["v"]["tg"] != 8:
+                raise ops.HipLibraryError("s2s_node_linear_vfrag is instantiated for 8 tiles per column block")
+            return d
+
+        return self._packs.get([p for lin in (self.linear_q, self.linear_kv, self.linear_q_points, self.linear_kv_points,
+                                              self.linear_out) for p in (lin.weight, lin.bias)], build)
+
+    @staticmethod
+    def use_planes(n_res: int) -> bool:
+        """The pre-split (planes) attention kernel serves lengths that are multiples of its 32-residue tiles."""
+        return n_res % 32 == 0 and os.environ.get("S2S_IPA_PATH", "planes") != "f32"
+
+    def attention_planes(self, s_xp, B: int, N: int, r7, mask, pair_proj):
+        """Projections -> points -> attention core on pre-split operands.  s_xp: packed planes of s [B*N, c_s].
+        -> packed planes of linear_out's input [B*N, H*(c_hidden + 4 Pv + c_z/4)]"""
+        w, d, M, H = self.node_packs(), self._derived(), B * N, self.no_heads
+        lin = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], M, x["k"], x["n"], x["tg"], **kw)  # noqa: E731
+        _, q_xp = lin(w["q"], want_f32=False, want_xp=True)
+        _, k_xp = lin(w["k"], want_f32=False, want_xp=True)
+        v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, w["v"]["k"], w["v"]["n"], self.c_hidden // 32)
+        qp, _ = lin(w["qp"])
+        kvp, _ = lin(w["kvp"])
+        pts = ops.ipa_prep_points_planes(r7, qp, kvp, d["hw"], H, self.no_qk_points, self.no_v_points, self.c_hidden)
+        attn_bias, pair_z = pair_proj
+        feats, feats_xp = ops.ipa_attention_planes(q_xp, k_xp, v_vf, pts, attn_bias, pair_z, mask, r7, H, self.c_hidden,
+                                                   self.no_qk_points, self.no_v_points, self.c_z // 4, self.inf, self.eps,
+                                                   logits_inplace=True)
+        c0 = H * self.c_hidden
+        f2 = feats.view(M, -1)
+        ops.pack_planes(f2, col0=c0, n_cols=f2.shape[1] - c0, out=feats_xp, out_k=f2.shape[1], k0=c0)
+        return feats_xp
 
     def pair_proj_weights(self):
         """(packed [linear_b; down_z] weight, bias64, the same matrix as one bf16x3 weight stage): what a pair-stream
@@ -78,6 +125,13 @@ class InvariantPointAttention(nn.Module):
         d = self._derived()
         r7 = (_rigids7 if _rigids7 is not None else r.to_tensor_7()).type(torch.float32).contiguous()
         mask = mask.type(torch.float32).contiguous()
+        if self.use_planes(s.shape[1]) and self.c_hidden == 256:
+            B, N = s.shape[:2]
+            pp = _pair_proj if _pair_proj is not None else ops.pair_project(z.contiguous(), d["wp"], d["b64"])
+            feats_xp = self.attention_planes(ops.pack_planes(s.reshape(B * N, -1).float().contiguous()), B, N, r7, mask, pp)
+            w = self.node_packs()["out"]
+            out, _ = ops.node_linear(feats_xp, w["w"], w["b"], B * N, w["k"], w["n"], w["tg"])
+            return out.view(B, N, -1)
         q = self.linear_q(s)
         kv = self.linear_kv(s)
         q_pts, k_pts, v_pts = ops.ipa_prep_points(r7, self.linear_q_points(s).contiguous(),
@@ -165,9 +219,9 @@ class TranslationIPA(nn.Module):
             out = {}
             for b in range(self.num_blocks):
                 ipa = T[f"ipa_{b}"]
-                d = {"q": pk(ipa.linear_q), "kv": pk(ipa.linear_kv), "qp": pk(ipa.linear_q_points),
-                     "kvp": pk(ipa.linear_kv_points), "out": pk(ipa.linear_out, True), "skip": pk(T[f"skip_embed_{b}"]),
-                     "lin": pk(T[f"linear_{b}"], True), "bb": pk(T[f"bb_update_{b}"].linear)}
+                d = dict(ipa.node_packs())
+                d.update({"skip": pk(T[f"skip_embed_{b}"]), "lin": pk(T[f"linear_{b}"], True),
+                          "bb": pk(T[f"bb_update_{b}"].linear)})
                 nt = T[f"node_transition_{b}"]
                 d["nt1"], d["nt2"], d["nt3"] = pk(nt.linear_1, True), pk(nt.linear_2, True), pk(nt.linear_3, True)
                 d["layers"] = []
@@ -234,18 +288,21 @@ class TranslationIPA(nn.Module):
             w, ipa = W[b], T[f"ipa_{b}"]
             d = ipa._derived()
             # ---- InvariantPointAttention (:100-268): projections -> points -> attention core -> linear_out (+mask, +residual, LN)
-            q, _ = lin(s_xp, w["q"])
-            kv, _ = lin(s_xp, w["kv"])
-            qp, _ = lin(s_xp, w["qp"])
-            kvp, _ = lin(s_xp, w["kvp"])
-            q_pts, k_pts, v_pts = ops.ipa_prep_points(curr7, qp.view(B, N, -1), kvp.view(B, N, -1), ipa.no_heads, ipa.no_qk_points,
-                                                      ipa.no_v_points)
             attn_bias, pair_z = proj if proj is not None else ops.pair_project(edge_embed.contiguous(), d["wp"], d["b64"])
             proj = None
-            feats = ops.ipa_attention(q.view(B, N, ipa.no_heads, -1), kv.view(B, N, ipa.no_heads, -1), q_pts, k_pts, v_pts, attn_bias,
-                                      pair_z, node_mask, curr7, d["hw"], ipa.no_heads, ipa.c_hidden, ipa.no_qk_points, ipa.no_v_points,
-                                      ipa.c_z // 4, ipa.inf, ipa.eps, logits_inplace=True)
-            feats_xp = ops.pack_planes(feats.view(M, -1))
+            if ipa.use_planes(N):
+                feats_xp = ipa.attention_planes(s_xp, B, N, curr7, node_mask, (attn_bias, pair_z))
+            else:
+                q, _ = lin(s_xp, w["q"])
+                kv, _ = lin(s_xp, w["kv"])
+                qp, _ = lin(s_xp, w["qp"])
+                kvp, _ = lin(s_xp, w["kvp"])
+                q_pts, k_pts, v_pts = ops.ipa_prep_points(curr7, qp.view(B, N, -1), kvp.view(B, N, -1), ipa.no_heads,
+                                                          ipa.no_qk_points, ipa.no_v_points)
+                feats = ops.ipa_attention(q.view(B, N, ipa.no_heads, -1), kv.view(B, N, ipa.no_heads, -1), q_pts, k_pts, v_pts,
+                                          attn_bias, pair_z, node_mask, curr7, d["hw"], ipa.no_heads, ipa.c_hidden,
+                                          ipa.no_qk_points, ipa.no_v_points, ipa.c_z // 4, ipa.inf, ipa.eps, logits_inplace=True)
+                feats_xp = ops.pack_planes(feats.view(M, -1))
             ln = T[f"ipa_ln_{b}"]
             x_f32 = torch.empty(M, D, device=dev, dtype=torch.float32)     # [node_embed | skip_embed(init)] (:356)
             x_xp = ops.xp_alloc(M, D, dev)

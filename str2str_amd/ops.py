@@ -33,6 +33,8 @@ _SIGNATURES = {
     "s2s_ipa_prep_points": [_vp] * 6 + [_ll, _i, _i, _i, _i, _vp],
     "s2s_ipa_attention": [_vp] * 12 + [_i, _i, _i, _i, _i, _i, _i, _f, _f, _vp],
     "s2s_ipa_opair": [_vp] * 4 + [_i, _i, _i, _i, _i, _i, _vp],
+    "s2s_ipa_prep_points_planes": [_vp] * 9 + [_ll, _i, _i, _i, _i, _vp],
+    "s2s_ipa_attention_planes": [_vp] * 15 + [_i] * 8 + [_f, _f, _vp],
     "s2s_rigid_compose_update": [_vp] * 4 + [_ll, _vp],
     "s2s_rigid_scale_trans": [_vp, _vp, _ll, _f, _i, _vp],
     "s2s_set_backbone_tables": [_vp] * 4,
@@ -393,6 +395,62 @@ def ipa_attention(q, kv, q_pts, k_pts, v_pts, attn_bias, pair_z, mask, rigids7, 
 
     _check(_timed("s2s_ipa_attention", launch), "s2s_ipa_attention/s2s_ipa_opair")
     return out
+
+
+def ipa_prep_points_planes(rigids7, q_pts_lin, kv_pts_lin, head_w_scaled, n_heads=8, n_qk=8, n_v=12, c_hidden=256):
+    """Global-frame points of a block as MFMA fragments + the squared-norm terms of the logits (s2s_ipa_prep_points_planes).
+    B*N must be a multiple of 32.  -> (qp_xp, kp_xp, vp_vf, q2, k2)"""
+    lib = load_library()
+    _req(rigids7, name="rigids7"); _req(q_pts_lin, name="q_pts_lin"); _req(kv_pts_lin, name="kv_pts_lin")
+    _req(head_w_scaled, name="head_w")
+    M = rigids7.numel() // 7
+    if M % 32:
+        raise HipLibraryError("ipa_prep_points_planes: the number of frames must be a multiple of 32")
+    dev, rt = rigids7.device, M // 32
+    qp = torch.empty(rt * n_heads * 2 * 3 * 64 * 8, dtype=torch.int16, device=dev)
+    kp = torch.empty_like(qp)
+    vp = torch.empty(rt * n_heads * 4 * 3 * 64 * 8, dtype=torch.int16, device=dev)
+    q2 = torch.empty(rt, n_heads, 32, dtype=torch.float32, device=dev)
+    k2 = torch.empty_like(q2)
+    _check(lib.s2s_ipa_prep_points_planes(_p(rigids7), _p(q_pts_lin), _p(kv_pts_lin), _p(head_w_scaled), _p(qp), _p(kp), _p(vp),
+                                          _p(q2), _p(k2), M, n_heads, n_qk, n_v, c_hidden, _stream()),
+           "s2s_ipa_prep_points_planes")
+    return qp, kp, vp, q2, k2
+
+
+def ipa_attention_planes(q_xp, k_xp, v_vf, points, attn_bias, pair_z, mask, rigids7, n_heads=8, c_hidden=256, n_qk=8, n_v=12,
+                         c_pz=32, inf=1e5, eps=1e-8, logits_inplace=False):
+    """Attention core on pre-split operands + pair term (n_res % 32 == 0).  ``points`` = ipa_prep_points_planes(...).
+    -> (feats fp32 [B,N,feat] with the o_pt / o_pair columns valid, feats_xp packed planes with the o columns valid); the
+    caller packs columns H*c_hidden.. of ``feats`` into ``feats_xp`` (ops.pack_planes) to complete linear_out's input."""
+    lib = load_library()
+    B, N = mask.shape
+    qp, kp, vp, q2, k2 = points
+    for n, t in (("attn_bias", attn_bias), ("pair_z", pair_z), ("mask", mask), ("rigids7", rigids7), ("q2", q2), ("k2", k2)):
+        _req(t, name=n)
+    for n, t in (("q_xp", q_xp), ("k_xp", k_xp), ("v_vf", v_vf), ("qp_xp", qp), ("kp_xp", kp), ("vp_vf", vp)):
+        _req(t, torch.int16, n)
+    if N % 32:
+        raise HipLibraryError("ipa_attention_planes: n_res must be a multiple of 32 (use ipa_attention)")
+    if attn_bias.shape != (B, n_heads, N, N) or pair_z.shape != (B, N, N, c_pz):
+        raise HipLibraryError("ipa_attention_planes: attn_bias must be [B,H,N,N] and pair_z [B,N,N,c_pz]")
+    feat = n_heads * (c_hidden + 4 * n_v + c_pz)
+    out = torch.empty(B, N, feat, device=mask.device, dtype=torch.float32)
+    out_xp = xp_alloc(B * N, feat, mask.device)
+    logits = attn_bias if logits_inplace else torch.empty_like(attn_bias)
+    stats = torch.empty(B, n_heads, N, 2, device=mask.device, dtype=torch.float32)
+
+    def launch():
+        rc = lib.s2s_ipa_attention_planes(_p(q_xp), _p(k_xp), _p(v_vf), _p(qp), _p(kp), _p(vp), _p(q2), _p(k2), _p(attn_bias),
+                                          _p(logits), _p(stats), _p(mask), _p(rigids7), _p(out), _p(out_xp), feat // 16, B, N,
+                                          n_heads, c_hidden, n_qk, n_v, c_pz, inf, eps, _stream())
+        if rc:
+            return rc
+        return lib.s2s_ipa_opair(_p(logits), _p(stats), _p(pair_z), _p(out), B, N, n_heads, c_pz, feat,
+                                 n_heads * (c_hidden + 4 * n_v), _stream())
+
+    _check(_timed("s2s_ipa_attention", launch), "s2s_ipa_attention_planes/s2s_ipa_opair")
+    return out, out_xp
 
 
 def rigid_compose_update(rigids7, update6, mask, out=None):
