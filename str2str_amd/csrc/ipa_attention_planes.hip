@@ -201,14 +201,23 @@ constexpr int CT = 8;
 // halves meet through LDS (added in the same order by both, so both waves see bit-identical logits and maxima); in the second
 // phase half x owns the accumulators of output tiles 5x .. 5x+4 (80 AGPRs).
 //
-// Two phases per workgroup instead of an online softmax:
+// Two phases per work item (sample, head, 64 query residues) instead of an online softmax:
 //   phase 1, key tiles 0 .. NT-1:  S^T -> masked logits -> global (the [B,H,N,N] buffer s2s_ipa_opair reads anyway), row maximum
 //   phase 2, key tiles 0 .. NT-1:  logits back from L2, p = exp(s - max), row sum, O^T += V^T P^T
 // The accumulators are never rescaled (a VALU pass over 80 matrix-core registers per tile, which also dragged the whole
 // register allocation into accvgpr copies), the query fragments are dead in phase 2, and the K images (phase 1) and V images
-// (phase 2) do not coexist in LDS: one stream of 2 NT images through two 60 KiB buffers, image g in buffer g & 1, fetched by
-// LDS-DMA a whole step ahead, a few 1 KiB pieces at a time between MFMA groups (a burst of 15 stalls the issuing wave for
-// ~3 k cycles: the LDS-DMA path takes one piece per ~37 cycles per CU).  One workgroup barrier per key tile and phase.
+// (phase 2) do not coexist in LDS: one stream of images through two 60 KiB buffers, image g in buffer g & 1.  The logit
+// arithmetic of tile t-1 rides between the MFMAs of tile t, the exp / split of tile t+1 between those of tile t (one wave per
+// SIMD: nothing else fills the matrix pipe's shadow).
+//
+// Image g goes global -> VGPR (one step before it is written) -> LDS (one step before it is read), 14 / 15 pieces of 1 KiB per
+// wave, one "copy slot" (ds_write of a piece + re-load of its register) per few MFMAs.  LDS-DMA (global_load_lds_dwordx4) would
+// need no registers but costs the issuing wave ~150 cycles per piece on this part -- as much per key tile as the tile's MFMAs.
+// Every VMEM operation of the loops is UNCONDITIONAL (a piece that does not exist re-loads / re-stores piece 12): vmcnt
+// counts in order, and a load issued on one side of a branch makes hipcc fall back to s_waitcnt vmcnt(0) at every older use.
+//
+// Workgroups are persistent: the image stream runs across work items (images 2 NT, 2 NT + 1 of an item are images 0, 1 of the
+// next one), so only the first item of a workgroup pays the cold start (14 k cycles = 13 % of an item before this).
 struct PlaneStage {
     bf16x8 img[2][OT * 2 * 3 * 64];   // 2 x 60 KiB: K image [k-step 18][plane][lane] (54 KiB) or V image [tile 10][u][plane][lane]
     float4 xs[2][4][4][64];           // 32 KiB: partial S^T, [tile parity][wave][r / 4][lane]
@@ -228,101 +237,126 @@ __device__ __forceinline__ f32x4v load_l2(__amdgpu_buffer_rsrc_t rsrc, int byte_
 __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) {
     __shared__ __attribute__((aligned(16))) PlaneStage st;
     const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
-    const int wave = threadIdx.x >> 6, half = wave & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = wave & 1;   // scalar: addresses stay on the SALU
     const int N = a.N, H = a.H;
     const int NT = N / 32;                        // key tiles = row tiles per sample
     const int n_qb = (NT + 1) / 2;
-    int bid = blockIdx.x;
-    if (a.xcd_remap) bid = (bid & 7) * (int)(gridDim.x >> 3) + (bid >> 3);
-    const int qb = bid % n_qb; bid /= n_qb;
-    const int head = bid % H;
-    const int b = bid / H;
-    const int qt = qb * 2 + (wave >> 1);          // this pair's query tile within the sample
-    const bool wvalid = qt < NT;                  // odd tile count: the last workgroup has an idle pair (it still copies and syncs)
-    const int qtc = wvalid ? qt : NT - 1;
-    const long long rt_q = (long long)b * NT + qtc;
-    const int i = qtc * 32 + c;
-    const long long row_i = (long long)b * N + i;
+    const int n_items = a.B * H * n_qb;
+    const float c1 = sqrtf(1.0f / (3 * 256));
+    const float c2 = sqrtf(1.0f / 3);
 
-    // ---- the image stream: g < NT: K image of key tile g (48 pieces of k_xp + 6 of kp_xp); else V image of tile g - NT (48 + 12)
-    const long long k_tile_stride = (long long)16 * H * 3 * 64, p_tile_stride = (long long)H * 6 * 64;
-    const long long v_tile_stride = (long long)H * 48 * 64, vp_tile_stride = (long long)H * 12 * 64;
-    const bf16x8* k_src0 = a.k_xp + (((long long)b * NT * (16 * H) + 16 * head) * 3) * 64 + wave * 64 + lane;
-    const bf16x8* kp_src0 = a.kp_xp + (((long long)b * NT * H + head) * 6) * 64 + wave * 64 + lane;
-    const bf16x8* v_src0 = a.v_vf + (((long long)b * NT * H + head) * 48) * 64 + wave * 64 + lane;
-    const bf16x8* vp_src0 = a.vp_vf + (((long long)b * NT * H + head) * 12) * 64 + wave * 64 + lane;
-    // Image g goes global -> VGPR (stage_load, one step before it is written) -> LDS (stage_store, one step before it is read):
-    // 14 / 15 pieces of 1 KiB per wave.  (LDS-DMA -- global_load_lds_dwordx4 -- would need no registers, but costs the issuing wave
-    // ~150 cycles per piece on this part: 2.3 k cycles per key tile, as much as the tile's MFMAs; only image 0 uses it.)
-    bf16x8 stg[15];
+    struct Item { int b, head, qb; };
+    auto decode = [&](int item) -> Item {
+        // Workgroup w runs on XCD w % 8 (observed dispatch order; a speed assumption only) and gridDim.x is a multiple of 8: give
+        // every XCD (private L2) a contiguous range of logical ids, so the query blocks of one (sample, head) -- which read the
+        // same K / V images -- run side by side on one XCD.
+        int bid = item;
+        if (a.xcd_remap) bid = (bid & 7) * (n_items >> 3) + (bid >> 3);
+        Item it;
+        it.qb = bid % n_qb; bid /= n_qb;
+        it.head = bid % H;
+        it.b = bid / H;
+        return it;
+    };
+    int item = blockIdx.x;
+    Item cur = decode(item);
+    Item nxt = item + (int)gridDim.x < n_items ? decode(item + (int)gridDim.x) : cur;
+
+    // ---- the image stream of an item: g < NT: K image of key tile g (48 pieces of k_xp + 6 of kp_xp); g < 2 NT: V image of tile
+    // g - NT (48 of v_vf + 12 of vp_vf); g = 2 NT, 2 NT + 1: images 0, 1 of the next item.  Piece p of this wave: p < 12: piece
+    // wave + 4 p of the first array, else piece wave + 4 (p - 12) of the second.  All of this is wave-uniform (scalar).
+    auto piece_ok = [&](int gg, int p) -> bool {   // K images have 54 pieces: piece 13 only for waves 0, 1; no piece 14
+        return gg >= NT || p < 13 || (p == 13 && wave < 2);
+    };
     auto piece_src = [&](int g, int p) -> const bf16x8* {
-        if (g < NT) return p < 12 ? k_src0 + g * k_tile_stride + p * 256 : kp_src0 + g * p_tile_stride + (p - 12) * 256;
-        return p < 12 ? v_src0 + (g - NT) * v_tile_stride + p * 256 : vp_src0 + (g - NT) * vp_tile_stride + (p - 12) * 256;
+        const bool nx = g >= 2 * NT;
+        const int gg = nx ? g - 2 * NT : g;
+        const int bb = nx ? nxt.b : cur.b, hh = nx ? nxt.head : cur.head;
+        const bool isk = gg < NT;
+        const long long rt = (long long)bb * NT + (isk ? gg : gg - NT);
+        const int pm = piece_ok(gg, p) ? p : 12;
+        if (pm < 12)
+            return (isk ? a.k_xp + ((rt * (16 * H) + 16 * hh) * 3) * 64 : a.v_vf + ((rt * H + hh) * 48) * 64) + (wave + 4 * pm) * 64;
+        return (isk ? a.kp_xp + ((rt * H + hh) * 6) * 64 : a.vp_vf + ((rt * H + hh) * 12) * 64) + (wave + 4 * (pm - 12)) * 64;
     };
-    auto piece_ok = [&](int g, int p) -> bool {   // wave-uniform: K images have 54 pieces (piece 13 only for waves 0, 1; no piece 14)
-        return g < 2 * NT && (g >= NT || p < 13 || (p == 13 && wave < 2));
+    auto piece_dst = [&](int g, int p) -> bf16x8* {
+        const int gg = g >= 2 * NT ? g - 2 * NT : g;
+        const int pm = piece_ok(gg, p) ? p : 12;
+        return st.img[g & 1] + (pm < 12 ? wave + 4 * pm : 48 + wave + 4 * (pm - 12)) * 64;
     };
-    // Every VMEM operation of the steady-state loops is UNCONDITIONAL (a piece that does not exist is replaced by a re-load of
-    // piece 12 / the last image): vmcnt counts in order, and a load that is only issued on one side of a branch makes hipcc
-    // fall back to s_waitcnt vmcnt(0) at every use of an older one -- each copy slot then waited for the load issued in the
-    // previous slot.
-    auto stage_load = [&](int g, int p) {
-        const int gc = min(g, 2 * NT - 1);
-        stg[p] = *piece_src(gc, piece_ok(gc, p) ? p : 12);
-    };
-    // one copy slot: piece p of image g_store leaves its register for LDS, the same register is refilled with piece p of the image
-    // after it.  15 slots spread evenly over a step keep the texture path (64 B / clock / CU, shared by the four waves) from
-    // backing up into the issuing wave -- a burst of 8 loads per wave costs it ~1 k cycles.
-    auto stage_slot = [&](int g_store, int p) {
+    bf16x8 stg[15];
+    auto stage_load = [&](int g, int p) { stg[p] = piece_src(g, p)[lane]; };
+    // one copy slot: piece p of image g leaves its register for LDS, the register is refilled with piece p of image g + 1
+    auto stage_slot = [&](int g, int p) {
         if (p < 15) {
-            if (piece_ok(g_store, p)) st.img[g_store & 1][(p < 12 ? wave + 4 * p : 48 + wave + 4 * (p - 12)) * 64 + lane] = stg[p];
-            stage_load(g_store + 1, p);
+            piece_dst(g, p)[lane] = stg[p];
+            stage_load(g + 1, p);
         }
     };
-    auto small = [&](int t) {  // per-key scalars of key tile t (wave 3: k2, wave 2: mask)
+    auto small = [&](const Item& it, int t) {  // per-key scalars of key tile t (wave 3: k2, wave 2: mask)
         if (t < NT) {
-            if (wave == 3 && lane < 32) st.k2[t & 3][lane] = a.k2[(((long long)b * NT + t) * H + head) * 32 + lane];
-            if (wave == 2 && lane < 32) st.km[t & 3][lane] = a.mask[(long long)b * N + t * 32 + lane];
+            if (wave == 3 && lane < 32) st.k2[t & 3][lane] = a.k2[(((long long)it.b * NT + t) * H + it.head) * 32 + lane];
+            if (wave == 2 && lane < 32) st.km[t & 3][lane] = a.mask[(long long)it.b * N + t * 32 + lane];
         }
     };
 
+    // ---- cold start: image 0 straight into LDS, image 1 into the staging registers
     IPROBE(126);
 #pragma unroll
-    for (int p = 0; p < 14; ++p)   // image 0 straight into LDS
-        if (piece_ok(0, p))
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)piece_src(0, p), (lds_ptr_t)(st.img[0] + (p < 12 ? wave + 4 * p : 48 + wave + 4 * (p - 12)) * 64), 16, 0, 0);
+    for (int p = 0; p < 14; ++p)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(piece_src(0, p) + lane), (lds_ptr_t)piece_dst(0, p), 16, 0, 0);
 #pragma unroll
     for (int p = 0; p < 15; ++p) stage_load(1, p);
-    small(0);
-    small(1);
+    small(cur, 0);
+    small(cur, 1);
+    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // the LDS-DMA pieces (older than the 15 staged loads)
+    __syncthreads();
+    IPROBE(127);
 
-    // ---- this wave's query fragments (B operands): k-steps 9 half .. 9 half + 8 of [16 of q_xp | 2 of qp_xp], three planes each
+    // ---- per-item state of a lane; the query fragments, scalars and the first bias tile of the NEXT item are fetched before the
+    // epilogue of the current one (the registers are free there and the epilogue covers the HBM latency)
+    struct LaneItem { long long rt_q, row_i, brow0; int i; float q2, mask; };
+    auto lane_item = [&](const Item& it) -> LaneItem {
+        const int qt = it.qb * 2 + (wave >> 1);      // this pair's query tile within the sample
+        // odd tile count: the second pair of the last workgroup has no tile of its own; it repeats the first pair's (identical
+        // values to identical addresses) so that no memory operation is conditional
+        const int qtc = qt < NT ? qt : NT - 1;
+        LaneItem L;
+        L.rt_q = (long long)it.b * NT + qtc;
+        L.i = qtc * 32 + c;
+        L.row_i = (long long)it.b * N + L.i;
+        L.brow0 = (((long long)it.b * H + it.head) * N + L.i) * N + 4 * h;
+        L.q2 = a.q2[(L.rt_q * H + it.head) * 32 + c];
+        L.mask = a.mask[L.row_i];
+        return L;
+    };
     bf16x8 qf[KH][3];
-    {
-        const bf16x8* qs = a.q_xp + ((rt_q * (16 * H) + 16 * head) * 3) * 64 + lane;
-        const bf16x8* ps = a.qp_xp + ((rt_q * H + head) * 6) * 64 + lane;
+    float4 bias_cur[4], bias_prev[4];
+    // this wave's query fragments (B operands): k-steps 9 half .. 9 half + 8 of [16 of q_xp | 2 of qp_xp], three planes each
+    auto load_queries = [&](const Item& it, const LaneItem& L) {
+        const bf16x8* qs = a.q_xp + ((L.rt_q * (16 * H) + 16 * it.head) * 3) * 64;
+        const bf16x8* ps = a.qp_xp + ((L.rt_q * H + it.head) * 6) * 64;
 #pragma unroll
         for (int x = 0; x < KH; ++x) {
             const int ks = KH * half + x;   // wave-uniform
 #pragma unroll
-            for (int p = 0; p < 3; ++p) qf[x][p] = ks < 16 ? qs[(ks * 3 + p) * 64] : ps[((ks - 16) * 3 + p) * 64];
+            for (int p = 0; p < 3; ++p) qf[x][p] = (ks < 16 ? qs + (ks * 3 + p) * 64 : ps + ((ks - 16) * 3 + p) * 64)[lane];
         }
-    }
-    const float q2_i = a.q2[(rt_q * H + head) * 32 + c];
-    const float mask_i = a.mask[row_i];
-    const float c1 = sqrtf(1.0f / (3 * 256));
-    const float c2 = sqrtf(1.0f / 3);
-    const long long brow0 = (((long long)b * H + head) * N + i) * N + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias_cur[g] = *reinterpret_cast<const float4*>(a.attn_bias + L.brow0 + 8 * g);
+    };
+    LaneItem Lc = lane_item(cur);
+    load_queries(cur, Lc);
+    for (;;) {
+    const int b = cur.b, head = cur.head;
+    const long long rt_q = Lc.rt_q, row_i = Lc.row_i, brow0 = Lc.brow0;
+    const int i = Lc.i;
+    const float q2_i = Lc.q2, mask_i = Lc.mask;
     float m_run = -INFINITY;
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    IPROBE(127);
 
     // =========================================================== phase 1: logits and row maxima
     // Software pipeline: the logit arithmetic of tile t-1 (VALU + LDS reads) is issued between the MFMAs of tile t, one element
     // per two MFMAs, so it runs in the shadow of the matrix pipe (one wave per SIMD: nothing else would fill it).
-    float4 bias_cur[4], bias_prev[4];
     float tmax = -INFINITY;
     float4 k2g, kmg;   // per-key scalars of the 4 keys 8g + 4h .. of the element group being evaluated
     auto logit_elem = [&](int tp, int r, const float4 (&xa)[4], const float4 (&xb)[4], float (&sl)[16]) {
@@ -362,7 +396,7 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
             for (int g = 0; g < 4; ++g) bias_prev[g] = bias_cur[g];
         }
         // this lane's 16 bias values of tile t (keys 32 t + 8 g + 4 h + e): one 128 B line per (query, tile)
-        if constexpr (have) {
+        if constexpr (have && prev) {   // (tile 0's came with the query fragments)
 #pragma unroll
             for (int g = 0; g < 4; ++g) bias_cur[g] = *reinterpret_cast<const float4*>(a.attn_bias + brow0 + t * 32 + 8 * g);
         }
@@ -416,7 +450,7 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
         IPROBE(6 * t + 2);
         __syncthreads();                                   // partial sums and image t + 1 visible; buffer t & 1 released
         IPROBE(6 * t + 3);
-        if constexpr (have) small(t + 2);
+        if constexpr (have) small(cur, t + 2);
         IPROBE(6 * t + 4);
     };
     step1(0, std::true_type{}, std::false_type{});
@@ -459,7 +493,7 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
     auto step2 = [&](int t, auto more_c, auto first_c) {
         constexpr bool more = decltype(more_c)::value, first = decltype(first_c)::value;
         IPROBE(60 + 6 * t + 0);
-        if constexpr (!first) __syncthreads();             // V(t) visible; every wave is done with V(t - 1)
+        if constexpr (!first) __syncthreads();               // V(t) visible; every wave is done with V(t - 1)
         IPROBE(60 + 6 * t + 1);
         // ---------------- O^T += V^T . P^T for this wave's five output tiles
         const bf16x8* v_half = st.img[(NT + t) & 1] + OH * half * 384 + lane;
@@ -545,10 +579,13 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
     }
     IPROBE(121);
 
+    // ---------------- the next item's query side (unconditionally: after the last item nxt == cur and the values are unused)
+    const bool last = item + (int)gridDim.x >= n_items;
+    const LaneItem Ln = lane_item(nxt);
+    load_queries(nxt, Ln);
     // ---------------- epilogue
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (!wvalid) return;
     {
         // o: accumulator registers 8u .. 8u+7 of channel tile T = fragment k-step 16 head + 2T + u of this row tile (chain order)
         bf16x8* o = a.out_xp + ((rt_q * a.xp_ksteps + 16 * head) * 3) * 64 + lane;
@@ -604,6 +641,18 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
         st2[1] = l_tot;
     }
     IPROBE(122);
+
+    // ---------------- next item: its image 0 is already in buffer 0, its image 1 in the staging registers
+    item += (int)gridDim.x;
+    if (last) break;
+    cur = nxt;
+    Lc = Ln;
+    nxt = item + (int)gridDim.x < n_items ? decode(item + (int)gridDim.x) : cur;
+    __syncthreads();   // every wave is done with the last V image (buffer 1) before image 1 of the next item is written there
+    small(cur, 0);
+    small(cur, 1);
+    __syncthreads();
+    }
 }
 
 }  // namespace
@@ -635,18 +684,20 @@ extern "C" int s2s_ipa_attention_planes(const void* q_xp, const void* k_xp, cons
         out_xp_ksteps < 16 * n_heads || !out_xp)
         return (int)hipErrorInvalidValue;
     const int n_qb = (n_res + 63) / 64;
-    const long long blocks = (long long)n_samples * n_heads * n_qb;
+    const long long items = (long long)n_samples * n_heads * n_qb;
     static const int remap_env = getenv("S2S_IPA_XCD") ? atoi(getenv("S2S_IPA_XCD")) : 1;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ipa_attention_planes_kernel),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 0);
-        (void)e;
-        attr_set = true;
+    // persistent workgroups, one per CU (153 KiB of LDS each); a multiple of 8 so that workgroup w stays on XCD w % 8
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorUnknown;
+        n_cu = prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : prop.multiProcessorCount;
     }
+    const long long blocks = items < n_cu ? items : n_cu;
     PlaneArgs a{(const bf16x8*)q_xp, (const bf16x8*)k_xp, (const bf16x8*)v_vf, (const bf16x8*)qp_xp, (const bf16x8*)kp_xp,
                 (const bf16x8*)vp_vf, q2, k2, attn_bias, logits_out, stats_out, mask, rigids7, out, (bf16x8*)out_xp, out_xp_ksteps,
-                n_samples, n_res, n_heads, inf, eps, (remap_env && blocks % 8 == 0 && n_qb > 1) ? 1 : 0};
+                n_samples, n_res, n_heads, inf, eps, (remap_env && items % 8 == 0 && blocks % 8 == 0 && n_qb > 1) ? 1 : 0};
     hipLaunchKernelGGL(ipa_attention_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }
