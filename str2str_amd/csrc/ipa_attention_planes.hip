@@ -268,16 +268,39 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
     auto piece_ok = [&](int gg, int p) -> bool {   // K images have 54 pieces: piece 13 only for waves 0, 1; no piece 14
         return gg >= NT || p < 13 || (p == 13 && wave < 2);
     };
-    auto piece_src = [&](int g, int p) -> const bf16x8* {
+    // sources as buffer resources over the whole arrays (the host checks that they are < 4 GiB): the per-piece offset is a scalar,
+    // the per-lane part (lane * 16) one constant VGPR -- no vector address arithmetic in a copy slot
+    const long long n_rt = (long long)a.B * NT;
+    const __amdgpu_buffer_rsrc_t r_k = __builtin_amdgcn_make_buffer_rsrc((void*)a.k_xp, 0, (int)(n_rt * 16 * H * 3072), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_kp = __builtin_amdgcn_make_buffer_rsrc((void*)a.kp_xp, 0, (int)(n_rt * H * 6144), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_v = __builtin_amdgcn_make_buffer_rsrc((void*)a.v_vf, 0, (int)(n_rt * H * 49152), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_vp = __builtin_amdgcn_make_buffer_rsrc((void*)a.vp_vf, 0, (int)(n_rt * H * 12288), 0x00020000);
+    const int lane16 = lane * 16;
+    auto piece_load = [&](int g, int p) -> bf16x8 {
         const bool nx = g >= 2 * NT;
         const int gg = nx ? g - 2 * NT : g;
         const int bb = nx ? nxt.b : cur.b, hh = nx ? nxt.head : cur.head;
-        const bool isk = gg < NT;
-        const long long rt = (long long)bb * NT + (isk ? gg : gg - NT);
-        const int pm = piece_ok(gg, p) ? p : 12;
+        const bool isk = __builtin_amdgcn_readfirstlane(gg < NT);   // (everything here is wave-uniform; keep it on the SALU even
+        const unsigned rt = (unsigned)(bb * NT + (isk ? gg : gg - NT));      //  when the allocator parked an input in a VGPR)
+        const int pm = __builtin_amdgcn_readfirstlane(piece_ok(gg, p) ? p : 12);
+        u32x4 r;
+        if (p < 12) {
+            const unsigned off = (isk ? (rt * (16 * H) + 16 * hh) * 3 : (rt * H + hh) * 48) * 1024u + (wave + 4 * pm) * 1024u;
+            r = __builtin_amdgcn_raw_buffer_load_b128(isk ? r_k : r_v, lane16, __builtin_amdgcn_readfirstlane((int)off), 0);
+        } else {
+            const unsigned off = (rt * H + hh) * (isk ? 6u : 12u) * 1024u + (wave + 4 * (pm - 12)) * 1024u;
+            r = __builtin_amdgcn_raw_buffer_load_b128(isk ? r_kp : r_vp, lane16, __builtin_amdgcn_readfirstlane((int)off), 0);
+        }
+        return __builtin_bit_cast(bf16x8, r);
+    };
+    // cold start only (LDS-DMA wants a flat address)
+    auto piece_src = [&](int g, int p) -> const bf16x8* {
+        const bool isk = g < NT;
+        const long long rt = (long long)cur.b * NT + (isk ? g : g - NT);
+        const int pm = piece_ok(g, p) ? p : 12;
         if (pm < 12)
-            return (isk ? a.k_xp + ((rt * (16 * H) + 16 * hh) * 3) * 64 : a.v_vf + ((rt * H + hh) * 48) * 64) + (wave + 4 * pm) * 64;
-        return (isk ? a.kp_xp + ((rt * H + hh) * 6) * 64 : a.vp_vf + ((rt * H + hh) * 12) * 64) + (wave + 4 * (pm - 12)) * 64;
+            return (isk ? a.k_xp + ((rt * (16 * H) + 16 * cur.head) * 3) * 64 : a.v_vf + ((rt * H + cur.head) * 48) * 64) + (wave + 4 * pm) * 64;
+        return (isk ? a.kp_xp + ((rt * H + cur.head) * 6) * 64 : a.vp_vf + ((rt * H + cur.head) * 12) * 64) + (wave + 4 * (pm - 12)) * 64;
     };
     auto piece_dst = [&](int g, int p) -> bf16x8* {
         const int gg = g >= 2 * NT ? g - 2 * NT : g;
@@ -285,7 +308,7 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
         return st.img[g & 1] + (pm < 12 ? wave + 4 * pm : 48 + wave + 4 * (pm - 12)) * 64;
     };
     bf16x8 stg[15];
-    auto stage_load = [&](int g, int p) { stg[p] = piece_src(g, p)[lane]; };
+    auto stage_load = [&](int g, int p) { stg[p] = piece_load(g, p); };
     // one copy slot: piece p of image g leaves its register for LDS, the register is refilled with piece p of image g + 1
     auto stage_slot = [&](int g, int p) {
         if (p < 15) {
@@ -293,12 +316,16 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
             stage_load(g + 1, p);
         }
     };
-    auto small = [&](const Item& it, int t) {  // per-key scalars of key tile t (wave 3: k2, wave 2: mask)
-        if (t < NT) {
-            if (wave == 3 && lane < 32) st.k2[t & 3][lane] = a.k2[(((long long)it.b * NT + t) * H + it.head) * 32 + lane];
-            if (wave == 2 && lane < 32) st.km[t & 3][lane] = a.mask[(long long)it.b * N + t * 32 + lane];
-        }
+    // per-key scalars of a key tile (k2 and the key mask, 32 floats each) reach LDS slot t & 3 two steps before tile t's logits
+    // are formed; the value is loaded a step before it is stored (waves 2, 3 store; every wave loads: no conditional VMEM).
+    auto small_load = [&](const Item& it, int t) -> float {
+        const int tc = min(t, NT - 1);
+        return (wave & 1) ? a.k2[(((long long)it.b * NT + tc) * H + it.head) * 32 + c] : a.mask[(long long)it.b * N + tc * 32 + c];
     };
+    auto small_store = [&](int t, float v) {
+        if (wave >= 2 && lane < 32 && t < NT) ((wave & 1) ? st.k2 : st.km)[t & 3][lane] = v;
+    };
+    float sm_val;
 
     // ---- cold start: image 0 straight into LDS, image 1 into the staging registers
     IPROBE(126);
@@ -307,9 +334,10 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
         __builtin_amdgcn_global_load_lds((gbl_ptr_t)(piece_src(0, p) + lane), (lds_ptr_t)piece_dst(0, p), 16, 0, 0);
 #pragma unroll
     for (int p = 0; p < 15; ++p) stage_load(1, p);
-    small(cur, 0);
-    small(cur, 1);
-    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");   // the LDS-DMA pieces (older than the 15 staged loads)
+    small_store(0, small_load(cur, 0));
+    small_store(1, small_load(cur, 1));
+    sm_val = small_load(cur, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     IPROBE(127);
 
@@ -347,7 +375,15 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
     };
     LaneItem Lc = lane_item(cur);
     load_queries(cur, Lc);
+    float sm_n0, sm_n1, sm_n2;   // the next item's per-key scalars of tiles 0 .. 2
+#ifdef S2S_IPA_PROBE
+    int probe_item = 0;
+#endif
     for (;;) {
+#ifdef S2S_IPA_PROBE
+    if (probe_item < 16) IPROBE(100 + probe_item);
+    ++probe_item;
+#endif
     const int b = cur.b, head = cur.head;
     const long long rt_q = Lc.rt_q, row_i = Lc.row_i, brow0 = Lc.brow0;
     const int i = Lc.i;
@@ -375,7 +411,7 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
         x = x + a.inf * (mask_i * kmv - 1.0f);
         sl[r] = x;
         tmax = fmaxf(tmax, x);
-        if (r == 15) {   // both waves of a pair hold the same 16 logits: half 0 stores keys 8g + .. of g = 0, 1, half 1 those of g = 2, 3
+        if (r == 15) {
 #pragma unroll
             for (int k = 0; k < 2; ++k)
                 *reinterpret_cast<float4*>(a.logits + brow0 + tp * 32 + 16 * half + 8 * k) =
@@ -450,7 +486,7 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
         IPROBE(6 * t + 2);
         __syncthreads();                                   // partial sums and image t + 1 visible; buffer t & 1 released
         IPROBE(6 * t + 3);
-        if constexpr (have) small(cur, t + 2);
+        if constexpr (have) { small_store(t + 2, sm_val); sm_val = small_load(cur, t + 3); }
         IPROBE(6 * t + 4);
     };
     step1(0, std::true_type{}, std::false_type{});
@@ -478,18 +514,15 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
     bf16x8 pc[2][3], pn[2][3];   // P^T planes of the current / next tile: [k-step u][plane]
     float pe[16];
     auto p_elem = [&](int r) {   // probability of element r of the tile whose logits sit in lg
-        const int g = r >> 2, e = r & 3;
-        pe[r] = exp_neg(lg[g][e] - m_run);
+        pe[r] = exp_neg(lg[r >> 2][r & 3] - m_run);
         l_run += pe[r];
     };
 #pragma unroll
     for (int r = 0; r < 16; ++r) p_elem(r);
     split8(pe, pc[0][0], pc[0][1], pc[0][2]);
     split8(pe + 8, pc[1][0], pc[1][1], pc[1][2]);
-    if (NT > 1) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) lg[g] = load_l2(lrsrc, loff0 + 128 + 32 * g);
-    }
+    for (int g = 0; g < 4; ++g) lg[g] = load_l2(lrsrc, loff0 + min(1, NT - 1) * 128 + 32 * g);
     auto step2 = [&](int t, auto more_c, auto first_c) {
         constexpr bool more = decltype(more_c)::value, first = decltype(first_c)::value;
         IPROBE(60 + 6 * t + 0);
@@ -504,60 +537,51 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
 #pragma unroll
                 for (int p = 0; p < 3; ++p) d[u][p] = pa[(u * 3 + p) * 64];
         };
-        bf16x8 vf[5][2][3];   // all five tiles' fragments: tile x + 2 is fetched while tiles x, x + 1 multiply
+        bf16x8 vf[5][2][3];   // all five tiles' fragments
         load_v(0, vf[0]);
         load_v(1, vf[1]);
         __builtin_amdgcn_sched_barrier(0);
+        load_v(2, vf[2]);
+        load_v(3, vf[3]);
+        load_v(4, vf[4]);
+        __builtin_amdgcn_sched_barrier(0);
+        // product order of a k-step u (small terms first): (V plane, P plane) = (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        {   // tiles 0, 1: two independent accumulators back to back; probabilities 0 .. 11 of the next tile and copy slots 0 .. 5 ride here
+            f32x16 oa = O[0], ob = O[1];
 #pragma unroll
-        for (int xp = 0; xp < 2; ++xp) {   // tiles (0, 1), (2, 3): two independent accumulators back to back
-            if (xp == 0) { load_v(2, vf[2]); load_v(3, vf[3]); } else { load_v(4, vf[4]); }
-            __builtin_amdgcn_sched_barrier(0);
-            const bf16x8 (&va)[2][3] = vf[2 * xp], (&vb)[2][3] = vf[2 * xp + 1];
-            f32x16 oa = O[2 * xp], ob = O[2 * xp + 1];
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int q4 = 4 * (2 * xp + u);   // elements q4 .. q4+3 of the next tile's probabilities ride here
-                oa = mfma_b16(va[u][2], pc[u][0], oa); ob = mfma_b16(vb[u][2], pc[u][0], ob);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (more) p_elem(q4);
-                if constexpr (!first) stage_slot(NT + t + 1, 3 * (2 * xp + u) + 0);
-                __builtin_amdgcn_sched_barrier(0);
-                oa = mfma_b16(va[u][0], pc[u][2], oa); ob = mfma_b16(vb[u][0], pc[u][2], ob);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (more) p_elem(q4 + 1);
-                if constexpr (!first) stage_slot(NT + t + 1, 3 * (2 * xp + u) + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                oa = mfma_b16(va[u][1], pc[u][1], oa); ob = mfma_b16(vb[u][1], pc[u][1], ob);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (more) p_elem(q4 + 2);
-                if constexpr (!first) stage_slot(NT + t + 1, 3 * (2 * xp + u) + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                oa = mfma_b16(va[u][1], pc[u][0], oa); ob = mfma_b16(vb[u][1], pc[u][0], ob);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (more) p_elem(q4 + 3);
-                __builtin_amdgcn_sched_barrier(0);
-                oa = mfma_b16(va[u][0], pc[u][1], oa); ob = mfma_b16(vb[u][0], pc[u][1], ob);
-                oa = mfma_b16(va[u][0], pc[u][0], oa); ob = mfma_b16(vb[u][0], pc[u][0], ob);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            O[2 * xp] = oa; O[2 * xp + 1] = ob;
-            __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < 6; ++k) {
+                    oa = mfma_b16(vf[0][u][PA[k]], pc[u][PB[k]], oa); ob = mfma_b16(vf[1][u][PA[k]], pc[u][PB[k]], ob);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (more) p_elem(6 * u + k);
+                    if constexpr (!first) { if (k & 1) stage_slot(NT + t + 1, 3 * u + (k >> 1)); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            O[0] = oa; O[1] = ob;
         }
-        {
-            // the fifth tile is one dependent chain (an MFMA every ~64 cycles): the split of the next tile's probabilities fills it
-            f32x16 o = O[4];
-            const bf16x8 (&va)[2][3] = vf[4];
+        {   // tiles 2, 3, 4: three accumulators; probabilities 12 .. 15, the split of all 16 and copy slots 6 .. 14
+            f32x16 oa = O[2], ob = O[3], oc = O[4];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                o = mfma_b16(va[u][2], pc[u][0], o); o = mfma_b16(va[u][0], pc[u][2], o); o = mfma_b16(va[u][1], pc[u][1], o);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (more) split8(pe + 8 * u, pn[u][0], pn[u][1], pn[u][2]);
-                if constexpr (!first) { stage_slot(NT + t + 1, 12 + 2 * u); stage_slot(NT + t + 1, 13 + 2 * u); }
-                __builtin_amdgcn_sched_barrier(0);
-                o = mfma_b16(va[u][1], pc[u][0], o); o = mfma_b16(va[u][0], pc[u][1], o); o = mfma_b16(va[u][0], pc[u][0], o);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            O[4] = o;
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    oa = mfma_b16(vf[2][u][PA[k]], pc[u][PB[k]], oa); ob = mfma_b16(vf[3][u][PA[k]], pc[u][PB[k]], ob);
+                    oc = mfma_b16(vf[4][u][PA[k]], pc[u][PB[k]], oc);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (more) {
+                        if (u == 0 && k < 4) p_elem(12 + k);
+                        if (u == 0 && k == 4) split8(pe, pn[0][0], pn[0][1], pn[0][2]);
+                        if (u == 1 && k == 0) split8(pe + 8, pn[1][0], pn[1][1], pn[1][2]);
+                    }
+                    if constexpr (!first) {
+                        if (u == 0 && k < 4) stage_slot(NT + t + 1, 6 + k);
+                        if (u == 1 && k >= 1) stage_slot(NT + t + 1, 9 + k);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            O[2] = oa; O[3] = ob; O[4] = oc;
         }
         if constexpr (more) {
 #pragma unroll
@@ -583,6 +607,7 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
     const bool last = item + (int)gridDim.x >= n_items;
     const LaneItem Ln = lane_item(nxt);
     load_queries(nxt, Ln);
+    sm_n0 = small_load(nxt, 0); sm_n1 = small_load(nxt, 1); sm_n2 = small_load(nxt, 2);
     // ---------------- epilogue
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
@@ -649,8 +674,9 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
     Lc = Ln;
     nxt = item + (int)gridDim.x < n_items ? decode(item + (int)gridDim.x) : cur;
     __syncthreads();   // every wave is done with the last V image (buffer 1) before image 1 of the next item is written there
-    small(cur, 0);
-    small(cur, 1);
+    small_store(0, sm_n0);
+    small_store(1, sm_n1);
+    sm_val = sm_n2;
     __syncthreads();
     }
 }
@@ -685,6 +711,8 @@ extern "C" int s2s_ipa_attention_planes(const void* q_xp, const void* k_xp, cons
         return (int)hipErrorInvalidValue;
     const int n_qb = (n_res + 63) / 64;
     const long long items = (long long)n_samples * n_heads * n_qb;
+    // the kernel addresses its fragment arrays through 32-bit buffer offsets
+    if ((long long)n_samples * (n_res / 32) * 16 * n_heads * 3072 >= (1ll << 32)) return (int)hipErrorInvalidValue;
     static const int remap_env = getenv("S2S_IPA_XCD") ? atoi(getenv("S2S_IPA_XCD")) : 1;
     // persistent workgroups, one per CU (153 KiB of LDS each); a multiple of 8 so that workgroup w stays on XCD w % 8
     static int n_cu = 0;

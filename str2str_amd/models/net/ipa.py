@@ -83,9 +83,10 @@ class InvariantPointAttention(nn.Module):
                                               self.linear_out) for p in (lin.weight, lin.bias)], build)
 
     @staticmethod
-    def use_planes(n_res: int) -> bool:
-        """The pre-split (planes) attention kernel serves lengths that are multiples of its 32-residue tiles."""
-        return n_res % 32 == 0 and os.environ.get("S2S_IPA_PATH", "planes") != "f32"
+    def use_planes(n_res: int, n_rows: int = 0) -> bool:
+        """The pre-split (planes) attention kernel serves lengths that are multiples of its 32-residue tiles (and fragment
+        arrays below 4 GiB: it addresses them through 32-bit buffer offsets)."""
+        return n_res % 32 == 0 and n_rows * 12288 < (1 << 32) and os.environ.get("S2S_IPA_PATH", "planes") != "f32"
 
     def attention_planes(self, s_xp, B: int, N: int, r7, mask, pair_proj):
         """Projections -> points -> attention core on pre-split operands.  s_xp: packed planes of s [B*N, c_s].
@@ -125,7 +126,7 @@ class InvariantPointAttention(nn.Module):
         d = self._derived()
         r7 = (_rigids7 if _rigids7 is not None else r.to_tensor_7()).type(torch.float32).contiguous()
         mask = mask.type(torch.float32).contiguous()
-        if self.use_planes(s.shape[1]) and self.c_hidden == 256:
+        if self.use_planes(s.shape[1], s.shape[0] * s.shape[1]) and self.c_hidden == 256:
             B, N = s.shape[:2]
             pp = _pair_proj if _pair_proj is not None else ops.pair_project(z.contiguous(), d["wp"], d["b64"])
             feats_xp = self.attention_planes(ops.pack_planes(s.reshape(B * N, -1).float().contiguous()), B, N, r7, mask, pp)
@@ -290,7 +291,7 @@ class TranslationIPA(nn.Module):
             # ---- InvariantPointAttention (:100-268): projections -> points -> attention core -> linear_out (+mask, +residual, LN)
             attn_bias, pair_z = proj if proj is not None else ops.pair_project(edge_embed.contiguous(), d["wp"], d["b64"])
             proj = None
-            if ipa.use_planes(N):
+            if ipa.use_planes(N, M):
                 feats_xp = ipa.attention_planes(s_xp, B, N, curr7, node_mask, (attn_bias, pair_z))
             else:
                 q, _ = lin(s_xp, w["q"])

@@ -36,3 +36,5 @@ for k in range(NT):
     print(f"tile {k}: " + "  |  ".join("%5d %5d" % (t[w, o + 1] - t[w, o], t[w, o + 3] - t[w, o + 1]) for w in range(4)))
 print("phase 1 total:", [int(t[w, 120] - t[w, 127]) for w in range(4)], " phase 2 total:", [int(t[w, 121] - t[w, 120]) for w in range(4)],
       " epilogue:", [int(t[w, 122] - t[w, 121]) for w in range(4)])
+print("item start to item start:", [int(t[0, 101 + k] - t[0, 100 + k]) for k in range(15)])
+print("(kernel start to first item:", int(t[0, 100] - t[0, 126]), ")")
