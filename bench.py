@@ -290,7 +290,7 @@ def main():
                 "algorithmic_flops_per_launch": alg, "executed_mfma_flops_per_launch": executed,
                 "fp32_equivalent_tflops": alg / (et_ms * 1e-3) / 1e12,
                 "fp32_equivalent_vs_fp32_mfma_peak": alg / (et_ms * 1e-3) / MFMA_FP32_PEAK}
-            line["ipa_kernel"] = {"bound": "hbm", "kernel": "s2s_ipa_attention (+ s2s_ipa_opair)", "mean_launch_ms": ipa_ms,
+            line["ipa_kernel"] = {"bound": "hbm", "kernel": "s2s_ipa_attention_planes (n_res % 32 == 0; else s2s_ipa_attention) + s2s_ipa_opair", "mean_launch_ms": ipa_ms,
                                   "launches_timed": ipa_n, "achieved": ipa_bytes / (ipa_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                                   "unit": "GB/s", "frac": ipa_bytes / (ipa_ms * 1e-3) / HBM_PEAK,
                                   "algorithmic_bytes_per_launch": ipa_bytes}

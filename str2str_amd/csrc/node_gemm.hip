@@ -183,6 +183,29 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     // k-steps in pairs (buffer parity is static: KS is even); loads past the end of the stream are clamped and never consumed
+#ifndef S2S_NODE_XDEPTH
+#define S2S_NODE_XDEPTH 1
+#endif
+#if S2S_NODE_XDEPTH == 2
+    // activation fragments fetched TWO k-steps ahead (they come from HBM / a remote L2, ~2 us away; a k-step is ~0.9 us)
+    bf16x8 xc[3];
+    x_load(1, xb);
+    for (int ks = 0; ks < KS; ks += 2) {
+        x_load(ks + 2, xc);
+        compute(0, xa);
+        w_store(1);
+        w_load(ks + 2);
+        __syncthreads();
+        x_load(ks + 3, xa);
+        compute(1, xb);
+        w_store(0);
+        w_load(ks + 3);
+        __syncthreads();
+        // rotate: (xa, xb) <- (k-step ks + 2, ks + 3)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { const bf16x8 t = xa[p]; xa[p] = xc[p]; xb[p] = t; }
+    }
+#else
     for (int ks = 0; ks < KS; ks += 2) {
         x_load(ks + 1, xb);
         compute(0, xa);
@@ -195,6 +218,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
         w_load(ks + 3);
         __syncthreads();
     }
+#endif
 
     const int col_base = cb * TG * 32;
     if constexpr (VF) {
