@@ -10,24 +10,13 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB = os.path.join(ROOT, "str2str_amd", "csrc", "build", "probe", "libstr2str_hip_probe.so")
+LIB = os.path.join(ROOT, "str2str_amd", "csrc", "build", "lib_etprobe.so")
 
 if sys.argv[1] == "build":
     block = sys.argv[2] if len(sys.argv) > 2 else "3000"
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    src = [os.path.join(ROOT, "str2str_amd", "csrc", f) for f in
-           ("abi.hip", "rigid_kernels.hip", "se3_step.hip", "pair_mlp.hip", "pair_mlp_bf16.hip", "ipa_attention.hip")]
-    objs = []
-    for f in src:
-        o = os.path.join(os.path.dirname(LIB), os.path.basename(f).replace(".hip", ".o"))
-        extra = ["-DS2S_ET_PROBE=" + block] if f.endswith("pair_mlp_bf16.hip") else []
-        if f.endswith("pair_mlp_bf16.hip") or not os.path.exists(o):
-            subprocess.run(["hipcc", "-x", "hip", "-c", f, "-o", o, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
-                            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "str2str_amd", "csrc"),
-                            "-mllvm", "-pragma-unroll-threshold=10000000"] + extra + os.environ.get("PROBE_EXTRA", "").split(), check=True)
-        objs.append(o)
-    subprocess.run(["hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs, check=True)
-    print(LIB)
+    env = dict(os.environ, UNIT="pair_mlp_bf16")
+    subprocess.run([os.path.join(ROOT, "tools", "build_variant.sh"), "etprobe", "-DS2S_ET_PROBE=" + block] + sys.argv[3:], check=True,
+                   env=env, cwd=ROOT)
     sys.exit(0)
 
 os.environ["STR2STR_HIP_LIB"] = LIB
