@@ -393,6 +393,11 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
     // =========================================================== phase 1: logits and row maxima
     // Software pipeline: the logit arithmetic of tile t-1 (VALU + LDS reads) is issued between the MFMAs of tile t, one element
     // per two MFMAs, so it runs in the shadow of the matrix pipe (one wave per SIMD: nothing else would fill it).
+    // this (sample, head)'s [N, N] logit slab as a buffer resource: 32-bit offsets, cache policy on the instruction
+    const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.logits + ((long long)b * H + head) * N * N), 0,
+                                                                           N * N * 4, 0x00020000);
+    const int loff0 = (i * N + 4 * h) * 4;
+    f32x4v lg[4], lg1[4];   // logits of the tile whose probabilities are formed next (and of tile 1 across the phase change)
     float tmax = -INFINITY;
     float4 k2g, kmg;   // per-key scalars of the 4 keys 8g + 4h .. of the element group being evaluated
     auto logit_elem = [&](int tp, int r, const float4 (&xa)[4], const float4 (&xb)[4], float (&sl)[16]) {
@@ -419,8 +424,8 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
                                 half ? sl[11 + 4 * k] : sl[4 * k + 3]);
         }
     };
-    auto step1 = [&](int t, auto have_c, auto prev_c) {
-        constexpr bool have = decltype(have_c)::value, prev = decltype(prev_c)::value;
+    auto step1 = [&](int t, auto have_c, auto prev_c, auto flush_c) {
+        constexpr bool have = decltype(have_c)::value, prev = decltype(prev_c)::value, flush = decltype(flush_c)::value;
         const int par = t & 1;
         IPROBE(6 * t + 0);
         // partial sums of tile t-1 (both halves, added in the order half 0 + half 1 by both waves)
@@ -459,12 +464,10 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
                 const bf16x8 (&q)[3] = qf[x];
                 // copy slots 2x, 2x+1: image t + 1 -> LDS (its buffer was released by the barrier of tile t - 1), image t + 2 -> registers
                 S0 = mfma_b16(k[2], q[0], S0); S1 = mfma_b16(k[0], q[2], S1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (prev && 2 * x < 16) logit_elem(t - 1, 2 * x, xa, xb, sl);
+                if (prev && 2 * x < 16) logit_elem(t - 1, 2 * x, xa, xb, sl);   // (same scheduling region as the MFMA pair)
                 stage_slot(t + 1, 2 * x);
                 __builtin_amdgcn_sched_barrier(0);
                 S0 = mfma_b16(k[1], q[1], S0); S1 = mfma_b16(k[1], q[0], S1);
-                __builtin_amdgcn_sched_barrier(0);
                 if (prev && 2 * x + 1 < 16) logit_elem(t - 1, 2 * x + 1, xa, xb, sl);
                 stage_slot(t + 1, 2 * x + 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -477,21 +480,31 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
                 st.xs[par][wave][g][lane] = make_float4(S0[4 * g] + S1[4 * g], S0[4 * g + 1] + S1[4 * g + 1],
                                                         S0[4 * g + 2] + S1[4 * g + 2], S0[4 * g + 3] + S1[4 * g + 3]);
         } else {
+            // The logits of tiles 0 and 1 were stored in steps 1 and 2 and flushed (vmcnt(0) of every wave + barrier) by the last
+            // regular step when NT >= 3: fetch them now, under this step's work -- read after the phase change they cost two
+            // serial HBM latencies (~10 k cycles per item).
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                lg[g] = load_l2(lrsrc, loff0 + 32 * g);
+                lg1[g] = load_l2(lrsrc, loff0 + min(1, NT - 1) * 128 + 32 * g);
+            }
 #pragma unroll
             for (int p = 0; p < 15; ++p) stage_slot(t + 1, p);
 #pragma unroll
             for (int r = 0; r < 16; ++r) logit_elem(t - 1, r, xa, xb, sl);   // the last tile's logits: nothing left to hide them under
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and they must have reached L2 before phase 2 reads them back
         }
+        if constexpr (flush) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // logits stored so far have reached L2
         IPROBE(6 * t + 2);
         __syncthreads();                                   // partial sums and image t + 1 visible; buffer t & 1 released
         IPROBE(6 * t + 3);
         if constexpr (have) { small_store(t + 2, sm_val); sm_val = small_load(cur, t + 3); }
         IPROBE(6 * t + 4);
     };
-    step1(0, std::true_type{}, std::false_type{});
-    for (int t = 1; t < NT; ++t) step1(t, std::true_type{}, std::true_type{});
-    step1(NT, std::false_type{}, std::true_type{});
+    step1(0, std::true_type{}, std::false_type{}, std::false_type{});
+    for (int t = 1; t + 1 < NT; ++t) step1(t, std::true_type{}, std::true_type{}, std::false_type{});
+    if (NT > 1) step1(NT - 1, std::true_type{}, std::true_type{}, std::true_type{});
+    step1(NT, std::false_type{}, std::true_type{}, std::false_type{});
     m_run = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     // images NT (= V(0)) and NT + 1 are in flight; the last tile's logits have reached L2 (vmcnt(0) + barrier above)
     IPROBE(120);
@@ -504,25 +517,31 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
     float l_run = 0.f;
-    // this (sample, head)'s [N, N] logit slab as a buffer resource: 32-bit offsets, cache policy on the instruction
-    const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.logits + ((long long)b * H + head) * N * N), 0,
-                                                                           N * N * 4, 0x00020000);
-    const int loff0 = (i * N + 4 * h) * 4;
-    f32x4v lg[4];
+    if (NT < 3) {   // too few steps for the early fetch to be ordered behind the stores: read tiles 0, 1 again
 #pragma unroll
-    for (int g = 0; g < 4; ++g) lg[g] = load_l2(lrsrc, loff0 + 32 * g);
+        for (int g = 0; g < 4; ++g) {
+            lg[g] = load_l2(lrsrc, loff0 + 32 * g);
+            lg1[g] = load_l2(lrsrc, loff0 + min(1, NT - 1) * 128 + 32 * g);
+        }
+    }
     bf16x8 pc[2][3], pn[2][3];   // P^T planes of the current / next tile: [k-step u][plane]
     float pe[16];
-    auto p_elem = [&](int r) {   // probability of element r of the tile whose logits sit in lg
-        pe[r] = exp_neg(lg[r >> 2][r & 3] - m_run);
+    auto p_elem = [&](int r, bool pin) {   // probability of element r of the tile whose logits sit in lg
+        float x = lg[r >> 2][r & 3];
+        // pin: the value becomes known HERE (an opaque asm with a memory clobber, sandwiched between this slot's LDS stores), so the
+        // exp / split arithmetic stays between the MFMAs it is written next to -- hipcc otherwise collects it at the tail of the
+        // previous step, in front of the barrier, where nothing hides it (~1 k cycles per step)
+        if (pin) asm volatile("" : "+v"(x) :: "memory");
+        pe[r] = exp_neg(x - m_run);
         l_run += pe[r];
+        if (pin) asm volatile("" : "+v"(pe[r]), "+v"(l_run) :: "memory");   // ... and is complete here (no sinking to the loop tail)
     };
 #pragma unroll
-    for (int r = 0; r < 16; ++r) p_elem(r);
+    for (int r = 0; r < 16; ++r) p_elem(r, false);
     split8(pe, pc[0][0], pc[0][1], pc[0][2]);
     split8(pe + 8, pc[1][0], pc[1][1], pc[1][2]);
 #pragma unroll
-    for (int g = 0; g < 4; ++g) lg[g] = load_l2(lrsrc, loff0 + min(1, NT - 1) * 128 + 32 * g);
+    for (int g = 0; g < 4; ++g) lg[g] = lg1[g];
     auto step2 = [&](int t, auto more_c, auto first_c) {
         constexpr bool more = decltype(more_c)::value, first = decltype(first_c)::value;
         IPROBE(60 + 6 * t + 0);
@@ -538,30 +557,57 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
                 for (int p = 0; p < 3; ++p) d[u][p] = pa[(u * 3 + p) * 64];
         };
         bf16x8 vf[5][2][3];   // all five tiles' fragments
+        // (the fragments of tiles 2 .. 4 are requested between the first MFMA groups: 30 KiB per wave up front left the
+        // matrix pipe idle for ~1 k cycles at the start of every step while the four waves' reads drained through the LDS)
         load_v(0, vf[0]);
         load_v(1, vf[1]);
         __builtin_amdgcn_sched_barrier(0);
-        load_v(2, vf[2]);
-        load_v(3, vf[3]);
-        load_v(4, vf[4]);
-        __builtin_amdgcn_sched_barrier(0);
         // product order of a k-step u (small terms first): (V plane, P plane) = (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-        {   // tiles 0, 1: two independent accumulators back to back; probabilities 0 .. 11 of the next tile and copy slots 0 .. 5 ride here
+        // The VALU work for the NEXT tile's probabilities is spread over this tile's 24 MFMA groups (gi = 0 .. 11: tiles 0, 1 on two
+        // accumulators; gi = 12 .. 23: tiles 2, 3, 4 on three): exp of element gi in groups 0 .. 15, the 3-way split of element
+        // pair j in group 9 + 2j -- ~10-20 VALU instructions per group, what two or three 32-cycle MFMAs cover.  (In two blocks of
+        // ~75 instructions they left the matrix pipe idle for ~1 k cycles per step.)  Copy slots: groups 0 .. 14; the logits of
+        // tile t + 2 are requested in group 16, when lg is dead and half a step before the loop head needs them (hipcc copies them
+        // there behind an s_waitcnt vmcnt(0), so every load of a step is issued in its first two thirds).
+        auto split_pair = [&](int j) {   // elements 2j, 2j+1 of pe -> element pair (j & 3) of the planes of k-step j >> 2
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float v = pe[2 * j + q];
+                const __bf16 a_ = (__bf16)v;
+                const float r1 = v - (float)a_;
+                const __bf16 b_ = (__bf16)r1;
+                pn[j >> 2][0][2 * (j & 3) + q] = a_; pn[j >> 2][1][2 * (j & 3) + q] = b_; pn[j >> 2][2][2 * (j & 3) + q] = (__bf16)(r1 - (float)b_);
+            }
+            asm volatile("" : "+v"(pn[j >> 2][0]), "+v"(pn[j >> 2][1]), "+v"(pn[j >> 2][2]) :: "memory");   // done here, not at the loop tail
+        };
+        auto ride = [&](int gi) {
+            if constexpr (more) {
+                if (gi < 16) p_elem(gi, true);
+                if (gi >= 9 && (gi & 1)) split_pair((gi - 9) >> 1);
+                if (gi == 16) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) lg[g] = load_l2(lrsrc, loff0 + min(t + 2, NT - 1) * 128 + 32 * g);
+                }
+            }
+            if constexpr (!first) { if (gi < 15) stage_slot(NT + t + 1, gi); }
+            if (gi == 0) load_v(2, vf[2]);
+            if (gi == 3) load_v(3, vf[3]);
+            if (gi == 6) load_v(4, vf[4]);
+        };
+        {
             f32x16 oa = O[0], ob = O[1];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
                     oa = mfma_b16(vf[0][u][PA[k]], pc[u][PB[k]], oa); ob = mfma_b16(vf[1][u][PA[k]], pc[u][PB[k]], ob);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (more) p_elem(6 * u + k);
-                    if constexpr (!first) { if (k & 1) stage_slot(NT + t + 1, 3 * u + (k >> 1)); }
+                    ride(6 * u + k);   // (same scheduling region as the MFMAs: hipcc interleaves the VALU between them)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             O[0] = oa; O[1] = ob;
         }
-        {   // tiles 2, 3, 4: three accumulators; probabilities 12 .. 15, the split of all 16 and copy slots 6 .. 14
+        {
             f32x16 oa = O[2], ob = O[3], oc = O[4];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
@@ -569,23 +615,12 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
                 for (int k = 0; k < 6; ++k) {
                     oa = mfma_b16(vf[2][u][PA[k]], pc[u][PB[k]], oa); ob = mfma_b16(vf[3][u][PA[k]], pc[u][PB[k]], ob);
                     oc = mfma_b16(vf[4][u][PA[k]], pc[u][PB[k]], oc);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if constexpr (more) {
-                        if (u == 0 && k < 4) p_elem(12 + k);
-                        if (u == 0 && k == 4) split8(pe, pn[0][0], pn[0][1], pn[0][2]);
-                        if (u == 1 && k == 0) split8(pe + 8, pn[1][0], pn[1][1], pn[1][2]);
-                    }
-                    if constexpr (!first) {
-                        if (u == 0 && k < 4) stage_slot(NT + t + 1, 6 + k);
-                        if (u == 1 && k >= 1) stage_slot(NT + t + 1, 9 + k);
-                    }
+                    ride(12 + 6 * u + k);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             O[2] = oa; O[3] = ob; O[4] = oc;
         }
         if constexpr (more) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) lg[g] = load_l2(lrsrc, loff0 + min(t + 2, NT - 1) * 128 + 32 * g);
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -594,6 +629,7 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
         __builtin_amdgcn_sched_barrier(0);
         IPROBE(60 + 6 * t + 3);
     };
+    IPROBE(123);
     if (NT > 1) {
         step2(0, std::true_type{}, std::true_type{});
         for (int t = 1; t + 1 < NT; ++t) step2(t, std::true_type{}, std::false_type{});

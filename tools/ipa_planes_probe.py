@@ -38,3 +38,7 @@ print("phase 1 total:", [int(t[w, 120] - t[w, 127]) for w in range(4)], " phase 
       " epilogue:", [int(t[w, 122] - t[w, 121]) for w in range(4)])
 print("item start to item start:", [int(t[0, 101 + k] - t[0, 100 + k]) for k in range(15)])
 print("(kernel start to first item:", int(t[0, 100] - t[0, 126]), ")")
+print("phase-2 prologue (accumulator init, probabilities of tile 0):", [int(t[w, 123] - t[w, 120]) for w in range(4)],
+      " last step end -> 121:", [int(t[w, 121] - t[w, 60 + 6 * (NT - 1) + 3]) for w in range(4)])
+print("phase 2, end of step t -> start of step t + 1:", [[int(t[w, 60 + 6 * (k + 1)] - t[w, 60 + 6 * k + 3]) for k in range(NT - 1)] for w in range(2)])
+print("phase 1, end of step t -> start of step t + 1:", [[int(t[w, 6 * (k + 1)] - t[w, 6 * k + 4]) for k in range(NT)] for w in range(2)])
