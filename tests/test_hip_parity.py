@@ -257,10 +257,11 @@ def test_ipa_golden(net_rough):
     check(f"{_test_name()}: rel err", rel(out.cpu().numpy()[valid], g["out"][valid]), 2e-5)
 
 
-# N % 32 == 0 runs the planes kernel (csrc/ipa_attention_planes.hip): 96 = odd tile count (a wave pair without a tile of its own),
+# N % 32 == 0 runs the planes kernel (csrc/ipa_attention_planes.hip): 32 / 64 = one / two key tiles (the short-stream paths of the
+# two-phase pipeline), 96 = odd tile count (a wave pair without a tile of its own),
 # 256 / 512 = the BASELINE lengths, (3, 64) = several work items per persistent workgroup chain; the other lengths run the
 # fp32-operand kernel (N = 300: ragged last tile, three query blocks, two chunks in s2s_ipa_opair)
-@pytest.mark.parametrize("B,N", [(1, 7), (2, 40), (1, 96), (3, 64), (1, 256), (1, 300), (1, 512)])
+@pytest.mark.parametrize("B,N", [(1, 7), (2, 32), (2, 40), (1, 96), (3, 64), (1, 256), (1, 300), (1, 512)])
 def test_ipa_vs_oracle(net_rough, B, N):
     from oracle import geometry as OG
     from oracle import net as ON

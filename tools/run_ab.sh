@@ -1,12 +1,9 @@
+export S2S_BENCH_BACKEND=gloo
 mkdir -p gpurun_out/ab
-python tools/et_probe.py run --B 16 --N 256 > gpurun_out/ab/et_probe_roll.txt 2>&1; python - <<'PY'
-import re
-tot=[0]*4; rows=[]
-for l in open('gpurun_out/ab/et_probe_roll.txt'):
-    m=re.match(r"slot\s+(\d+) stage.*?:\s+(-?\d+)\s+(-?\d+)\s+(-?\d+)\s+(-?\d+)", l)
-    if m and int(m.group(1))<239:
-        v=[int(m.group(k)) for k in range(2,6)]; rows.append((int(m.group(1)), v))
-        for k in range(4): tot[k]+=v[k]
-print("sum over slots 0..238:", tot)
-print("slots 186..230:", [(r[0], max(r[1])) for r in rows if 186<=r[0]<=230])
-PY
+for cfg in cfg2 cfg3 cfg5; do
+  extra="--replicas 8 --denoise-steps 4"
+  [ $cfg = cfg2 ] && extra="--replicas 8 --n-res 64 --denoise-steps 4"
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --config $cfg --steps 1 --warmup 0 --no-cpu-baseline $extra 2> gpurun_out/ab/dist_$cfg.err | tail -1 | python -c "
+import json,sys
+l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg', l['n_gpus'], round(l['value'],2), l['distributed'])" || tail -5 gpurun_out/ab/dist_$cfg.err
+done
