@@ -282,6 +282,46 @@ def test_ipa_vs_oracle(net_rough, B, N):
     check(f"{_test_name()}: rel err", rel(out.cpu().numpy()[valid], ref.numpy()[valid]), 2e-5)
 
 
+def test_ipa_planes_kernel_matches_fp32_operand_kernel(net_rough):
+    """The two attention paths side by side on the same inputs (ops level, through the C ABI): s2s_ipa_attention_planes on operands
+    pre-split by the GEMM epilogues / the point kernel vs s2s_ipa_attention on the fp32 projections -- o (decoded from the packed
+    planes), o_pt and o_pair columns.  Several work items per persistent workgroup chain (B x H x N/64 = 48 items)."""
+    from str2str_amd import ops
+
+    ipa = net_rough.translator.trunk["ipa_1"]
+    B, N, H = 3, 64, 8
+    M = B * N
+    g = torch.Generator().manual_seed(11)
+    s = torch.randn(M, 256, generator=g).to(DEV)
+    q4 = torch.randn(B, N, 4, generator=g)
+    r7 = torch.cat([q4 / q4.norm(dim=-1, keepdim=True), torch.randn(B, N, 3, generator=g)], -1).contiguous().to(DEV)
+    bias = torch.randn(B, H, N, N, generator=g).to(DEV)
+    pz = torch.randn(B, N, N, 32, generator=g).to(DEV)
+    mask = torch.ones(B, N)
+    mask[1, -5:] = 0
+    mask = mask.to(DEV)
+    with torch.no_grad():
+        w, d = ipa.node_packs(), ipa._derived()
+        s_xp = ops.pack_planes(s)
+        lin = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], M, x["k"], x["n"], x["tg"], **kw)  # noqa: E731
+        _, q_xp = lin(w["q"], want_f32=False, want_xp=True)
+        _, k_xp = lin(w["k"], want_f32=False, want_xp=True)
+        v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, 256, 2048, 8)
+        qp, _ = lin(w["qp"])
+        kvp, _ = lin(w["kvp"])
+        pts = ops.ipa_prep_points_planes(r7, qp, kvp, d["hw"])
+        feats, fxp = ops.ipa_attention_planes(q_xp, k_xp, v_vf, pts, bias, pz, mask, r7)
+        q, _ = lin(w["q"])
+        kv, _ = lin(w["kv"])
+        q_pts, k_pts, v_pts = ops.ipa_prep_points(r7, qp.view(B, N, -1), kvp.view(B, N, -1), 8, 8, 12)
+        ref = ops.ipa_attention(q.view(B, N, H, -1), kv.view(B, N, H, -1), q_pts, k_pts, v_pts, bias, pz, mask, r7, d["hw"]).view(M, -1)
+    got = ops.unpack_planes(fxp, M, 2688)
+    got[:, 2048:] = feats.view(M, -1)[:, 2048:]
+    valid = mask.reshape(-1).bool()
+    for name, sl in (("o", slice(0, 2048)), ("o_pt", slice(2048, 2432)), ("o_pair", slice(2432, 2688))):
+        check(f"ipa planes vs fp32-operand kernel, {name}", rel(got[valid][:, sl], ref[valid][:, sl]), 5e-6)
+
+
 def test_se3_step_golden(diffuser):
     from str2str_amd.common.rigid_utils import Rigid
 
