@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
     constexpr int kSlots = 8 * kStages;
     __shared__ __attribute__((aligned(16))) char s_w[2][kStageBytes];
     __shared__ __attribute__((aligned(16))) float s_vec[512 + 64];  // b2 | b3 | gamma | beta | projection bias
-    __shared__ float s_bins[64];                                     // distogram bin lower edges
+    __shared__ __attribute__((aligned(16))) float s_bins[64 + 4];    // distogram bin lower edges (ascending), padded with 3e38
     const int lane = threadIdx.x & 63, h = lane >> 5, wave = threadIdx.x >> 6;
 
     // ---- weight pipe (identical to the edge transition's)
@@ -523,16 +523,22 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
     cp_load_b(0);
 
     // ---- per-tile context: the four first-layer rows of this lane's pair
+    // node_b / rel_tab / bin_tab come COLUMN-BLOCKED: [32 chunks of 4 channels][rows][4], so that the 16 B a lane wants of
+    // its pair's row sit next to the neighbouring pairs' (consecutive j -> consecutive rows): one load instruction touches
+    // 8 cache lines instead of 32.  Lane part of the address in voffset, chunk pair (2G, 2G+1) in the scalar offset.
     struct Ctx {
-        const float *ra, *rb, *rr, *rk;
+        const float* ra;
+        unsigned vb, vr, vk;   // byte offsets of (row, chunk h) in node_b / rel_tab / bin_tab
         float kb;
-        float* orow;
         long long p, boff;
         float em;
         bool valid;
     };
     const long long NN = (long long)N * N;
-    // setup in two halves so that the per-pair loads (CA coordinates, residue indices, masks) are in flight for a slot
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)node_b, 0, (unsigned)(M / N * 512), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)rel_tab, 0, n_rel * 512, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)bin_tab, 0, n_bins * 512, 0x00020000);
+    // setup in two halves so that the per-pair loads (CA coordinates, residue indices, masks) are in flight for a few slots
     // before they are consumed; the distogram edges sit in LDS (s_bins)
     struct Raw {
         long long p, bi, bj, bb;
@@ -541,16 +547,32 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
         float mi, mj;
         bool valid;
     };
+    // pair index < 2^31: 32-bit index arithmetic, division by N through floor(2^32 / N) (quotient short by at most one for
+    // p < 2^31; a 64-bit division is ~100 VALU instructions)
+    const bool small_m = M < (1ll << 31) && N >= 2;
+    const unsigned n_magic = small_m ? (unsigned)((1ull << 32) / (unsigned)N) : 0u;
+    auto div_n = [&](unsigned x, unsigned& q, unsigned& r) {
+        q = __umulhi(x, n_magic);
+        r = x - q * (unsigned)N;
+        if (r >= (unsigned)N) { ++q; r -= (unsigned)N; }
+    };
     auto setup_a = [&](long long wg_tile) -> Raw {
         long long p = (wg_tile * 4 + wave) * 32 + (lane & 31);
         Raw r;
         r.valid = p < M;
         if (!r.valid) p = M - 1;
         r.p = p;
-        r.bb = p / NN;
-        const long long rem = p - r.bb * NN;
-        r.bi = r.bb * N + rem / N;
-        r.bj = r.bb * N + rem % N;
+        // p = (bb N + i) N + j:  global row bi = p / N,  j = p - bi N,  bb = bi / N
+        if (small_m) {
+            unsigned bi, j, bb, i;
+            div_n((unsigned)p, bi, j);
+            div_n(bi, bb, i);
+            r.bi = bi; r.bb = bb; r.bj = bb * (unsigned)N + j;
+        } else {
+            r.bi = p / N;
+            r.bb = r.bi / N;
+            r.bj = r.bb * N + (p - r.bi * N);
+        }
         r.ax = ca[r.bi * 3 + 0]; r.ay = ca[r.bi * 3 + 1]; r.az = ca[r.bi * 3 + 2];
         r.bx = ca[r.bj * 3 + 0]; r.by = ca[r.bj * 3 + 1]; r.bz = ca[r.bj * 3 + 2];
         r.ii = residue_idx[r.bi];
@@ -565,20 +587,32 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
         // distogram bin of this pair (no FMA contraction: mirrors torch.linalg.norm of the difference; geo_utils.py:44-56)
         const float dx = r.ax - r.bx, dy = r.ay - r.by, dz = r.az - r.bz;
         const float dist = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
-        int bin = -1;
-        for (int k = 0; k < n_bins; ++k) {
-            const float lo = s_bins[k];
-            const float up = (k + 1 < n_bins) ? s_bins[k + 1] : 1e8f;
-            if (dist > lo && dist < up) bin = k;
+        // the reference's one-hot (dist > lower[k]) * (dist < upper[k]), upper = lower[k+1] (1e8 for the last): with ascending
+        // edges (torch.linspace) that is k = #{edges < dist} - 1 unless dist sits exactly on the next edge (then no bin at all)
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {  // s_bins is padded with 3e38 up to 68 entries
+            const float4 e = *reinterpret_cast<const float4*>(&s_bins[4 * u]);
+            cnt += (e.x < dist) + (e.y < dist) + (e.z < dist) + (e.w < dist);
+        }
+#pragma nounroll
+        for (int k = 32; k < n_bins; k += 4) {  // (22 bins in the released model: never taken)
+            const float4 e = *reinterpret_cast<const float4*>(&s_bins[k]);
+            cnt += (e.x < dist) + (e.y < dist) + (e.z < dist) + (e.w < dist);
+        }
+        int bin = cnt - 1;
+        if (bin >= 0) {
+            const float up = (bin + 1 < n_bins) ? s_bins[bin + 1] : 1e8f;
+            if (!(dist < up)) bin = -1;
         }
         long long d = r.ii - r.ij + rel_off;
         d = d < 0 ? 0 : (d >= n_rel ? n_rel - 1 : d);
         c.ra = node_a + r.bi * 128;
-        c.rb = node_b + r.bj * 128;
-        c.rr = rel_tab + d * 128;
-        c.rk = bin_tab + (long long)(bin < 0 ? 0 : bin) * 128;
+        const unsigned jj = (unsigned)(r.bj - r.bb * N);
+        c.vb = ((unsigned)r.bb * 32u * (unsigned)N + (unsigned)h * (unsigned)N + jj) * 16u;
+        c.vr = ((unsigned)h * (unsigned)n_rel + (unsigned)d) * 16u;
+        c.vk = ((unsigned)h * (unsigned)n_bins + (unsigned)(bin < 0 ? 0 : bin)) * 16u;
         c.kb = bin < 0 ? 0.f : 1.f;
-        c.orow = out + r.p * 128;
         c.p = r.p;
         c.boff = r.p + 7 * r.bb * NN;
         c.em = r.mi * r.mj;
@@ -605,16 +639,20 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
         }
     };
     float tmp[64];
-    auto row_tmp = [&](const float* r) {
+    auto row_cb = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned vo, int rows, float (&dst)[64], int G0, int G1) {
 #pragma unroll
-        for (int G = 0; G < 16; ++G) {
-            const float4 v = ldg4(r, G, h);
-            tmp[4 * G + 0] = v.x; tmp[4 * G + 1] = v.y; tmp[4 * G + 2] = v.z; tmp[4 * G + 3] = v.w;
+        for (int G = G0; G < G1; ++G) {  // chunk 2G + h of the row: scalar offset 2G rows-blocks of 16 B
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, G * 32 * rows, 0);
+            dst[4 * G + 0] = __uint_as_float(v.x); dst[4 * G + 1] = __uint_as_float(v.y);
+            dst[4 * G + 2] = __uint_as_float(v.z); dst[4 * G + 3] = __uint_as_float(v.w);
         }
     };
-    auto row_add = [&](float scale) {
-#pragma unroll
-        for (int i = 0; i < 64; ++i) g1[i] += scale * tmp[i];
+    auto row_add = [&](float scale) {  // pinned: left alone, the compiler sinks these adds to the splits 20 slots later and keeps
+#pragma unroll                         // (spills) all four loaded rows until then
+        for (int i = 0; i < 64; ++i) {
+            g1[i] += scale * tmp[i];
+            asm volatile("" : "+v"(g1[i]));
+        }
     };
     // ReLU + split of first-layer k-step ks (registers 8ks .. 8ks+7 of g1: chain order) into planes
     auto g1_split = [&](bf16x8 (&dst)[3], int ks) {
@@ -626,7 +664,7 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
 
     const long long n_wt = (M + 127) / 128;
     long long wt = blockIdx.x;
-    if (threadIdx.x < 64) s_bins[threadIdx.x] = threadIdx.x < n_bins ? bin_lower[threadIdx.x] : 3.0e38f;
+    if (threadIdx.x < 68) s_bins[threadIdx.x] = (int)threadIdx.x < n_bins ? bin_lower[threadIdx.x] : 3.0e38f;
     __syncthreads();
     Ctx cur = setup_b(setup_a(wt));
     bf16x8 xp[8][3];  // planes of the current layer's input (8 k-steps of 16)
@@ -638,9 +676,9 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
         cp_store_a(0);
         cp_load_a(1);
         cp_store_b(0);
-        row_tmp(cur.rb); row_add(1.0f);
-        row_tmp(cur.rr); row_add(1.0f);
-        row_tmp(cur.rk); row_add(cur.kb);
+        row_cb(rs_b, cur.vb, N, tmp, 0, 16); row_add(1.0f);
+        row_cb(rs_r, cur.vr, n_rel, tmp, 0, 16); row_add(1.0f);
+        row_cb(rs_k, cur.vk, n_bins, tmp, 0, 16); row_add(cur.kb);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) g1_split(xp[ks], ks);
     }
@@ -653,21 +691,94 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
         for (int k = 0; k < 6; ++k) f[k] = s[64 * k];
     };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // The VALU work of a tile is cut into per-k-step pieces, each pinned (empty asm on its inputs / outputs: otherwise the
+    // compiler sinks a piece to its first use, i.e. in FRONT of the MFMAs that wait for it) into a slot whose MFMAs do not depend
+    // on it, and interleaved with them by sched_group_barrier.
+    auto pin_frag = [&](bf16x8 (&x)[3]) { asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2])); };
+    // accumulator start = bias (registers 4 rq + q of tile t <-> channel 32 t + 8 rq + 4 h + q)
+    auto bias16 = [&](const float* vec, int t) -> f32x16 {
+        const float4 b0 = ldg4(vec, 4 * t, h), b1 = ldg4(vec, 4 * t + 1, h), b2v = ldg4(vec, 4 * t + 2, h), b3v = ldg4(vec, 4 * t + 3, h);
+        return f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2v.x, b2v.y, b2v.z, b2v.w, b3v.x, b3v.y, b3v.z, b3v.w};
+    };
+    // layer-2 output (bias already in the accumulator): ReLU + split of k-step k -> layer-3 input planes xp[k]
+    auto l2_piece = [&](auto kc) {
+        constexpr int k = decltype(kc)::value, t = k / 2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rq = 2 * (k & 1) + u;
+            const float xx[4] = {fmaxf(a2[t][4 * rq + 0], 0.f), fmaxf(a2[t][4 * rq + 1], 0.f), fmaxf(a2[t][4 * rq + 2], 0.f),
+                                 fmaxf(a2[t][4 * rq + 3], 0.f)};
+            split4(xx, xp[k][0], xp[k][1], xp[k][2], 4 * u);
+        }
+        pin_frag(xp[k]);
+    };
+    float ln_mean = 0.f, ln_rstd = 0.f;
+    bf16x8 xq[2][3];  // LayerNorm output planes of the projection's current / next k-step
+    // LayerNorm output of k-step k (16 channels): scale, shift, edge mask, store (+ planes for the projection)
+    __amdgpu_buffer_rsrc_t rs_out;  // this tile's 32 output rows; rows past M are outside num_records: their stores are dropped
+    auto out_rsrc = [&](long long wg_tile) {
+        const long long p0 = (wg_tile * 4 + __builtin_amdgcn_readfirstlane(wave)) * 32;
+        const long long left = M - p0;
+        rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (p0 < M ? p0 : 0) * 128), 0,
+                                                   (unsigned)(left <= 0 ? 0 : (left < 32 ? left : 32)) * 512u, 0x00020000);
+    };
+    auto ln_piece = [&](auto kc, const Ctx& c) {
+        constexpr int k = decltype(kc)::value, t = k / 2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rq = 2 * (k & 1) + u, g = 4 * t + rq;
+            const float4 ga = ldg4(s_vec + 256, g, h), be = ldg4(s_vec + 384, g, h);
+            float4 o;
+            // explicit roundings: the fused-projection and the plain variant of this kernel must agree bit for bit
+            o.x = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 0] - ln_mean, ln_rstd), ga.x, be.x), c.em);
+            o.y = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 1] - ln_mean, ln_rstd), ga.y, be.y), c.em);
+            o.z = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 2] - ln_mean, ln_rstd), ga.z, be.z), c.em);
+            o.w = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 3] - ln_mean, ln_rstd), ga.w, be.w), c.em);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)},
+                                                   rs_out, (unsigned)((lane & 31) * 512 + h * 16), g * 32, 0);
+            if constexpr (PROJ) {
+                const float xx[4] = {o.x, o.y, o.z, o.w};
+                split4(xx, xq[k & 1][0], xq[k & 1][1], xq[k & 1][2], 4 * u);
+            }
+        }
+        if constexpr (PROJ) pin_frag(xq[k & 1]);
+    };
+    // rows of the next tile's first layer, eight 16 B loads per slot (a burst of 32 per wave backs up the vector memory
+    // pipe and with it the wave's MFMA issue)
+    auto row_load8 = [&](const float* r, float (&dst)[64], int half) {
+#pragma unroll
+        for (int G = 8 * half; G < 8 * half + 8; ++G) {
+            const float4 v = ldg4(r, G, h);
+            dst[4 * G + 0] = v.x; dst[4 * G + 1] = v.y; dst[4 * G + 2] = v.z; dst[4 * G + 3] = v.w;
+        }
+    };
     S2S_LDS_BARRIER();
     fetch(0, 0, fr[0]);
 
+#ifdef S2S_ET_PROBE
+    int probe_it = 0;
+#endif
     for (;;) {
     const long long wt_next = wt + gridDim.x;
     const bool has_next = wt_next < n_wt;
     Ctx nxt = cur;
     Raw nraw;
-    bf16x8 xpn[8][3];
+    bf16x8 xl[3];  // the next tile's last k-step (xp[7] is read by the final layer's last slot)
+    f32x16 init0, init1;
     static_for<0, kSlots>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         constexpr int stage = s / 8, ss = s % 8, par = stage & 1;
         constexpr int layer = s / 16;             // 0: layer 2, 1: layer 3, 2: projection
         constexpr int ks = layer < 2 ? (s % 16) / 2 : s - 32;
         constexpr int pr = layer < 2 ? s % 2 : 0;
+#ifdef S2S_ET_PROBE
+        if (probe_it == 3) PROBE(300 + s);
+#endif
+        // ---------------- top of the slot: LDS / global loads whose results are used under later MFMAs
+        if constexpr (layer < 2 && ks == 0) {  // this slot's two accumulators start from the bias
+            init0 = bias16(s_vec + 128 * layer, 2 * pr);
+            init1 = bias16(s_vec + 128 * layer, 2 * pr + 1);
+        }
         if constexpr (ss < 7) {
             fetch(par, ss + 1, fr[(s + 1) & 1]);
             if constexpr (ss == 0) cp_load_b((stage + 1) % kStages);
@@ -676,20 +787,30 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
             S2S_LDS_BARRIER();
             fetch(par ^ 1, 0, fr[(s + 1) & 1]);
         }
-        // next tile: context at slot 2, its four rows under layers 2 and 3
+        // next tile: per-pair loads at slot 0, context under slot 4, then its four first-layer rows
         if constexpr (s == 0) nraw = setup_a(has_next ? wt_next : wt);
-        if constexpr (s == 4) row_set(nxt.ra);
-        if constexpr (s == 8) row_tmp(nxt.rb);
-        if constexpr (s == 12) row_tmp(nxt.rr);
-        if constexpr (s == 17) row_tmp(nxt.rk);
+        if constexpr (s == 30) out_rsrc(wt);
+        if constexpr (s == 5) row_load8(nxt.ra, g1, 0);
+        if constexpr (s == 6) row_load8(nxt.ra, g1, 1);
+        if constexpr (s == 7) row_cb(rs_b, nxt.vb, N, tmp, 0, 8);
+        if constexpr (s == 8) row_cb(rs_b, nxt.vb, N, tmp, 8, 16);
+        if constexpr (s == 13) row_cb(rs_r, nxt.vr, n_rel, tmp, 0, 8);
+        if constexpr (s == 14) row_cb(rs_r, nxt.vr, n_rel, tmp, 8, 16);
+        if constexpr (s == 18) row_cb(rs_k, nxt.vk, n_bins, tmp, 0, 8);
+        if constexpr (s == 19) row_cb(rs_k, nxt.vk, n_bins, tmp, 8, 16);
         __builtin_amdgcn_sched_barrier(0);
 
+        // ---------------- the 12 MFMAs and the VALU pieces that run under them
         const bf16x8 (&f)[6] = fr[s & 1];
-        const bf16x8 (&x)[3] = xp[ks];
+        const bf16x8 (&x)[3] = layer < 2 ? xp[ks] : xq[ks & 1];
         f32x16& t0 = layer == 0 ? a2[2 * pr] : (layer == 1 ? a3[2 * pr] : pq[0]);
         f32x16& t1 = layer == 0 ? a2[2 * pr + 1] : (layer == 1 ? a3[2 * pr + 1] : pq[1]);
         if constexpr (ks == 0) {
-            t0 = mfma_bf16(f[2], x[0], zero16); t1 = mfma_bf16(f[5], x[0], zero16);
+            if constexpr (layer < 2) {
+                t0 = mfma_bf16(f[2], x[0], init0); t1 = mfma_bf16(f[5], x[0], init1);
+            } else {
+                t0 = mfma_bf16(f[2], x[0], zero16); t1 = mfma_bf16(f[5], x[0], zero16);
+            }
         } else {
             t0 = mfma_bf16(f[2], x[0], t0); t1 = mfma_bf16(f[5], x[0], t1);
         }
@@ -698,69 +819,55 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
         t0 = mfma_bf16(f[1], x[0], t0); t1 = mfma_bf16(f[4], x[0], t1);
         t0 = mfma_bf16(f[0], x[1], t0); t1 = mfma_bf16(f[3], x[1], t1);
         t0 = mfma_bf16(f[0], x[0], t0); t1 = mfma_bf16(f[3], x[0], t1);
-        if constexpr (s == 2) nxt = setup_b(nraw);
-        if constexpr (s == 10) row_add(1.0f);
-        if constexpr (s == 14) row_add(1.0f);
-        if constexpr (s == 19) row_add(nxt.kb);
-        if constexpr (s >= 22 && s < 30) g1_split(xpn[s - 22], s - 22);  // ReLU + split of the next tile's first layer
+        if constexpr (s == 4) nxt = setup_b(nraw);
+        if constexpr (s == 12) row_add(1.0f);     // a + b   (same association as the fp32 kernel: ((a + b) + r) + kb k)
+        if constexpr (s == 17) row_add(1.0f);     // + relative-position row
+        if constexpr (s == 22) row_add(nxt.kb);   // + distogram row
+        // layer-2 output, k-step k (read by slots 16 + 2k, 17 + 2k) under slot 14 + 2k; k-step 0 is exposed after slot 15
+        if constexpr (s >= 16 && s <= 28 && s % 2 == 0) l2_piece(IC<(s - 14) / 2>{});
+        // next tile's first layer: k-step k of xp is last read by slot 17 + 2k, so k = 0..6 go under slots 24..30 and the
+        // last one (under slot 23) into xl
+        if constexpr (s >= 24 && s < 31) { g1_split(xp[s - 24], s - 24); pin_frag(xp[s - 24]); }
+        if constexpr (s == 23) { g1_split(xl, 7); pin_frag(xl); }
+        // LayerNorm output k-step k + 1 under projection slot 32 + k
+        if constexpr (PROJ && s >= 32 && s < 39) ln_piece(IC<s - 31>{}, cur);
         if constexpr (ss == 1) cp_store_a(par ^ 1);
         if constexpr (ss == 5) cp_store_b(par ^ 1);
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA,
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // up to eight VALU instructions behind it
+        }
         __builtin_amdgcn_sched_barrier(0);
 
         // ---------------- exposed steps
-        if constexpr (s == 15) {  // layer-2 output: + b2, ReLU, split -> layer-3 input planes
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const float4 bq = ldg4(s_vec, 4 * t + rq, h);
-                    const float xx[4] = {fmaxf(a2[t][4 * rq + 0] + bq.x, 0.f), fmaxf(a2[t][4 * rq + 1] + bq.y, 0.f),
-                                         fmaxf(a2[t][4 * rq + 2] + bq.z, 0.f), fmaxf(a2[t][4 * rq + 3] + bq.w, 0.f)};
-                    split4(xx, xp[2 * t + (rq >> 1)][0], xp[2 * t + (rq >> 1)][1], xp[2 * t + (rq >> 1)][2], 4 * (rq & 1));
-                }
-        }
-        if constexpr (s == 31) {  // layer-3 output: + b3, LayerNorm, edge mask, store (+ planes for the projection)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const float4 bq = ldg4(s_vec + 128, 4 * t + rq, h);
-                    a3[t][4 * rq + 0] += bq.x; a3[t][4 * rq + 1] += bq.y; a3[t][4 * rq + 2] += bq.z; a3[t][4 * rq + 3] += bq.w;
-                }
+        if constexpr (s == 15) l2_piece(IC<0>{});
+        if constexpr (s == 31) {  // layer-3 output (bias included): LayerNorm statistics
             float sum = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sum += a3[t][r];
-            const float mean = xhalf_sum(sum) * (1.0f / 128);
+            ln_mean = xhalf_sum(sum) * (1.0f / 128);
             float var = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float dd = a3[t][r] - mean;
-                    var += dd * dd;
+                    const float dd = a3[t][r] - ln_mean;
+                    var = __fmaf_rn(dd, dd, var);
                 }
-            const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / 128) + ln_eps);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const int g = 4 * t + rq;
-                    const float4 ga = ldg4(s_vec + 256, g, h), be = ldg4(s_vec + 384, g, h);
-                    float4 o;
-                    o.x = ((a3[t][4 * rq + 0] - mean) * rstd * ga.x + be.x) * cur.em;
-                    o.y = ((a3[t][4 * rq + 1] - mean) * rstd * ga.y + be.y) * cur.em;
-                    o.z = ((a3[t][4 * rq + 2] - mean) * rstd * ga.z + be.z) * cur.em;
-                    o.w = ((a3[t][4 * rq + 3] - mean) * rstd * ga.w + be.w) * cur.em;
-                    if (cur.valid) *reinterpret_cast<float4*>(cur.orow + 8 * g + 4 * h) = o;
-                    if constexpr (PROJ) {
-                        const float xx[4] = {o.x, o.y, o.z, o.w};
-                        split4(xx, xp[2 * t + (rq >> 1)][0], xp[2 * t + (rq >> 1)][1], xp[2 * t + (rq >> 1)][2], 4 * (rq & 1));
-                    }
-                }
+            ln_rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / 128) + ln_eps);
+            if constexpr (PROJ) {
+                ln_piece(IC<0>{}, cur);
+            } else {
+                static_for<0, 8>([&](auto kc) { ln_piece(kc, cur); });
+            }
         }
     });
+#ifdef S2S_ET_PROBE
+    if (probe_it == 3) PROBE(300 + kSlots);
+#endif
     if constexpr (PROJ) {
         if (cur.valid) {
             const float4 b0 = ldg4(s_vec + 512, 0, h);
@@ -778,11 +885,14 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
             }
         }
     }
+#ifdef S2S_ET_PROBE
+    if (probe_it == 3) PROBE(301 + kSlots);
+    ++probe_it;
+#endif
     if (!has_next) break;
     cur = nxt;
     wt = wt_next;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { xp[i][0] = xpn[i][0]; xp[i][1] = xpn[i][1]; xp[i][2] = xpn[i][2]; }
+    xp[7][0] = xl[0]; xp[7][1] = xl[1]; xp[7][2] = xl[2];
     if constexpr (kStages % 2 == 1) {  // odd stage count: the next tile's stage 0 sits in the other buffer
         lds_char* sw = lds_image[0];
         lds_image[0] = lds_image[1];
@@ -834,6 +944,8 @@ extern "C" int s2s_edge_embed_bf16x6(const float* node_a, const float* node_b, c
     const long long M = (long long)n_samples * n_res * n_res;
     if (M <= 0) return 0;
     if (n_bins > 64) return (int)hipErrorInvalidValue;  // the distogram edges are staged in a 64-entry LDS table
+    // the column-blocked tables are read through 32-bit buffer offsets
+    if ((long long)n_samples * n_res * 512 >= (1ll << 32) || (long long)n_rel * 512 >= (1ll << 32)) return (int)hipErrorInvalidValue;
     const long long wg_tiles = (M + 127) / 128;
     int n_cu = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)

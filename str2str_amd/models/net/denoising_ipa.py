@@ -108,6 +108,7 @@ class EmbeddingModule(nn.Module):
                 out["bin_tab"] = w0[:, 2 * t1 + ie:2 * t1 + ie + nb].t().contiguous()
             else:  # no distogram columns: a single zero row that is never selected (ca = 0 -> no bin)
                 out["bin_tab"] = w0.new_zeros(1, w0.shape[0])
+            out["bin_tab_cb"] = ops.column_blocked(out["bin_tab"])  # gather layout of the split-bf16 kernel
             out["bin_lower"] = torch.linspace(self._dims[2], self._dims[3], nb).to(w0.device)
             return out
 
@@ -131,6 +132,7 @@ class EmbeddingModule(nn.Module):
             rel = F.linear(self.position_embed(d).float().to(dev), w_rel).contiguous()
             node_pos = F.linear(self.position_embed(idx_cpu).float().to(dev), wn_pos).contiguous()  # [B, L, node width]
             self._idx_val = (rel, span, node_pos, residue_idx.to(dev).contiguous())
+            self._rel_cb = ops.column_blocked(rel)
             self._idx_key = key
         return self._idx_val
 
@@ -176,7 +178,10 @@ class EmbeddingModule(nn.Module):
                                                          post_mask=None if mask is None else mask.reshape(M), want_xp=True)
         node_embed = node_embed.view(B, L, -1)
         node_a = (tl(w["w_row_t"], w["b0"])[:, None, :] + fixed * w["w_row_f"]).expand(B, L, -1).contiguous()
-        node_b = (tl(w["w_col_t"])[:, None, :] + fixed * w["w_col_f"]).expand(B, L, -1).contiguous()
+        if self.mfma_mode == "bf16x6":  # column part straight in the kernel's gather layout [B, 32 chunks, L, 4]
+            node_b = (tl(w["w_col_t"]).view(-1, 32, 1, 4) + fixed[:, None] * w["w_col_f"].view(1, 32, 1, 4)).expand(B, 32, L, 4).contiguous()
+        else:
+            node_b = (tl(w["w_col_t"])[:, None, :] + fixed * w["w_col_f"]).expand(B, L, -1).contiguous()
         ca = self_conditioning_ca.to(dev).float().contiguous() if self.self_conditioning else t_emb.new_zeros(B, L, 3)
         e2, e4, ln = self.edge_embed[2], self.edge_embed[4], self.edge_embed[5]
         if self.mfma_mode == "bf16x6":
@@ -184,9 +189,9 @@ class EmbeddingModule(nn.Module):
             if next_proj is not None:  # 5-stage stream: W2 | W3 | the first IPA block's projection stage
                 stream = self._proj_cache.get([w["wstream"], next_proj[2]], lambda: torch.cat([w["wstream"], next_proj[2]]))
                 proj = (stream, next_proj[1])
-            edge_embed = ops.edge_embed_bf16x6(node_a, node_b, rel_tab, w["bin_tab"], w["bin_lower"], idx_dev, ca,
+            edge_embed = ops.edge_embed_bf16x6(node_a, node_b, self._rel_cb, w["bin_tab_cb"], w["bin_lower"], idx_dev, ca,
                                                w["wstream"], e2.bias, e4.bias, ln.weight, ln.bias, mask, span, ln.eps,
-                                               proj=proj)
+                                               proj=proj, column_blocked_tables=True)
         else:
             edge_embed = ops.edge_embed(node_a, node_b, rel_tab, w["bin_tab"], w["bin_lower"], idx_dev, ca, w["w2p"],
                                         w["w3p"], e2.bias, e4.bias, ln.weight, ln.bias, mask, span, ln.eps,

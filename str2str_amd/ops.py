@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib = None
 _tables_loaded = False
@@ -311,11 +311,22 @@ def pack_bf16x3_embed_stream(w2: torch.Tensor, w3: torch.Tensor) -> torch.Tensor
     return blob
 
 
+def column_blocked(t: torch.Tensor) -> torch.Tensor:
+    """[..., rows, 128] -> [..., 32, rows, 4]: element [c][row][q] = channel 4c + q (the gather layout of s2s_edge_embed_bf16x6)."""
+    *lead, rows, ch = t.shape
+    return t.reshape(*lead, rows, ch // 4, 4).transpose(-3, -2).contiguous()
+
+
 def edge_embed_bf16x6(node_a, node_b, rel_table, bin_table, bin_lower, residue_idx, ca, wstream, b2, b3, gamma, beta, mask,
-                      rel_offset: int, ln_eps=1e-5, out=None, proj=None):
-    """Edge embedding on split-bf16 MFMA; ``proj`` = (5-stage stream, bias64) also returns (attn_bias, pair_z)."""
+                      rel_offset: int, ln_eps=1e-5, out=None, proj=None, column_blocked_tables=False):
+    """Edge embedding on split-bf16 MFMA; ``proj`` = (5-stage stream, bias64) also returns (attn_bias, pair_z).
+    node_b / rel_table / bin_table: [.., rows, 128], or already ``column_blocked`` ([.., 32, rows, 4]) with the flag set."""
     lib = load_library()
     B, N = node_a.shape[0], node_a.shape[1]
+    if not column_blocked_tables:
+        node_b, rel_table, bin_table = column_blocked(node_b), column_blocked(rel_table), column_blocked(bin_table)
+    if node_b.shape != (B, 32, N, 4) or rel_table.shape[0] != 32 or bin_table.shape[0] != 32:
+        raise HipLibraryError("edge_embed_bf16x6: tables are not column-blocked [.., 32, rows, 4]")
     for n, t in (("node_a", node_a), ("node_b", node_b), ("rel_table", rel_table), ("bin_table", bin_table),
                  ("bin_lower", bin_lower), ("ca", ca), ("b2", b2), ("b3", b3), ("gamma", gamma), ("beta", beta)):
         _req(t, name=n)
@@ -335,7 +346,7 @@ def edge_embed_bf16x6(node_a, node_b, rel_table, bin_table, bin_lower, residue_i
         out = torch.empty(B, N, N, 128, device=node_a.device, dtype=torch.float32)
     _check(lib.s2s_edge_embed_bf16x6(_p(node_a), _p(node_b), _p(rel_table), _p(bin_table), _p(bin_lower), _p(residue_idx),
                                      _p(ca), _p(wstream), _p(b2), _p(b3), _p(gamma), _p(beta), _p(mask), _p(out), B, N,
-                                     int(rel_offset), rel_table.shape[0], bin_table.shape[0], ln_eps, _p(pb), _p(pbias),
+                                     int(rel_offset), rel_table.shape[1], bin_table.shape[1], ln_eps, _p(pb), _p(pbias),
                                      _p(ppz), _stream()), "s2s_edge_embed_bf16x6")
     return out if proj is None else (out, pbias, ppz)
 

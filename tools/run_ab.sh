@@ -1,10 +1,3 @@
-mkdir -p gpurun_out/final
-date +%s > gpurun_out/final/t0
-true
-python bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err;  python - <<'PY'
-import json
-l=json.loads(open('gpurun_out/final/bench_default.json').read().strip().splitlines()[-1])
-print({k:l[k] for k in ('metric','value','unit','n_gpus','steps','warmup','ms_per_step','higher_is_better','scaling','vs_baseline','dtype','data')})
-print(l['roofline']['frac'], l['ipa_kernel']['frac'], l['cpu_baseline']['value'], l['cpu_baseline']['cores'])
-PY
-echo elapsed $(( $(date +%s) - $(cat gpurun_out/final/t0) )) s
+export STR2STR_HIP_LIB=$PWD/str2str_amd/csrc/build/lib_ee2.so
+python tools/ee_time.py 2>/dev/null
+timeout 900 python -m pytest tests -m gpu -x -q -k "embed or forward or trajectory or teacher" 2>&1 | tail -5
