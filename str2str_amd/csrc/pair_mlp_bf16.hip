@@ -547,38 +547,34 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
         float mi, mj;
         bool valid;
     };
-    // pair index < 2^31: 32-bit index arithmetic, division by N through floor(2^32 / N) (quotient short by at most one for
-    // p < 2^31; a 64-bit division is ~100 VALU instructions)
-    const bool small_m = M < (1ll << 31) && N >= 2;
-    const unsigned n_magic = small_m ? (unsigned)((1ull << 32) / (unsigned)N) : 0u;
+    // The launcher keeps the pair count of one launch below 2^31: 32-bit index arithmetic, division by N through
+    // floor(2^32 / N) (quotient short by at most one for x < 2^31; a 64-bit division is ~100 VALU instructions).
+    const unsigned n_magic = N >= 2 ? (unsigned)((1ull << 32) / (unsigned)N) : 0u;
     auto div_n = [&](unsigned x, unsigned& q, unsigned& r) {
-        q = __umulhi(x, n_magic);
+        q = N >= 2 ? __umulhi(x, n_magic) : x;
         r = x - q * (unsigned)N;
-        if (r >= (unsigned)N) { ++q; r -= (unsigned)N; }
+        const bool fix = r >= (unsigned)N;
+        q = fix ? q + 1 : q;
+        r = fix ? r - (unsigned)N : r;
     };
+    const float* mask_or_any = mask ? mask : ca;  // always a readable [B N] float array: no branch around the mask loads
     auto setup_a = [&](long long wg_tile) -> Raw {
         long long p = (wg_tile * 4 + wave) * 32 + (lane & 31);
         Raw r;
         r.valid = p < M;
-        if (!r.valid) p = M - 1;
+        p = r.valid ? p : M - 1;
         r.p = p;
         // p = (bb N + i) N + j:  global row bi = p / N,  j = p - bi N,  bb = bi / N
-        if (small_m) {
-            unsigned bi, j, bb, i;
-            div_n((unsigned)p, bi, j);
-            div_n(bi, bb, i);
-            r.bi = bi; r.bb = bb; r.bj = bb * (unsigned)N + j;
-        } else {
-            r.bi = p / N;
-            r.bb = r.bi / N;
-            r.bj = r.bb * N + (p - r.bi * N);
-        }
+        unsigned bi, j, bb, i;
+        div_n((unsigned)p, bi, j);
+        div_n(bi, bb, i);
+        r.bi = bi; r.bb = bb; r.bj = bb * (unsigned)N + j;
         r.ax = ca[r.bi * 3 + 0]; r.ay = ca[r.bi * 3 + 1]; r.az = ca[r.bi * 3 + 2];
         r.bx = ca[r.bj * 3 + 0]; r.by = ca[r.bj * 3 + 1]; r.bz = ca[r.bj * 3 + 2];
         r.ii = residue_idx[r.bi];
         r.ij = residue_idx[r.bj];
-        r.mi = mask ? mask[r.bi] : 1.0f;
-        r.mj = mask ? mask[r.bj] : 1.0f;
+        r.mi = mask_or_any[r.bi];
+        r.mj = mask_or_any[r.bj];
         return r;
     };
     auto setup_b = [&](const Raw& r) -> Ctx {
@@ -591,20 +587,13 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
         // edges (torch.linspace) that is k = #{edges < dist} - 1 unless dist sits exactly on the next edge (then no bin at all)
         int cnt = 0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {  // s_bins is padded with 3e38 up to 68 entries
+        for (int u = 0; u < 8; ++u) {  // s_bins: n_bins <= 32 edges | 1e8 (the last bin's upper edge) | 3e38 ...
             const float4 e = *reinterpret_cast<const float4*>(&s_bins[4 * u]);
             cnt += (e.x < dist) + (e.y < dist) + (e.z < dist) + (e.w < dist);
         }
-#pragma nounroll
-        for (int k = 32; k < n_bins; k += 4) {  // (22 bins in the released model: never taken)
-            const float4 e = *reinterpret_cast<const float4*>(&s_bins[k]);
-            cnt += (e.x < dist) + (e.y < dist) + (e.z < dist) + (e.w < dist);
-        }
-        int bin = cnt - 1;
-        if (bin >= 0) {
-            const float up = (bin + 1 < n_bins) ? s_bins[bin + 1] : 1e8f;
-            if (!(dist < up)) bin = -1;
-        }
+        cnt = cnt > n_bins ? n_bins : cnt;                  // dist beyond 1e8 when n_bins < 32: no bin, as below
+        const float up = s_bins[cnt];                       // upper edge of bin cnt - 1
+        const int bin = (cnt >= 1 && dist < up) ? cnt - 1 : -1;
         long long d = r.ii - r.ij + rel_off;
         d = d < 0 ? 0 : (d >= n_rel ? n_rel - 1 : d);
         c.ra = node_a + r.bi * 128;
@@ -615,7 +604,7 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
         c.kb = bin < 0 ? 0.f : 1.f;
         c.p = r.p;
         c.boff = r.p + 7 * r.bb * NN;
-        c.em = r.mi * r.mj;
+        c.em = mask ? r.mi * r.mj : 1.0f;
         return c;
     };
     auto split4 = [&](const float (&x)[4], bf16x8& ph, bf16x8& pm, bf16x8& pl, int at) {
@@ -650,7 +639,7 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
     auto row_add = [&](float scale) {  // pinned: left alone, the compiler sinks these adds to the splits 20 slots later and keeps
 #pragma unroll                         // (spills) all four loaded rows until then
         for (int i = 0; i < 64; ++i) {
-            g1[i] += scale * tmp[i];
+            g1[i] = __fmaf_rn(scale, tmp[i], g1[i]);  // (explicit: both template variants must round alike)
             asm volatile("" : "+v"(g1[i]));
         }
     };
@@ -664,7 +653,7 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
 
     const long long n_wt = (M + 127) / 128;
     long long wt = blockIdx.x;
-    if (threadIdx.x < 68) s_bins[threadIdx.x] = (int)threadIdx.x < n_bins ? bin_lower[threadIdx.x] : 3.0e38f;
+    if (threadIdx.x < 68) s_bins[threadIdx.x] = (int)threadIdx.x < n_bins ? bin_lower[threadIdx.x] : ((int)threadIdx.x == n_bins ? 1e8f : 3.0e38f);
     __syncthreads();
     Ctx cur = setup_b(setup_a(wt));
     bf16x8 xp[8][3];  // planes of the current layer's input (8 k-steps of 16)
@@ -722,20 +711,32 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
         rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (p0 < M ? p0 : 0) * 128), 0,
                                                    (unsigned)(left <= 0 ? 0 : (left < 32 ? left : 32)) * 512u, 0x00020000);
     };
+    float4 lga[2], lbe[2];  // gamma / beta of the next LayerNorm piece, read at the top of its slot
+    auto ln_load = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int g = 4 * (k / 2) + 2 * (k & 1) + u;
+            lga[u] = ldg4(s_vec + 256, g, h);
+            lbe[u] = ldg4(s_vec + 384, g, h);
+        }
+    };
     auto ln_piece = [&](auto kc, const Ctx& c) {
         constexpr int k = decltype(kc)::value, t = k / 2;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int rq = 2 * (k & 1) + u, g = 4 * t + rq;
-            const float4 ga = ldg4(s_vec + 256, g, h), be = ldg4(s_vec + 384, g, h);
+            const float4 ga = lga[u], be = lbe[u];
             float4 o;
+            // (the channel offset goes into the store's immediate field, not into an SGPR soffset: a 128-bit buffer store with an
+            // SGPR offset followed by VALU writes of its data registers lost the last lanes' data in the plain variant)
             // explicit roundings: the fused-projection and the plain variant of this kernel must agree bit for bit
             o.x = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 0] - ln_mean, ln_rstd), ga.x, be.x), c.em);
             o.y = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 1] - ln_mean, ln_rstd), ga.y, be.y), c.em);
             o.z = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 2] - ln_mean, ln_rstd), ga.z, be.z), c.em);
             o.w = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 3] - ln_mean, ln_rstd), ga.w, be.w), c.em);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)},
-                                                   rs_out, (unsigned)((lane & 31) * 512 + h * 16), g * 32, 0);
+                                                   rs_out, (unsigned)((lane & 31) * 512 + h * 16) + g * 32, 0, 0);
             if constexpr (PROJ) {
                 const float xx[4] = {o.x, o.y, o.z, o.w};
                 split4(xx, xq[k & 1][0], xq[k & 1][1], xq[k & 1][2], 4 * u);
@@ -779,6 +780,7 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
             init0 = bias16(s_vec + 128 * layer, 2 * pr);
             init1 = bias16(s_vec + 128 * layer, 2 * pr + 1);
         }
+        if constexpr (PROJ && s >= 31 && s < 39) ln_load(IC<s - 31>{});
         if constexpr (ss < 7) {
             fetch(par, ss + 1, fr[(s + 1) & 1]);
             if constexpr (ss == 0) cp_load_b((stage + 1) % kStages);
@@ -787,8 +789,7 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
             S2S_LDS_BARRIER();
             fetch(par ^ 1, 0, fr[(s + 1) & 1]);
         }
-        // next tile: per-pair loads at slot 0, context under slot 4, then its four first-layer rows
-        if constexpr (s == 0) nraw = setup_a(has_next ? wt_next : wt);
+        // next tile: per-pair loads under slot 0, context under slot 4, then its four first-layer rows
         if constexpr (s == 30) out_rsrc(wt);
         if constexpr (s == 5) row_load8(nxt.ra, g1, 0);
         if constexpr (s == 6) row_load8(nxt.ra, g1, 1);
@@ -819,6 +820,7 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
         t0 = mfma_bf16(f[1], x[0], t0); t1 = mfma_bf16(f[4], x[0], t1);
         t0 = mfma_bf16(f[0], x[1], t0); t1 = mfma_bf16(f[3], x[1], t1);
         t0 = mfma_bf16(f[0], x[0], t0); t1 = mfma_bf16(f[3], x[0], t1);
+        if constexpr (s == 0) nraw = setup_a(has_next ? wt_next : wt);
         if constexpr (s == 4) nxt = setup_b(nraw);
         if constexpr (s == 12) row_add(1.0f);     // a + b   (same association as the fp32 kernel: ((a + b) + r) + kb k)
         if constexpr (s == 17) row_add(1.0f);     // + relative-position row
@@ -848,7 +850,7 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sum += a3[t][r];
-            ln_mean = xhalf_sum(sum) * (1.0f / 128);
+            ln_mean = __fmul_rn(xhalf_sum(sum), 1.0f / 128);
             float var = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -857,11 +859,11 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
                     const float dd = a3[t][r] - ln_mean;
                     var = __fmaf_rn(dd, dd, var);
                 }
-            ln_rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / 128) + ln_eps);
+            ln_rstd = 1.0f / sqrtf(__fmaf_rn(xhalf_sum(var), 1.0f / 128, ln_eps));
             if constexpr (PROJ) {
                 ln_piece(IC<0>{}, cur);
             } else {
-                static_for<0, 8>([&](auto kc) { ln_piece(kc, cur); });
+                static_for<0, 8>([&](auto kc) { ln_load(kc); ln_piece(kc, cur); });
             }
         }
     });
@@ -941,25 +943,39 @@ extern "C" int s2s_edge_embed_bf16x6(const float* node_a, const float* node_b, c
                                      const float* ln_beta, const float* mask, float* out, int n_samples, int n_res,
                                      int rel_offset, int n_rel, int n_bins, float ln_eps, const float* proj_bias_cat64,
                                      float* proj_attn_bias, float* proj_pair_z, void* stream) {
-    const long long M = (long long)n_samples * n_res * n_res;
-    if (M <= 0) return 0;
-    if (n_bins > 64) return (int)hipErrorInvalidValue;  // the distogram edges are staged in a 64-entry LDS table
-    // the column-blocked tables are read through 32-bit buffer offsets
-    if ((long long)n_samples * n_res * 512 >= (1ll << 32) || (long long)n_rel * 512 >= (1ll << 32)) return (int)hipErrorInvalidValue;
-    const long long wg_tiles = (M + 127) / 128;
+    if (n_samples <= 0 || n_res <= 0) return 0;
+    if (n_bins > 32) return (int)hipErrorInvalidValue;  // the distogram edges are counted from a 32-entry LDS table
+    // 32-bit pair indices and buffer offsets inside a launch: split the samples over several launches when needed
+    const long long NN = (long long)n_res * n_res;
+    if (NN >= (1ll << 31) || (long long)n_rel * 512 >= (1ll << 32)) return (int)hipErrorInvalidValue;
+    long long chunk = ((1ll << 31) - 1) / NN;
+    const long long rows_cap = ((1ll << 32) - 1) / ((long long)n_res * 512);  // node_b descriptor
+    if (rows_cap < chunk) chunk = rows_cap;
+    if (chunk < 1) return (int)hipErrorInvalidValue;
     int n_cu = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
         n_cu = 256;
-    const long long grid = wg_tiles < n_cu ? wg_tiles : n_cu;
-    if (proj_attn_bias)
-        hipLaunchKernelGGL(edge_embed_bf16_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, node_a, node_b,
-                           rel_table, bin_table, bin_lower, residue_idx, ca_xyz, (const char*)weight_stream, b2, b3, ln_gamma,
-                           ln_beta, mask, out, M, n_res, rel_offset, n_rel, n_bins, ln_eps, proj_bias_cat64, proj_attn_bias,
-                           proj_pair_z);
-    else
-        hipLaunchKernelGGL(edge_embed_bf16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, node_a, node_b,
-                           rel_table, bin_table, bin_lower, residue_idx, ca_xyz, (const char*)weight_stream, b2, b3, ln_gamma,
-                           ln_beta, mask, out, M, n_res, rel_offset, n_rel, n_bins, ln_eps, (const float*)nullptr,
-                           (float*)nullptr, (float*)nullptr);
+    for (long long b0 = 0; b0 < n_samples; b0 += chunk) {
+        const long long nb = n_samples - b0 < chunk ? n_samples - b0 : chunk;
+        const long long M = nb * NN, rows0 = b0 * n_res;
+        const long long wg_tiles = (M + 127) / 128;
+        const long long grid = wg_tiles < n_cu ? wg_tiles : n_cu;
+        const float* na = node_a + rows0 * 128;
+        const float* nbp = node_b + rows0 * 128;
+        const long long* ridx = residue_idx + rows0;
+        const float* cap = ca_xyz + rows0 * 3;
+        const float* mk = mask ? mask + rows0 : nullptr;
+        float* o = out + b0 * NN * 128;
+        if (proj_attn_bias)
+            hipLaunchKernelGGL(edge_embed_bf16_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, na, nbp,
+                               rel_table, bin_table, bin_lower, ridx, cap, (const char*)weight_stream, b2, b3, ln_gamma, ln_beta,
+                               mk, o, M, n_res, rel_offset, n_rel, n_bins, ln_eps, proj_bias_cat64,
+                               proj_attn_bias + b0 * 8 * NN, proj_pair_z + b0 * NN * 32);
+        else
+            hipLaunchKernelGGL(edge_embed_bf16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, na, nbp,
+                               rel_table, bin_table, bin_lower, ridx, cap, (const char*)weight_stream, b2, b3, ln_gamma, ln_beta,
+                               mk, o, M, n_res, rel_offset, n_rel, n_bins, ln_eps, (const float*)nullptr, (float*)nullptr,
+                               (float*)nullptr);
+    }
     return (int)hipGetLastError();
 }
