@@ -755,6 +755,7 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
     };
     S2S_LDS_BARRIER();
     fetch(0, 0, fr[0]);
+    f32x16 initA0 = bias16(s_vec, 0), initA1 = bias16(s_vec, 1), initB0, initB1;
 
 #ifdef S2S_ET_PROBE
     int probe_it = 0;
@@ -765,7 +766,6 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
     Ctx nxt = cur;
     Raw nraw;
     bf16x8 xl[3];  // the next tile's last k-step (xp[7] is read by the final layer's last slot)
-    f32x16 init0, init1;
     static_for<0, kSlots>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         constexpr int stage = s / 8, ss = s % 8, par = stage & 1;
@@ -776,10 +776,11 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
         if (probe_it == 3) PROBE(300 + s);
 #endif
         // ---------------- top of the slot: LDS / global loads whose results are used under later MFMAs
-        if constexpr (layer < 2 && ks == 0) {  // this slot's two accumulators start from the bias
-            init0 = bias16(s_vec + 128 * layer, 2 * pr);
-            init1 = bias16(s_vec + 128 * layer, 2 * pr + 1);
-        }
+        // the accumulators of a layer's first two slots start from the bias, read one slot ahead (A: slots 0 / 16, B: 1 / 17)
+        if constexpr (s == kSlots - 1) { initA0 = bias16(s_vec, 0); initA1 = bias16(s_vec, 1); }
+        if constexpr (s == 0) { initB0 = bias16(s_vec, 2); initB1 = bias16(s_vec, 3); }
+        if constexpr (s == 15) { initA0 = bias16(s_vec + 128, 0); initA1 = bias16(s_vec + 128, 1); }
+        if constexpr (s == 16) { initB0 = bias16(s_vec + 128, 2); initB1 = bias16(s_vec + 128, 3); }
         if constexpr (PROJ && s >= 31 && s < 39) ln_load(IC<s - 31>{});
         if constexpr (ss < 7) {
             fetch(par, ss + 1, fr[(s + 1) & 1]);
@@ -808,7 +809,7 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
         f32x16& t1 = layer == 0 ? a2[2 * pr + 1] : (layer == 1 ? a3[2 * pr + 1] : pq[1]);
         if constexpr (ks == 0) {
             if constexpr (layer < 2) {
-                t0 = mfma_bf16(f[2], x[0], init0); t1 = mfma_bf16(f[5], x[0], init1);
+                t0 = mfma_bf16(f[2], x[0], pr == 0 ? initA0 : initB0); t1 = mfma_bf16(f[5], x[0], pr == 0 ? initA1 : initB1);
             } else {
                 t0 = mfma_bf16(f[2], x[0], zero16); t1 = mfma_bf16(f[5], x[0], zero16);
             }
@@ -825,8 +826,9 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
         if constexpr (s == 12) row_add(1.0f);     // a + b   (same association as the fp32 kernel: ((a + b) + r) + kb k)
         if constexpr (s == 17) row_add(1.0f);     // + relative-position row
         if constexpr (s == 22) row_add(nxt.kb);   // + distogram row
-        // layer-2 output, k-step k (read by slots 16 + 2k, 17 + 2k) under slot 14 + 2k; k-step 0 is exposed after slot 15
+        // layer-2 output, k-step k (read by slots 16 + 2k, 17 + 2k) under slot 14 + 2k, k-step 0 under slot 15
         if constexpr (s >= 16 && s <= 28 && s % 2 == 0) l2_piece(IC<(s - 14) / 2>{});
+        if constexpr (s == 15) l2_piece(IC<0>{});   // tiles 0, 1 of the layer-2 output are complete after slot 14
         // next tile's first layer: k-step k of xp is last read by slot 17 + 2k, so k = 0..6 go under slots 24..30 and the
         // last one (under slot 23) into xl
         if constexpr (s >= 24 && s < 31) { g1_split(xp[s - 24], s - 24); pin_frag(xp[s - 24]); }
@@ -843,7 +845,6 @@ __global__ void __launch_bounds__(256) edge_embed_bf16_kernel(
         __builtin_amdgcn_sched_barrier(0);
 
         // ---------------- exposed steps
-        if constexpr (s == 15) l2_piece(IC<0>{});
         if constexpr (s == 31) {  // layer-3 output (bias included): LayerNorm statistics
             float sum = 0.f;
 #pragma unroll

@@ -19,8 +19,9 @@ with torch.no_grad():
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(10):
+    iters = int(os.environ.get("EE_ITERS", "10"))
+    for _ in range(iters):
         run()
     e1.record()
     torch.cuda.synchronize()
-print(os.environ.get("STR2STR_HIP_LIB", "main").split("/")[-1], "embedder ms:", round(e0.elapsed_time(e1) / 10, 3))
+print(os.environ.get("STR2STR_HIP_LIB", "main").split("/")[-1], "embedder ms:", round(e0.elapsed_time(e1) / iters, 3))
