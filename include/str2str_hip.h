@@ -56,6 +56,16 @@ int s2s_edge_transition_bf16x6(const float* edge, const float* node_ab, const fl
                                const float* mask, float* out, int n_samples, int n_res, float ln_eps,
                                const float* proj_bias_cat64, float* proj_attn_bias, float* proj_pair_z, void* stream);
 
+/* The same operator on split-f16 MFMA ("f16x3", csrc/pair_mlp_f16.hip): every fp32 operand as two f16 numbers (11 + 11 bits + the
+ * residue's sign = fp32's 24), products w_h x_h + w_h x_l + w_l x_h with exact 2^+-5 scalings of the small factors, fp32
+ * accumulation -- three matrix instructions per block instead of six, the dropped w_l x_l below one fp32 rounding as in bf16x6.
+ * Activations must stay below f16's 65504.  weight_stream: 30 (+1 with the fused projection) stages x 32 KiB of f16 A fragments
+ * (W_h, W_ls) in slot order (ops.pack_f16x3_stream, ops.pack_f16x2_layer for the projection stage). */
+int s2s_edge_transition_f16x3(const float* edge, const float* node_ab, const float* node_p, const void* weight_stream,
+                              const float* b2, const float* bf, const float* ln_gamma, const float* ln_beta,
+                              const float* mask, float* out, int n_samples, int n_res, float ln_eps,
+                              const float* proj_bias_cat64, float* proj_attn_bias, float* proj_pair_z, void* stream);
+
 /* EmbeddingModule.forward, edge branch (src/models/net/denoising_ipa.py:137-158, calc_distogram
  * src/common/geo_utils.py:44-56) + edge-mask multiply (denoising_ipa.py:187).
  *   node_a/node_b [B,N,128]: row / column parts of the first Linear (incl. bias in node_a)

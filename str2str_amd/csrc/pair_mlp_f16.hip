@@ -1,0 +1,441 @@
+// EdgeTransition on split-f16 MFMA ("f16x3"): the schedule of csrc/pair_mlp_bf16.hip (same slots, phases, weight pipe, persistent
+// workgroups -- read its header first) with HALF the matrix instructions per slot and TWO THIRDS of the weight fragments.
+//
+// Every fp32 operand is split into two f16 numbers  x = x_h + x_l (+ <= 2^-24 |x|),  x_h = rn16(x), x_l = rn16(x - x_h)  --
+// 11 + 11 significant bits plus the sign of the residue, i.e. fp32's 24 -- and a product keeps  w_h x_h + w_h x_l + w_l x_h  (the
+// dropped w_l x_l is below one fp32 rounding of the product, like the plane pairs bf16x6 drops) on v_mfma_f32_32x32x16_f16 with
+// fp32 accumulation: 3 MFMAs per (k-step, tile) instead of 6.  f16's narrow exponent is handled by exact power-of-two scalings
+// of the small factors: the weight side stores  W_h, W_ls = rn16(2^5 w_l)  (2 A fragments per (k-step, tile), 4 KiB per slot,
+// 32 KiB stages, 0.94 MB stream), the activation side keeps three plane registers  x_h, x_l, x_hs = 2^-5 x_h  and the products
+// are  W_h x_h + W_h x_l + W_ls x_hs.  A value of x_l below f16's normal range (|x| < 0.25) is rounded to 2^-25 absolute --
+// 1.7e-8 rms on an O(1) output, under fp32's own rounding; activations must stay below f16's 65504 (they are LayerNorm
+// outputs and one hidden layer away from them).  The parity suite runs this mode against the same oracle and tolerances.
+#include <hip/hip_runtime.h>
+
+#include "str2str_hip.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kStageBytes = 32 * 1024;  // 8 slots x 4 fragments x 1 KiB
+constexpr int kStagesBase = 30;         // + 1 stage (8 slots) for the fused pair projection of the next IPA block
+
+__device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float4 ldg4(const float* __restrict__ base, int g, int h) {
+    return *reinterpret_cast<const float4*>(base + 8 * g + 4 * h);
+}
+__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+template <int I> struct IC { static constexpr int value = I; };
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(IC<B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// slot s of the schedule: phase 0 = A (layer 1), 1 = B (layer 2), 2 = F (final layer)
+struct SlotDesc { int phase, t, a, b; };  // A: tile t, a = k-step pair 0..3;  B: tile t, a = u (k-step 2t+u), b = tile pair 0..5;
+                                          // F: a = k-step 0..23, b = tile pair 0..1
+constexpr SlotDesc slot_desc(int s) {
+    if (s < 8) return {0, s / 4, s % 4, 0};
+    if (s < 168) {
+        const int tau = s - 8, blk = tau / 16, o = tau % 16;
+        if (o < 12) return {1, blk, o / 6, o % 6};
+        return {0, blk + 2, o - 12, 0};
+    }
+    if (s < 192) {
+        const int tau = s - 168;
+        return {1, 10 + tau / 12, (tau % 12) / 6, tau % 6};
+    }
+    if (s < 240) return {2, 0, (s - 192) / 2, (s - 192) % 2};
+    return {3, 0, s - 240, 0};  // P: fused projection k-step s - 240 (both output tiles)
+}
+
+#define S2S_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// PROJ: the next IPA block's linear_b / down_z fused as a 31st weight stage (see pair_mlp_bf16.hip)
+template <bool PROJ>
+__global__ void __launch_bounds__(256) edge_transition_f16_kernel(
+    const float* __restrict__ edge, const float* __restrict__ node_ab, const float* __restrict__ node_p,
+    const char* __restrict__ wblob, const float* __restrict__ b2, const float* __restrict__ bf,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask,
+    float* __restrict__ out, long long M, int N, float ln_eps, const float* __restrict__ proj_b,
+    float* __restrict__ proj_bias_out, float* __restrict__ proj_pz_out) {
+    constexpr int kStages = kStagesBase + (PROJ ? 1 : 0);
+    constexpr int kSlots = 8 * kStages;
+    __shared__ __attribute__((aligned(16))) char s_w[2][kStageBytes];
+    __shared__ __attribute__((aligned(16))) float s_vec[768 + 64];  // b2 | bf | gamma | beta | projection bias
+    const int lane = threadIdx.x & 63, h = lane >> 5, wave = threadIdx.x >> 6;
+
+    // ---- weight pipe (see header).  Each wave moves one contiguous 12 KiB of every stage.
+    const unsigned voff = wave * 8192 + lane * 16;
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* lds_image[2] = {(lds_char*)&s_w[0][lane * 16], (lds_char*)&s_w[1][lane * 16]};
+    asm volatile("" : "+v"(lds_image[0]), "+v"(lds_image[1]));  // opaque: every LDS access = base register + immediate
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wblob, 0, kStages * kStageBytes, 0x00020000);
+    auto ldw = [&](unsigned vo, int so) -> f32x4 {
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, vo, so, 0);
+        return f32x4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+    };
+    // scalars on purpose: an array captured by the lambdas is demoted to memory by hipcc
+    f32x4 c0, c1, c2, c3;  // staging group A (first half of the quarter)
+    f32x4 e0, e1, e2, e3;  // staging group B (second half)
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    auto cp_load_a = [&](int stage) {
+        const int so = stage * kStageBytes;  // compile-time at every call site
+        c0 = ldw(voff, so); c1 = ldw(voff + 1024, so); c2 = ldw(voff + 2048, so); c3 = ldw(voff + 3072, so);
+    };
+    auto cp_load_b = [&](int stage) {
+        const int so = stage * kStageBytes + 4096;
+        e0 = ldw(voff, so); e1 = ldw(voff + 1024, so); e2 = ldw(voff + 2048, so); e3 = ldw(voff + 3072, so);
+    };
+    auto cp_store_a = [&](int par) {
+        lds_char* d = lds_image[par] + wave * 8192;
+        *(lds_f4*)(d) = c0; *(lds_f4*)(d + 1024) = c1; *(lds_f4*)(d + 2048) = c2; *(lds_f4*)(d + 3072) = c3;
+    };
+    auto cp_store_b = [&](int par) {
+        lds_char* d = lds_image[par] + (wave * 8192 + 4096);
+        *(lds_f4*)(d) = e0; *(lds_f4*)(d + 1024) = e1; *(lds_f4*)(d + 2048) = e2; *(lds_f4*)(d + 3072) = e3;
+    };
+    cp_load_a(0);
+    cp_load_b(0);
+
+    // ---- persistent workgroup: tiles of 128 pairs (32 per wave) blockIdx.x, blockIdx.x + gridDim.x, ...
+    struct PairCtx {
+        const float *erow, *arow, *brow, *npi, *npj;
+        float* orow;
+        long long p, boff;  // flat pair index; offset of head 0 of this pair in a head-major [B,8,N,N] tensor
+        float em;
+        bool valid;
+    };
+    const long long NN = (long long)N * N;
+    auto setup = [&](long long wg_tile) -> PairCtx {
+        long long p = (wg_tile * 4 + wave) * 32 + (lane & 31);
+        PairCtx c;
+        c.valid = p < M;
+        if (!c.valid) p = M - 1;  // waves / lanes past the end run on the last pair and store nothing
+        const long long bb = p / NN;
+        const long long rem = p - bb * NN;
+        const long long bi = bb * N + rem / N, bj = bb * N + rem % N;
+        c.erow = edge + p * 128;
+        c.arow = node_ab + bi * 768;        // A_i + b1, 384 channels
+        c.brow = node_ab + bj * 768 + 384;  // B_j
+        c.npi = node_p + bi * 128;
+        c.npj = node_p + bj * 128;
+        c.orow = out + p * 128;
+        c.p = p;
+        c.boff = p + 7 * bb * NN;
+        c.em = mask ? mask[bi] * mask[bj] : 1.0f;
+        return c;
+    };
+    const long long n_wt = (M + 127) / 128;
+    long long wt = blockIdx.x;
+    PairCtx cur = setup(wt);
+
+    // ---- the pair's 128 edge channels, split once: xpl[ks][plane] = B operand of layer-1 k-step ks.  Element j of k-step
+    //      2t+u is channel 32t + 8(2u + (j>>2)) + 4h + (j&3): the accumulator layout of a 128-channel block (register 8u+j of
+    //      tile t), so the exact sum of the three planes later serves as the residual row of block 0 without a second read.
+    f16x8 xpl[8][3];
+    // planes (x_h, x_l, x_hs = 2^-5 x_h), see the header
+    auto split4 = [&](const float (&x)[4], f16x8& ph, f16x8& pm, f16x8& pl, int at) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const _Float16 a = (_Float16)x[j];
+            const float r1 = x[j] - (float)a;
+            ph[at + j] = a; pm[at + j] = (_Float16)r1; pl[at + j] = a * (_Float16)0.03125f;
+        }
+    };
+    {
+        float4 xv[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) xv[i] = ldg4(cur.erow, i, h);  // accumulator ("chain") channel order, see xpl
+        for (int i = threadIdx.x; i < 768; i += 256)
+            s_vec[i] = i < 384 ? b2[i] : (i < 512 ? bf[i - 384] : (i < 640 ? gamma[i - 512] : beta[i - 640]));
+        if (PROJ && threadIdx.x < 64) s_vec[768 + threadIdx.x] = proj_b[threadIdx.x];
+        cp_store_a(0);
+        cp_load_a(1);
+        cp_store_b(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float x[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+            split4(x, xpl[i >> 1][0], xpl[i >> 1][1], xpl[i >> 1][2], 4 * (i & 1));
+        }
+    }
+
+    f32x16 a1t[2];     // layer-1 tiles t (even / odd)
+    f32x16 a2[12];     // layer-2 accumulators, then relu(.)+residual = the final layer's input
+    f32x16 a3[4];
+    f32x16 pq[2];      // fused projection accumulators (64 padded output rows)
+    float sa[16], sb[16];  // per-node seeds A_i(+b1), B_j of the a1 tile that is split next
+    auto seeds_load = [&](const PairCtx& c, int t) {  // C layout of tile t: register 4rq + e = channel 32t + 8rq + 4h + e
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const float4 x = ldg4(c.arow + 32 * t, rq, h), y = ldg4(c.brow + 32 * t, rq, h);
+            sa[4 * rq + 0] = x.x; sa[4 * rq + 1] = x.y; sa[4 * rq + 2] = x.z; sa[4 * rq + 3] = x.w;
+            sb[4 * rq + 0] = y.x; sb[4 * rq + 1] = y.y; sb[4 * rq + 2] = y.z; sb[4 * rq + 3] = y.w;
+        }
+    };
+    seeds_load(cur, 0);
+
+    f16x8 fr[2][4];  // A fragments of the current / next slot: (W_h, W_ls) of two (k-step, tile) units
+    f16x8 xp[2][3];  // layer 2: planes of k-steps 2t, 2t+1 of the current a1 tile; final layer: current / next k-step
+    auto fetch = [&](int par, int slot_in_stage, f16x8 (&f)[4]) {
+        typedef __attribute__((address_space(3))) f16x8 lds_frag;
+        const lds_frag* s = (const lds_frag*)lds_image[par] + slot_in_stage * 4 * 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f[k] = s[64 * k];
+    };
+    // quarter qd (registers 4qd..4qd+3) of  relu(a1 tile + seeds)  -> planes of k-step qd>>1, elements 4(qd&1)..
+    auto s_quarter = [&](const f32x16& tile_acc, auto qc) {
+        constexpr int qd = decltype(qc)::value;
+        float x[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = fmaxf(tile_acc[4 * qd + j] + sa[4 * qd + j] + sb[4 * qd + j], 0.f);
+        split4(x, xp[qd >> 1][0], xp[qd >> 1][1], xp[qd >> 1][2], 4 * (qd & 1));
+    };
+    float rs[64];  // one 128-channel residual row in accumulator layout
+    auto row_load = [&](const float* r) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float4 v = ldg4(r, g, h);
+            rs[4 * g + 0] = v.x; rs[4 * g + 1] = v.y; rs[4 * g + 2] = v.z; rs[4 * g + 3] = v.w;
+        }
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    S2S_LDS_BARRIER();  // stage 0 and s_vec are in LDS
+    fetch(0, 0, fr[0]);
+
+    auto ln_epilogue = [&]() {
+    // ---- + bf, LayerNorm(128) over the pair's channels (half here, half in lane^32), edge mask, store
+    const float em = cur.em;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const float4 bq = ldg4(s_vec + 384, 4 * t + rq, h);
+            a3[t][4 * rq + 0] += bq.x; a3[t][4 * rq + 1] += bq.y; a3[t][4 * rq + 2] += bq.z; a3[t][4 * rq + 3] += bq.w;
+        }
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += a3[t][r];
+    const float mean = xhalf_sum(sum) * (1.0f / 128);
+    float var = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float dd = a3[t][r] - mean;
+            var += dd * dd;
+        }
+    const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / 128) + ln_eps);
+    float* orow = cur.orow;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int g = 4 * t + rq;
+            const float4 ga = ldg4(s_vec + 512, g, h), be = ldg4(s_vec + 640, g, h);
+            float4 o;
+            o.x = ((a3[t][4 * rq + 0] - mean) * rstd * ga.x + be.x) * em;
+            o.y = ((a3[t][4 * rq + 1] - mean) * rstd * ga.y + be.y) * em;
+            o.z = ((a3[t][4 * rq + 2] - mean) * rstd * ga.z + be.z) * em;
+            o.w = ((a3[t][4 * rq + 3] - mean) * rstd * ga.w + be.w) * em;
+            if (cur.valid) *reinterpret_cast<float4*>(orow + 8 * g + 4 * h) = o;
+            a3[t][4 * rq + 0] = o.x; a3[t][4 * rq + 1] = o.y; a3[t][4 * rq + 2] = o.z; a3[t][4 * rq + 3] = o.w;  // projection input
+        }
+    };
+
+    for (;;) {
+    const long long wt_next = wt + gridDim.x;
+    const bool has_next = wt_next < n_wt;
+    PairCtx nxt = cur;  // next tile's context, edge row and planes: produced under the last 16 slots of this tile
+    float4 xv[16];
+    f16x8 xpn[8][3];
+    static_for<0, kSlots>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr SlotDesc d = slot_desc(s);
+        constexpr int stage = s / 8, ss = s % 8, par = stage & 1;
+
+        // ---------------- top of the slot: next slot's fragments, weight copy, loads that land under later slots
+        // weight pipe: group A of stage+2 is loaded at slot 4 and stored after slot 1 of the next stage (5 slots later);
+        // group B of stage+1 is loaded at slot 0 and stored after slot 5.  Both land in the buffer this stage's
+        // predecessor used, which is free from that stage's barrier (top of its slot 7) on.
+        if constexpr (ss < 7) {
+            fetch(par, ss + 1, fr[(s + 1) & 1]);
+            if constexpr (ss == 0) cp_load_b((stage + 1) % kStages);   // the pipe wraps into the next tile's stages 0, 1
+            if constexpr (ss == 4) cp_load_a((stage + 2) % kStages);
+        } else {
+            S2S_LDS_BARRIER();
+            fetch(par ^ 1, 0, fr[(s + 1) & 1]);
+        }
+        // next tile: context + edge row at the start of the last final-layer block, seeds of its tile 0 near the end
+        if constexpr (s == 224) {
+            nxt = setup(has_next ? wt_next : wt);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xv[i] = ldg4(nxt.erow, i, h);
+        }
+        if constexpr (s == 236) seeds_load(nxt, 0);
+        // seeds of a1 tile t+1 are fetched late in B_t (they are consumed under A_{t+2}, or right after B_10 for tile 11)
+        if constexpr (d.phase == 1 && d.a == 1 && d.b == 3 && d.t + 1 < 12) seeds_load(cur, d.t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---------------- the 12 MFMAs
+        const f16x8 (&f)[4] = fr[s & 1];
+        if constexpr (d.phase == 0) {
+            f32x16& acc = a1t[d.t & 1];
+            const f16x8 (&x0)[3] = xpl[2 * d.a], (&x1)[3] = xpl[2 * d.a + 1];
+            if constexpr (d.a == 0) acc = mfma_f16(f[1], x0[2], zero16); else acc = mfma_f16(f[1], x0[2], acc);  // W_ls x_hs
+            acc = mfma_f16(f[0], x0[1], acc);  // W_h x_l
+            acc = mfma_f16(f[0], x0[0], acc);  // W_h x_h
+            acc = mfma_f16(f[3], x1[2], acc);
+            acc = mfma_f16(f[2], x1[1], acc);
+            acc = mfma_f16(f[2], x1[0], acc);
+            // under A_t: relu + seeds + split of tile t-1, a quarter per slot
+            if constexpr (d.t >= 1) s_quarter(a1t[(d.t - 1) & 1], IC<d.a>{});
+        } else if constexpr (d.phase == 3) {
+            const f16x8 (&x)[3] = xpl[d.a];
+            f32x16 &t0 = pq[0], &t1 = pq[1];
+            if constexpr (d.a == 0) {
+                t0 = mfma_f16(f[1], x[2], zero16); t1 = mfma_f16(f[3], x[2], zero16);
+            } else {
+                t0 = mfma_f16(f[1], x[2], t0); t1 = mfma_f16(f[3], x[2], t1);
+            }
+            t0 = mfma_f16(f[0], x[1], t0); t1 = mfma_f16(f[2], x[1], t1);
+            t0 = mfma_f16(f[0], x[0], t0); t1 = mfma_f16(f[2], x[0], t1);
+        } else {
+            constexpr bool fin = d.phase == 2;
+            constexpr bool first = fin ? d.a == 0 : (d.t == 0 && d.a == 0);
+            f32x16& t0 = fin ? a3[2 * d.b] : a2[2 * d.b];
+            f32x16& t1 = fin ? a3[2 * d.b + 1] : a2[2 * d.b + 1];
+            const f16x8 (&x)[3] = fin ? xpl[d.a & 7] : xp[d.a];
+            if constexpr (first) {
+                t0 = mfma_f16(f[1], x[2], zero16); t1 = mfma_f16(f[3], x[2], zero16);
+            } else {
+                t0 = mfma_f16(f[1], x[2], t0); t1 = mfma_f16(f[3], x[2], t1);  // W_ls x_hs
+            }
+            t0 = mfma_f16(f[0], x[1], t0); t1 = mfma_f16(f[2], x[1], t1);  // W_h x_l
+            t0 = mfma_f16(f[0], x[0], t0); t1 = mfma_f16(f[2], x[0], t1);  // W_h x_h
+        }
+        if constexpr (s >= 228 && s < 236) {  // split of the next tile's edge row, one k-step per slot
+            constexpr int i = s - 228;
+            const float x0[4] = {xv[2 * i].x, xv[2 * i].y, xv[2 * i].z, xv[2 * i].w};
+            const float x1[4] = {xv[2 * i + 1].x, xv[2 * i + 1].y, xv[2 * i + 1].z, xv[2 * i + 1].w};
+            split4(x0, xpn[i][0], xpn[i][1], xpn[i][2], 0);
+            split4(x1, xpn[i][0], xpn[i][1], xpn[i][2], 4);
+        }
+        if constexpr (ss == 1) cp_store_a(par ^ 1);
+        if constexpr (ss == 5) cp_store_b(par ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---------------- exposed steps
+        if constexpr (s == 179) {  // B_10 done: tile 11 -> planes (nothing left to hide it under)
+            s_quarter(a1t[1], IC<0>{}); s_quarter(a1t[1], IC<1>{}); s_quarter(a1t[1], IC<2>{}); s_quarter(a1t[1], IC<3>{});
+        }
+        // Layer-2 epilogue + split, one 128-channel block (= 8 final-layer k-steps) at a time, right before the final
+        // layer consumes it:  relu(a2 + b2) + x,  x = [e | n'_i | n'_j]  (layers.py:181), in accumulator layout, split
+        // while the values are in VGPRs into the plane registers the edge row used during layers 1-2.
+        if constexpr (PROJ && s == 239) {
+            // LayerNorm output (stored, and kept in a3) -> planes of the 8 projection k-steps (chain order)
+            ln_epilogue();
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const float x[4] = {a3[t][4 * rq + 0], a3[t][4 * rq + 1], a3[t][4 * rq + 2], a3[t][4 * rq + 3]};
+                    split4(x, xpl[2 * t + (rq >> 1)][0], xpl[2 * t + (rq >> 1)][1], xpl[2 * t + (rq >> 1)][2], 4 * (rq & 1));
+                }
+        }
+        if constexpr (s == 191 || s == 207 || s == 223) {
+            constexpr int pb = (s - 191) / 16;
+            if constexpr (pb == 0) {  // residual block 0 = the edge row itself = x_h + x_l of its planes (to 2^-24 |x|)
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        rs[8 * ks + j] = (float)xpl[ks][0][j] + (float)xpl[ks][1][j];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const float4 bq = ldg4(s_vec + 128 * pb, 4 * t + rq, h);
+                    const f32x16& a = a2[4 * pb + t];
+                    const float x[4] = {fmaxf(a[4 * rq + 0] + bq.x, 0.f) + rs[16 * t + 4 * rq + 0],
+                                        fmaxf(a[4 * rq + 1] + bq.y, 0.f) + rs[16 * t + 4 * rq + 1],
+                                        fmaxf(a[4 * rq + 2] + bq.z, 0.f) + rs[16 * t + 4 * rq + 2],
+                                        fmaxf(a[4 * rq + 3] + bq.w, 0.f) + rs[16 * t + 4 * rq + 3]};
+                    split4(x, xpl[2 * t + (rq >> 1)][0], xpl[2 * t + (rq >> 1)][1], xpl[2 * t + (rq >> 1)][2], 4 * (rq & 1));
+                }
+            if constexpr (pb < 2) row_load(pb == 0 ? cur.npi : cur.npj);  // lands under the next 16 slots
+        }
+    });
+
+    if constexpr (!PROJ) ln_epilogue();
+    if constexpr (PROJ) {
+        // rows 0..7 (+ bias) -> attention bias, head-major; rows 8..39 -> pair_z channel row - 8 (same map as pair_mlp.hip)
+        if (cur.valid) {
+            const float4 b0 = ldg4(s_vec + 768, 0, h);
+            float* o = proj_bias_out + cur.boff + 4 * h * NN;
+            o[0] = pq[0][0] + b0.x;
+            o[NN] = pq[0][1] + b0.y;
+            o[2 * NN] = pq[0][2] + b0.z;
+            o[3 * NN] = pq[0][3] + b0.w;
+#pragma unroll
+            for (int g = 1; g <= 4; ++g) {
+                const int t = g >> 2, rq = g & 3;
+                const float4 bq = ldg4(s_vec + 768, g, h);
+                *reinterpret_cast<float4*>(proj_pz_out + cur.p * 32 + 8 * (g - 1) + 4 * h) =
+                    make_float4(pq[t][4 * rq + 0] + bq.x, pq[t][4 * rq + 1] + bq.y, pq[t][4 * rq + 2] + bq.z, pq[t][4 * rq + 3] + bq.w);
+            }
+        }
+    }
+    if (!has_next) break;
+    cur = nxt;
+    wt = wt_next;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { xpl[i][0] = xpn[i][0]; xpl[i][1] = xpn[i][1]; xpl[i][2] = xpn[i][2]; }
+    if constexpr (kStages % 2 == 1) {  // odd stage count: the next tile's stage 0 sits in the other buffer
+        lds_char* sw = lds_image[0];
+        lds_image[0] = lds_image[1];
+        lds_image[1] = sw;
+    }
+    }  // persistent tile loop
+}
+
+}  // namespace
+
+extern "C" int s2s_edge_transition_f16x3(const float* edge, const float* node_ab, const float* node_p,
+                                         const void* weight_stream, const float* b2, const float* bf,
+                                         const float* ln_gamma, const float* ln_beta, const float* mask, float* out,
+                                         int n_samples, int n_res, float ln_eps, const float* proj_bias_cat64,
+                                         float* proj_attn_bias, float* proj_pair_z, void* stream) {
+    const long long M = (long long)n_samples * n_res * n_res;
+    if (M <= 0) return 0;
+    const long long wg_tiles = (M + 127) / 128;
+    static int n_cu = 0;  // persistent workgroups, one per CU
+    if (n_cu == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+            n_cu = 256;
+    }
+    const long long grid = wg_tiles < n_cu ? wg_tiles : n_cu;
+    if (proj_attn_bias)
+        hipLaunchKernelGGL(edge_transition_f16_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, edge, node_ab,
+                           node_p, (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mask, out, M, n_res, ln_eps,
+                           proj_bias_cat64, proj_attn_bias, proj_pair_z);
+    else
+        hipLaunchKernelGGL(edge_transition_f16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, edge, node_ab,
+                           node_p, (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mask, out, M, n_res, ln_eps,
+                           (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    return (int)hipGetLastError();
+}

@@ -178,13 +178,13 @@ class EmbeddingModule(nn.Module):
                                                          post_mask=None if mask is None else mask.reshape(M), want_xp=True)
         node_embed = node_embed.view(B, L, -1)
         node_a = (tl(w["w_row_t"], w["b0"])[:, None, :] + fixed * w["w_row_f"]).expand(B, L, -1).contiguous()
-        if self.mfma_mode == "bf16x6":  # column part straight in the kernel's gather layout [B, 32 chunks, L, 4]
+        if self.mfma_mode != "f32":  # column part straight in the kernel's gather layout [B, 32 chunks, L, 4]
             node_b = (tl(w["w_col_t"]).view(-1, 32, 1, 4) + fixed[:, None] * w["w_col_f"].view(1, 32, 1, 4)).expand(B, 32, L, 4).contiguous()
         else:
             node_b = (tl(w["w_col_t"])[:, None, :] + fixed * w["w_col_f"]).expand(B, L, -1).contiguous()
         ca = self_conditioning_ca.to(dev).float().contiguous() if self.self_conditioning else t_emb.new_zeros(B, L, 3)
         e2, e4, ln = self.edge_embed[2], self.edge_embed[4], self.edge_embed[5]
-        if self.mfma_mode == "bf16x6":
+        if self.mfma_mode != "f32":   # ("f16x3" only exists for the edge transition: the embedding stays on bf16x6)
             proj = None
             if next_proj is not None:  # 5-stage stream: W2 | W3 | the first IPA block's projection stage
                 stream = self._proj_cache.get([w["wstream"], next_proj[2]], lambda: torch.cat([w["wstream"], next_proj[2]]))

@@ -56,7 +56,8 @@ class InvariantPointAttention(nn.Module):
             wcat64 = wcat.new_zeros(64, wcat.shape[1])
             wcat64[: wcat.shape[0]] = wcat
             return {"wp": ops.pack_weight(wcat), "b64": b64.contiguous(), "hw": hw.contiguous(),
-                    "wp_bf16x3": ops.pack_bf16x3_layer(wcat64, "chain").reshape(-1).view(torch.int16).contiguous()}
+                    "wp_bf16x3": ops.pack_bf16x3_layer(wcat64, "chain").reshape(-1).view(torch.int16).contiguous(),
+                    "wp_f16x2": ops.pack_f16x2_layer(wcat64, "chain").reshape(-1).view(torch.int16).contiguous()}
 
         return self._cache.get([self.linear_b.weight, self.linear_b.bias, self.down_z.weight, self.down_z.bias,
                                 self.head_weights], build)
@@ -112,7 +113,7 @@ class InvariantPointAttention(nn.Module):
         """(packed [linear_b; down_z] weight, bias64, the same matrix as one bf16x3 weight stage): what a pair-stream
         producer needs to emit this block's attention bias / pair_z in its own epilogue."""
         d = self._derived()
-        return d["wp"], d["b64"], d["wp_bf16x3"]
+        return d["wp"], d["b64"], d["wp_bf16x3"], d["wp_f16x2"]
 
     def forward(self, s: torch.Tensor, z: torch.Tensor, r, mask: torch.Tensor, _rigids7: Optional[torch.Tensor] = None,
                 _pair_proj=None):

@@ -107,8 +107,9 @@ class EdgeTransition(nn.Module):
         # fp32 accumulation — dropped products below one fp32 rounding, i.e. fp32-equivalent (csrc/pair_mlp_bf16.hip), 1.7x faster.
         # "f32": v_mfma_f32_32x32x2_f32 (csrc/pair_mlp.hip).  Both pass the same parity suite.
         self.mfma_mode = os.environ.get("S2S_EDGE_MFMA", "bf16x6")
-        if self.mfma_mode not in ("bf16x6", "f32"):
-            raise ValueError(f"S2S_EDGE_MFMA={self.mfma_mode!r}: expected 'bf16x6' or 'f32'")
+        # "f16x3": two-way f16 split, three products per block (csrc/pair_mlp_f16.hip); the embedder treats it as "bf16x6".
+        if self.mfma_mode not in ("bf16x6", "f16x3", "f32"):
+            raise ValueError(f"S2S_EDGE_MFMA={self.mfma_mode!r}: expected 'bf16x6', 'f16x3' or 'f32'")
 
     def _packed(self):
         w1, w2, wf = self.trunk[0], self.trunk[2], self.final_layer
@@ -121,6 +122,7 @@ class EdgeTransition(nn.Module):
                 "wfp": ops.pack_weight(wf.weight.float(), tile_major=True),
                 # node halves of layer 1: [W1[:, ce:ce+cb] ; W1[:, ce+cb:]] applied to n' (+ b1 on the row part)
                 "wstream": ops.pack_bf16x3_stream(w1.weight[:, :ce].float(), w2.weight.float(), wf.weight.float()),
+                "wstream_f16": ops.pack_f16x3_stream(w1.weight[:, :ce].float(), w2.weight.float(), wf.weight.float()),
                 "w_ab": torch.cat([w1.weight[:, ce:ce + self._shape[1]], w1.weight[:, ce + self._shape[1]:]], dim=0).float().contiguous(),
                 "b_ab": torch.cat([w1.bias, torch.zeros_like(w1.bias)]).float().contiguous(),
             }
@@ -143,6 +145,14 @@ class EdgeTransition(nn.Module):
             raise ops.HipLibraryError(f"EdgeTransition kernel is built for c_z=128, c_s=256 (got {self._shape})")
         pk = self._packed()
         mask = None if edge_mask_1d is None else edge_mask_1d.type(torch.float32).contiguous()
+        if self.mfma_mode == "f16x3":
+            proj = None
+            if next_proj is not None:
+                stream = self._proj_cache.get([pk["wstream_f16"], next_proj[3]], lambda: torch.cat([pk["wstream_f16"], next_proj[3]]))
+                proj = (stream, next_proj[1])
+            return ops.edge_transition_f16x3(edge_embed.contiguous(), node_ab, n_p, pk["wstream_f16"], self.trunk[2].bias,
+                                             self.final_layer.bias, self.layer_norm.weight, self.layer_norm.bias, mask,
+                                             self.layer_norm.eps, proj=proj)
         if self.mfma_mode == "bf16x6":
             proj = None
             if next_proj is not None:  # 31-stage stream: this layer's 30 stages + the next block's projection stage

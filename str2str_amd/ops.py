@@ -27,6 +27,7 @@ _SIGNATURES = {
     "s2s_abi_version": [],
     "s2s_edge_transition": [_vp] * 12 + [_i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "s2s_edge_transition_bf16x6": [_vp] * 10 + [_i, _i, _f, _vp, _vp, _vp, _vp],
+    "s2s_edge_transition_f16x3": [_vp] * 10 + [_i, _i, _f, _vp, _vp, _vp, _vp],
     "s2s_edge_embed": [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "s2s_edge_embed_bf16x6": [_vp] * 14 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "s2s_pair_project": [_vp] * 5 + [_i, _i, _vp],
@@ -166,7 +167,7 @@ def split_bf16x3(w: torch.Tensor):
     return h, m, l
 
 
-def pack_bf16x3_layer(w: torch.Tensor, kind: str) -> torch.Tensor:
+def pack_bf16x3_layer(w: torch.Tensor, kind: str, _fp32_fragments: bool = False) -> torch.Tensor:
     """[Mout, K] fp32 -> bf16 fragments [K/16 k-steps][Mout/32 tiles][3 planes][64 lanes][8] for
     v_mfma_f32_32x32x16_bf16 A operands.  Element j of lane (m, g) in k-step ks is W[32t+m][k(ks,g,j)] with
       kind "row"  : k = 16*ks + 8*g + j                                   (B operand read from a memory row)
@@ -188,6 +189,8 @@ def pack_bf16x3_layer(w: torch.Tensor, kind: str) -> torch.Tensor:
         raise ValueError(kind)
     wg = w.float()[:, lab.to(w.device)]  # [Mout, KS, 2, 8]
     wg = wg.reshape(T, 32, KS, 2, 8).permute(2, 0, 3, 1, 4).reshape(KS, T, 64, 8)  # lane = 32*g + m
+    if _fp32_fragments:
+        return wg.contiguous()
     planes = torch.stack(split_bf16x3(wg), dim=2)  # [KS, T, 3, 64, 8]
     return planes.contiguous()
 
@@ -213,7 +216,62 @@ def pack_bf16x3_stream(w1_edge: torch.Tensor, w2: torch.Tensor, wf: torch.Tensor
     return blob
 
 
+def pack_f16x2_layer(w: torch.Tensor, kind: str = "chain") -> torch.Tensor:
+    """[Mout, K] fp32 -> f16 fragments [K/16][Mout/32][2 planes (W_h, W_ls)][64][8] for v_mfma_f32_32x32x16_f16 A operands
+    (lane / element order of ``pack_bf16x3_layer``):  W_h = rn16(w),  W_ls = rn16(2^5 (w - W_h))  -- csrc/pair_mlp_f16.hip."""
+    planes = pack_bf16x3_layer(w, kind, _fp32_fragments=True)  # [KS, T, 64, 8] fp32 in fragment order
+    h = planes.to(torch.float16)
+    ls = ((planes - h.float()) * 32.0).to(torch.float16)
+    return torch.stack([h, ls], dim=2).contiguous()
+
+
+def pack_f16x3_stream(w1_edge: torch.Tensor, w2: torch.Tensor, wf: torch.Tensor) -> torch.Tensor:
+    """The weight stream of s2s_edge_transition_f16x3 as int16: the slot order of ``pack_bf16x3_stream`` with 4 fragments per
+    slot ((W_h, W_ls) of two (k-step, tile) units; 8 slots = one 32 KiB stage, 30 stages)."""
+    l1, l2, lf = pack_f16x2_layer(w1_edge), pack_f16x2_layer(w2), pack_f16x2_layer(wf)
+    A = lambda t: l1[:, t]
+    B = lambda t: l2[2 * t:2 * t + 2]
+    pieces = [A(0), A(1)]
+    for t in range(10):
+        pieces += [B(t), A(t + 2)]
+    pieces += [B(10), B(11), lf]
+    blob = torch.cat([x.contiguous().reshape(-1) for x in pieces]).view(torch.int16).contiguous()
+    assert blob.numel() * 2 == 30 * 32 * 1024, blob.numel()
+    return blob
+
+
 # ------------------------------------------------------------------------------------------ ops
+def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps=1e-5, out=None, proj=None):
+    """EdgeTransition on split-f16 MFMA (three products per block instead of bf16x6's six; csrc/pair_mlp_f16.hip); contract
+    of ``edge_transition_bf16x6`` with 32 KiB stages (``pack_f16x3_stream`` + the next block's ``pack_f16x2_layer`` stage)."""
+    lib = load_library()
+    B, N = edge.shape[0], edge.shape[1]
+    _req(edge, name="edge")
+    if edge.shape != (B, N, N, 128) or node_ab.shape != (B, N, 768) or node_p.shape != (B, N, 128):
+        raise HipLibraryError("edge_transition_f16x3: bad shapes")
+    for n, t in (("node_ab", node_ab), ("node_p", node_p), ("b2", b2), ("bf", bf), ("gamma", gamma), ("beta", beta)):
+        _req(t, name=n)
+    pb = pbias = ppz = None
+    if proj is not None:
+        wstream, pb = proj
+        _req(pb, name="proj.b64")
+        pbias = torch.empty(B, 8, N, N, device=edge.device, dtype=torch.float32)
+        ppz = torch.empty(B, N, N, 32, device=edge.device, dtype=torch.float32)
+    _req(wstream, torch.int16, "wstream")
+    if wstream.numel() * 2 != (31 if proj is not None else 30) * 32 * 1024:
+        raise HipLibraryError("edge_transition_f16x3: weight stream has the wrong number of stages")
+    if mask is not None:
+        _req(mask, name="mask")
+    if out is None:
+        out = torch.empty_like(edge)
+    elif out.data_ptr() == edge.data_ptr():
+        raise HipLibraryError("edge_transition: out may not alias edge")
+    _check(_timed("s2s_edge_transition", lambda: lib.s2s_edge_transition_f16x3(
+        _p(edge), _p(node_ab), _p(node_p), _p(wstream), _p(b2), _p(bf), _p(gamma), _p(beta), _p(mask), _p(out), B, N,
+        ln_eps, _p(pb), _p(pbias), _p(ppz), _stream())), "s2s_edge_transition_f16x3")
+    return out if proj is None else (out, pbias, ppz)
+
+
 def edge_transition_bf16x6(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps=1e-5, out=None, proj=None):
     """EdgeTransition on split-bf16 MFMA (fp32-equivalent accuracy); same contract as ``edge_transition``.
     ``proj`` = (31-stage stream = this layer's 30 stages + the next IPA block's projection stage, bias64) also

@@ -1,7 +1,2 @@
-mkdir -p gpurun_out
-python tools/ee_probe.py run --B 128 --N 256 > gpurun_out/ee_probe.txt 2>&1
-for v in "" ee4 "" ee4; do
-if [ -n "$v" ]; then export STR2STR_HIP_LIB=$PWD/str2str_amd/csrc/build/lib_$v.so; else unset STR2STR_HIP_LIB; fi
-python tools/ee_time.py 2>/dev/null
-done
-timeout 900 python -m pytest tests -m gpu -x -q -k "embed or forward or trajectory or teacher" 2>&1 | tail -3
+timeout 900 python -m pytest tests -m gpu -x -q -k "edge_transition" 2>&1 | tail -5
+for m in bf16x6 f16x3 bf16x6 f16x3; do S2S_EDGE_MFMA=$m python tools/et_only.py --B 128 --N 256 --iters 20 --proj --mode $m 2>/dev/null | tail -1; done
