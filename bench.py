@@ -79,8 +79,8 @@ def traffic_from_profiles(pairs, mode):
     """HBM bytes per launch of the dominant kernel.  NOT measured in this run: PMC counters need rocprofv3 around the
     process (separate --pmc passes, tools/pmc_hbm_traffic.sh), so the committed pass at B = 16, N = 256 is scaled by the
     pairs of this launch and labelled as such.  (None, None) if the file is absent."""
-    for name in ("r02_pmc_hbm_traffic.json", "r01i_pmc_hbm_traffic.json"):
-        key = "edge_transition_bf16x6" if mode == "bf16x6" else "edge_transition"
+    for name in ("r02i_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01i_pmc_hbm_traffic.json"):
+        key = {"bf16x6": "edge_transition_bf16x6", "f16x3": "edge_transition_f16x3"}.get(mode, "edge_transition")
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)["kernels"][key]["bytes_per_pair_corrected"] * pairs, f"profiles/{name} (PMC pass at B=16, N=256, scaled per pair)"
@@ -265,7 +265,8 @@ def main():
             "metric": METRIC if a.config == "cfg2" else f"sampled conformations/sec (whole node), BASELINE {a.config}",
             "value": total / elapsed, "unit": "conformations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if mode == "f32" else "f32 (pair MLP on exact 3-way bf16 split MFMA, fp32 accumulate)",
+            "dtype": {"f32": "f32", "bf16x6": "f32 (pair MLP on exact 3-way bf16 split MFMA, fp32 accumulate)",
+                      "f16x3": "f32 (edge transition on 2-way f16 split MFMA, edge embedding on 3-way bf16 split MFMA; fp32 accumulate, fp32-equivalent)"}[mode],
             "data": "synthetic",
             "config": {"workload": workload, "n_res": N, "replicas_per_gpu": B, "denoise_steps": S,
                        "parallelism": f"replica-shard x{world}", "edge_mfma_mode": mode, "rng": a.rng,
@@ -277,14 +278,15 @@ def main():
         if a.config in ("cfg2", "cfg4") and et_n:
             pairs = pairs_main
             alg = pairs * FLOPS_PER_PAIR_ET                       # fp32 multiply-add flops the operator needs
-            executed = alg * (6 if mode == "bf16x6" else 1)       # bf16x6: six bf16 plane-pair products per fp32 product
-            peak = MFMA_BF16_PEAK if mode == "bf16x6" else MFMA_FP32_PEAK
+            executed = alg * {"bf16x6": 6, "f16x3": 3}.get(mode, 1)   # low-precision products executed per fp32 product
+            peak = MFMA_FP32_PEAK if mode == "f32" else MFMA_BF16_PEAK  # f16 and bf16 MFMA share the dense peak
             ach = executed / (et_ms * 1e-3)
             traffic, traffic_src = traffic_from_profiles(pairs, mode)
             ipa_bytes = B * 4 * (9512 * N + 40 * N * N)
             line["roofline"] = {
                 "bound": "mfma",
-                "kernel": "s2s_edge_transition" + ("_bf16x6 (edge_transition_bf16_kernel)" if mode == "bf16x6" else " (edge_transition_kernel)"),
+                "kernel": "s2s_edge_transition" + {"bf16x6": "_bf16x6 (edge_transition_bf16_kernel)",
+                                                   "f16x3": "_f16x3 (edge_transition_f16_kernel)"}.get(mode, " (edge_transition_kernel)"),
                 "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": traffic, "traffic_source": traffic_src, "launches_timed": et_n, "mean_launch_ms": et_ms,
                 "algorithmic_flops_per_launch": alg, "executed_mfma_flops_per_launch": executed,

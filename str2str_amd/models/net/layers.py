@@ -103,10 +103,11 @@ class EdgeTransition(nn.Module):
         self._shape = (edge_embed_in, bias_embed_size, hidden, edge_embed_out, num_layers)
         self._cache = ParamCache()
         self._proj_cache = ParamCache()
-        # "bf16x6" (default): exact 3-way bf16 split of both operands, six plane-pair products on the bf16 MFMA with
-        # fp32 accumulation — dropped products below one fp32 rounding, i.e. fp32-equivalent (csrc/pair_mlp_bf16.hip), 1.7x faster.
-        # "f32": v_mfma_f32_32x32x2_f32 (csrc/pair_mlp.hip).  Both pass the same parity suite.
-        self.mfma_mode = os.environ.get("S2S_EDGE_MFMA", "bf16x6")
+        # "f16x3" (default): two-way f16 split of both operands (11 + 11 bits + sign = fp32's 24), three products per block with
+        # exact 2^+-5 scalings of the small factors, fp32 accumulation (csrc/pair_mlp_f16.hip): 1.65x faster than
+        # "bf16x6": exact 3-way bf16 split, six plane-pair products (csrc/pair_mlp_bf16.hip), which is 1.6x faster than
+        # "f32": v_mfma_f32_32x32x2_f32 (csrc/pair_mlp.hip).  All three pass the same parity suite.
+        self.mfma_mode = os.environ.get("S2S_EDGE_MFMA", "f16x3")
         # "f16x3": two-way f16 split, three products per block (csrc/pair_mlp_f16.hip); the embedder treats it as "bf16x6".
         if self.mfma_mode not in ("bf16x6", "f16x3", "f32"):
             raise ValueError(f"S2S_EDGE_MFMA={self.mfma_mode!r}: expected 'bf16x6', 'f16x3' or 'f32'")

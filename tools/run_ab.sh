@@ -1,2 +1,9 @@
-timeout 900 python -m pytest tests -m gpu -x -q -k "edge_transition" 2>&1 | tail -5
-for m in bf16x6 f16x3 bf16x6 f16x3; do S2S_EDGE_MFMA=$m python tools/et_only.py --B 128 --N 256 --iters 20 --proj --mode $m 2>/dev/null | tail -1; done
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_f16.json 2> gpurun_out/bench_f16.err
+tail -1 gpurun_out/bench_f16.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['mean_launch_ms'], d['roofline']['frac'], d['ipa_kernel']['mean_launch_ms'])"
+bash tools/pmc_hbm_traffic.sh gpurun_out/r02i_pmc_hbm_traffic.json 16 256 > gpurun_out/pmc.log 2>&1
+python -c "
+import json; d=json.load(open('gpurun_out/r02i_pmc_hbm_traffic.json'))
+for k,v in d['kernels'].items(): print(k, round(v['bytes_per_pair_corrected'],1) if 'bytes_per_pair_corrected' in v else v)
+"
