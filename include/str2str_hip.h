@@ -94,6 +94,15 @@ int s2s_edge_embed_bf16x6(const float* node_a, const float* node_b, const float*
                           int n_rel, int n_bins, float ln_eps, const float* proj_bias_cat64, float* proj_attn_bias,
                           float* proj_pair_z, void* stream);
 
+/* The edge embedding on split-f16 MFMA (see s2s_edge_transition_f16x3): arguments and table layouts of s2s_edge_embed_bf16x6,
+ * weight_stream = 4 (+1) stages x 32 KiB of (W_h, W_ls) fragments (ops.pack_f16x3_embed_stream). */
+int s2s_edge_embed_f16x3(const float* node_a, const float* node_b, const float* rel_table, const float* bin_table,
+                         const float* bin_lower, const long long* residue_idx, const float* ca_xyz,
+                         const void* weight_stream, const float* b2, const float* b3, const float* ln_gamma,
+                         const float* ln_beta, const float* mask, float* out, int n_samples, int n_res, int rel_offset,
+                         int n_rel, int n_bins, float ln_eps, const float* proj_bias_cat64, float* proj_attn_bias,
+                         float* proj_pair_z, void* stream);
+
 /* linear_b and down_z of InvariantPointAttention (src/models/net/ipa.py:177, :253) in one pass over z.
  *   w_packed: [linear_b.weight (8 rows); down_z.weight (32 rows); 24 zero rows] (64x128) packed
  *   bias_cat64 [64]; attn_bias [B,8,N,N] (head-major: what s2s_ipa_attention streams per head); pair_z [B,N,N,32]. */

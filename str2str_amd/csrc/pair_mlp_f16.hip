@@ -412,6 +412,421 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     }  // persistent tile loop
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Edge embedding on split-f16 MFMA: the kernel of csrc/pair_mlp_bf16.hip (edge_embed_bf16_kernel: gathers, slot schedule, pinned
+// VALU pieces -- documented there) with the f16x3 products and 32 KiB weight stages (W2 | W3 | [linear_b; down_z]).
+template <bool PROJ>
+__global__ void __launch_bounds__(256) edge_embed_f16_kernel(
+    const float* __restrict__ node_a, const float* __restrict__ node_b, const float* __restrict__ rel_tab,
+    const float* __restrict__ bin_tab, const float* __restrict__ bin_lower, const long long* __restrict__ residue_idx,
+    const float* __restrict__ ca, const char* __restrict__ wblob, const float* __restrict__ b2, const float* __restrict__ b3,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask, float* __restrict__ out,
+    long long M, int N, int rel_off, int n_rel, int n_bins, float ln_eps, const float* __restrict__ proj_b,
+    float* __restrict__ proj_bias_out, float* __restrict__ proj_pz_out) {
+    constexpr int kStages = PROJ ? 5 : 4;
+    constexpr int kSlots = 8 * kStages;
+    __shared__ __attribute__((aligned(16))) char s_w[2][kStageBytes];
+    __shared__ __attribute__((aligned(16))) float s_vec[512 + 64];  // b2 | b3 | gamma | beta | projection bias
+    __shared__ __attribute__((aligned(16))) float s_bins[64 + 4];    // distogram bin lower edges (ascending), padded with 3e38
+    const int lane = threadIdx.x & 63, h = lane >> 5, wave = threadIdx.x >> 6;
+
+    // ---- weight pipe (identical to the edge transition's)
+    const unsigned voff = wave * 8192 + lane * 16;
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* lds_image[2] = {(lds_char*)&s_w[0][lane * 16], (lds_char*)&s_w[1][lane * 16]};
+    asm volatile("" : "+v"(lds_image[0]), "+v"(lds_image[1]));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wblob, 0, kStages * kStageBytes, 0x00020000);
+    auto ldw = [&](unsigned vo, int so) -> f32x4 {
+        const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, vo, so, 0);
+        return f32x4{__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w)};
+    };
+    f32x4 c0, c1, c2, c3, e0, e1, e2, e3;
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    auto cp_load_a = [&](int stage) {
+        const int so = stage * kStageBytes;
+        c0 = ldw(voff, so); c1 = ldw(voff + 1024, so); c2 = ldw(voff + 2048, so); c3 = ldw(voff + 3072, so);
+    };
+    auto cp_load_b = [&](int stage) {
+        const int so = stage * kStageBytes + 4096;
+        e0 = ldw(voff, so); e1 = ldw(voff + 1024, so); e2 = ldw(voff + 2048, so); e3 = ldw(voff + 3072, so);
+    };
+    auto cp_store_a = [&](int par) {
+        lds_char* d = lds_image[par] + wave * 8192;
+        *(lds_f4*)(d) = c0; *(lds_f4*)(d + 1024) = c1; *(lds_f4*)(d + 2048) = c2; *(lds_f4*)(d + 3072) = c3;
+    };
+    auto cp_store_b = [&](int par) {
+        lds_char* d = lds_image[par] + (wave * 8192 + 4096);
+        *(lds_f4*)(d) = e0; *(lds_f4*)(d + 1024) = e1; *(lds_f4*)(d + 2048) = e2; *(lds_f4*)(d + 3072) = e3;
+    };
+    cp_load_a(0);
+    cp_load_b(0);
+
+    // ---- per-tile context: the four first-layer rows of this lane's pair
+    // node_b / rel_tab / bin_tab come COLUMN-BLOCKED: [32 chunks of 4 channels][rows][4], so that the 16 B a lane wants of
+    // its pair's row sit next to the neighbouring pairs' (consecutive j -> consecutive rows): one load instruction touches
+    // 8 cache lines instead of 32.  Lane part of the address in voffset, chunk pair (2G, 2G+1) in the scalar offset.
+    struct Ctx {
+        const float* ra;
+        unsigned vb, vr, vk;   // byte offsets of (row, chunk h) in node_b / rel_tab / bin_tab
+        float kb;
+        long long p, boff;
+        float em;
+        bool valid;
+    };
+    const long long NN = (long long)N * N;
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)node_b, 0, (unsigned)(M / N * 512), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)rel_tab, 0, n_rel * 512, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)bin_tab, 0, n_bins * 512, 0x00020000);
+    // setup in two halves so that the per-pair loads (CA coordinates, residue indices, masks) are in flight for a few slots
+    // before they are consumed; the distogram edges sit in LDS (s_bins)
+    struct Raw {
+        long long p, bi, bj, bb;
+        float ax, ay, az, bx, by, bz;
+        long long ii, ij;
+        float mi, mj;
+        bool valid;
+    };
+    // The launcher keeps the pair count of one launch below 2^31: 32-bit index arithmetic, division by N through
+    // floor(2^32 / N) (quotient short by at most one for x < 2^31; a 64-bit division is ~100 VALU instructions).
+    const unsigned n_magic = N >= 2 ? (unsigned)((1ull << 32) / (unsigned)N) : 0u;
+    auto div_n = [&](unsigned x, unsigned& q, unsigned& r) {
+        q = N >= 2 ? __umulhi(x, n_magic) : x;
+        r = x - q * (unsigned)N;
+        const bool fix = r >= (unsigned)N;
+        q = fix ? q + 1 : q;
+        r = fix ? r - (unsigned)N : r;
+    };
+    const float* mask_or_any = mask ? mask : ca;  // always a readable [B N] float array: no branch around the mask loads
+    auto setup_a = [&](long long wg_tile) -> Raw {
+        long long p = (wg_tile * 4 + wave) * 32 + (lane & 31);
+        Raw r;
+        r.valid = p < M;
+        p = r.valid ? p : M - 1;
+        r.p = p;
+        // p = (bb N + i) N + j:  global row bi = p / N,  j = p - bi N,  bb = bi / N
+        unsigned bi, j, bb, i;
+        div_n((unsigned)p, bi, j);
+        div_n(bi, bb, i);
+        r.bi = bi; r.bb = bb; r.bj = bb * (unsigned)N + j;
+        r.ax = ca[r.bi * 3 + 0]; r.ay = ca[r.bi * 3 + 1]; r.az = ca[r.bi * 3 + 2];
+        r.bx = ca[r.bj * 3 + 0]; r.by = ca[r.bj * 3 + 1]; r.bz = ca[r.bj * 3 + 2];
+        r.ii = residue_idx[r.bi];
+        r.ij = residue_idx[r.bj];
+        r.mi = mask_or_any[r.bi];
+        r.mj = mask_or_any[r.bj];
+        return r;
+    };
+    auto setup_b = [&](const Raw& r) -> Ctx {
+        Ctx c;
+        c.valid = r.valid;
+        // distogram bin of this pair (no FMA contraction: mirrors torch.linalg.norm of the difference; geo_utils.py:44-56)
+        const float dx = r.ax - r.bx, dy = r.ay - r.by, dz = r.az - r.bz;
+        const float dist = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+        // the reference's one-hot (dist > lower[k]) * (dist < upper[k]), upper = lower[k+1] (1e8 for the last): with ascending
+        // edges (torch.linspace) that is k = #{edges < dist} - 1 unless dist sits exactly on the next edge (then no bin at all)
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {  // s_bins: n_bins <= 32 edges | 1e8 (the last bin's upper edge) | 3e38 ...
+            const float4 e = *reinterpret_cast<const float4*>(&s_bins[4 * u]);
+            cnt += (e.x < dist) + (e.y < dist) + (e.z < dist) + (e.w < dist);
+        }
+        cnt = cnt > n_bins ? n_bins : cnt;                  // dist beyond 1e8 when n_bins < 32: no bin, as below
+        const float up = s_bins[cnt];                       // upper edge of bin cnt - 1
+        const int bin = (cnt >= 1 && dist < up) ? cnt - 1 : -1;
+        long long d = r.ii - r.ij + rel_off;
+        d = d < 0 ? 0 : (d >= n_rel ? n_rel - 1 : d);
+        c.ra = node_a + r.bi * 128;
+        const unsigned jj = (unsigned)(r.bj - r.bb * N);
+        c.vb = ((unsigned)r.bb * 32u * (unsigned)N + (unsigned)h * (unsigned)N + jj) * 16u;
+        c.vr = ((unsigned)h * (unsigned)n_rel + (unsigned)d) * 16u;
+        c.vk = ((unsigned)h * (unsigned)n_bins + (unsigned)(bin < 0 ? 0 : bin)) * 16u;
+        c.kb = bin < 0 ? 0.f : 1.f;
+        c.p = r.p;
+        c.boff = r.p + 7 * r.bb * NN;
+        c.em = mask ? r.mi * r.mj : 1.0f;
+        return c;
+    };
+    auto split4 = [&](const float (&x)[4], f16x8& ph, f16x8& pm, f16x8& pl, int at) {  // planes (x_h, x_l, 2^-5 x_h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const _Float16 a = (_Float16)x[j];
+            const float r1 = x[j] - (float)a;
+            ph[at + j] = a; pm[at + j] = (_Float16)r1; pl[at + j] = a * (_Float16)0.03125f;
+        }
+    };
+    // first-layer sum in accumulator layout: g1[4G + q] = channel 8G + 4h + q, built row by row (same association as the
+    // fp32 kernel: ((a + b) + r) + kb*k)
+    float g1[64];
+    auto row_set = [&](const float* r) {
+#pragma unroll
+        for (int G = 0; G < 16; ++G) {
+            const float4 v = ldg4(r, G, h);
+            g1[4 * G + 0] = v.x; g1[4 * G + 1] = v.y; g1[4 * G + 2] = v.z; g1[4 * G + 3] = v.w;
+        }
+    };
+    float tmp[64];
+    auto row_cb = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned vo, int rows, float (&dst)[64], int G0, int G1) {
+#pragma unroll
+        for (int G = G0; G < G1; ++G) {  // chunk 2G + h of the row: scalar offset 2G rows-blocks of 16 B
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, G * 32 * rows, 0);
+            dst[4 * G + 0] = __uint_as_float(v.x); dst[4 * G + 1] = __uint_as_float(v.y);
+            dst[4 * G + 2] = __uint_as_float(v.z); dst[4 * G + 3] = __uint_as_float(v.w);
+        }
+    };
+    auto row_add = [&](float scale) {  // pinned: left alone, the compiler sinks these adds to the splits 20 slots later and keeps
+#pragma unroll                         // (spills) all four loaded rows until then
+        for (int i = 0; i < 64; ++i) {
+            g1[i] = __fmaf_rn(scale, tmp[i], g1[i]);  // (explicit: both template variants must round alike)
+            asm volatile("" : "+v"(g1[i]));
+        }
+    };
+    // ReLU + split of first-layer k-step ks (registers 8ks .. 8ks+7 of g1: chain order) into planes
+    auto g1_split = [&](f16x8 (&dst)[3], int ks) {
+        const float x0[4] = {fmaxf(g1[8 * ks + 0], 0.f), fmaxf(g1[8 * ks + 1], 0.f), fmaxf(g1[8 * ks + 2], 0.f), fmaxf(g1[8 * ks + 3], 0.f)};
+        const float x1[4] = {fmaxf(g1[8 * ks + 4], 0.f), fmaxf(g1[8 * ks + 5], 0.f), fmaxf(g1[8 * ks + 6], 0.f), fmaxf(g1[8 * ks + 7], 0.f)};
+        split4(x0, dst[0], dst[1], dst[2], 0);
+        split4(x1, dst[0], dst[1], dst[2], 4);
+    };
+
+    const long long n_wt = (M + 127) / 128;
+    long long wt = blockIdx.x;
+    if (threadIdx.x < 68) s_bins[threadIdx.x] = (int)threadIdx.x < n_bins ? bin_lower[threadIdx.x] : ((int)threadIdx.x == n_bins ? 1e8f : 3.0e38f);
+    __syncthreads();
+    Ctx cur = setup_b(setup_a(wt));
+    f16x8 xp[8][3];  // planes of the current layer's input (8 k-steps of 16)
+    {
+        row_set(cur.ra);
+        for (int i = threadIdx.x; i < 512; i += 256)
+            s_vec[i] = i < 128 ? b2[i] : (i < 256 ? b3[i - 128] : (i < 384 ? gamma[i - 256] : beta[i - 384]));
+        if (PROJ && threadIdx.x < 64) s_vec[512 + threadIdx.x] = proj_b[threadIdx.x];
+        cp_store_a(0);
+        cp_load_a(1);
+        cp_store_b(0);
+        row_cb(rs_b, cur.vb, N, tmp, 0, 16); row_add(1.0f);
+        row_cb(rs_r, cur.vr, n_rel, tmp, 0, 16); row_add(1.0f);
+        row_cb(rs_k, cur.vk, n_bins, tmp, 0, 16); row_add(cur.kb);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) g1_split(xp[ks], ks);
+    }
+    f32x16 a2[4], a3[4], pq[2];
+    f16x8 fr[2][4];
+    auto fetch = [&](int par, int slot_in_stage, f16x8 (&f)[4]) {
+        typedef __attribute__((address_space(3))) f16x8 lds_frag;
+        const lds_frag* s = (const lds_frag*)lds_image[par] + slot_in_stage * 4 * 64;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) f[k] = s[64 * k];
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // The VALU work of a tile is cut into per-k-step pieces, each pinned (empty asm on its inputs / outputs: otherwise the
+    // compiler sinks a piece to its first use, i.e. in FRONT of the MFMAs that wait for it) into a slot whose MFMAs do not depend
+    // on it, and interleaved with them by sched_group_barrier.
+    auto pin_frag = [&](f16x8 (&x)[3]) { asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2])); };
+    // accumulator start = bias (registers 4 rq + q of tile t <-> channel 32 t + 8 rq + 4 h + q)
+    auto bias16 = [&](const float* vec, int t) -> f32x16 {
+        const float4 b0 = ldg4(vec, 4 * t, h), b1 = ldg4(vec, 4 * t + 1, h), b2v = ldg4(vec, 4 * t + 2, h), b3v = ldg4(vec, 4 * t + 3, h);
+        return f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2v.x, b2v.y, b2v.z, b2v.w, b3v.x, b3v.y, b3v.z, b3v.w};
+    };
+    // layer-2 output (bias already in the accumulator): ReLU + split of k-step k -> layer-3 input planes xp[k]
+    auto l2_piece = [&](auto kc) {
+        constexpr int k = decltype(kc)::value, t = k / 2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rq = 2 * (k & 1) + u;
+            const float xx[4] = {fmaxf(a2[t][4 * rq + 0], 0.f), fmaxf(a2[t][4 * rq + 1], 0.f), fmaxf(a2[t][4 * rq + 2], 0.f),
+                                 fmaxf(a2[t][4 * rq + 3], 0.f)};
+            split4(xx, xp[k][0], xp[k][1], xp[k][2], 4 * u);
+        }
+        pin_frag(xp[k]);
+    };
+    float ln_mean = 0.f, ln_rstd = 0.f;
+    f16x8 xq[2][3];  // LayerNorm output planes of the projection's current / next k-step
+    // LayerNorm output of k-step k (16 channels): scale, shift, edge mask, store (+ planes for the projection)
+    __amdgpu_buffer_rsrc_t rs_out;  // this tile's 32 output rows; rows past M are outside num_records: their stores are dropped
+    auto out_rsrc = [&](long long wg_tile) {
+        const long long p0 = (wg_tile * 4 + __builtin_amdgcn_readfirstlane(wave)) * 32;
+        const long long left = M - p0;
+        rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (p0 < M ? p0 : 0) * 128), 0,
+                                                   (unsigned)(left <= 0 ? 0 : (left < 32 ? left : 32)) * 512u, 0x00020000);
+    };
+    float4 lga[2], lbe[2];  // gamma / beta of the next LayerNorm piece, read at the top of its slot
+    auto ln_load = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int g = 4 * (k / 2) + 2 * (k & 1) + u;
+            lga[u] = ldg4(s_vec + 256, g, h);
+            lbe[u] = ldg4(s_vec + 384, g, h);
+        }
+    };
+    auto ln_piece = [&](auto kc, const Ctx& c) {
+        constexpr int k = decltype(kc)::value, t = k / 2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int rq = 2 * (k & 1) + u, g = 4 * t + rq;
+            const float4 ga = lga[u], be = lbe[u];
+            float4 o;
+            // (the channel offset goes into the store's immediate field, not into an SGPR soffset: a 128-bit buffer store with an
+            // SGPR offset followed by VALU writes of its data registers lost the last lanes' data in the plain variant)
+            // explicit roundings: the fused-projection and the plain variant of this kernel must agree bit for bit
+            o.x = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 0] - ln_mean, ln_rstd), ga.x, be.x), c.em);
+            o.y = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 1] - ln_mean, ln_rstd), ga.y, be.y), c.em);
+            o.z = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 2] - ln_mean, ln_rstd), ga.z, be.z), c.em);
+            o.w = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 3] - ln_mean, ln_rstd), ga.w, be.w), c.em);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)},
+                                                   rs_out, (unsigned)((lane & 31) * 512 + h * 16) + g * 32, 0, 0);
+            if constexpr (PROJ) {
+                const float xx[4] = {o.x, o.y, o.z, o.w};
+                split4(xx, xq[k & 1][0], xq[k & 1][1], xq[k & 1][2], 4 * u);
+            }
+        }
+        if constexpr (PROJ) pin_frag(xq[k & 1]);
+    };
+    // rows of the next tile's first layer, eight 16 B loads per slot (a burst of 32 per wave backs up the vector memory
+    // pipe and with it the wave's MFMA issue)
+    auto row_load8 = [&](const float* r, float (&dst)[64], int half) {
+#pragma unroll
+        for (int G = 8 * half; G < 8 * half + 8; ++G) {
+            const float4 v = ldg4(r, G, h);
+            dst[4 * G + 0] = v.x; dst[4 * G + 1] = v.y; dst[4 * G + 2] = v.z; dst[4 * G + 3] = v.w;
+        }
+    };
+    S2S_LDS_BARRIER();
+    fetch(0, 0, fr[0]);
+    f32x16 initA0 = bias16(s_vec, 0), initA1 = bias16(s_vec, 1), initB0, initB1;
+
+    for (;;) {
+    const long long wt_next = wt + gridDim.x;
+    const bool has_next = wt_next < n_wt;
+    Ctx nxt = cur;
+    Raw nraw;
+    f16x8 xl[3];  // the next tile's last k-step (xp[7] is read by the final layer's last slot)
+    static_for<0, kSlots>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        constexpr int stage = s / 8, ss = s % 8, par = stage & 1;
+        constexpr int layer = s / 16;             // 0: layer 2, 1: layer 3, 2: projection
+        constexpr int ks = layer < 2 ? (s % 16) / 2 : s - 32;
+        constexpr int pr = layer < 2 ? s % 2 : 0;
+        // ---------------- top of the slot: LDS / global loads whose results are used under later MFMAs
+        // the accumulators of a layer's first two slots start from the bias, read one slot ahead (A: slots 0 / 16, B: 1 / 17)
+        if constexpr (s == kSlots - 1) { initA0 = bias16(s_vec, 0); initA1 = bias16(s_vec, 1); }
+        if constexpr (s == 0) { initB0 = bias16(s_vec, 2); initB1 = bias16(s_vec, 3); }
+        if constexpr (s == 15) { initA0 = bias16(s_vec + 128, 0); initA1 = bias16(s_vec + 128, 1); }
+        if constexpr (s == 16) { initB0 = bias16(s_vec + 128, 2); initB1 = bias16(s_vec + 128, 3); }
+        if constexpr (PROJ && s >= 31 && s < 39) ln_load(IC<s - 31>{});
+        if constexpr (ss < 7) {
+            fetch(par, ss + 1, fr[(s + 1) & 1]);
+            if constexpr (ss == 0) cp_load_b((stage + 1) % kStages);
+            if constexpr (ss == 4) cp_load_a((stage + 2) % kStages);
+        } else {
+            S2S_LDS_BARRIER();
+            fetch(par ^ 1, 0, fr[(s + 1) & 1]);
+        }
+        // next tile: per-pair loads under slot 0, context under slot 4, then its four first-layer rows
+        if constexpr (s == 30) out_rsrc(wt);
+        if constexpr (s == 5) row_load8(nxt.ra, g1, 0);
+        if constexpr (s == 6) row_load8(nxt.ra, g1, 1);
+        if constexpr (s == 7) row_cb(rs_b, nxt.vb, N, tmp, 0, 8);
+        if constexpr (s == 8) row_cb(rs_b, nxt.vb, N, tmp, 8, 16);
+        if constexpr (s == 13) row_cb(rs_r, nxt.vr, n_rel, tmp, 0, 8);
+        if constexpr (s == 14) row_cb(rs_r, nxt.vr, n_rel, tmp, 8, 16);
+        if constexpr (s == 18) row_cb(rs_k, nxt.vk, n_bins, tmp, 0, 8);
+        if constexpr (s == 19) row_cb(rs_k, nxt.vk, n_bins, tmp, 8, 16);
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---------------- the 12 MFMAs and the VALU pieces that run under them
+        const f16x8 (&f)[4] = fr[s & 1];
+        const f16x8 (&x)[3] = layer < 2 ? xp[ks] : xq[ks & 1];
+        f32x16& t0 = layer == 0 ? a2[2 * pr] : (layer == 1 ? a3[2 * pr] : pq[0]);
+        f32x16& t1 = layer == 0 ? a2[2 * pr + 1] : (layer == 1 ? a3[2 * pr + 1] : pq[1]);
+        if constexpr (ks == 0) {
+            if constexpr (layer < 2) {
+                t0 = mfma_f16(f[1], x[2], pr == 0 ? initA0 : initB0); t1 = mfma_f16(f[3], x[2], pr == 0 ? initA1 : initB1);
+            } else {
+                t0 = mfma_f16(f[1], x[2], zero16); t1 = mfma_f16(f[3], x[2], zero16);
+            }
+        } else {
+            t0 = mfma_f16(f[1], x[2], t0); t1 = mfma_f16(f[3], x[2], t1);  // W_ls x_hs
+        }
+        t0 = mfma_f16(f[0], x[1], t0); t1 = mfma_f16(f[2], x[1], t1);      // W_h x_l
+        t0 = mfma_f16(f[0], x[0], t0); t1 = mfma_f16(f[2], x[0], t1);      // W_h x_h
+        if constexpr (s == 0) nraw = setup_a(has_next ? wt_next : wt);
+        if constexpr (s == 4) nxt = setup_b(nraw);
+        if constexpr (s == 12) row_add(1.0f);     // a + b   (same association as the fp32 kernel: ((a + b) + r) + kb k)
+        if constexpr (s == 17) row_add(1.0f);     // + relative-position row
+        if constexpr (s == 22) row_add(nxt.kb);   // + distogram row
+        // layer-2 output, k-step k (read by slots 16 + 2k, 17 + 2k) under slot 14 + 2k, k-step 0 under slot 15
+        if constexpr (s >= 16 && s <= 28 && s % 2 == 0) l2_piece(IC<(s - 14) / 2>{});
+        if constexpr (s == 15) l2_piece(IC<0>{});   // tiles 0, 1 of the layer-2 output are complete after slot 14
+        // next tile's first layer: k-step k of xp is last read by slot 17 + 2k, so k = 0..6 go under slots 24..30 and the
+        // last one (under slot 23) into xl
+        if constexpr (s >= 24 && s < 31) { g1_split(xp[s - 24], s - 24); pin_frag(xp[s - 24]); }
+        if constexpr (s == 23) { g1_split(xl, 7); pin_frag(xl); }
+        // LayerNorm output k-step k + 1 under projection slot 32 + k
+        if constexpr (PROJ && s >= 32 && s < 39) ln_piece(IC<s - 31>{}, cur);
+        if constexpr (ss == 1) cp_store_a(par ^ 1);
+        if constexpr (ss == 5) cp_store_b(par ^ 1);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA,
+            __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // up to eight VALU instructions behind it
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---------------- exposed steps
+        if constexpr (s == 31) {  // layer-3 output (bias included): LayerNorm statistics
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += a3[t][r];
+            ln_mean = __fmul_rn(xhalf_sum(sum), 1.0f / 128);
+            float var = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float dd = a3[t][r] - ln_mean;
+                    var = __fmaf_rn(dd, dd, var);
+                }
+            ln_rstd = 1.0f / sqrtf(__fmaf_rn(xhalf_sum(var), 1.0f / 128, ln_eps));
+            if constexpr (PROJ) {
+                ln_piece(IC<0>{}, cur);
+            } else {
+                static_for<0, 8>([&](auto kc) { ln_load(kc); ln_piece(kc, cur); });
+            }
+        }
+    });
+    if constexpr (PROJ) {
+        if (cur.valid) {
+            const float4 b0 = ldg4(s_vec + 512, 0, h);
+            float* o = proj_bias_out + cur.boff + 4 * h * NN;
+            o[0] = pq[0][0] + b0.x;
+            o[NN] = pq[0][1] + b0.y;
+            o[2 * NN] = pq[0][2] + b0.z;
+            o[3 * NN] = pq[0][3] + b0.w;
+#pragma unroll
+            for (int g = 1; g <= 4; ++g) {
+                const int t = g >> 2, rq = g & 3;
+                const float4 bq = ldg4(s_vec + 512, g, h);
+                *reinterpret_cast<float4*>(proj_pz_out + cur.p * 32 + 8 * (g - 1) + 4 * h) =
+                    make_float4(pq[t][4 * rq + 0] + bq.x, pq[t][4 * rq + 1] + bq.y, pq[t][4 * rq + 2] + bq.z, pq[t][4 * rq + 3] + bq.w);
+            }
+        }
+    }
+    if (!has_next) break;
+    cur = nxt;
+    wt = wt_next;
+    xp[7][0] = xl[0]; xp[7][1] = xl[1]; xp[7][2] = xl[2];
+    if constexpr (kStages % 2 == 1) {  // odd stage count: the next tile's stage 0 sits in the other buffer
+        lds_char* sw = lds_image[0];
+        lds_image[0] = lds_image[1];
+        lds_image[1] = sw;
+    }
+    }  // persistent tile loop
+}
+
+
 }  // namespace
 
 extern "C" int s2s_edge_transition_f16x3(const float* edge, const float* node_ab, const float* node_p,
@@ -437,5 +852,48 @@ extern "C" int s2s_edge_transition_f16x3(const float* edge, const float* node_ab
         hipLaunchKernelGGL(edge_transition_f16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, edge, node_ab,
                            node_p, (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mask, out, M, n_res, ln_eps,
                            (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    return (int)hipGetLastError();
+}
+
+extern "C" int s2s_edge_embed_f16x3(const float* node_a, const float* node_b, const float* rel_table, const float* bin_table,
+                                     const float* bin_lower, const long long* residue_idx, const float* ca_xyz,
+                                     const void* weight_stream, const float* b2, const float* b3, const float* ln_gamma,
+                                     const float* ln_beta, const float* mask, float* out, int n_samples, int n_res,
+                                     int rel_offset, int n_rel, int n_bins, float ln_eps, const float* proj_bias_cat64,
+                                     float* proj_attn_bias, float* proj_pair_z, void* stream) {
+    if (n_samples <= 0 || n_res <= 0) return 0;
+    if (n_bins > 32) return (int)hipErrorInvalidValue;  // the distogram edges are counted from a 32-entry LDS table
+    // 32-bit pair indices and buffer offsets inside a launch: split the samples over several launches when needed
+    const long long NN = (long long)n_res * n_res;
+    if (NN >= (1ll << 31) || (long long)n_rel * 512 >= (1ll << 32)) return (int)hipErrorInvalidValue;
+    long long chunk = ((1ll << 31) - 1) / NN;
+    const long long rows_cap = ((1ll << 32) - 1) / ((long long)n_res * 512);  // node_b descriptor
+    if (rows_cap < chunk) chunk = rows_cap;
+    if (chunk < 1) return (int)hipErrorInvalidValue;
+    int n_cu = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        n_cu = 256;
+    for (long long b0 = 0; b0 < n_samples; b0 += chunk) {
+        const long long nb = n_samples - b0 < chunk ? n_samples - b0 : chunk;
+        const long long M = nb * NN, rows0 = b0 * n_res;
+        const long long wg_tiles = (M + 127) / 128;
+        const long long grid = wg_tiles < n_cu ? wg_tiles : n_cu;
+        const float* na = node_a + rows0 * 128;
+        const float* nbp = node_b + rows0 * 128;
+        const long long* ridx = residue_idx + rows0;
+        const float* cap = ca_xyz + rows0 * 3;
+        const float* mk = mask ? mask + rows0 : nullptr;
+        float* o = out + b0 * NN * 128;
+        if (proj_attn_bias)
+            hipLaunchKernelGGL(edge_embed_f16_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, na, nbp,
+                               rel_table, bin_table, bin_lower, ridx, cap, (const char*)weight_stream, b2, b3, ln_gamma, ln_beta,
+                               mk, o, M, n_res, rel_offset, n_rel, n_bins, ln_eps, proj_bias_cat64,
+                               proj_attn_bias + b0 * 8 * NN, proj_pair_z + b0 * NN * 32);
+        else
+            hipLaunchKernelGGL(edge_embed_f16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, na, nbp,
+                               rel_table, bin_table, bin_lower, ridx, cap, (const char*)weight_stream, b2, b3, ln_gamma, ln_beta,
+                               mk, o, M, n_res, rel_offset, n_rel, n_bins, ln_eps, (const float*)nullptr, (float*)nullptr,
+                               (float*)nullptr);
+    }
     return (int)hipGetLastError();
 }

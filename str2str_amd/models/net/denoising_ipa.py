@@ -74,8 +74,9 @@ class EmbeddingModule(nn.Module):
         self._dims = (init_embed_size, num_bins, float(min_bin), float(max_bin), edge_embed_size)
         self._wcache = ParamCache()
         self._proj_cache = ParamCache()
-        # pair-stream MLP arithmetic: "bf16x6" (split-bf16 MFMA, fp32-equivalent, default) or "f32" (exact fp32 MFMA)
-        self.mfma_mode = os.environ.get("S2S_EDGE_MFMA", "bf16x6")
+        # pair-stream MLP arithmetic: "f16x3" (two-way f16 split MFMA, default), "bf16x6" (three-way bf16 split MFMA; both
+        # fp32-equivalent) or "f32" (exact fp32 MFMA) -- see EdgeTransition in layers.py
+        self.mfma_mode = os.environ.get("S2S_EDGE_MFMA", "f16x3")
         self._idx_key = None
         self._idx_val = None
         self._idx_src = None
@@ -103,6 +104,7 @@ class EmbeddingModule(nn.Module):
                 "w2p": ops.pack_weight(e2.weight.float()), "w3p": ops.pack_weight(e4.weight.float()),
                 "node_mlp": [_pack_node(self.node_embed[2]), _pack_node(self.node_embed[4])],
                 "wstream": ops.pack_bf16x3_embed_stream(e2.weight.float(), e4.weight.float()),
+                "wstream_f16": ops.pack_f16x3_embed_stream(e2.weight.float(), e4.weight.float()),
             }
             if self.self_conditioning:
                 out["bin_tab"] = w0[:, 2 * t1 + ie:2 * t1 + ie + nb].t().contiguous()
@@ -184,14 +186,17 @@ class EmbeddingModule(nn.Module):
             node_b = (tl(w["w_col_t"])[:, None, :] + fixed * w["w_col_f"]).expand(B, L, -1).contiguous()
         ca = self_conditioning_ca.to(dev).float().contiguous() if self.self_conditioning else t_emb.new_zeros(B, L, 3)
         e2, e4, ln = self.edge_embed[2], self.edge_embed[4], self.edge_embed[5]
-        if self.mfma_mode != "f32":   # ("f16x3" only exists for the edge transition: the embedding stays on bf16x6)
+        if self.mfma_mode != "f32":
+            f16 = self.mfma_mode == "f16x3"
+            ws = w["wstream_f16"] if f16 else w["wstream"]
             proj = None
             if next_proj is not None:  # 5-stage stream: W2 | W3 | the first IPA block's projection stage
-                stream = self._proj_cache.get([w["wstream"], next_proj[2]], lambda: torch.cat([w["wstream"], next_proj[2]]))
+                pw = next_proj[3] if f16 else next_proj[2]
+                stream = self._proj_cache.get([ws, pw], lambda: torch.cat([ws, pw]))
                 proj = (stream, next_proj[1])
-            edge_embed = ops.edge_embed_bf16x6(node_a, node_b, self._rel_cb, w["bin_tab_cb"], w["bin_lower"], idx_dev, ca,
-                                               w["wstream"], e2.bias, e4.bias, ln.weight, ln.bias, mask, span, ln.eps,
-                                               proj=proj, column_blocked_tables=True)
+            fn = ops.edge_embed_f16x3 if f16 else ops.edge_embed_bf16x6
+            edge_embed = fn(node_a, node_b, self._rel_cb, w["bin_tab_cb"], w["bin_lower"], idx_dev, ca, ws, e2.bias, e4.bias,
+                            ln.weight, ln.bias, mask, span, ln.eps, proj=proj, column_blocked_tables=True)
         else:
             edge_embed = ops.edge_embed(node_a, node_b, rel_tab, w["bin_tab"], w["bin_lower"], idx_dev, ca, w["w2p"],
                                         w["w3p"], e2.bias, e4.bias, ln.weight, ln.bias, mask, span, ln.eps,

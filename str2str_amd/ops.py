@@ -30,6 +30,7 @@ _SIGNATURES = {
     "s2s_edge_transition_f16x3": [_vp] * 10 + [_i, _i, _f, _vp, _vp, _vp, _vp],
     "s2s_edge_embed": [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "s2s_edge_embed_bf16x6": [_vp] * 14 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "s2s_edge_embed_f16x3": [_vp] * 14 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "s2s_pair_project": [_vp] * 5 + [_i, _i, _vp],
     "s2s_ipa_prep_points": [_vp] * 6 + [_ll, _i, _i, _i, _i, _vp],
     "s2s_ipa_attention": [_vp] * 12 + [_i, _i, _i, _i, _i, _i, _i, _f, _f, _vp],
@@ -375,11 +376,26 @@ def column_blocked(t: torch.Tensor) -> torch.Tensor:
     return t.reshape(*lead, rows, ch // 4, 4).transpose(-3, -2).contiguous()
 
 
+def pack_f16x3_embed_stream(w2: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
+    """The 4-stage (32 KiB each) weight stream of s2s_edge_embed_f16x3: layer 2 then layer 3, [8 k-steps][4 tiles][(W_h, W_ls)];
+    the projection stage (``InvariantPointAttention._derived()['wp_f16x2']``) may be appended as the 5th."""
+    blob = torch.cat([pack_f16x2_layer(w2, "chain").reshape(-1), pack_f16x2_layer(w3, "chain").reshape(-1)])
+    blob = blob.view(torch.int16).contiguous()
+    assert blob.numel() * 2 == 4 * 32 * 1024
+    return blob
+
+
+def edge_embed_f16x3(*args, **kw):
+    """Edge embedding on split-f16 MFMA (csrc/pair_mlp_f16.hip); arguments of ``edge_embed_bf16x6`` with 32 KiB stages."""
+    return edge_embed_bf16x6(*args, _f16=True, **kw)
+
+
 def edge_embed_bf16x6(node_a, node_b, rel_table, bin_table, bin_lower, residue_idx, ca, wstream, b2, b3, gamma, beta, mask,
-                      rel_offset: int, ln_eps=1e-5, out=None, proj=None, column_blocked_tables=False):
+                      rel_offset: int, ln_eps=1e-5, out=None, proj=None, column_blocked_tables=False, _f16=False):
     """Edge embedding on split-bf16 MFMA; ``proj`` = (5-stage stream, bias64) also returns (attn_bias, pair_z).
     node_b / rel_table / bin_table: [.., rows, 128], or already ``column_blocked`` ([.., 32, rows, 4]) with the flag set."""
     lib = load_library()
+    entry, stage_kib = ("s2s_edge_embed_f16x3", 32) if _f16 else ("s2s_edge_embed_bf16x6", 48)
     B, N = node_a.shape[0], node_a.shape[1]
     if not column_blocked_tables:
         node_b, rel_table, bin_table = column_blocked(node_b), column_blocked(rel_table), column_blocked(bin_table)
@@ -396,16 +412,16 @@ def edge_embed_bf16x6(node_a, node_b, rel_table, bin_table, bin_lower, residue_i
         pbias = torch.empty(B, 8, N, N, device=node_a.device, dtype=torch.float32)
         ppz = torch.empty(B, N, N, 32, device=node_a.device, dtype=torch.float32)
     _req(wstream, torch.int16, "wstream")
-    if wstream.numel() * 2 != (5 if proj is not None else 4) * 48 * 1024:
-        raise HipLibraryError("edge_embed_bf16x6: weight stream has the wrong number of stages")
+    if wstream.numel() * 2 != (5 if proj is not None else 4) * stage_kib * 1024:
+        raise HipLibraryError(f"{entry}: weight stream has the wrong number of stages")
     if mask is not None:
         _req(mask, name="mask")
     if out is None:
         out = torch.empty(B, N, N, 128, device=node_a.device, dtype=torch.float32)
-    _check(lib.s2s_edge_embed_bf16x6(_p(node_a), _p(node_b), _p(rel_table), _p(bin_table), _p(bin_lower), _p(residue_idx),
-                                     _p(ca), _p(wstream), _p(b2), _p(b3), _p(gamma), _p(beta), _p(mask), _p(out), B, N,
-                                     int(rel_offset), rel_table.shape[1], bin_table.shape[1], ln_eps, _p(pb), _p(pbias),
-                                     _p(ppz), _stream()), "s2s_edge_embed_bf16x6")
+    _check(getattr(lib, entry)(_p(node_a), _p(node_b), _p(rel_table), _p(bin_table), _p(bin_lower), _p(residue_idx),
+                               _p(ca), _p(wstream), _p(b2), _p(b3), _p(gamma), _p(beta), _p(mask), _p(out), B, N,
+                               int(rel_offset), rel_table.shape[1], bin_table.shape[1], ln_eps, _p(pb), _p(pbias),
+                               _p(ppz), _stream()), entry)
     return out if proj is None else (out, pbias, ppz)
 
 

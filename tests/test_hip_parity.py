@@ -219,7 +219,7 @@ def test_edge_transition_vs_oracle(net_rough, B, N, mode):
     check(f"{_test_name()}: rel err", rel(out, ref), 2e-5)
 
 
-@pytest.mark.parametrize("mode", ["bf16x6", "f32"])
+@pytest.mark.parametrize("mode", ["bf16x6", "f16x3", "f32"])
 def test_edge_embed_golden(net_rough, mode):
     g = golden("embedding.npz")
     prev = _set_edge_mode(net_rough, mode)
