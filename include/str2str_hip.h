@@ -198,11 +198,13 @@ int s2s_se3_step(const float* x0_7, const float* xt_7, const float* mask, const 
                  double coordinate_scaling, int probability_flow, int center_trans, double noise_scale,
                  void* stream);
 
-/* ---- Per-node dense layers (split-bf16 MFMA, fp32-equivalent) ----
+/* ---- Per-node dense layers (split-f16 MFMA "f16x3", fp32-equivalent; see s2s_edge_transition_f16x3) ----
  * Activations travel between these layers as PACKED PLANES ("XP"): for X [M, K],
- *   XP[rt = row/32][ks = K/16][plane 3][lane 64][8] bf16, lane = 32 g + (row & 31),
- *   element j = plane of X[row][32 (ks>>1) + (r&3) + 8 (r>>2) + 4 g], r = 8 (ks&1) + j   (exact 3-way bf16 split h, m, l);
- * rows past M inside the last row tile are zero. */
+ *   XP[rt = row/32][ks = K/16][plane 3][lane 64][8] 16-bit, lane = 32 g + (row & 31),
+ *   element j = plane of X[row][32 (ks>>1) + (r&3) + 8 (r>>2) + 4 g], r = 8 (ks&1) + j;
+ * the planes of the node stream are f16 (x_h = rn16(x), x_l = rn16(x - x_h), x_hs = 2^-5 x_h); the operands of the IPA attention
+ * kernel (q / k projections: out_xp_format = 1) are exact three-way bf16 planes (h, m, l).  Rows past M inside the last row tile
+ * are zero. */
 
 /* fp32 row-major x [n_rows, ld], columns col0 .. col0 + n_cols (n_cols % 32 == 0), optionally scaled per row, -> k-steps
  * xp_kstep0 .. of an XP buffer holding xp_ksteps k-steps (concatenation along K = k-step ranges). */
@@ -216,11 +218,13 @@ int s2s_pack_planes(const float* x, long long n_rows, int ld, int col0, int n_co
  *     columns (gamma/beta given; needs n_out == 32 * tiles_per_block);  v *= post_mask[row]
  *   xp: packed planes of the input [n_rows, k_in]; w_packed: ops.pack_node_weight(W [n_out, k_in], tiles_per_block);
  *   outputs: out_f32[row * out_ld + out_col0 + col] and/or the packed planes of the result as k-steps out_xp_kstep0 .. of an XP
- *   buffer with out_xp_ksteps k-steps (the input format of the next layer).  Any pointer may be NULL to skip that step. */
+ *   buffer with out_xp_ksteps k-steps (out_xp_format 0: f16 planes, the input format of the next layer; 1: bf16 planes for the
+ *   attention kernel).  Any pointer may be NULL to skip that step. */
 int s2s_node_linear(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
                     int tiles_per_block, const float* pre_scale, int relu, const float* pre_mask, const float* residual,
                     int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_mask,
-                    float* out_f32, int out_ld, int out_col0, void* out_xp, int out_xp_ksteps, int out_xp_kstep0, void* stream);
+                    float* out_f32, int out_ld, int out_col0, void* out_xp, int out_xp_ksteps, int out_xp_kstep0,
+                    int out_xp_format, void* stream);
 
 /* The same GEMM with the operands swapped, for a projection whose output is consumed as the A operand of a later product over
  * its ROWS (the value projection of InvariantPointAttention, ipa.py:132-141, consumed by the PV step): the result (+ bias) is

@@ -173,17 +173,17 @@ __global__ void __launch_bounds__(256) enc_attention_kernel(const float* __restr
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (2 * t + u >= DH / 16) continue;
-                bf16x8 ph, pm, pl;
+                // f16 planes of the node stream (x_h, x_l, 2^-5 x_h), csrc/node_gemm.hip
+                typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                f16x8 ph, pl, ps;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float v = O[t][8 * u + j] * inv;
-                    const __bf16 a_ = (__bf16)v;
-                    const float r1 = v - (float)a_;
-                    const __bf16 b_ = (__bf16)r1;
-                    ph[j] = a_; pm[j] = b_; pl[j] = (__bf16)(r1 - (float)b_);
+                    const _Float16 a_ = (_Float16)v;
+                    ph[j] = a_; pl[j] = (_Float16)(v - (float)a_); ps[j] = a_ * (_Float16)0.03125f;
                 }
                 bf16x8* q = o + ((2 * t + u) * 3) * 64;
-                q[0] = ph; q[64] = pm; q[128] = pl;
+                q[0] = __builtin_bit_cast(bf16x8, ph); q[64] = __builtin_bit_cast(bf16x8, pl); q[128] = __builtin_bit_cast(bf16x8, ps);
             }
     }
 }

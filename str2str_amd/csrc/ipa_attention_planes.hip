@@ -659,10 +659,16 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = O[x][8 * u + j] * inv;
-                bf16x8 ph, pm, pl;
-                split8(v, ph, pm, pl);
+                // this output is an INPUT of the node stream (linear_out, s2s_node_linear): f16 planes (x_h, x_l, 2^-5 x_h)
+                typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                f16x8 ph, pl, ps;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const _Float16 hh = (_Float16)v[j];
+                    ph[j] = hh; pl[j] = (_Float16)(v[j] - (float)hh); ps[j] = hh * (_Float16)0.03125f;
+                }
                 bf16x8* q = o + ((2 * T + u) * 3) * 64;
-                q[0] = ph; q[64] = pm; q[128] = pl;
+                q[0] = __builtin_bit_cast(bf16x8, ph); q[64] = __builtin_bit_cast(bf16x8, pl); q[128] = __builtin_bit_cast(bf16x8, ps);
             }
         }
     }

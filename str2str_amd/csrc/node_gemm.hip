@@ -1,24 +1,28 @@
-// Per-node dense layers on split-bf16 MFMA ("bf16x6", fp32-equivalent; see pair_mlp_bf16.hip): every nn.Linear of the trunk that acts
-// on the [B*N, c] node stream -- linear_q / linear_kv / point projections, linear_out, skip_embed, the transformer's in/out
-// projections and feed-forward, trunk.linear_b, NodeTransition, BackboneUpdate, EdgeTransition.initial_embed and the per-node
-// halves of its first layer, TorsionAngleHead (reference src/models/net/ipa.py:131-171,259-266,312-317,357-366;
+// Per-node dense layers on split-f16 MFMA ("f16x3", fp32-equivalent; the formulation of pair_mlp_f16.hip): every nn.Linear of the
+// trunk that acts on the [B*N, c] node stream -- linear_q / linear_kv / point projections, linear_out, skip_embed, the transformer's
+// in/out projections and feed-forward, trunk.linear_b, NodeTransition, BackboneUpdate, EdgeTransition.initial_embed and the
+// per-node halves of its first layer, TorsionAngleHead (reference src/models/net/ipa.py:131-171,259-266,312-317,357-366;
 // layers.py:128-145,188-241) -- with bias / ReLU / mask / residual / LayerNorm fused into the epilogue.
 //
 // Formulation (the edge kernel's, transposed):  Y^T[out, row] = W . X^T.   A operand = weight fragment (shared by the 4 waves
 // of a workgroup through LDS, double buffered), B operand = activation fragment of the wave's own 32 rows.  In that
 // orientation the accumulator layout of a layer IS the B-operand layout of the next one, so activations travel between
 // layers as PACKED PLANES ("XP"): for X [M, K]
-//     XP[rt = row/32][ks = K/16][plane 3][lane 64][8] bf16,  lane = 32 g + (row & 31),
+//     XP[rt = row/32][ks = K/16][plane 3][lane 64][8] 16-bit,  lane = 32 g + (row & 31),
 //     element j = plane of X[row][32 (ks>>1) + (r&3) + 8 (r>>2) + 4 g],  r = 8 (ks&1) + j        ("chain" order)
 // i.e. exactly the 1 KiB a wave's B-fragment load wants: every global access of this kernel is lane-linear (16 B per lane,
 // 1 KiB per instruction), there is no LDS staging, no swizzle and no split VALU on the input side -- a value is split into
-// its three planes ONCE, in the epilogue of the kernel that produced it (or by s2s_pack_planes for fp32 inputs).
-// Weights are packed on the host in the same chain order (ops.pack_node_weight): [col block][k-step][tile][plane 3][lane][8].
+// its planes ONCE, in the epilogue of the kernel that produced it (or by s2s_pack_planes for fp32 inputs).
+// Planes of the node stream: f16 (x_h = rn16(x), x_l = rn16(x - x_h), x_hs = 2^-5 x_h); a product keeps
+//     W_h x_h + W_h x_l + W_ls x_hs,   W_h = rn16(w), W_ls = rn16(2^5 (w - W_h))
+// -- 3 MFMAs and 2 weight fragments per (k-step, tile); what is dropped (w_l x_l) is below one fp32 rounding.  The q / k
+// projections feed the IPA attention kernel, whose operands are exact three-way bf16 planes (h, m, l): out_xp_format = 1 writes
+// those instead.  Weights are packed on the host in chain order (ops.pack_node_weight): [col block][k-step][tile][2][lane][8].
 //
 // Per workgroup: 4 waves x 32 rows, TG output tiles of 32 columns (TG x 16 accumulator registers per lane), one weight stage
-// (one k-step: TG tiles x 3 planes = 3 TG KiB) per barrier, two workgroups per CU.  Per (k-step, tile): 3 ds_read_b128 + 6
-// MFMAs (plane pairs lh, hl, mm, mh, hm, hh).  The weight stage of the NEXT k-step travels global -> VGPR during a stage and
-// VGPR -> LDS at its end, the wave's own activation fragments are fetched one k-step ahead.
+// (one k-step: TG tiles x 2 planes = 2 TG KiB) per barrier, two workgroups per CU.  Per (k-step, tile): 2 ds_read_b128 + 3
+// MFMAs.  The weight stage of the NEXT k-step travels global -> VGPR during a stage and VGPR -> LDS at its end, the wave's own
+// activation fragments are fetched one k-step ahead.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -30,10 +34,11 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ f32x16 mfma_bf16(bf16x8 a, bf16x8 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+__device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
@@ -49,9 +54,30 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& ph, bf16x8& pm, b
     }
 }
 
+// planes of the node stream: (x_h, x_l, 2^-5 x_h), see the header
+__device__ __forceinline__ void split8_f16(const float* v, f16x8& ph, f16x8& pl, f16x8& ps) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 a = (_Float16)v[j];
+        ph[j] = a; pl[j] = (_Float16)(v[j] - (float)a); ps[j] = a * (_Float16)0.03125f;
+    }
+}
+// 8 values -> three 16 B plane fragments 64 fragments apart, in the requested format
+__device__ __forceinline__ void store_planes(f16x8* q, const float* v, bool bf16_planes) {
+    if (bf16_planes) {
+        bf16x8 ph, pm, pl;
+        split8(v, ph, pm, pl);
+        q[0] = __builtin_bit_cast(f16x8, ph); q[64] = __builtin_bit_cast(f16x8, pm); q[128] = __builtin_bit_cast(f16x8, pl);
+    } else {
+        f16x8 ph, pl, ps;
+        split8_f16(v, ph, pl, ps);
+        q[0] = ph; q[64] = pl; q[128] = ps;
+    }
+}
+
 struct GemmArgs {
-    const bf16x8* xp;        // packed activation planes [RT][KS][3][64] fragments
-    const char* wpk;         // packed weights [n_col_blocks][KS][TG][3][64][8] bf16
+    const f16x8* xp;         // packed activation planes [RT][KS][3][64] fragments (f16 planes)
+    const char* wpk;         // packed weights [n_col_blocks][KS][TG][2][64][8] f16 (W_h, W_ls)
     const float* bias;       // [Nout] or NULL
     const float* pre_scale;  // [M] or NULL: acc *= pre_scale[row] before the bias (input rows were to be scaled)
     const float* pre_mask;   // [M] or NULL: (acc + bias) *= pre_mask[row]
@@ -60,8 +86,8 @@ struct GemmArgs {
     const float* ln_beta;
     const float* post_mask;  // [M] or NULL: applied last
     float* out_f32;          // [M, out_ld] (columns out_col0 + ...) or NULL
-    bf16x8* out_xp;          // packed planes of the output as a K' = 16 * xp_KS wide activation, at k-step offset xp_ks0, or NULL
-    bf16x8* out_vf;          // VF kernels only: the output as A fragments of a [32 rows x 32 columns] x 2 k-step tiling (see below)
+    f16x8* out_xp;           // packed planes of the output as a K' = 16 * xp_KS wide activation, at k-step offset xp_ks0, or NULL
+    bf16x8* out_vf;          // VF kernels only (exact three-way bf16 planes: the attention kernel's PV operands): the output as A fragments of a [32 rows x 32 columns] x 2 k-step tiling (see below)
     int vf_tiles_per_head;   // column tiles (of 32) per head
     long long M;
     int KS;                  // K / 16 (even)
@@ -69,6 +95,7 @@ struct GemmArgs {
     int res_ld, out_ld, out_col0, xp_KS, xp_ks0;
     int relu;
     float ln_eps;
+    int xp_bf16;             // out_xp as exact three-way bf16 planes (operands of the IPA attention kernel) instead of f16 planes
 };
 
 // VF: operands swapped -- Y[row, col] = X . W^T with A = the activation fragment, B = the weight fragment -- so that a lane owns
@@ -78,12 +105,12 @@ struct GemmArgs {
 //   out_vf[row tile][head][column tile in head][k-step u][plane 3][lane 64][8]   (bf16; 1 KiB per (u, plane), lane-linear)
 template <int TG, int WAVES, bool VF>
 __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
-    // One weight stage = ONE k-step (TG tiles x 3 planes = 3 TG KiB), double buffered: 6 TG KiB of LDS and <= 256 registers, so
+    // One weight stage = ONE k-step (TG tiles x 2 planes = 2 TG KiB), double buffered: 4 TG KiB of LDS and <= 256 registers, so
     // two workgroups share a CU (two waves per SIMD): one's barrier / LDS latency hides under the other's MFMAs.
     // (Measured and dropped: LDS-DMA for the weight copy, 2-wave workgroups for single-column-block shapes, and persistent
     // workgroups walking several column blocks with one continuous weight stream -- each slower than this plain form.)
-    constexpr int kStage = 3 * TG * 1024;
-    constexpr int kFrags = 3 * TG;                          // 1 KiB pieces per stage
+    constexpr int kStage = 2 * TG * 1024;
+    constexpr int kFrags = 2 * TG;                          // 1 KiB pieces per stage
     constexpr int kPieces = (kFrags + WAVES - 1) / WAVES;   // per wave
     extern __shared__ __attribute__((aligned(16))) char s_w[];  // 2 stages
     const int lane = threadIdx.x & 63, h = lane >> 5;
@@ -95,7 +122,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
 
     typedef __attribute__((address_space(3))) char lds_char;
     typedef __attribute__((address_space(3))) f32x4 lds_f4;
-    typedef __attribute__((address_space(3))) bf16x8 lds_frag;
+    typedef __attribute__((address_space(3))) f16x8 lds_frag;
 
     // weight copy global -> VGPR -> LDS (an LDS-DMA copy costs ~100 issue cycles per 1 KiB piece on the wave that issues it,
     // measured slower here as in the edge kernel): piece k of this wave = KiB number WAVES k + wave of the stage
@@ -117,11 +144,11 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
             if (WAVES * k + WAVES - 1 < kFrags || WAVES * k + wave < kFrags) *(lds_f4*)(dst + (WAVES * k + wave) * 1024) = wst[k];
         }
     };
-    const bf16x8* xsrc = a.xp + (rtc * KS) * 3 * 64 + lane;
-    bf16x8 xa[3], xb[3];  // activation fragments (planes) of the current / next k-step
-    auto x_load = [&](int ks, bf16x8 (&x)[3]) {
+    const f16x8* xsrc = a.xp + (rtc * KS) * 3 * 64 + lane;
+    f16x8 xa[3], xb[3];  // activation fragments (planes) of the current / next k-step
+    auto x_load = [&](int ks, f16x8 (&x)[3]) {
         ks = ks < KS ? ks : KS - 1;
-        const bf16x8* p = xsrc + (long long)ks * 3 * 64;
+        const f16x8* p = xsrc + (long long)ks * 3 * 64;
         x[0] = p[0]; x[1] = p[64]; x[2] = p[128];
     };
 
@@ -135,35 +162,29 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
 
     // tiles in pairs (two interleaved accumulators); the fragments of the next pair are fetched before the current pair's MFMAs
     constexpr int NP = (TG + 1) / 2;
-    auto compute = [&](int par, const bf16x8 (&x)[3]) {
+    auto compute = [&](int par, const f16x8 (&x)[3]) {
         const lds_frag* wl = (const lds_frag*)((lds_char*)s_w + par * kStage) + lane;
-        bf16x8 f[2][6];
-        auto fetch = [&](int p, bf16x8 (&d)[6]) {
-            const lds_frag* q = wl + (2 * p) * 3 * 64;
-            d[0] = q[0]; d[1] = q[64]; d[2] = q[128];
-            if (2 * p + 1 < TG) { d[3] = q[192]; d[4] = q[256]; d[5] = q[320]; }
+        f16x8 f[2][4];
+        auto fetch = [&](int p, f16x8 (&d)[4]) {
+            const lds_frag* q = wl + (2 * p) * 2 * 64;
+            d[0] = q[0]; d[1] = q[64];
+            if (2 * p + 1 < TG) { d[2] = q[128]; d[3] = q[192]; }
         };
         fetch(0, f[0]);
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             if (p + 1 < NP) fetch(p + 1, f[(p + 1) & 1]);
-            const bf16x8 (&w)[6] = f[p & 1];
-            auto mm = [&](const bf16x8& wf, const bf16x8& xf, f32x16 c) { return VF ? mfma_bf16(xf, wf, c) : mfma_bf16(wf, xf, c); };
+            const f16x8 (&w)[4] = f[p & 1];
+            auto mm = [&](const f16x8& wf, const f16x8& xf, f32x16 c) { return VF ? mfma_f16(xf, wf, c) : mfma_f16(wf, xf, c); };
             if (2 * p + 1 < TG) {
                 f32x16 c = acc[2 * p], d = acc[2 * p + 1];
-                c = mm(w[2], x[0], c); d = mm(w[5], x[0], d);  // (l,h)
-                c = mm(w[0], x[2], c); d = mm(w[3], x[2], d);  // (h,l)
-                c = mm(w[1], x[1], c); d = mm(w[4], x[1], d);  // (m,m)
-                c = mm(w[1], x[0], c); d = mm(w[4], x[0], d);  // (m,h)
-                c = mm(w[0], x[1], c); d = mm(w[3], x[1], d);  // (h,m)
-                c = mm(w[0], x[0], c); d = mm(w[3], x[0], d);  // (h,h)
+                c = mm(w[1], x[2], c); d = mm(w[3], x[2], d);  // W_ls x_hs
+                c = mm(w[0], x[1], c); d = mm(w[2], x[1], d);  // W_h x_l
+                c = mm(w[0], x[0], c); d = mm(w[2], x[0], d);  // W_h x_h
                 acc[2 * p] = c; acc[2 * p + 1] = d;
             } else {
                 f32x16 c = acc[2 * p];
-                c = mm(w[2], x[0], c);
-                c = mm(w[0], x[2], c);
-                c = mm(w[1], x[1], c);
-                c = mm(w[1], x[0], c);
+                c = mm(w[1], x[2], c);
                 c = mm(w[0], x[1], c);
                 c = mm(w[0], x[0], c);
                 acc[2 * p] = c;
@@ -188,7 +209,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
 #endif
 #if S2S_NODE_XDEPTH == 2
     // activation fragments fetched TWO k-steps ahead (they come from HBM / a remote L2, ~2 us away; a k-step is ~0.9 us)
-    bf16x8 xc[3];
+    f16x8 xc[3];
     x_load(1, xb);
     for (int ks = 0; ks < KS; ks += 2) {
         x_load(ks + 2, xc);
@@ -203,7 +224,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
         __syncthreads();
         // rotate: (xa, xb) <- (k-step ks + 2, ks + 3)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { const bf16x8 t = xa[p]; xa[p] = xc[p]; xb[p] = t; }
+        for (int p = 0; p < 3; ++p) { const f16x8 t = xa[p]; xa[p] = xc[p]; xb[p] = t; }
     }
 #else
     for (int ks = 0; ks < KS; ks += 2) {
@@ -316,7 +337,8 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
     if (a.out_xp && rt < n_rt) {
         // the accumulator layout is the next layer's B-operand layout: k-step 2 (cb TG + t) + u = registers 8u .. 8u+7 of tile t.
         // Rows past M inside the last row tile are written as zeros (they are read, never stored, by the consumer).
-        bf16x8* o = a.out_xp + ((rt * a.xp_KS + a.xp_ks0 + 2 * (cb * TG)) * 3) * 64 + lane;
+        f16x8* o = a.out_xp + ((rt * a.xp_KS + a.xp_ks0 + 2 * (cb * TG)) * 3) * 64 + lane;
+        const bool bf16_planes = a.xp_bf16 != 0;
 #pragma unroll
         for (int t = 0; t < TG; ++t)
 #pragma unroll
@@ -324,10 +346,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = valid ? acc[t][8 * u + j] : 0.f;
-                bf16x8 ph, pmid, pl;
-                split8(v, ph, pmid, pl);
-                bf16x8* q = o + ((2 * t + u) * 3) * 64;
-                q[0] = ph; q[64] = pmid; q[128] = pl;
+                store_planes(o + ((2 * t + u) * 3) * 64, v, bf16_planes);
             }
     }
 }
@@ -335,7 +354,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
 // fp32 row-major [M, ld] (columns col0 .. col0 + 16 KS) -> packed planes at k-step offset ks0 of an XP buffer with xp_KS k-steps.
 // One wave per (row tile, k-step): lane (row m, half g) gathers its 8 chain-ordered channels (two float4), splits, stores 3 x 16 B.
 __global__ void __launch_bounds__(256) pack_planes_kernel(const float* __restrict__ x, long long M, int ld, int col0, int KS,
-                                                          bf16x8* __restrict__ xp, int xp_KS, int ks0, const float* __restrict__ row_scale) {
+                                                          f16x8* __restrict__ xp, int xp_KS, int ks0, const float* __restrict__ row_scale) {
     const int lane = threadIdx.x & 63, g = lane >> 5;
     const long long unit = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long n_rt = (M + 31) / 32;
@@ -352,15 +371,12 @@ __global__ void __launch_bounds__(256) pack_planes_kernel(const float* __restric
         v[0] = lo.x * sc; v[1] = lo.y * sc; v[2] = lo.z * sc; v[3] = lo.w * sc;
         v[4] = hi.x * sc; v[5] = hi.y * sc; v[6] = hi.z * sc; v[7] = hi.w * sc;
     }
-    bf16x8 ph, pm, pl;
-    split8(v, ph, pm, pl);
-    bf16x8* o = xp + ((rt * xp_KS + ks0 + ks) * 3) * 64 + lane;
-    o[0] = ph; o[64] = pm; o[128] = pl;
+    store_planes(xp + ((rt * xp_KS + ks0 + ks) * 3) * 64 + lane, v, false);
 }
 
 template <int TG, int WAVES, bool VF = false>
 int launch_gemm_w(const GemmArgs& a, hipStream_t stream) {
-    constexpr int lds = 2 * 3 * TG * 1024;
+    constexpr int lds = 2 * 2 * TG * 1024;
     static bool attr_set = false;
     if (!attr_set) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&node_gemm_kernel<TG, WAVES, VF>),
@@ -389,7 +405,7 @@ extern "C" int s2s_pack_planes(const float* x, long long n_rows, int ld, int col
     const int KS = n_cols / 16;
     const long long units = ((n_rows + 31) / 32) * KS;
     hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n_rows, ld, col0, KS,
-                       (bf16x8*)xp, xp_ksteps, xp_kstep0, row_scale);
+                       (f16x8*)xp, xp_ksteps, xp_kstep0, row_scale);
     return (int)hipGetLastError();
 }
 
@@ -397,7 +413,7 @@ extern "C" int s2s_node_linear(const void* xp, const void* w_packed, const float
                                int tiles_per_block, const float* pre_scale, int relu, const float* pre_mask, const float* residual,
                                int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_mask,
                                float* out_f32, int out_ld, int out_col0, void* out_xp, int out_xp_ksteps, int out_xp_kstep0,
-                               void* stream) {
+                               int out_xp_format, void* stream) {
     if (n_rows <= 0) return 0;
     const int TG = tiles_per_block;
     if (!xp || !w_packed || k_in <= 0 || k_in % 32 || n_out <= 0 || n_out % (32 * TG) || (!out_f32 && !out_xp))
@@ -407,8 +423,10 @@ extern "C" int s2s_node_linear(const void* xp, const void* w_packed, const float
     if (out_f32 && (out_ld % 4 || out_col0 % 4)) return (int)hipErrorInvalidValue;
     if (residual && residual_ld % 4) return (int)hipErrorInvalidValue;
     if (out_xp && (out_xp_kstep0 < 0 || out_xp_kstep0 % 2 || out_xp_kstep0 + n_out / 16 > out_xp_ksteps)) return (int)hipErrorInvalidValue;
-    GemmArgs a{(const bf16x8*)xp, (const char*)w_packed, bias, pre_scale, pre_mask, residual, ln_gamma, ln_beta, post_mask, out_f32,
-               (bf16x8*)out_xp, nullptr, 0, n_rows, k_in / 16, ncb, residual_ld, out_ld, out_col0, out_xp_ksteps, out_xp_kstep0, relu, ln_eps};
+    if (out_xp_format != 0 && out_xp_format != 1) return (int)hipErrorInvalidValue;
+    GemmArgs a{(const f16x8*)xp, (const char*)w_packed, bias, pre_scale, pre_mask, residual, ln_gamma, ln_beta, post_mask, out_f32,
+               (f16x8*)out_xp, nullptr, 0, n_rows, k_in / 16, ncb, residual_ld, out_ld, out_col0, out_xp_ksteps, out_xp_kstep0, relu, ln_eps,
+               out_xp_format};
     hipStream_t st = (hipStream_t)stream;
     switch (TG) {
         case 1: return launch_gemm<1>(a, st);
@@ -429,7 +447,7 @@ extern "C" int s2s_node_linear_vfrag(const void* xp, const void* w_packed, const
     if (!xp || !w_packed || !out_vf || k_in <= 0 || k_in % 32 || n_out <= 0 || n_out % (32 * TG) || tiles_per_head <= 0 ||
         (n_out / 32) % tiles_per_head)
         return (int)hipErrorInvalidValue;
-    GemmArgs a{(const bf16x8*)xp, (const char*)w_packed, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-               (bf16x8*)out_vf, tiles_per_head, n_rows, k_in / 16, n_out / (32 * TG), 0, 0, 0, 0, 0, 0, 0.f};
+    GemmArgs a{(const f16x8*)xp, (const char*)w_packed, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+               (bf16x8*)out_vf, tiles_per_head, n_rows, k_in / 16, n_out / (32 * TG), 0, 0, 0, 0, 0, 0, 0.f, 0};
     return launch_gemm_w<TG, 4, true>(a, (hipStream_t)stream);
 }

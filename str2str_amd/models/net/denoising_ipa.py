@@ -74,6 +74,7 @@ class EmbeddingModule(nn.Module):
         self._dims = (init_embed_size, num_bins, float(min_bin), float(max_bin), edge_embed_size)
         self._wcache = ParamCache()
         self._proj_cache = ParamCache()
+        self._proj_cache_f16 = ParamCache()
         # pair-stream MLP arithmetic: "f16x3" (two-way f16 split MFMA, default), "bf16x6" (three-way bf16 split MFMA; both
         # fp32-equivalent) or "f32" (exact fp32 MFMA) -- see EdgeTransition in layers.py
         self.mfma_mode = os.environ.get("S2S_EDGE_MFMA", "f16x3")
@@ -192,7 +193,8 @@ class EmbeddingModule(nn.Module):
             proj = None
             if next_proj is not None:  # 5-stage stream: W2 | W3 | the first IPA block's projection stage
                 pw = next_proj[3] if f16 else next_proj[2]
-                stream = self._proj_cache.get([ws, pw], lambda: torch.cat([ws, pw]))
+                cache = self._proj_cache_f16 if f16 else self._proj_cache   # one slot per mode (captured HIP graphs keep the pointer)
+                stream = cache.get([ws, pw], lambda: torch.cat([ws, pw]))
                 proj = (stream, next_proj[1])
             fn = ops.edge_embed_f16x3 if f16 else ops.edge_embed_bf16x6
             edge_embed = fn(node_a, node_b, self._rel_cb, w["bin_tab_cb"], w["bin_lower"], idx_dev, ca, ws, e2.bias, e4.bias,

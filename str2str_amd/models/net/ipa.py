@@ -94,8 +94,8 @@ class InvariantPointAttention(nn.Module):
         -> packed planes of linear_out's input [B*N, H*(c_hidden + 4 Pv + c_z/4)]"""
         w, d, M, H = self.node_packs(), self._derived(), B * N, self.no_heads
         lin = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], M, x["k"], x["n"], x["tg"], **kw)  # noqa: E731
-        _, q_xp = lin(w["q"], want_f32=False, want_xp=True)
-        _, k_xp = lin(w["k"], want_f32=False, want_xp=True)
+        _, q_xp = lin(w["q"], want_f32=False, want_xp=True, xp_bf16=True)   # attention operands: exact three-way bf16 planes
+        _, k_xp = lin(w["k"], want_f32=False, want_xp=True, xp_bf16=True)
         v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, w["v"]["k"], w["v"]["n"], self.c_hidden // 32)
         qp, _ = lin(w["qp"])
         kvp, _ = lin(w["kvp"])

@@ -103,6 +103,7 @@ class EdgeTransition(nn.Module):
         self._shape = (edge_embed_in, bias_embed_size, hidden, edge_embed_out, num_layers)
         self._cache = ParamCache()
         self._proj_cache = ParamCache()
+        self._proj_cache_f16 = ParamCache()   # one slot per arithmetic mode: a captured HIP graph keeps pointing at its stream
         # "f16x3" (default): two-way f16 split of both operands (11 + 11 bits + sign = fp32's 24), three products per block with
         # exact 2^+-5 scalings of the small factors, fp32 accumulation (csrc/pair_mlp_f16.hip): 1.65x faster than
         # "bf16x6": exact 3-way bf16 split, six plane-pair products (csrc/pair_mlp_bf16.hip), which is 1.6x faster than
@@ -149,7 +150,7 @@ class EdgeTransition(nn.Module):
         if self.mfma_mode == "f16x3":
             proj = None
             if next_proj is not None:
-                stream = self._proj_cache.get([pk["wstream_f16"], next_proj[3]], lambda: torch.cat([pk["wstream_f16"], next_proj[3]]))
+                stream = self._proj_cache_f16.get([pk["wstream_f16"], next_proj[3]], lambda: torch.cat([pk["wstream_f16"], next_proj[3]]))
                 proj = (stream, next_proj[1])
             return ops.edge_transition_f16x3(edge_embed.contiguous(), node_ab, n_p, pk["wstream_f16"], self.trunk[2].bias,
                                              self.final_layer.bias, self.layer_norm.weight, self.layer_norm.bias, mask,

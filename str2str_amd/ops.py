@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _lib = None
 _tables_loaded = False
@@ -44,7 +44,7 @@ _SIGNATURES = {
     "s2s_se3_step": [_vp] * 12 + [_i, _i, _d, _d, _i, _i, _d, _vp],
     "s2s_forward_marginal": [_vp] * 7 + [_i, _vp, _vp, _f, _vp, _i, _i, _vp],
     "s2s_pack_planes": [_vp, _ll, _i, _i, _i, _vp, _i, _i, _vp, _vp],
-    "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
+    "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
     "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _vp],
     "s2s_encoder_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "s2s_ca_sample_stats": [_vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
@@ -656,7 +656,7 @@ def node_tiles(n_out: int, whole_row: bool = False) -> int:
 
 
 def pack_node_weight(w: torch.Tensor, tiles_per_block: int) -> torch.Tensor:
-    """[n_out, k_in] fp32 -> int16 blob [n_out/(32 TG)][k_in/16][TG][3][64][8] of chain-ordered bf16x3 A fragments
+    """[n_out, k_in] fp32 -> int16 blob [n_out/(32 TG)][k_in/16][TG][2][64][8] of chain-ordered f16 A fragments (W_h, W_ls)
     (s2s_node_linear).  n_out is zero-padded to a multiple of 32 first."""
     n_out, k = w.shape
     pad = (-n_out) % 32
@@ -664,14 +664,14 @@ def pack_node_weight(w: torch.Tensor, tiles_per_block: int) -> torch.Tensor:
         w = torch.cat([w, w.new_zeros(pad, k)], dim=0)
     if k % 32 or (w.shape[0] // 32) % tiles_per_block:
         raise ValueError("k_in must be a multiple of 32 and n_out/32 of tiles_per_block")
-    fr = pack_bf16x3_layer(w.float(), "chain")                      # [KS, T, 3, 64, 8]
+    fr = pack_f16x2_layer(w.float(), "chain")                       # [KS, T, 2, 64, 8]
     KS, T = fr.shape[:2]
-    fr = fr.reshape(KS, T // tiles_per_block, tiles_per_block, 3, 64, 8).permute(1, 0, 2, 3, 4, 5)
+    fr = fr.reshape(KS, T // tiles_per_block, tiles_per_block, 2, 64, 8).permute(1, 0, 2, 3, 4, 5)
     return fr.contiguous().view(torch.int16).reshape(-1)
 
 
 def xp_alloc(n_rows: int, k: int, device) -> torch.Tensor:
-    """Packed-plane activation buffer for [n_rows, k] (int16 storage of bf16; see include/str2str_hip.h)."""
+    """Packed-plane activation buffer for [n_rows, k] (int16 storage of three 16-bit planes; see include/str2str_hip.h)."""
     return torch.empty(((n_rows + 31) // 32) * (k // 16) * 3 * 64 * 8, dtype=torch.int16, device=device)
 
 
@@ -694,17 +694,18 @@ def pack_planes(x2d: torch.Tensor, col0: int = 0, n_cols: Optional[int] = None, 
 
 def node_linear(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles: int, *, pre_scale=None, relu=False, pre_mask=None,
                 residual=None, ln=None, post_mask=None, out_f32=None, out_col0: int = 0, want_f32=True, out_xp=None,
-                out_xp_k: Optional[int] = None, out_xp_k0: int = 0, want_xp=False):
+                out_xp_k: Optional[int] = None, out_xp_k0: int = 0, want_xp=False, xp_bf16=False):
     """One fused per-node layer (s2s_node_linear).  ``residual`` [n_rows, ld] fp32 (its leading n_out columns are added);
     ``ln`` = (gamma, beta, eps); ``out_f32`` a preallocated [n_rows, ld] buffer written at ``out_col0`` (allocated
-    [n_rows, n_out] when ``want_f32``); ``out_xp`` likewise for the packed planes.  -> (out_f32 or None, out_xp or None)."""
+    [n_rows, n_out] when ``want_f32``); ``out_xp`` likewise for the packed planes (``xp_bf16``: as exact three-way bf16 planes,
+    the operand format of the IPA attention kernel, instead of the node stream's f16 planes).  -> (out_f32 or None, out_xp or None)."""
     lib = load_library()
     _req(xp, torch.int16, "xp"); _req(wpk, torch.int16, "w_packed")
     dev = xp.device
     for n, t in (("bias", bias), ("pre_scale", pre_scale), ("pre_mask", pre_mask), ("residual", residual), ("post_mask", post_mask)):
         if t is not None:
             _req(t, name=n)
-    if xp.numel() != ((n_rows + 31) // 32) * (k_in // 16) * 1536 or wpk.numel() != n_out * k_in * 3:
+    if xp.numel() != ((n_rows + 31) // 32) * (k_in // 16) * 1536 or wpk.numel() != n_out * k_in * 2:
         raise HipLibraryError(f"node_linear: operand sizes do not match M={n_rows} K={k_in} N={n_out}")
     if out_f32 is None and want_f32:
         out_f32 = torch.empty(n_rows, n_out, device=dev, dtype=torch.float32)
@@ -723,7 +724,7 @@ def node_linear(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles: int, *
         _p(xp), _p(wpk), _p(bias), n_rows, k_in, n_out, tiles, _p(pre_scale), int(bool(relu)), _p(pre_mask), _p(residual),
         residual.shape[-1] if residual is not None else 0, _p(g), _p(b), float(eps), _p(post_mask), _p(out_f32),
         out_f32.shape[-1] if out_f32 is not None else 0, out_col0, _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16,
-        _stream())), "s2s_node_linear")
+        int(bool(xp_bf16)), _stream())), "s2s_node_linear")
     return out_f32, out_xp
 
 
@@ -787,10 +788,13 @@ def ca_pwd_js(ref_ca: torch.Tensor, pred_ca: torch.Tensor, offset: int = 3, n_bi
     return out
 
 
-def unpack_planes(xp: torch.Tensor, n_rows: int, k: int) -> torch.Tensor:
-    """XP -> fp32 [n_rows, k] (sum of the three planes; for tests and debugging)."""
+def unpack_planes(xp: torch.Tensor, n_rows: int, k: int, bf16: bool = False) -> torch.Tensor:
+    """XP -> fp32 [n_rows, k] (x_h + x_l of the f16 planes, or h + m + l of bf16 planes; for tests and debugging)."""
     KS = k // 16
-    fr = xp.view(torch.bfloat16).reshape(-1, KS, 3, 2, 32, 8).float().sum(2)    # [RT, KS, g, m, j]
+    if bf16:
+        fr = xp.view(torch.bfloat16).reshape(-1, KS, 3, 2, 32, 8).float().sum(2)    # [RT, KS, g, m, j]
+    else:
+        fr = xp.view(torch.float16).reshape(-1, KS, 3, 2, 32, 8).float()[:, :, :2].sum(2)
     ks = torch.arange(KS)[:, None, None]
     g = torch.arange(2)[None, :, None]
     j = torch.arange(8)[None, None, :]

@@ -75,8 +75,9 @@ def _graph_key(net, feats, b, N):
             continue  # per-step inputs are copied into the static buffers at every replay
         h.update(k.encode()); h.update(str(tuple(v.shape)).encode()); h.update(v.detach().cpu().numpy().tobytes())
     tr = getattr(net, "translator", None)
-    return (id(net), sum(p._version for p in net.parameters()), b, N, bool(getattr(tr, "exact_padding", False)),
-            h.hexdigest())
+    modes = tuple(sorted({getattr(m, "mfma_mode") for m in net.modules() if hasattr(m, "mfma_mode")}))  # which kernels were captured
+    return (id(net), sum(p._version for p in net.parameters()), b, N, bool(getattr(tr, "exact_padding", False)), modes,
+            os.environ.get("S2S_IPA_PATH", "planes"), h.hexdigest())
 
 
 def _maybe_graph(net, feats, b, N, trace, n_steps):

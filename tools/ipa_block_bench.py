@@ -53,8 +53,8 @@ alg = B * 4 * (9512 * N + 40 * N * N)
 with torch.no_grad():
     print(f"planes path  B={B} N={N}")
     tot = 0.0
-    (_, q_xp), t = timeit("q  -> planes", lambda: lin(w["q"], want_f32=False, want_xp=True)); tot += t
-    (_, k_xp), t = timeit("k  -> planes", lambda: lin(w["k"], want_f32=False, want_xp=True)); tot += t
+    (_, q_xp), t = timeit("q  -> planes", lambda: lin(w["q"], want_f32=False, want_xp=True, xp_bf16=True)); tot += t
+    (_, k_xp), t = timeit("k  -> planes", lambda: lin(w["k"], want_f32=False, want_xp=True, xp_bf16=True)); tot += t
     v_vf, t = timeit("v  -> A fragments", lambda: ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, 256, 2048, 8)); tot += t
     (qp, _), t = timeit("q points (linear)", lambda: lin(w["qp"])); tot += t
     (kvp, _), t = timeit("kv points (linear)", lambda: lin(w["kvp"])); tot += t

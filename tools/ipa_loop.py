@@ -28,8 +28,8 @@ s_xp = ops.pack_planes(s)
 w, d = ipa.node_packs(), ipa._derived()
 lin = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], M, x["k"], x["n"], x["tg"], **kw)  # noqa: E731
 with torch.no_grad():
-    _, q_xp = lin(w["q"], want_f32=False, want_xp=True)
-    _, k_xp = lin(w["k"], want_f32=False, want_xp=True)
+    _, q_xp = lin(w["q"], want_f32=False, want_xp=True, xp_bf16=True)
+    _, k_xp = lin(w["k"], want_f32=False, want_xp=True, xp_bf16=True)
     v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, 256, 2048, 8)
     qp, _ = lin(w["qp"]); kvp, _ = lin(w["kvp"])
     pts = ops.ipa_prep_points_planes(r7, qp, kvp, d["hw"])
