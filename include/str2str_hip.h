@@ -151,6 +151,19 @@ int s2s_ipa_attention_planes(const void* q_xp, const void* k_xp, const void* v_v
                              int out_xp_ksteps, int n_samples, int n_res, int n_heads, int c_hidden, int n_qk_points,
                              int n_v_points, int c_pair_z, float inf, float eps, void* stream);
 
+/* The same two entry points on f16 pair operands (csrc/ipa_attention_f16.hip): every operand as (x_h, x_l) f16 planes -- TWO planes
+ * per fragment group in all the arrays above -- and three products per block (a_h b_h + a_h b_l + a_l b_h) instead of six: half the
+ * matrix instructions and two thirds of the operand bytes.  q_xp / k_xp from s2s_node_linear with out_xp_format 2, v_vf from
+ * s2s_node_linear_vfrag with out_format 1.  Same outputs (out_xp: f16 planes of the node stream). */
+int s2s_ipa_prep_points_f16(const float* rigids7, const float* q_pts_lin, const float* kv_pts_lin, const float* head_w_scaled,
+                               void* qp_xp, void* kp_xp, void* vp_vf, float* q2, float* k2, long long n_frames, int n_heads,
+                               int n_qk_points, int n_v_points, int c_hidden, void* stream);
+int s2s_ipa_attention_f16(const void* q_xp, const void* k_xp, const void* v_vf, const void* qp_xp, const void* kp_xp,
+                             const void* vp_vf, const float* q2, const float* k2, const float* attn_bias, float* logits_out,
+                             float* stats_out, const float* mask, const float* rigids7, float* out, void* out_xp,
+                             int out_xp_ksteps, int n_samples, int n_res, int n_heads, int c_hidden, int n_qk_points,
+                             int n_v_points, int c_pair_z, float inf, float eps, void* stream);
+
 /* The pair term of InvariantPointAttention.forward (src/models/net/ipa.py:253-257):
  *   o_pair[b,i,h,:] = sum_j softmax_j(logits[b,h,i,:])[j] * pair_z[b,i,j,:]
  * from the logits / statistics s2s_ipa_attention stored, streaming pair_z [B,N,N,c_pair_z] once for all heads;
@@ -218,8 +231,9 @@ int s2s_pack_planes(const float* x, long long n_rows, int ld, int col0, int n_co
  *     columns (gamma/beta given; needs n_out == 32 * tiles_per_block);  v *= post_mask[row]
  *   xp: packed planes of the input [n_rows, k_in]; w_packed: ops.pack_node_weight(W [n_out, k_in], tiles_per_block);
  *   outputs: out_f32[row * out_ld + out_col0 + col] and/or the packed planes of the result as k-steps out_xp_kstep0 .. of an XP
- *   buffer with out_xp_ksteps k-steps (out_xp_format 0: f16 planes, the input format of the next layer; 1: bf16 planes for the
- *   attention kernel).  Any pointer may be NULL to skip that step. */
+ *   buffer with out_xp_ksteps k-steps (out_xp_format 0: f16 planes, the input format of the next layer; 1: exact three-way bf16
+ *   planes for s2s_ipa_attention_planes; 2: f16 pair planes (x_h, x_l), TWO planes per k-step, for s2s_ipa_attention_f16).
+ *   Any pointer may be NULL to skip that step. */
 int s2s_node_linear(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
                     int tiles_per_block, const float* pre_scale, int relu, const float* pre_mask, const float* residual,
                     int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_mask,
@@ -230,9 +244,10 @@ int s2s_node_linear(const void* xp, const void* w_packed, const float* bias, lon
  * its ROWS (the value projection of InvariantPointAttention, ipa.py:132-141, consumed by the PV step): the result (+ bias) is
  * stored as bf16x3 MFMA A fragments  out_vf[row tile (32 rows)][head][column tile (32 cols) in head][k-step u (16 rows)][plane]
  * [lane 64][8], element j of lane (column c, half h) = row (r&3) + 8 (r>>2) + 4 h, r = 8 u + j, of the tile.  w_packed as for
- * s2s_node_linear with tiles_per_block = 8. */
+ * s2s_node_linear with tiles_per_block = 8.  out_format 0: three bf16 planes (s2s_ipa_attention_planes), 1: f16 pair planes
+ * (x_h, x_l), two per fragment group (s2s_ipa_attention_f16). */
 int s2s_node_linear_vfrag(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
-                          int tiles_per_head, void* out_vf, void* stream);
+                          int tiles_per_head, void* out_vf, int out_format, void* stream);
 
 /* Self-attention core of the trunk's TransformerEncoderLayer (src/models/net/ipa.py:312-317,357; torch.nn.MultiheadAttention with
  * d_model = n_heads * head_dim, head_dim = 80): softmax(q k^T / sqrt(head_dim) + key_bias[j]) v per (sample, head), exact fp32 MFMA.

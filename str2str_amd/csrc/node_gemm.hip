@@ -62,12 +62,17 @@ __device__ __forceinline__ void split8_f16(const float* v, f16x8& ph, f16x8& pl,
         ph[j] = a; pl[j] = (_Float16)(v[j] - (float)a); ps[j] = a * (_Float16)0.03125f;
     }
 }
-// 8 values -> three 16 B plane fragments 64 fragments apart, in the requested format
-__device__ __forceinline__ void store_planes(f16x8* q, const float* v, bool bf16_planes) {
-    if (bf16_planes) {
+// 8 values -> 16 B plane fragments 64 fragments apart: format 0 = f16 planes of the node stream (x_h, x_l, 2^-5 x_h),
+// 1 = exact three-way bf16 planes, 2 = f16 pair (x_h, x_l) (two planes per k-step: the caller's stride differs)
+__device__ __forceinline__ void store_planes(f16x8* q, const float* v, int fmt) {
+    if (fmt == 1) {
         bf16x8 ph, pm, pl;
         split8(v, ph, pm, pl);
         q[0] = __builtin_bit_cast(f16x8, ph); q[64] = __builtin_bit_cast(f16x8, pm); q[128] = __builtin_bit_cast(f16x8, pl);
+    } else if (fmt == 2) {
+        f16x8 ph, pl, ps;
+        split8_f16(v, ph, pl, ps);
+        q[0] = ph; q[64] = pl;
     } else {
         f16x8 ph, pl, ps;
         split8_f16(v, ph, pl, ps);
@@ -95,7 +100,8 @@ struct GemmArgs {
     int res_ld, out_ld, out_col0, xp_KS, xp_ks0;
     int relu;
     float ln_eps;
-    int xp_bf16;             // out_xp as exact three-way bf16 planes (operands of the IPA attention kernel) instead of f16 planes
+    int xp_bf16;             // out_xp format: 0 f16 planes of the node stream, 1 exact three-way bf16 planes, 2 f16 pair planes
+                             // (1, 2: operands of the IPA attention kernels; VF kernels: 0 = bf16 triples, 1 = f16 pairs)
 };
 
 // VF: operands swapped -- Y[row, col] = X . W^T with A = the activation fragment, B = the weight fragment -- so that a lane owns
@@ -249,8 +255,9 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
             for (int t = 0; t < TG; ++t) {
                 const int T = cb * TG + t;
                 const float bv = a.bias ? a.bias[32 * T + (lane & 31)] : 0.f;
+                const int vpl = a.xp_bf16 ? 2 : 3;   // planes per fragment group
                 bf16x8* o = a.out_vf + ((((rt * (a.n_col_blocks * TG / a.vf_tiles_per_head) + T / a.vf_tiles_per_head) * a.vf_tiles_per_head +
-                                          T % a.vf_tiles_per_head) * 2) * 3) * 64 + lane;
+                                          T % a.vf_tiles_per_head) * 2) * vpl) * 64 + lane;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     float v[8];
@@ -259,9 +266,15 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
                         const int r = 8 * u + j;
                         v[j] = (rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < a.M) ? acc[t][r] + bv : 0.f;
                     }
-                    bf16x8 ph, pmid, pl;
-                    split8(v, ph, pmid, pl);
-                    o[(u * 3) * 64] = ph; o[(u * 3 + 1) * 64] = pmid; o[(u * 3 + 2) * 64] = pl;
+                    if (a.xp_bf16) {   // f16 pair (x_h, x_l): operands of s2s_ipa_attention_f16
+                        f16x8 ph, pl, ps;
+                        split8_f16(v, ph, pl, ps);
+                        o[(u * 2) * 64] = __builtin_bit_cast(bf16x8, ph); o[(u * 2 + 1) * 64] = __builtin_bit_cast(bf16x8, pl);
+                    } else {
+                        bf16x8 ph, pmid, pl;
+                        split8(v, ph, pmid, pl);
+                        o[(u * 3) * 64] = ph; o[(u * 3 + 1) * 64] = pmid; o[(u * 3 + 2) * 64] = pl;
+                    }
                 }
             }
         }
@@ -337,8 +350,8 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
     if (a.out_xp && rt < n_rt) {
         // the accumulator layout is the next layer's B-operand layout: k-step 2 (cb TG + t) + u = registers 8u .. 8u+7 of tile t.
         // Rows past M inside the last row tile are written as zeros (they are read, never stored, by the consumer).
-        f16x8* o = a.out_xp + ((rt * a.xp_KS + a.xp_ks0 + 2 * (cb * TG)) * 3) * 64 + lane;
-        const bool bf16_planes = a.xp_bf16 != 0;
+        const int fmt = a.xp_bf16, npl = fmt == 2 ? 2 : 3;
+        f16x8* o = a.out_xp + ((rt * a.xp_KS + a.xp_ks0 + 2 * (cb * TG)) * npl) * 64 + lane;
 #pragma unroll
         for (int t = 0; t < TG; ++t)
 #pragma unroll
@@ -346,7 +359,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = valid ? acc[t][8 * u + j] : 0.f;
-                store_planes(o + ((2 * t + u) * 3) * 64, v, bf16_planes);
+                store_planes(o + ((2 * t + u) * npl) * 64, v, fmt);
             }
     }
 }
@@ -371,7 +384,7 @@ __global__ void __launch_bounds__(256) pack_planes_kernel(const float* __restric
         v[0] = lo.x * sc; v[1] = lo.y * sc; v[2] = lo.z * sc; v[3] = lo.w * sc;
         v[4] = hi.x * sc; v[5] = hi.y * sc; v[6] = hi.z * sc; v[7] = hi.w * sc;
     }
-    store_planes(xp + ((rt * xp_KS + ks0 + ks) * 3) * 64 + lane, v, false);
+    store_planes(xp + ((rt * xp_KS + ks0 + ks) * 3) * 64 + lane, v, 0);
 }
 
 template <int TG, int WAVES, bool VF = false>
@@ -423,7 +436,7 @@ extern "C" int s2s_node_linear(const void* xp, const void* w_packed, const float
     if (out_f32 && (out_ld % 4 || out_col0 % 4)) return (int)hipErrorInvalidValue;
     if (residual && residual_ld % 4) return (int)hipErrorInvalidValue;
     if (out_xp && (out_xp_kstep0 < 0 || out_xp_kstep0 % 2 || out_xp_kstep0 + n_out / 16 > out_xp_ksteps)) return (int)hipErrorInvalidValue;
-    if (out_xp_format != 0 && out_xp_format != 1) return (int)hipErrorInvalidValue;
+    if (out_xp_format < 0 || out_xp_format > 2) return (int)hipErrorInvalidValue;
     GemmArgs a{(const f16x8*)xp, (const char*)w_packed, bias, pre_scale, pre_mask, residual, ln_gamma, ln_beta, post_mask, out_f32,
                (f16x8*)out_xp, nullptr, 0, n_rows, k_in / 16, ncb, residual_ld, out_ld, out_col0, out_xp_ksteps, out_xp_kstep0, relu, ln_eps,
                out_xp_format};
@@ -441,13 +454,13 @@ extern "C" int s2s_node_linear(const void* xp, const void* w_packed, const float
 }
 
 extern "C" int s2s_node_linear_vfrag(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
-                                     int tiles_per_head, void* out_vf, void* stream) {
+                                     int tiles_per_head, void* out_vf, int out_format, void* stream) {
     if (n_rows <= 0) return 0;
     constexpr int TG = 8;
     if (!xp || !w_packed || !out_vf || k_in <= 0 || k_in % 32 || n_out <= 0 || n_out % (32 * TG) || tiles_per_head <= 0 ||
         (n_out / 32) % tiles_per_head)
         return (int)hipErrorInvalidValue;
     GemmArgs a{(const f16x8*)xp, (const char*)w_packed, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-               (bf16x8*)out_vf, tiles_per_head, n_rows, k_in / 16, n_out / (32 * TG), 0, 0, 0, 0, 0, 0, 0.f, 0};
+               (bf16x8*)out_vf, tiles_per_head, n_rows, k_in / 16, n_out / (32 * TG), 0, 0, 0, 0, 0, 0, 0.f, out_format ? 1 : 0};
     return launch_gemm_w<TG, 4, true>(a, (hipStream_t)stream);
 }

@@ -87,23 +87,27 @@ class InvariantPointAttention(nn.Module):
     def use_planes(n_res: int, n_rows: int = 0) -> bool:
         """The pre-split (planes) attention kernel serves lengths that are multiples of its 32-residue tiles (and fragment
         arrays below 4 GiB: it addresses them through 32-bit buffer offsets)."""
-        return n_res % 32 == 0 and n_rows * 12288 < (1 << 32) and os.environ.get("S2S_IPA_PATH", "planes") != "f32"
+        return n_res % 32 == 0 and n_rows * 12288 < (1 << 32) and os.environ.get("S2S_IPA_PATH", "f16") != "f32"
 
     def attention_planes(self, s_xp, B: int, N: int, r7, mask, pair_proj):
         """Projections -> points -> attention core on pre-split operands.  s_xp: packed planes of s [B*N, c_s].
         -> packed planes of linear_out's input [B*N, H*(c_hidden + 4 Pv + c_z/4)]"""
         w, d, M, H = self.node_packs(), self._derived(), B * N, self.no_heads
         lin = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], M, x["k"], x["n"], x["tg"], **kw)  # noqa: E731
-        _, q_xp = lin(w["q"], want_f32=False, want_xp=True, xp_bf16=True)   # attention operands: exact three-way bf16 planes
-        _, k_xp = lin(w["k"], want_f32=False, want_xp=True, xp_bf16=True)
-        v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, w["v"]["k"], w["v"]["n"], self.c_hidden // 32)
+        # attention operands: f16 pair planes (S2S_IPA_PATH=f16, default: s2s_ipa_attention_f16, three products per block) or
+        # exact three-way bf16 planes (S2S_IPA_PATH=planes: s2s_ipa_attention_planes, six products)
+        f16 = os.environ.get("S2S_IPA_PATH", "f16") == "f16"
+        fmt = 2 if f16 else 1
+        _, q_xp = lin(w["q"], want_f32=False, want_xp=True, xp_format=fmt)
+        _, k_xp = lin(w["k"], want_f32=False, want_xp=True, xp_format=fmt)
+        v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, w["v"]["k"], w["v"]["n"], self.c_hidden // 32, f16=f16)
         qp, _ = lin(w["qp"])
         kvp, _ = lin(w["kvp"])
-        pts = ops.ipa_prep_points_planes(r7, qp, kvp, d["hw"], H, self.no_qk_points, self.no_v_points, self.c_hidden)
+        pts = ops.ipa_prep_points_planes(r7, qp, kvp, d["hw"], H, self.no_qk_points, self.no_v_points, self.c_hidden, f16=f16)
         attn_bias, pair_z = pair_proj
         feats, feats_xp = ops.ipa_attention_planes(q_xp, k_xp, v_vf, pts, attn_bias, pair_z, mask, r7, H, self.c_hidden,
                                                    self.no_qk_points, self.no_v_points, self.c_z // 4, self.inf, self.eps,
-                                                   logits_inplace=True)
+                                                   logits_inplace=True, f16=f16)
         c0 = H * self.c_hidden
         f2 = feats.view(M, -1)
         ops.pack_planes(f2, col0=c0, n_cols=f2.shape[1] - c0, out=feats_xp, out_k=f2.shape[1], k0=c0)

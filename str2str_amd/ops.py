@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _lib = None
 _tables_loaded = False
@@ -37,6 +37,8 @@ _SIGNATURES = {
     "s2s_ipa_opair": [_vp] * 4 + [_i, _i, _i, _i, _i, _i, _vp],
     "s2s_ipa_prep_points_planes": [_vp] * 9 + [_ll, _i, _i, _i, _i, _vp],
     "s2s_ipa_attention_planes": [_vp] * 15 + [_i] * 8 + [_f, _f, _vp],
+    "s2s_ipa_prep_points_f16": [_vp] * 9 + [_ll, _i, _i, _i, _i, _vp],
+    "s2s_ipa_attention_f16": [_vp] * 15 + [_i] * 8 + [_f, _f, _vp],
     "s2s_rigid_compose_update": [_vp] * 4 + [_ll, _vp],
     "s2s_rigid_scale_trans": [_vp, _vp, _ll, _f, _i, _vp],
     "s2s_set_backbone_tables": [_vp] * 4,
@@ -45,7 +47,7 @@ _SIGNATURES = {
     "s2s_forward_marginal": [_vp] * 7 + [_i, _vp, _vp, _f, _vp, _i, _i, _vp],
     "s2s_pack_planes": [_vp, _ll, _i, _i, _i, _vp, _i, _i, _vp, _vp],
     "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
-    "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _vp],
+    "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp],
     "s2s_encoder_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "s2s_ca_sample_stats": [_vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
     "s2s_ca_pwd_js": [_vp, _i, _vp, _i, _i, _i, _i, _d, _vp, _vp],
@@ -482,9 +484,9 @@ def ipa_attention(q, kv, q_pts, k_pts, v_pts, attn_bias, pair_z, mask, rigids7, 
     return out
 
 
-def ipa_prep_points_planes(rigids7, q_pts_lin, kv_pts_lin, head_w_scaled, n_heads=8, n_qk=8, n_v=12, c_hidden=256):
-    """Global-frame points of a block as MFMA fragments + the squared-norm terms of the logits (s2s_ipa_prep_points_planes).
-    B*N must be a multiple of 32.  -> (qp_xp, kp_xp, vp_vf, q2, k2)"""
+def ipa_prep_points_planes(rigids7, q_pts_lin, kv_pts_lin, head_w_scaled, n_heads=8, n_qk=8, n_v=12, c_hidden=256, f16=False):
+    """Global-frame points of a block as MFMA fragments + the squared-norm terms of the logits (s2s_ipa_prep_points_planes, or
+    s2s_ipa_prep_points_f16 with two f16 planes per fragment group).  B*N must be a multiple of 32.  -> (qp_xp, kp_xp, vp_vf, q2, k2)"""
     lib = load_library()
     _req(rigids7, name="rigids7"); _req(q_pts_lin, name="q_pts_lin"); _req(kv_pts_lin, name="kv_pts_lin")
     _req(head_w_scaled, name="head_w")
@@ -492,20 +494,23 @@ def ipa_prep_points_planes(rigids7, q_pts_lin, kv_pts_lin, head_w_scaled, n_head
     if M % 32:
         raise HipLibraryError("ipa_prep_points_planes: the number of frames must be a multiple of 32")
     dev, rt = rigids7.device, M // 32
-    qp = torch.empty(rt * n_heads * 2 * 3 * 64 * 8, dtype=torch.int16, device=dev)
+    npl = 2 if f16 else 3
+    qp = torch.empty(rt * n_heads * 2 * npl * 64 * 8, dtype=torch.int16, device=dev)
     kp = torch.empty_like(qp)
-    vp = torch.empty(rt * n_heads * 4 * 3 * 64 * 8, dtype=torch.int16, device=dev)
+    vp = torch.empty(rt * n_heads * 4 * npl * 64 * 8, dtype=torch.int16, device=dev)
     q2 = torch.empty(rt, n_heads, 32, dtype=torch.float32, device=dev)
     k2 = torch.empty_like(q2)
-    _check(lib.s2s_ipa_prep_points_planes(_p(rigids7), _p(q_pts_lin), _p(kv_pts_lin), _p(head_w_scaled), _p(qp), _p(kp), _p(vp),
-                                          _p(q2), _p(k2), M, n_heads, n_qk, n_v, c_hidden, _stream()),
-           "s2s_ipa_prep_points_planes")
+    fn = lib.s2s_ipa_prep_points_f16 if f16 else lib.s2s_ipa_prep_points_planes
+    _check(fn(_p(rigids7), _p(q_pts_lin), _p(kv_pts_lin), _p(head_w_scaled), _p(qp), _p(kp), _p(vp), _p(q2), _p(k2), M, n_heads, n_qk,
+              n_v, c_hidden, _stream()), "s2s_ipa_prep_points_planes/_f16")
     return qp, kp, vp, q2, k2
 
 
 def ipa_attention_planes(q_xp, k_xp, v_vf, points, attn_bias, pair_z, mask, rigids7, n_heads=8, c_hidden=256, n_qk=8, n_v=12,
-                         c_pz=32, inf=1e5, eps=1e-8, logits_inplace=False):
+                         c_pz=32, inf=1e5, eps=1e-8, logits_inplace=False, f16=False):
     """Attention core on pre-split operands + pair term (n_res % 32 == 0).  ``points`` = ipa_prep_points_planes(...).
+    ``f16``: every operand as f16 pair planes (s2s_ipa_attention_f16; q/k from node_linear(xp_format=2), v from
+    node_linear_vfrag(f16=True), points from ipa_prep_points_planes(f16=True)) instead of three-way bf16 planes.
     -> (feats fp32 [B,N,feat] with the o_pt / o_pair columns valid, feats_xp packed planes with the o columns valid); the
     caller packs columns H*c_hidden.. of ``feats`` into ``feats_xp`` (ops.pack_planes) to complete linear_out's input."""
     lib = load_library()
@@ -526,9 +531,9 @@ def ipa_attention_planes(q_xp, k_xp, v_vf, points, attn_bias, pair_z, mask, rigi
     stats = torch.empty(B, n_heads, N, 2, device=mask.device, dtype=torch.float32)
 
     def launch():
-        rc = lib.s2s_ipa_attention_planes(_p(q_xp), _p(k_xp), _p(v_vf), _p(qp), _p(kp), _p(vp), _p(q2), _p(k2), _p(attn_bias),
-                                          _p(logits), _p(stats), _p(mask), _p(rigids7), _p(out), _p(out_xp), feat // 16, B, N,
-                                          n_heads, c_hidden, n_qk, n_v, c_pz, inf, eps, _stream())
+        fn = lib.s2s_ipa_attention_f16 if f16 else lib.s2s_ipa_attention_planes
+        rc = fn(_p(q_xp), _p(k_xp), _p(v_vf), _p(qp), _p(kp), _p(vp), _p(q2), _p(k2), _p(attn_bias), _p(logits), _p(stats), _p(mask),
+                _p(rigids7), _p(out), _p(out_xp), feat // 16, B, N, n_heads, c_hidden, n_qk, n_v, c_pz, inf, eps, _stream())
         if rc:
             return rc
         return lib.s2s_ipa_opair(_p(logits), _p(stats), _p(pair_z), _p(out), B, N, n_heads, c_pz, feat,
@@ -694,11 +699,12 @@ def pack_planes(x2d: torch.Tensor, col0: int = 0, n_cols: Optional[int] = None, 
 
 def node_linear(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles: int, *, pre_scale=None, relu=False, pre_mask=None,
                 residual=None, ln=None, post_mask=None, out_f32=None, out_col0: int = 0, want_f32=True, out_xp=None,
-                out_xp_k: Optional[int] = None, out_xp_k0: int = 0, want_xp=False, xp_bf16=False):
+                out_xp_k: Optional[int] = None, out_xp_k0: int = 0, want_xp=False, xp_bf16=False, xp_format: Optional[int] = None):
     """One fused per-node layer (s2s_node_linear).  ``residual`` [n_rows, ld] fp32 (its leading n_out columns are added);
     ``ln`` = (gamma, beta, eps); ``out_f32`` a preallocated [n_rows, ld] buffer written at ``out_col0`` (allocated
     [n_rows, n_out] when ``want_f32``); ``out_xp`` likewise for the packed planes (``xp_bf16``: as exact three-way bf16 planes,
-    the operand format of the IPA attention kernel, instead of the node stream's f16 planes).  -> (out_f32 or None, out_xp or None)."""
+    the operand format of the IPA attention kernel, instead of the node stream's f16 planes; ``xp_format`` = 2: f16 pair planes,
+    two per k-step, for the f16 attention kernel).  -> (out_f32 or None, out_xp or None)."""
     lib = load_library()
     _req(xp, torch.int16, "xp"); _req(wpk, torch.int16, "w_packed")
     dev = xp.device
@@ -711,9 +717,12 @@ def node_linear(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles: int, *
         out_f32 = torch.empty(n_rows, n_out, device=dev, dtype=torch.float32)
     if out_f32 is not None:
         _req(out_f32, name="out_f32")
+    fmt = int(xp_format) if xp_format is not None else int(bool(xp_bf16))
     if out_xp is None and want_xp:
         out_xp_k = n_out if out_xp_k is None else out_xp_k
         out_xp = xp_alloc(n_rows, out_xp_k, dev)
+        if fmt == 2:
+            out_xp = out_xp[: out_xp.numel() // 3 * 2]
     if out_xp is not None:
         out_xp_k = n_out if out_xp_k is None else out_xp_k
         _req(out_xp, torch.int16, "out_xp")
@@ -724,23 +733,23 @@ def node_linear(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles: int, *
         _p(xp), _p(wpk), _p(bias), n_rows, k_in, n_out, tiles, _p(pre_scale), int(bool(relu)), _p(pre_mask), _p(residual),
         residual.shape[-1] if residual is not None else 0, _p(g), _p(b), float(eps), _p(post_mask), _p(out_f32),
         out_f32.shape[-1] if out_f32 is not None else 0, out_col0, _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16,
-        int(bool(xp_bf16)), _stream())), "s2s_node_linear")
+        fmt, _stream())), "s2s_node_linear")
     return out_f32, out_xp
 
 
-def node_linear_vfrag(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles_per_head: int = 8, out=None):
+def node_linear_vfrag(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles_per_head: int = 8, out=None, f16: bool = False):
     """Projection stored as bf16x3 A fragments over 32-row tiles (s2s_node_linear_vfrag; the value projection of the IPA).
     -> int16 buffer [row tiles][heads][tiles_per_head][2][3][64][8]."""
     lib = load_library()
     _req(xp, torch.int16, "xp"); _req(wpk, torch.int16, "w_packed")
     if bias is not None:
         _req(bias, name="bias")
-    n_el = ((n_rows + 31) // 32) * (n_out // 32) * 2 * 3 * 64 * 8
+    n_el = ((n_rows + 31) // 32) * (n_out // 32) * 2 * (2 if f16 else 3) * 64 * 8   # f16: pair planes (x_h, x_l)
     if out is None:
         out = torch.empty(n_el, dtype=torch.int16, device=xp.device)
     _req(out, torch.int16, "out_vf")
     _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_vfrag(_p(xp), _p(wpk), _p(bias), n_rows, k_in, n_out, tiles_per_head,
-                                                                       _p(out), _stream())), "s2s_node_linear_vfrag")
+                                                                       _p(out), int(bool(f16)), _stream())), "s2s_node_linear_vfrag")
     return out
 
 

@@ -77,7 +77,7 @@ def _graph_key(net, feats, b, N):
     tr = getattr(net, "translator", None)
     modes = tuple(sorted({getattr(m, "mfma_mode") for m in net.modules() if hasattr(m, "mfma_mode")}))  # which kernels were captured
     return (id(net), sum(p._version for p in net.parameters()), b, N, bool(getattr(tr, "exact_padding", False)), modes,
-            os.environ.get("S2S_IPA_PATH", "planes"), h.hexdigest())
+            os.environ.get("S2S_IPA_PATH", "f16"), h.hexdigest())
 
 
 def _maybe_graph(net, feats, b, N, trace, n_steps):

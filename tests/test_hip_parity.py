@@ -291,7 +291,8 @@ def test_ipa_vs_oracle(net_rough, B, N):
     check(f"{_test_name()}: rel err", rel(out.cpu().numpy()[valid], ref.numpy()[valid]), 2e-5)
 
 
-def test_ipa_planes_kernel_matches_fp32_operand_kernel(net_rough):
+@pytest.mark.parametrize("f16", [True, False], ids=["f16", "bf16"])
+def test_ipa_planes_kernel_matches_fp32_operand_kernel(net_rough, f16):
     """The two attention paths side by side on the same inputs (ops level, through the C ABI): s2s_ipa_attention_planes on operands
     pre-split by the GEMM epilogues / the point kernel vs s2s_ipa_attention on the fp32 projections -- o (decoded from the packed
     planes), o_pt and o_pair columns.  Several work items per persistent workgroup chain (B x H x N/64 = 48 items)."""
@@ -313,13 +314,14 @@ def test_ipa_planes_kernel_matches_fp32_operand_kernel(net_rough):
         w, d = ipa.node_packs(), ipa._derived()
         s_xp = ops.pack_planes(s)
         lin = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], M, x["k"], x["n"], x["tg"], **kw)  # noqa: E731
-        _, q_xp = lin(w["q"], want_f32=False, want_xp=True, xp_bf16=True)
-        _, k_xp = lin(w["k"], want_f32=False, want_xp=True, xp_bf16=True)
-        v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, 256, 2048, 8)
+        fmt = 2 if f16 else 1
+        _, q_xp = lin(w["q"], want_f32=False, want_xp=True, xp_format=fmt)
+        _, k_xp = lin(w["k"], want_f32=False, want_xp=True, xp_format=fmt)
+        v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, 256, 2048, 8, f16=f16)
         qp, _ = lin(w["qp"])
         kvp, _ = lin(w["kvp"])
-        pts = ops.ipa_prep_points_planes(r7, qp, kvp, d["hw"])
-        feats, fxp = ops.ipa_attention_planes(q_xp, k_xp, v_vf, pts, bias, pz, mask, r7)
+        pts = ops.ipa_prep_points_planes(r7, qp, kvp, d["hw"], f16=f16)
+        feats, fxp = ops.ipa_attention_planes(q_xp, k_xp, v_vf, pts, bias, pz, mask, r7, f16=f16)
         q, _ = lin(w["q"])
         kv, _ = lin(w["kv"])
         q_pts, k_pts, v_pts = ops.ipa_prep_points(r7, qp.view(B, N, -1), kvp.view(B, N, -1), 8, 8, 12)
@@ -328,7 +330,7 @@ def test_ipa_planes_kernel_matches_fp32_operand_kernel(net_rough):
     got[:, 2048:] = feats.view(M, -1)[:, 2048:]
     valid = mask.reshape(-1).bool()
     for name, sl in (("o", slice(0, 2048)), ("o_pt", slice(2048, 2432)), ("o_pair", slice(2432, 2688))):
-        check(f"ipa planes vs fp32-operand kernel, {name}", rel(got[valid][:, sl], ref[valid][:, sl]), 5e-6)
+        check(f"ipa {'f16' if f16 else 'bf16'} planes vs fp32-operand kernel, {name}", rel(got[valid][:, sl], ref[valid][:, sl]), 5e-6)
 
 
 def test_se3_step_golden(diffuser):
