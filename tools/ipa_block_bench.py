@@ -51,18 +51,20 @@ def timeit(name, fn):
 lin = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], M, x["k"], x["n"], x["tg"], **kw)  # noqa: E731
 alg = B * 4 * (9512 * N + 40 * N * N)
 with torch.no_grad():
-    print(f"planes path  B={B} N={N}")
-    tot = 0.0
-    (_, q_xp), t = timeit("q  -> planes", lambda: lin(w["q"], want_f32=False, want_xp=True, xp_bf16=True)); tot += t
-    (_, k_xp), t = timeit("k  -> planes", lambda: lin(w["k"], want_f32=False, want_xp=True, xp_bf16=True)); tot += t
-    v_vf, t = timeit("v  -> A fragments", lambda: ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, 256, 2048, 8)); tot += t
-    (qp, _), t = timeit("q points (linear)", lambda: lin(w["qp"])); tot += t
-    (kvp, _), t = timeit("kv points (linear)", lambda: lin(w["kvp"])); tot += t
-    pts, t = timeit("points -> fragments", lambda: ops.ipa_prep_points_planes(r7, qp, kvp, d["hw"])); tot += t
-    (feats, fxp), t_att = timeit("attention + o_pair", lambda: ops.ipa_attention_planes(q_xp, k_xp, v_vf, pts, bias, pz, mask, r7)); tot += t_att
-    f2 = feats.view(M, -1)
-    _, t = timeit("pack o_pt | o_pair", lambda: ops.pack_planes(f2, col0=2048, n_cols=640, out=fxp, out_k=2688, k0=2048)); tot += t
-    print(f"  total {tot:.3f} ms; attention + o_pair: algorithmic {alg / t_att / 1e6:.0f} GB/s = {alg / t_att / 1e6 / 80:.1f} % of 8 TB/s")
+    for f16 in (True, False):
+        print(f"{'f16 pair' if f16 else 'bf16 three-way'} planes path  B={B} N={N}")
+        tot = 0.0
+        fmt = 2 if f16 else 1
+        (_, q_xp), t = timeit("q  -> planes", lambda: lin(w["q"], want_f32=False, want_xp=True, xp_format=fmt)); tot += t
+        (_, k_xp), t = timeit("k  -> planes", lambda: lin(w["k"], want_f32=False, want_xp=True, xp_format=fmt)); tot += t
+        v_vf, t = timeit("v  -> A fragments", lambda: ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, 256, 2048, 8, f16=f16)); tot += t
+        (qp, _), t = timeit("q points (linear)", lambda: lin(w["qp"])); tot += t
+        (kvp, _), t = timeit("kv points (linear)", lambda: lin(w["kvp"])); tot += t
+        pts, t = timeit("points -> fragments", lambda: ops.ipa_prep_points_planes(r7, qp, kvp, d["hw"], f16=f16)); tot += t
+        (feats, fxp), t_att = timeit("attention + o_pair", lambda: ops.ipa_attention_planes(q_xp, k_xp, v_vf, pts, bias, pz, mask, r7, f16=f16)); tot += t_att
+        f2 = feats.view(M, -1)
+        _, t = timeit("pack o_pt | o_pair", lambda: ops.pack_planes(f2, col0=2048, n_cols=640, out=fxp, out_k=2688, k0=2048)); tot += t
+        print(f"  total {tot:.3f} ms; attention + o_pair: algorithmic {alg / t_att / 1e6:.0f} GB/s = {alg / t_att / 1e6 / 80:.1f} % of 8 TB/s")
     print("fp32-operand path")
     tot = 0.0
     (q, _), t = timeit("q", lambda: lin(w["q"])); tot += t
