@@ -266,7 +266,7 @@ def main():
             "value": total / elapsed, "unit": "conformations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x6": "f32 (pair MLP on exact 3-way bf16 split MFMA, fp32 accumulate)",
-                      "f16x3": "f32 (edge transition on 2-way f16 split MFMA, edge embedding on 3-way bf16 split MFMA; fp32 accumulate, fp32-equivalent)"}[mode],
+                      "f16x3": "f32 (matrix products on 2-way f16 split MFMA 'f16x3': 3 products per block, fp32 accumulate, fp32-equivalent)"}[mode],
             "data": "synthetic",
             "config": {"workload": workload, "n_res": N, "replicas_per_gpu": B, "denoise_steps": S,
                        "parallelism": f"replica-shard x{world}", "edge_mfma_mode": mode, "rng": a.rng,

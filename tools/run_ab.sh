@@ -1,3 +1,4 @@
-for p in planes f16 planes f16; do
-S2S_IPA_PATH=$p python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$p', round(d['value'],3), round(d['ms_per_step'],1), round(d['roofline']['mean_launch_ms'],3), round(d['ipa_kernel']['mean_launch_ms'],4), round(d['ipa_kernel']['frac'],4))"
-done
+mkdir -p gpurun_out/final
+S=$(date +%s); python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2; echo "smoke s: $(( $(date +%s) - S ))"
+S=$(date +%s); python bench.py > gpurun_out/final/bench_default.json 2> gpurun_out/final/bench_default.err; echo "default bench s: $(( $(date +%s) - S ))"
+tail -1 gpurun_out/final/bench_default.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print({k: d[k] for k in ('metric','value','unit','n_gpus','steps','warmup','ms_per_step','dtype','vs_baseline')}); print(d['roofline']['frac'], d['ipa_kernel']['frac'], d['cpu_baseline']['value'])"
