@@ -86,7 +86,8 @@ int s2s_edge_embed(const float* node_a, const float* node_b, const float* rel_ta
  *   Layout difference to s2s_edge_embed: node_b, rel_table and bin_table are COLUMN-BLOCKED --
  *   node_b [B][32][N][4], rel_table [32][n_rel][4], bin_table [32][n_bins][4], element [c][row][q] = channel 4c + q of that row
  *   (ops.column_blocked) -- so that the gathers of neighbouring pairs share cache lines; node_a stays [B,N,128];
- *   bin_lower must ascend (torch.linspace).  B*N*512 and n_rel*512 must stay below 2^32. */
+ *   bin_lower must ascend (torch.linspace), n_bins <= 32.  Pair indices are 32-bit inside a launch: the entry point splits the
+ *   samples over several launches when B*N*N >= 2^31 (N*N itself and n_rel*512 must stay below 2^31 / 2^32). */
 int s2s_edge_embed_bf16x6(const float* node_a, const float* node_b, const float* rel_table, const float* bin_table,
                           const float* bin_lower, const long long* residue_idx, const float* ca_xyz,
                           const void* weight_stream, const float* b2, const float* b3, const float* ln_gamma,

@@ -12,6 +12,8 @@
 // outputs and one hidden layer away from them).  The parity suite runs this mode against the same oracle and tolerances.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "str2str_hip.h"
 
 namespace {
@@ -866,7 +868,10 @@ extern "C" int s2s_edge_embed_f16x3(const float* node_a, const float* node_b, co
     // 32-bit pair indices and buffer offsets inside a launch: split the samples over several launches when needed
     const long long NN = (long long)n_res * n_res;
     if (NN >= (1ll << 31) || (long long)n_rel * 512 >= (1ll << 32)) return (int)hipErrorInvalidValue;
-    long long chunk = ((1ll << 31) - 1) / NN;
+    const char* cap_env = getenv("S2S_EE_MAX_PAIRS");   // test hook: a smaller per-launch pair budget exercises the split
+    long long cap = cap_env ? atoll(cap_env) : 0;
+    if (cap <= 0 || cap > (1ll << 31) - 1) cap = (1ll << 31) - 1;
+    long long chunk = cap / NN;
     const long long rows_cap = ((1ll << 32) - 1) / ((long long)n_res * 512);  // node_b descriptor
     if (rows_cap < chunk) chunk = rows_cap;
     if (chunk < 1) return (int)hipErrorInvalidValue;

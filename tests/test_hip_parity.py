@@ -243,6 +243,31 @@ def test_edge_embed_golden(net_rough, mode):
     assert len(bad) <= 2, (len(bad), bad[:8], d.max())
 
 
+def test_edge_embed_launch_split(net_rough, monkeypatch):
+    """The split-precision edge embedding keeps pair indices 32-bit inside a launch and splits the samples over launches beyond
+    2^31 pairs; S2S_EE_MAX_PAIRS lowers that budget so the split (pointer offsets of every per-sample array) is exercised here:
+    5 samples, one launch vs launches of 2 + 2 + 1 samples, bit-identical outputs incl. the fused projection."""
+    g = torch.Generator().manual_seed(3)
+    B, N = 5, 24
+    idx = torch.arange(N)[None].repeat(B, 1)
+    t = torch.rand(B, generator=g)
+    fixed = (torch.rand(B, N, generator=g) > 0.7).float().to(DEV)
+    ca = (torch.randn(B, N, 3, generator=g) * 8).to(DEV)
+    mask = (torch.rand(B, N, generator=g) > 0.1).float().to(DEV)
+    proj = net_rough.translator.trunk["ipa_0"].pair_proj_weights()
+    outs = []
+    for cap in (None, 2 * N * N + 7):
+        if cap is None:
+            monkeypatch.delenv("S2S_EE_MAX_PAIRS", raising=False)
+        else:
+            monkeypatch.setenv("S2S_EE_MAX_PAIRS", str(cap))
+        _, edge, (bias, pz) = net_rough.embedder(residue_idx=idx, t=t, fixed_mask=fixed, self_conditioning_ca=ca, node_mask=mask,
+                                                 next_proj=proj)
+        outs.append((edge.clone(), bias.clone(), pz.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_pair_project_vs_linear(net_rough):
     from str2str_amd import ops
 
