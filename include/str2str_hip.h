@@ -57,7 +57,7 @@ int s2s_edge_transition_bf16x6(const float* edge, const float* node_ab, const fl
                                const float* proj_bias_cat64, float* proj_attn_bias, float* proj_pair_z, void* stream);
 
 /* The same operator on split-f16 MFMA ("f16x3", csrc/pair_mlp_f16.hip): every fp32 operand as two f16 numbers (11 + 11 bits + the
- * residue's sign = fp32's 24), products w_h x_h + w_h x_l + w_l x_h with exact 2^+-5 scalings of the small factors, fp32
+ * residue's sign = fp32's 24), products w_h x_h + w_h x_l + w_l x_h with the weights stored as the split of 2^5 w (2^-5 back in the epilogues), fp32
  * accumulation -- three matrix instructions per block instead of six, the dropped w_l x_l below one fp32 rounding as in bf16x6.
  * Activations must stay below f16's 65504.  weight_stream: 30 (+1 with the fused projection) stages x 32 KiB of f16 A fragments
  * (W_h, W_ls) in slot order (ops.pack_f16x3_stream, ops.pack_f16x2_layer for the projection stage). */
@@ -214,10 +214,10 @@ int s2s_se3_step(const float* x0_7, const float* xt_7, const float* mask, const 
 
 /* ---- Per-node dense layers (split-f16 MFMA "f16x3", fp32-equivalent; see s2s_edge_transition_f16x3) ----
  * Activations travel between these layers as PACKED PLANES ("XP"): for X [M, K],
- *   XP[rt = row/32][ks = K/16][plane 3][lane 64][8] 16-bit, lane = 32 g + (row & 31),
+ *   XP[rt = row/32][ks = K/16][plane 2][lane 64][8] f16, lane = 32 g + (row & 31),
  *   element j = plane of X[row][32 (ks>>1) + (r&3) + 8 (r>>2) + 4 g], r = 8 (ks&1) + j;
- * the planes of the node stream are f16 (x_h = rn16(x), x_l = rn16(x - x_h), x_hs = 2^-5 x_h); the operands of the IPA attention
- * kernel (q / k projections: out_xp_format = 1) are exact three-way bf16 planes (h, m, l).  Rows past M inside the last row tile
+ * planes = the f16 pair (x_h = rn16(x), x_l = rn16(x - x_h)); the f16 attention kernel takes the same planes; the bf16 attention
+ * kernel takes exact three-way bf16 planes (h, m, l), three per k-step (out_xp_format = 1).  Rows past M inside the last row tile
  * are zero. */
 
 /* fp32 row-major x [n_rows, ld], columns col0 .. col0 + n_cols (n_cols % 32 == 0), optionally scaled per row, -> k-steps
@@ -232,8 +232,8 @@ int s2s_pack_planes(const float* x, long long n_rows, int ld, int col0, int n_co
  *     columns (gamma/beta given; needs n_out == 32 * tiles_per_block);  v *= post_mask[row]
  *   xp: packed planes of the input [n_rows, k_in]; w_packed: ops.pack_node_weight(W [n_out, k_in], tiles_per_block);
  *   outputs: out_f32[row * out_ld + out_col0 + col] and/or the packed planes of the result as k-steps out_xp_kstep0 .. of an XP
- *   buffer with out_xp_ksteps k-steps (out_xp_format 0: f16 planes, the input format of the next layer; 1: exact three-way bf16
- *   planes for s2s_ipa_attention_planes; 2: f16 pair planes (x_h, x_l), TWO planes per k-step, for s2s_ipa_attention_f16).
+ *   buffer with out_xp_ksteps k-steps (out_xp_format 0 (or 2): f16 pair planes -- the input format of the next layer and of
+ *   s2s_ipa_attention_f16; 1: exact three-way bf16 planes, three per k-step, for s2s_ipa_attention_planes).
  *   Any pointer may be NULL to skip that step. */
 int s2s_node_linear(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
                     int tiles_per_block, const float* pre_scale, int relu, const float* pre_mask, const float* residual,

@@ -167,23 +167,24 @@ __global__ void __launch_bounds__(256) enc_attention_kernel(const float* __restr
     if (out_xp) {
         // packed planes of the [B*N, D] result: fragment (row tile, k-step 5 head + 2t + u, plane, lane 32 h + row % 32)
         const int KS = D / 16;
-        bf16x8* o = out_xp + (((row >> 5) * KS + (DH / 16) * head) * 3) * 64 + 32 * h + (int)(row & 31);
+        bf16x8* o = out_xp + (((row >> 5) * KS + (DH / 16) * head) * 2) * 64 + 32 * h + (int)(row & 31);
 #pragma unroll
         for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 if (2 * t + u >= DH / 16) continue;
-                // f16 planes of the node stream (x_h, x_l, 2^-5 x_h), csrc/node_gemm.hip
+                // f16 pair planes of the node stream (x_h, x_l), csrc/node_gemm.hip
                 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-                f16x8 ph, pl, ps;
+                f16x8 ph, pl;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float v = O[t][8 * u + j] * inv;
+                    float v = O[t][8 * u + j] * inv;
+                    asm volatile("" : "+v"(v));   // one materialised fp32 value feeds both planes (see node_gemm.hip split8_f16)
                     const _Float16 a_ = (_Float16)v;
-                    ph[j] = a_; pl[j] = (_Float16)(v - (float)a_); ps[j] = a_ * (_Float16)0.03125f;
+                    ph[j] = a_; pl[j] = (_Float16)(v - (float)a_);
                 }
-                bf16x8* q = o + ((2 * t + u) * 3) * 64;
-                q[0] = __builtin_bit_cast(bf16x8, ph); q[64] = __builtin_bit_cast(bf16x8, pl); q[128] = __builtin_bit_cast(bf16x8, ps);
+                bf16x8* q = o + ((2 * t + u) * 2) * 64;
+                q[0] = __builtin_bit_cast(bf16x8, ph); q[64] = __builtin_bit_cast(bf16x8, pl);
             }
     }
 }

@@ -649,7 +649,7 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
     const float inv = 1.0f / l_tot;
     {
         // o: accumulator registers 8u .. 8u+7 of channel tile T = fragment k-step 16 head + 2T + u of this row tile (chain order)
-        bf16x8* o = a.out_xp + ((rt_q * a.xp_ksteps + 16 * head) * 3) * 64 + lane;
+        bf16x8* o = a.out_xp + ((rt_q * a.xp_ksteps + 16 * head) * 2) * 64 + lane;
 #pragma unroll
         for (int x = 0; x < OH; ++x) {
             const int T = OH * half + x;   // wave-uniform
@@ -659,16 +659,18 @@ __global__ void __launch_bounds__(256) ipa_attention_planes_kernel(PlaneArgs a) 
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = O[x][8 * u + j] * inv;
-                // this output is an INPUT of the node stream (linear_out, s2s_node_linear): f16 planes (x_h, x_l, 2^-5 x_h)
+                // this output is an INPUT of the node stream (linear_out, s2s_node_linear): f16 pair planes (x_h, x_l)
                 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-                f16x8 ph, pl, ps;
+                f16x8 ph, pl;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const _Float16 hh = (_Float16)v[j];
-                    ph[j] = hh; pl[j] = (_Float16)(v[j] - (float)hh); ps[j] = hh * (_Float16)0.03125f;
+                    float xv = v[j];
+                    asm volatile("" : "+v"(xv));   // one materialised fp32 value feeds both planes (see node_gemm.hip split8_f16)
+                    const _Float16 hh = (_Float16)xv;
+                    ph[j] = hh; pl[j] = (_Float16)(xv - (float)hh);
                 }
-                bf16x8* q = o + ((2 * T + u) * 3) * 64;
-                q[0] = __builtin_bit_cast(bf16x8, ph); q[64] = __builtin_bit_cast(bf16x8, pl); q[128] = __builtin_bit_cast(bf16x8, ps);
+                bf16x8* q = o + ((2 * T + u) * 2) * 64;
+                q[0] = __builtin_bit_cast(bf16x8, ph); q[64] = __builtin_bit_cast(bf16x8, pl);
             }
         }
     }

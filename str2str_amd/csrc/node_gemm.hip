@@ -8,15 +8,16 @@
 // of a workgroup through LDS, double buffered), B operand = activation fragment of the wave's own 32 rows.  In that
 // orientation the accumulator layout of a layer IS the B-operand layout of the next one, so activations travel between
 // layers as PACKED PLANES ("XP"): for X [M, K]
-//     XP[rt = row/32][ks = K/16][plane 3][lane 64][8] 16-bit,  lane = 32 g + (row & 31),
+//     XP[rt = row/32][ks = K/16][plane 2][lane 64][8] f16,  lane = 32 g + (row & 31),
 //     element j = plane of X[row][32 (ks>>1) + (r&3) + 8 (r>>2) + 4 g],  r = 8 (ks&1) + j        ("chain" order)
 // i.e. exactly the 1 KiB a wave's B-fragment load wants: every global access of this kernel is lane-linear (16 B per lane,
 // 1 KiB per instruction), there is no LDS staging, no swizzle and no split VALU on the input side -- a value is split into
 // its planes ONCE, in the epilogue of the kernel that produced it (or by s2s_pack_planes for fp32 inputs).
-// Planes of the node stream: f16 (x_h = rn16(x), x_l = rn16(x - x_h), x_hs = 2^-5 x_h); a product keeps
-//     W_h x_h + W_h x_l + W_ls x_hs,   W_h = rn16(w), W_ls = rn16(2^5 (w - W_h))
-// -- 3 MFMAs and 2 weight fragments per (k-step, tile); what is dropped (w_l x_l) is below one fp32 rounding.  The q / k
-// projections feed the IPA attention kernel, whose operands are exact three-way bf16 planes (h, m, l): out_xp_format = 1 writes
+// Planes of the node stream: the f16 pair (x_h = rn16(x), x_l = rn16(x - x_h)), TWO planes per k-step; a product keeps
+//     W_h x_h + W_h x_l + W_l x_h,   (W_h, W_l) = the same split of 2^5 w   (the factor keeps W_l in f16's normal range)
+// -- 3 MFMAs and 2 weight fragments per (k-step, tile); what is dropped (w_l x_l) is below one fp32 rounding; the accumulators
+// carry 32 x the output and the 2^-5 rides in the epilogue's first multiply-add.  The f16 attention kernel takes the same pair
+// planes (q / k projections); the bf16 attention kernel wants exact three-way bf16 planes (h, m, l): out_xp_format = 1 writes
 // those instead.  Weights are packed on the host in chain order (ops.pack_node_weight): [col block][k-step][tile][2][lane][8].
 //
 // Per workgroup: 4 waves x 32 rows, TG output tiles of 32 columns (TG x 16 accumulator registers per lane), one weight stage
@@ -54,35 +55,38 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& ph, bf16x8& pm, b
     }
 }
 
-// planes of the node stream: (x_h, x_l, 2^-5 x_h), see the header
-__device__ __forceinline__ void split8_f16(const float* v, f16x8& ph, f16x8& pl, f16x8& ps) {
+constexpr float kInvWS = 1.0f / 32.0f;   // weights are packed as the split of 2^5 w: accumulators carry 32 x the output
+
+// planes of the node stream: (x_h, x_l), see the header
+__device__ __forceinline__ void split8_f16(const float* v, f16x8& ph, f16x8& pl) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const _Float16 a = (_Float16)v[j];
-        ph[j] = a; pl[j] = (_Float16)(v[j] - (float)a); ps[j] = a * (_Float16)0.03125f;
+        // materialise the value first: with fp contraction the compiler otherwise derives x_h and x_l from DIFFERENT fused forms of
+        // the producing expression (v_fma_mix straight to f16 vs a product rounded to fp32 first), and near an f16 rounding tie the
+        // pair then misses x by a whole f16 ulp (seen in the attention kernels' output planes: 6 of 393 k elements off by 1e-4)
+        float xv = v[j];
+        asm volatile("" : "+v"(xv));
+        const _Float16 a = (_Float16)xv;
+        ph[j] = a; pl[j] = (_Float16)(xv - (float)a);
     }
 }
-// 8 values -> 16 B plane fragments 64 fragments apart: format 0 = f16 planes of the node stream (x_h, x_l, 2^-5 x_h),
-// 1 = exact three-way bf16 planes, 2 = f16 pair (x_h, x_l) (two planes per k-step: the caller's stride differs)
+// 8 values -> 16 B plane fragments 64 fragments apart: format 1 = exact three-way bf16 planes (three per k-step), otherwise the
+// f16 pair (x_h, x_l) (two per k-step) -- the caller's k-step stride follows
 __device__ __forceinline__ void store_planes(f16x8* q, const float* v, int fmt) {
     if (fmt == 1) {
         bf16x8 ph, pm, pl;
         split8(v, ph, pm, pl);
         q[0] = __builtin_bit_cast(f16x8, ph); q[64] = __builtin_bit_cast(f16x8, pm); q[128] = __builtin_bit_cast(f16x8, pl);
-    } else if (fmt == 2) {
-        f16x8 ph, pl, ps;
-        split8_f16(v, ph, pl, ps);
-        q[0] = ph; q[64] = pl;
     } else {
-        f16x8 ph, pl, ps;
-        split8_f16(v, ph, pl, ps);
-        q[0] = ph; q[64] = pl; q[128] = ps;
+        f16x8 ph, pl;
+        split8_f16(v, ph, pl);
+        q[0] = ph; q[64] = pl;
     }
 }
 
 struct GemmArgs {
-    const f16x8* xp;         // packed activation planes [RT][KS][3][64] fragments (f16 planes)
-    const char* wpk;         // packed weights [n_col_blocks][KS][TG][2][64][8] f16 (W_h, W_ls)
+    const f16x8* xp;         // packed activation planes [RT][KS][2][64] fragments (f16 pair)
+    const char* wpk;         // packed weights [n_col_blocks][KS][TG][2][64][8] f16: (W_h, W_l) of 32 w
     const float* bias;       // [Nout] or NULL
     const float* pre_scale;  // [M] or NULL: acc *= pre_scale[row] before the bias (input rows were to be scaled)
     const float* pre_mask;   // [M] or NULL: (acc + bias) *= pre_mask[row]
@@ -100,8 +104,8 @@ struct GemmArgs {
     int res_ld, out_ld, out_col0, xp_KS, xp_ks0;
     int relu;
     float ln_eps;
-    int xp_bf16;             // out_xp format: 0 f16 planes of the node stream, 1 exact three-way bf16 planes, 2 f16 pair planes
-                             // (1, 2: operands of the IPA attention kernels; VF kernels: 0 = bf16 triples, 1 = f16 pairs)
+    int xp_bf16;             // out_xp format: 0 (or 2) f16 pair planes, 1 exact three-way bf16 planes (bf16 attention kernel);
+                             // VF kernels: 0 = bf16 triples, 1 = f16 pairs
 };
 
 // VF: operands swapped -- Y[row, col] = X . W^T with A = the activation fragment, B = the weight fragment -- so that a lane owns
@@ -150,12 +154,12 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
             if (WAVES * k + WAVES - 1 < kFrags || WAVES * k + wave < kFrags) *(lds_f4*)(dst + (WAVES * k + wave) * 1024) = wst[k];
         }
     };
-    const f16x8* xsrc = a.xp + (rtc * KS) * 3 * 64 + lane;
-    f16x8 xa[3], xb[3];  // activation fragments (planes) of the current / next k-step
-    auto x_load = [&](int ks, f16x8 (&x)[3]) {
+    const f16x8* xsrc = a.xp + (rtc * KS) * 2 * 64 + lane;
+    f16x8 xa[2], xb[2];  // activation fragments (planes x_h, x_l) of the current / next k-step
+    auto x_load = [&](int ks, f16x8 (&x)[2]) {
         ks = ks < KS ? ks : KS - 1;
-        const f16x8* p = xsrc + (long long)ks * 3 * 64;
-        x[0] = p[0]; x[1] = p[64]; x[2] = p[128];
+        const f16x8* p = xsrc + (long long)ks * 2 * 64;
+        x[0] = p[0]; x[1] = p[64];
     };
 
     f32x16 acc[TG];
@@ -168,7 +172,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
 
     // tiles in pairs (two interleaved accumulators); the fragments of the next pair are fetched before the current pair's MFMAs
     constexpr int NP = (TG + 1) / 2;
-    auto compute = [&](int par, const f16x8 (&x)[3]) {
+    auto compute = [&](int par, const f16x8 (&x)[2]) {
         const lds_frag* wl = (const lds_frag*)((lds_char*)s_w + par * kStage) + lane;
         f16x8 f[2][4];
         auto fetch = [&](int p, f16x8 (&d)[4]) {
@@ -184,13 +188,13 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
             auto mm = [&](const f16x8& wf, const f16x8& xf, f32x16 c) { return VF ? mfma_f16(xf, wf, c) : mfma_f16(wf, xf, c); };
             if (2 * p + 1 < TG) {
                 f32x16 c = acc[2 * p], d = acc[2 * p + 1];
-                c = mm(w[1], x[2], c); d = mm(w[3], x[2], d);  // W_ls x_hs
+                c = mm(w[1], x[0], c); d = mm(w[3], x[0], d);  // W_l x_h
                 c = mm(w[0], x[1], c); d = mm(w[2], x[1], d);  // W_h x_l
                 c = mm(w[0], x[0], c); d = mm(w[2], x[0], d);  // W_h x_h
                 acc[2 * p] = c; acc[2 * p + 1] = d;
             } else {
                 f32x16 c = acc[2 * p];
-                c = mm(w[1], x[2], c);
+                c = mm(w[1], x[0], c);
                 c = mm(w[0], x[1], c);
                 c = mm(w[0], x[0], c);
                 acc[2 * p] = c;
@@ -201,7 +205,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
     const long long row = rt * 32 + (lane & 31);
     const bool valid = rt < n_rt && row < a.M;
     const long long rowc = valid ? row : a.M - 1;
-    const float ps = a.pre_scale ? a.pre_scale[rowc] : 1.0f;
+    const float ps = (a.pre_scale ? a.pre_scale[rowc] : 1.0f) * kInvWS;   // (the accumulators carry 32 x the product)
     const float pm = a.pre_mask ? a.pre_mask[rowc] : 1.0f;
 
     const int cb = blockIdx.y;
@@ -215,7 +219,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
 #endif
 #if S2S_NODE_XDEPTH == 2
     // activation fragments fetched TWO k-steps ahead (they come from HBM / a remote L2, ~2 us away; a k-step is ~0.9 us)
-    f16x8 xc[3];
+    f16x8 xc[2];
     x_load(1, xb);
     for (int ks = 0; ks < KS; ks += 2) {
         x_load(ks + 2, xc);
@@ -230,7 +234,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
         __syncthreads();
         // rotate: (xa, xb) <- (k-step ks + 2, ks + 3)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { const f16x8 t = xa[p]; xa[p] = xc[p]; xb[p] = t; }
+        for (int p = 0; p < 2; ++p) { const f16x8 t = xa[p]; xa[p] = xc[p]; xb[p] = t; }
     }
 #else
     for (int ks = 0; ks < KS; ks += 2) {
@@ -264,11 +268,11 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int r = 8 * u + j;
-                        v[j] = (rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < a.M) ? acc[t][r] + bv : 0.f;
+                        v[j] = (rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < a.M) ? __builtin_fmaf(acc[t][r], kInvWS, bv) : 0.f;
                     }
                     if (a.xp_bf16) {   // f16 pair (x_h, x_l): operands of s2s_ipa_attention_f16
-                        f16x8 ph, pl, ps;
-                        split8_f16(v, ph, pl, ps);
+                        f16x8 ph, pl;
+                        split8_f16(v, ph, pl);
                         o[(u * 2) * 64] = __builtin_bit_cast(bf16x8, ph); o[(u * 2 + 1) * 64] = __builtin_bit_cast(bf16x8, pl);
                     } else {
                         bf16x8 ph, pmid, pl;
@@ -350,7 +354,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
     if (a.out_xp && rt < n_rt) {
         // the accumulator layout is the next layer's B-operand layout: k-step 2 (cb TG + t) + u = registers 8u .. 8u+7 of tile t.
         // Rows past M inside the last row tile are written as zeros (they are read, never stored, by the consumer).
-        const int fmt = a.xp_bf16, npl = fmt == 2 ? 2 : 3;
+        const int fmt = a.xp_bf16, npl = fmt == 1 ? 3 : 2;
         f16x8* o = a.out_xp + ((rt * a.xp_KS + a.xp_ks0 + 2 * (cb * TG)) * npl) * 64 + lane;
 #pragma unroll
         for (int t = 0; t < TG; ++t)
@@ -384,7 +388,7 @@ __global__ void __launch_bounds__(256) pack_planes_kernel(const float* __restric
         v[0] = lo.x * sc; v[1] = lo.y * sc; v[2] = lo.z * sc; v[3] = lo.w * sc;
         v[4] = hi.x * sc; v[5] = hi.y * sc; v[6] = hi.z * sc; v[7] = hi.w * sc;
     }
-    store_planes(xp + ((rt * xp_KS + ks0 + ks) * 3) * 64 + lane, v, 0);
+    store_planes(xp + ((rt * xp_KS + ks0 + ks) * 2) * 64 + lane, v, 0);
 }
 
 template <int TG, int WAVES, bool VF = false>

@@ -4,10 +4,12 @@
 // Every fp32 operand is split into two f16 numbers  x = x_h + x_l (+ <= 2^-24 |x|),  x_h = rn16(x), x_l = rn16(x - x_h)  --
 // 11 + 11 significant bits plus the sign of the residue, i.e. fp32's 24 -- and a product keeps  w_h x_h + w_h x_l + w_l x_h  (the
 // dropped w_l x_l is below one fp32 rounding of the product, like the plane pairs bf16x6 drops) on v_mfma_f32_32x32x16_f16 with
-// fp32 accumulation: 3 MFMAs per (k-step, tile) instead of 6.  f16's narrow exponent is handled by exact power-of-two scalings
-// of the small factors: the weight side stores  W_h, W_ls = rn16(2^5 w_l)  (2 A fragments per (k-step, tile), 4 KiB per slot,
-// 32 KiB stages, 0.94 MB stream), the activation side keeps three plane registers  x_h, x_l, x_hs = 2^-5 x_h  and the products
-// are  W_h x_h + W_h x_l + W_ls x_hs.  A value of x_l below f16's normal range (|x| < 0.25) is rounded to 2^-25 absolute --
+// fp32 accumulation: 3 MFMAs per (k-step, tile) instead of 6.  f16's narrow exponent is handled by one exact power-of-two scaling:
+// the weight side stores the split of 2^5 w,  W_h = rn16(32 w), W_l = rn16(32 w - W_h)  (so that the small part stays in f16's
+// normal range; 2 A fragments per (k-step, tile), 4 KiB per slot, 32 KiB stages, 0.94 MB stream), the activation side two plane
+// registers  x_h, x_l,  the products are  W_h x_h + W_h x_l + W_l x_h  and the accumulators carry 32 x the layer output: the
+// factor 2^-5 rides in the multiply-add that adds the bias / seeds in every epilogue (LayerNorm, scale invariant, runs on the
+// scaled values with 1024 eps).  A value of x_l below f16's normal range (|x| < 0.25) is rounded to 2^-25 absolute --
 // 1.7e-8 rms on an O(1) output, under fp32's own rounding; activations must stay below f16's 65504 (they are LayerNorm
 // outputs and one hidden layer away from them).  The parity suite runs this mode against the same oracle and tolerances.
 #include <hip/hip_runtime.h>
@@ -25,6 +27,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kStageBytes = 32 * 1024;  // 8 slots x 4 fragments x 1 KiB
 constexpr int kStagesBase = 30;         // + 1 stage (8 slots) for the fused pair projection of the next IPA block
+constexpr float kWS = 32.0f, kInvWS = 1.0f / 32.0f;   // weights are packed as 2^5 w (see the header): accumulators carry 32 x the layer output
 
 __device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -145,14 +148,15 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     // ---- the pair's 128 edge channels, split once: xpl[ks][plane] = B operand of layer-1 k-step ks.  Element j of k-step
     //      2t+u is channel 32t + 8(2u + (j>>2)) + 4h + (j&3): the accumulator layout of a 128-channel block (register 8u+j of
     //      tile t), so the exact sum of the three planes later serves as the residual row of block 0 without a second read.
-    f16x8 xpl[8][3];
+    f16x8 xpl[8][2];
     // planes (x_h, x_l, x_hs = 2^-5 x_h), see the header
-    auto split4 = [&](const float (&x)[4], f16x8& ph, f16x8& pm, f16x8& pl, int at) {
+    auto split4 = [&](const float (&x)[4], f16x8& ph, f16x8& pm, int at) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const _Float16 a = (_Float16)x[j];
-            const float r1 = x[j] - (float)a;
-            ph[at + j] = a; pm[at + j] = (_Float16)r1; pl[at + j] = a * (_Float16)0.03125f;
+            float xv = x[j];
+            asm volatile("" : "+v"(xv));   // one materialised fp32 value feeds both planes (see node_gemm.hip split8_f16)
+            const _Float16 a = (_Float16)xv;
+            ph[at + j] = a; pm[at + j] = (_Float16)(xv - (float)a);
         }
     };
     {
@@ -168,7 +172,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float x[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
-            split4(x, xpl[i >> 1][0], xpl[i >> 1][1], xpl[i >> 1][2], 4 * (i & 1));
+            split4(x, xpl[i >> 1][0], xpl[i >> 1][1], 4 * (i & 1));
         }
     }
 
@@ -187,8 +191,8 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     };
     seeds_load(cur, 0);
 
-    f16x8 fr[2][4];  // A fragments of the current / next slot: (W_h, W_ls) of two (k-step, tile) units
-    f16x8 xp[2][3];  // layer 2: planes of k-steps 2t, 2t+1 of the current a1 tile; final layer: current / next k-step
+    f16x8 fr[2][4];  // A fragments of the current / next slot: (W_h, W_l) of two (k-step, tile) units
+    f16x8 xp[2][2];  // layer 2: planes of k-steps 2t, 2t+1 of the current a1 tile; final layer: current / next k-step
     auto fetch = [&](int par, int slot_in_stage, f16x8 (&f)[4]) {
         typedef __attribute__((address_space(3))) f16x8 lds_frag;
         const lds_frag* s = (const lds_frag*)lds_image[par] + slot_in_stage * 4 * 64;
@@ -200,8 +204,8 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         constexpr int qd = decltype(qc)::value;
         float x[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = fmaxf(tile_acc[4 * qd + j] + sa[4 * qd + j] + sb[4 * qd + j], 0.f);
-        split4(x, xp[qd >> 1][0], xp[qd >> 1][1], xp[qd >> 1][2], 4 * (qd & 1));
+        for (int j = 0; j < 4; ++j) x[j] = fmaxf(__builtin_fmaf(tile_acc[4 * qd + j], kInvWS, sa[4 * qd + j] + sb[4 * qd + j]), 0.f);
+        split4(x, xp[qd >> 1][0], xp[qd >> 1][1], 4 * (qd & 1));
     };
     float rs[64];  // one 128-channel residual row in accumulator layout
     auto row_load = [&](const float* r) {
@@ -223,7 +227,9 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
             const float4 bq = ldg4(s_vec + 384, 4 * t + rq, h);
-            a3[t][4 * rq + 0] += bq.x; a3[t][4 * rq + 1] += bq.y; a3[t][4 * rq + 2] += bq.z; a3[t][4 * rq + 3] += bq.w;
+            // (LayerNorm is scale invariant: the statistics run on the 32 x scaled accumulator, with 1024 eps)
+            a3[t][4 * rq + 0] = __builtin_fmaf(bq.x, kWS, a3[t][4 * rq + 0]); a3[t][4 * rq + 1] = __builtin_fmaf(bq.y, kWS, a3[t][4 * rq + 1]);
+            a3[t][4 * rq + 2] = __builtin_fmaf(bq.z, kWS, a3[t][4 * rq + 2]); a3[t][4 * rq + 3] = __builtin_fmaf(bq.w, kWS, a3[t][4 * rq + 3]);
         }
     float sum = 0.f;
 #pragma unroll
@@ -239,7 +245,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             const float dd = a3[t][r] - mean;
             var += dd * dd;
         }
-    const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / 128) + ln_eps);
+    const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / 128) + ln_eps * (kWS * kWS));
     float* orow = cur.orow;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -262,7 +268,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     const bool has_next = wt_next < n_wt;
     PairCtx nxt = cur;  // next tile's context, edge row and planes: produced under the last 16 slots of this tile
     float4 xv[16];
-    f16x8 xpn[8][3];
+    f16x8 xpn[8][2];
     static_for<0, kSlots>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         constexpr SlotDesc d = slot_desc(s);
@@ -295,22 +301,22 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         const f16x8 (&f)[4] = fr[s & 1];
         if constexpr (d.phase == 0) {
             f32x16& acc = a1t[d.t & 1];
-            const f16x8 (&x0)[3] = xpl[2 * d.a], (&x1)[3] = xpl[2 * d.a + 1];
-            if constexpr (d.a == 0) acc = mfma_f16(f[1], x0[2], zero16); else acc = mfma_f16(f[1], x0[2], acc);  // W_ls x_hs
+            const f16x8 (&x0)[2] = xpl[2 * d.a], (&x1)[2] = xpl[2 * d.a + 1];
+            if constexpr (d.a == 0) acc = mfma_f16(f[1], x0[0], zero16); else acc = mfma_f16(f[1], x0[0], acc);  // W_l x_h
             acc = mfma_f16(f[0], x0[1], acc);  // W_h x_l
             acc = mfma_f16(f[0], x0[0], acc);  // W_h x_h
-            acc = mfma_f16(f[3], x1[2], acc);
+            acc = mfma_f16(f[3], x1[0], acc);
             acc = mfma_f16(f[2], x1[1], acc);
             acc = mfma_f16(f[2], x1[0], acc);
             // under A_t: relu + seeds + split of tile t-1, a quarter per slot
             if constexpr (d.t >= 1) s_quarter(a1t[(d.t - 1) & 1], IC<d.a>{});
         } else if constexpr (d.phase == 3) {
-            const f16x8 (&x)[3] = xpl[d.a];
+            const f16x8 (&x)[2] = xpl[d.a];
             f32x16 &t0 = pq[0], &t1 = pq[1];
             if constexpr (d.a == 0) {
-                t0 = mfma_f16(f[1], x[2], zero16); t1 = mfma_f16(f[3], x[2], zero16);
+                t0 = mfma_f16(f[1], x[0], zero16); t1 = mfma_f16(f[3], x[0], zero16);
             } else {
-                t0 = mfma_f16(f[1], x[2], t0); t1 = mfma_f16(f[3], x[2], t1);
+                t0 = mfma_f16(f[1], x[0], t0); t1 = mfma_f16(f[3], x[0], t1);
             }
             t0 = mfma_f16(f[0], x[1], t0); t1 = mfma_f16(f[2], x[1], t1);
             t0 = mfma_f16(f[0], x[0], t0); t1 = mfma_f16(f[2], x[0], t1);
@@ -319,11 +325,11 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             constexpr bool first = fin ? d.a == 0 : (d.t == 0 && d.a == 0);
             f32x16& t0 = fin ? a3[2 * d.b] : a2[2 * d.b];
             f32x16& t1 = fin ? a3[2 * d.b + 1] : a2[2 * d.b + 1];
-            const f16x8 (&x)[3] = fin ? xpl[d.a & 7] : xp[d.a];
+            const f16x8 (&x)[2] = fin ? xpl[d.a & 7] : xp[d.a];
             if constexpr (first) {
-                t0 = mfma_f16(f[1], x[2], zero16); t1 = mfma_f16(f[3], x[2], zero16);
+                t0 = mfma_f16(f[1], x[0], zero16); t1 = mfma_f16(f[3], x[0], zero16);
             } else {
-                t0 = mfma_f16(f[1], x[2], t0); t1 = mfma_f16(f[3], x[2], t1);  // W_ls x_hs
+                t0 = mfma_f16(f[1], x[0], t0); t1 = mfma_f16(f[3], x[0], t1);  // W_l x_h
             }
             t0 = mfma_f16(f[0], x[1], t0); t1 = mfma_f16(f[2], x[1], t1);  // W_h x_l
             t0 = mfma_f16(f[0], x[0], t0); t1 = mfma_f16(f[2], x[0], t1);  // W_h x_h
@@ -332,8 +338,8 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             constexpr int i = s - 228;
             const float x0[4] = {xv[2 * i].x, xv[2 * i].y, xv[2 * i].z, xv[2 * i].w};
             const float x1[4] = {xv[2 * i + 1].x, xv[2 * i + 1].y, xv[2 * i + 1].z, xv[2 * i + 1].w};
-            split4(x0, xpn[i][0], xpn[i][1], xpn[i][2], 0);
-            split4(x1, xpn[i][0], xpn[i][1], xpn[i][2], 4);
+            split4(x0, xpn[i][0], xpn[i][1], 0);
+            split4(x1, xpn[i][0], xpn[i][1], 4);
         }
         if constexpr (ss == 1) cp_store_a(par ^ 1);
         if constexpr (ss == 5) cp_store_b(par ^ 1);
@@ -354,7 +360,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
                     const float x[4] = {a3[t][4 * rq + 0], a3[t][4 * rq + 1], a3[t][4 * rq + 2], a3[t][4 * rq + 3]};
-                    split4(x, xpl[2 * t + (rq >> 1)][0], xpl[2 * t + (rq >> 1)][1], xpl[2 * t + (rq >> 1)][2], 4 * (rq & 1));
+                    split4(x, xpl[2 * t + (rq >> 1)][0], xpl[2 * t + (rq >> 1)][1], 4 * (rq & 1));
                 }
         }
         if constexpr (s == 191 || s == 207 || s == 223) {
@@ -372,11 +378,11 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
                 for (int rq = 0; rq < 4; ++rq) {
                     const float4 bq = ldg4(s_vec + 128 * pb, 4 * t + rq, h);
                     const f32x16& a = a2[4 * pb + t];
-                    const float x[4] = {fmaxf(a[4 * rq + 0] + bq.x, 0.f) + rs[16 * t + 4 * rq + 0],
-                                        fmaxf(a[4 * rq + 1] + bq.y, 0.f) + rs[16 * t + 4 * rq + 1],
-                                        fmaxf(a[4 * rq + 2] + bq.z, 0.f) + rs[16 * t + 4 * rq + 2],
-                                        fmaxf(a[4 * rq + 3] + bq.w, 0.f) + rs[16 * t + 4 * rq + 3]};
-                    split4(x, xpl[2 * t + (rq >> 1)][0], xpl[2 * t + (rq >> 1)][1], xpl[2 * t + (rq >> 1)][2], 4 * (rq & 1));
+                    const float x[4] = {fmaxf(__builtin_fmaf(a[4 * rq + 0], kInvWS, bq.x), 0.f) + rs[16 * t + 4 * rq + 0],
+                                        fmaxf(__builtin_fmaf(a[4 * rq + 1], kInvWS, bq.y), 0.f) + rs[16 * t + 4 * rq + 1],
+                                        fmaxf(__builtin_fmaf(a[4 * rq + 2], kInvWS, bq.z), 0.f) + rs[16 * t + 4 * rq + 2],
+                                        fmaxf(__builtin_fmaf(a[4 * rq + 3], kInvWS, bq.w), 0.f) + rs[16 * t + 4 * rq + 3]};
+                    split4(x, xpl[2 * t + (rq >> 1)][0], xpl[2 * t + (rq >> 1)][1], 4 * (rq & 1));
                 }
             if constexpr (pb < 2) row_load(pb == 0 ? cur.npi : cur.npj);  // lands under the next 16 slots
         }
@@ -388,16 +394,17 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         if (cur.valid) {
             const float4 b0 = ldg4(s_vec + 768, 0, h);
             float* o = proj_bias_out + cur.boff + 4 * h * NN;
-            o[0] = pq[0][0] + b0.x;
-            o[NN] = pq[0][1] + b0.y;
-            o[2 * NN] = pq[0][2] + b0.z;
-            o[3 * NN] = pq[0][3] + b0.w;
+            o[0] = __builtin_fmaf(pq[0][0], kInvWS, b0.x);
+            o[NN] = __builtin_fmaf(pq[0][1], kInvWS, b0.y);
+            o[2 * NN] = __builtin_fmaf(pq[0][2], kInvWS, b0.z);
+            o[3 * NN] = __builtin_fmaf(pq[0][3], kInvWS, b0.w);
 #pragma unroll
             for (int g = 1; g <= 4; ++g) {
                 const int t = g >> 2, rq = g & 3;
                 const float4 bq = ldg4(s_vec + 768, g, h);
                 *reinterpret_cast<float4*>(proj_pz_out + cur.p * 32 + 8 * (g - 1) + 4 * h) =
-                    make_float4(pq[t][4 * rq + 0] + bq.x, pq[t][4 * rq + 1] + bq.y, pq[t][4 * rq + 2] + bq.z, pq[t][4 * rq + 3] + bq.w);
+                    make_float4(__builtin_fmaf(pq[t][4 * rq + 0], kInvWS, bq.x), __builtin_fmaf(pq[t][4 * rq + 1], kInvWS, bq.y),
+                                __builtin_fmaf(pq[t][4 * rq + 2], kInvWS, bq.z), __builtin_fmaf(pq[t][4 * rq + 3], kInvWS, bq.w));
             }
         }
     }
@@ -405,7 +412,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     cur = nxt;
     wt = wt_next;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { xpl[i][0] = xpn[i][0]; xpl[i][1] = xpn[i][1]; xpl[i][2] = xpn[i][2]; }
+    for (int i = 0; i < 8; ++i) { xpl[i][0] = xpn[i][0]; xpl[i][1] = xpn[i][1]; }
     if constexpr (kStages % 2 == 1) {  // odd stage count: the next tile's stage 0 sits in the other buffer
         lds_char* sw = lds_image[0];
         lds_image[0] = lds_image[1];
@@ -549,12 +556,13 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
         c.em = mask ? r.mi * r.mj : 1.0f;
         return c;
     };
-    auto split4 = [&](const float (&x)[4], f16x8& ph, f16x8& pm, f16x8& pl, int at) {  // planes (x_h, x_l, 2^-5 x_h)
+    auto split4 = [&](const float (&x)[4], f16x8& ph, f16x8& pm, int at) {  // planes (x_h, x_l)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const _Float16 a = (_Float16)x[j];
-            const float r1 = x[j] - (float)a;
-            ph[at + j] = a; pm[at + j] = (_Float16)r1; pl[at + j] = a * (_Float16)0.03125f;
+            float xv = x[j];
+            asm volatile("" : "+v"(xv));   // one materialised fp32 value feeds both planes (see node_gemm.hip split8_f16)
+            const _Float16 a = (_Float16)xv;
+            ph[at + j] = a; pm[at + j] = (_Float16)(xv - (float)a);
         }
     };
     // first-layer sum in accumulator layout: g1[4G + q] = channel 8G + 4h + q, built row by row (same association as the
@@ -584,11 +592,11 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
         }
     };
     // ReLU + split of first-layer k-step ks (registers 8ks .. 8ks+7 of g1: chain order) into planes
-    auto g1_split = [&](f16x8 (&dst)[3], int ks) {
+    auto g1_split = [&](f16x8 (&dst)[2], int ks) {
         const float x0[4] = {fmaxf(g1[8 * ks + 0], 0.f), fmaxf(g1[8 * ks + 1], 0.f), fmaxf(g1[8 * ks + 2], 0.f), fmaxf(g1[8 * ks + 3], 0.f)};
         const float x1[4] = {fmaxf(g1[8 * ks + 4], 0.f), fmaxf(g1[8 * ks + 5], 0.f), fmaxf(g1[8 * ks + 6], 0.f), fmaxf(g1[8 * ks + 7], 0.f)};
-        split4(x0, dst[0], dst[1], dst[2], 0);
-        split4(x1, dst[0], dst[1], dst[2], 4);
+        split4(x0, dst[0], dst[1], 0);
+        split4(x1, dst[0], dst[1], 4);
     };
 
     const long long n_wt = (M + 127) / 128;
@@ -596,7 +604,7 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
     if (threadIdx.x < 68) s_bins[threadIdx.x] = (int)threadIdx.x < n_bins ? bin_lower[threadIdx.x] : ((int)threadIdx.x == n_bins ? 1e8f : 3.0e38f);
     __syncthreads();
     Ctx cur = setup_b(setup_a(wt));
-    f16x8 xp[8][3];  // planes of the current layer's input (8 k-steps of 16)
+    f16x8 xp[8][2];  // planes of the current layer's input (8 k-steps of 16)
     {
         row_set(cur.ra);
         for (int i = threadIdx.x; i < 512; i += 256)
@@ -623,11 +631,12 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
     // The VALU work of a tile is cut into per-k-step pieces, each pinned (empty asm on its inputs / outputs: otherwise the
     // compiler sinks a piece to its first use, i.e. in FRONT of the MFMAs that wait for it) into a slot whose MFMAs do not depend
     // on it, and interleaved with them by sched_group_barrier.
-    auto pin_frag = [&](f16x8 (&x)[3]) { asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2])); };
+    auto pin_frag = [&](f16x8 (&x)[2]) { asm volatile("" : "+v"(x[0]), "+v"(x[1])); };
     // accumulator start = bias (registers 4 rq + q of tile t <-> channel 32 t + 8 rq + 4 h + q)
-    auto bias16 = [&](const float* vec, int t) -> f32x16 {
+    auto bias16 = [&](const float* vec, int t) -> f32x16 {   // 32 x bias (the accumulators carry 32 x the layer output)
         const float4 b0 = ldg4(vec, 4 * t, h), b1 = ldg4(vec, 4 * t + 1, h), b2v = ldg4(vec, 4 * t + 2, h), b3v = ldg4(vec, 4 * t + 3, h);
-        return f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2v.x, b2v.y, b2v.z, b2v.w, b3v.x, b3v.y, b3v.z, b3v.w};
+        return f32x16{kWS * b0.x, kWS * b0.y, kWS * b0.z, kWS * b0.w, kWS * b1.x, kWS * b1.y, kWS * b1.z, kWS * b1.w,
+                      kWS * b2v.x, kWS * b2v.y, kWS * b2v.z, kWS * b2v.w, kWS * b3v.x, kWS * b3v.y, kWS * b3v.z, kWS * b3v.w};
     };
     // layer-2 output (bias already in the accumulator): ReLU + split of k-step k -> layer-3 input planes xp[k]
     auto l2_piece = [&](auto kc) {
@@ -635,14 +644,14 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int rq = 2 * (k & 1) + u;
-            const float xx[4] = {fmaxf(a2[t][4 * rq + 0], 0.f), fmaxf(a2[t][4 * rq + 1], 0.f), fmaxf(a2[t][4 * rq + 2], 0.f),
-                                 fmaxf(a2[t][4 * rq + 3], 0.f)};
-            split4(xx, xp[k][0], xp[k][1], xp[k][2], 4 * u);
+            const float xx[4] = {fmaxf(a2[t][4 * rq + 0], 0.f) * kInvWS, fmaxf(a2[t][4 * rq + 1], 0.f) * kInvWS,
+                                 fmaxf(a2[t][4 * rq + 2], 0.f) * kInvWS, fmaxf(a2[t][4 * rq + 3], 0.f) * kInvWS};
+            split4(xx, xp[k][0], xp[k][1], 4 * u);
         }
         pin_frag(xp[k]);
     };
     float ln_mean = 0.f, ln_rstd = 0.f;
-    f16x8 xq[2][3];  // LayerNorm output planes of the projection's current / next k-step
+    f16x8 xq[2][2];  // LayerNorm output planes of the projection's current / next k-step
     // LayerNorm output of k-step k (16 channels): scale, shift, edge mask, store (+ planes for the projection)
     __amdgpu_buffer_rsrc_t rs_out;  // this tile's 32 output rows; rows past M are outside num_records: their stores are dropped
     auto out_rsrc = [&](long long wg_tile) {
@@ -679,7 +688,7 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
                                                    rs_out, (unsigned)((lane & 31) * 512 + h * 16) + g * 32, 0, 0);
             if constexpr (PROJ) {
                 const float xx[4] = {o.x, o.y, o.z, o.w};
-                split4(xx, xq[k & 1][0], xq[k & 1][1], xq[k & 1][2], 4 * u);
+                split4(xx, xq[k & 1][0], xq[k & 1][1], 4 * u);
             }
         }
         if constexpr (PROJ) pin_frag(xq[k & 1]);
@@ -702,7 +711,7 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
     const bool has_next = wt_next < n_wt;
     Ctx nxt = cur;
     Raw nraw;
-    f16x8 xl[3];  // the next tile's last k-step (xp[7] is read by the final layer's last slot)
+    f16x8 xl[2];  // the next tile's last k-step (xp[7] is read by the final layer's last slot)
     static_for<0, kSlots>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         constexpr int stage = s / 8, ss = s % 8, par = stage & 1;
@@ -738,17 +747,17 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
 
         // ---------------- the 12 MFMAs and the VALU pieces that run under them
         const f16x8 (&f)[4] = fr[s & 1];
-        const f16x8 (&x)[3] = layer < 2 ? xp[ks] : xq[ks & 1];
+        const f16x8 (&x)[2] = layer < 2 ? xp[ks] : xq[ks & 1];
         f32x16& t0 = layer == 0 ? a2[2 * pr] : (layer == 1 ? a3[2 * pr] : pq[0]);
         f32x16& t1 = layer == 0 ? a2[2 * pr + 1] : (layer == 1 ? a3[2 * pr + 1] : pq[1]);
         if constexpr (ks == 0) {
             if constexpr (layer < 2) {
-                t0 = mfma_f16(f[1], x[2], pr == 0 ? initA0 : initB0); t1 = mfma_f16(f[3], x[2], pr == 0 ? initA1 : initB1);
+                t0 = mfma_f16(f[1], x[0], pr == 0 ? initA0 : initB0); t1 = mfma_f16(f[3], x[0], pr == 0 ? initA1 : initB1);
             } else {
-                t0 = mfma_f16(f[1], x[2], zero16); t1 = mfma_f16(f[3], x[2], zero16);
+                t0 = mfma_f16(f[1], x[0], zero16); t1 = mfma_f16(f[3], x[0], zero16);
             }
         } else {
-            t0 = mfma_f16(f[1], x[2], t0); t1 = mfma_f16(f[3], x[2], t1);  // W_ls x_hs
+            t0 = mfma_f16(f[1], x[0], t0); t1 = mfma_f16(f[3], x[0], t1);  // W_l x_h
         }
         t0 = mfma_f16(f[0], x[1], t0); t1 = mfma_f16(f[2], x[1], t1);      // W_h x_l
         t0 = mfma_f16(f[0], x[0], t0); t1 = mfma_f16(f[2], x[0], t1);      // W_h x_h
@@ -791,7 +800,7 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
                     const float dd = a3[t][r] - ln_mean;
                     var = __fmaf_rn(dd, dd, var);
                 }
-            ln_rstd = 1.0f / sqrtf(__fmaf_rn(xhalf_sum(var), 1.0f / 128, ln_eps));
+            ln_rstd = 1.0f / sqrtf(__fmaf_rn(xhalf_sum(var), 1.0f / 128, ln_eps * (kWS * kWS)));   // (scaled accumulator: 1024 eps)
             if constexpr (PROJ) {
                 ln_piece(IC<0>{}, cur);
             } else {
@@ -803,23 +812,24 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
         if (cur.valid) {
             const float4 b0 = ldg4(s_vec + 512, 0, h);
             float* o = proj_bias_out + cur.boff + 4 * h * NN;
-            o[0] = pq[0][0] + b0.x;
-            o[NN] = pq[0][1] + b0.y;
-            o[2 * NN] = pq[0][2] + b0.z;
-            o[3 * NN] = pq[0][3] + b0.w;
+            o[0] = __builtin_fmaf(pq[0][0], kInvWS, b0.x);
+            o[NN] = __builtin_fmaf(pq[0][1], kInvWS, b0.y);
+            o[2 * NN] = __builtin_fmaf(pq[0][2], kInvWS, b0.z);
+            o[3 * NN] = __builtin_fmaf(pq[0][3], kInvWS, b0.w);
 #pragma unroll
             for (int g = 1; g <= 4; ++g) {
                 const int t = g >> 2, rq = g & 3;
                 const float4 bq = ldg4(s_vec + 512, g, h);
                 *reinterpret_cast<float4*>(proj_pz_out + cur.p * 32 + 8 * (g - 1) + 4 * h) =
-                    make_float4(pq[t][4 * rq + 0] + bq.x, pq[t][4 * rq + 1] + bq.y, pq[t][4 * rq + 2] + bq.z, pq[t][4 * rq + 3] + bq.w);
+                    make_float4(__builtin_fmaf(pq[t][4 * rq + 0], kInvWS, bq.x), __builtin_fmaf(pq[t][4 * rq + 1], kInvWS, bq.y),
+                                __builtin_fmaf(pq[t][4 * rq + 2], kInvWS, bq.z), __builtin_fmaf(pq[t][4 * rq + 3], kInvWS, bq.w));
             }
         }
     }
     if (!has_next) break;
     cur = nxt;
     wt = wt_next;
-    xp[7][0] = xl[0]; xp[7][1] = xl[1]; xp[7][2] = xl[2];
+    xp[7][0] = xl[0]; xp[7][1] = xl[1];
     if constexpr (kStages % 2 == 1) {  // odd stage count: the next tile's stage 0 sits in the other buffer
         lds_char* sw = lds_image[0];
         lds_image[0] = lds_image[1];

@@ -97,7 +97,7 @@ class InvariantPointAttention(nn.Module):
         # attention operands: f16 pair planes (S2S_IPA_PATH=f16, default: s2s_ipa_attention_f16, three products per block) or
         # exact three-way bf16 planes (S2S_IPA_PATH=planes: s2s_ipa_attention_planes, six products)
         f16 = os.environ.get("S2S_IPA_PATH", "f16") == "f16"
-        fmt = 2 if f16 else 1
+        fmt = 0 if f16 else 1
         _, q_xp = lin(w["q"], want_f32=False, want_xp=True, xp_format=fmt)
         _, k_xp = lin(w["k"], want_f32=False, want_xp=True, xp_format=fmt)
         v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, w["v"]["k"], w["v"]["n"], self.c_hidden // 32, f16=f16)

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 _lib = None
 _tables_loaded = False
@@ -221,10 +221,11 @@ def pack_bf16x3_stream(w1_edge: torch.Tensor, w2: torch.Tensor, wf: torch.Tensor
 
 def pack_f16x2_layer(w: torch.Tensor, kind: str = "chain") -> torch.Tensor:
     """[Mout, K] fp32 -> f16 fragments [K/16][Mout/32][2 planes (W_h, W_ls)][64][8] for v_mfma_f32_32x32x16_f16 A operands
-    (lane / element order of ``pack_bf16x3_layer``):  W_h = rn16(w),  W_ls = rn16(2^5 (w - W_h))  -- csrc/pair_mlp_f16.hip."""
-    planes = pack_bf16x3_layer(w, kind, _fp32_fragments=True)  # [KS, T, 64, 8] fp32 in fragment order
+    (lane / element order of ``pack_bf16x3_layer``): the f16 pair split of 2^5 w,  W_h = rn16(32 w),  W_l = rn16(32 w - W_h)  --
+    the power of two keeps W_l in f16's normal range; the kernels take 2^-5 back in their epilogues (csrc/pair_mlp_f16.hip)."""
+    planes = pack_bf16x3_layer(w, kind, _fp32_fragments=True) * 32.0  # [KS, T, 64, 8] fp32 in fragment order
     h = planes.to(torch.float16)
-    ls = ((planes - h.float()) * 32.0).to(torch.float16)
+    ls = (planes - h.float()).to(torch.float16)
     return torch.stack([h, ls], dim=2).contiguous()
 
 
@@ -675,9 +676,10 @@ def pack_node_weight(w: torch.Tensor, tiles_per_block: int) -> torch.Tensor:
     return fr.contiguous().view(torch.int16).reshape(-1)
 
 
-def xp_alloc(n_rows: int, k: int, device) -> torch.Tensor:
-    """Packed-plane activation buffer for [n_rows, k] (int16 storage of three 16-bit planes; see include/str2str_hip.h)."""
-    return torch.empty(((n_rows + 31) // 32) * (k // 16) * 3 * 64 * 8, dtype=torch.int16, device=device)
+def xp_alloc(n_rows: int, k: int, device, planes: int = 2) -> torch.Tensor:
+    """Packed-plane activation buffer for [n_rows, k] (int16 storage; two f16 planes per k-step for the node stream, three for the
+    bf16 operand format; see include/str2str_hip.h)."""
+    return torch.empty(((n_rows + 31) // 32) * (k // 16) * planes * 64 * 8, dtype=torch.int16, device=device)
 
 
 def pack_planes(x2d: torch.Tensor, col0: int = 0, n_cols: Optional[int] = None, out=None, out_k: Optional[int] = None,
@@ -703,26 +705,25 @@ def node_linear(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles: int, *
     """One fused per-node layer (s2s_node_linear).  ``residual`` [n_rows, ld] fp32 (its leading n_out columns are added);
     ``ln`` = (gamma, beta, eps); ``out_f32`` a preallocated [n_rows, ld] buffer written at ``out_col0`` (allocated
     [n_rows, n_out] when ``want_f32``); ``out_xp`` likewise for the packed planes (``xp_bf16``: as exact three-way bf16 planes,
-    the operand format of the IPA attention kernel, instead of the node stream's f16 planes; ``xp_format`` = 2: f16 pair planes,
-    two per k-step, for the f16 attention kernel).  -> (out_f32 or None, out_xp or None)."""
+    the operand format of the bf16 attention kernel, instead of the f16 pair planes the node stream and the f16 attention kernel
+    take).  -> (out_f32 or None, out_xp or None)."""
     lib = load_library()
     _req(xp, torch.int16, "xp"); _req(wpk, torch.int16, "w_packed")
     dev = xp.device
     for n, t in (("bias", bias), ("pre_scale", pre_scale), ("pre_mask", pre_mask), ("residual", residual), ("post_mask", post_mask)):
         if t is not None:
             _req(t, name=n)
-    if xp.numel() != ((n_rows + 31) // 32) * (k_in // 16) * 1536 or wpk.numel() != n_out * k_in * 2:
+    if xp.numel() != ((n_rows + 31) // 32) * (k_in // 16) * 1024 or wpk.numel() != n_out * k_in * 2:
         raise HipLibraryError(f"node_linear: operand sizes do not match M={n_rows} K={k_in} N={n_out}")
     if out_f32 is None and want_f32:
         out_f32 = torch.empty(n_rows, n_out, device=dev, dtype=torch.float32)
     if out_f32 is not None:
         _req(out_f32, name="out_f32")
     fmt = int(xp_format) if xp_format is not None else int(bool(xp_bf16))
+    fmt = 0 if fmt == 2 else fmt   # (2 = "f16 pair planes": since the node stream itself uses them, the same as 0)
     if out_xp is None and want_xp:
         out_xp_k = n_out if out_xp_k is None else out_xp_k
-        out_xp = xp_alloc(n_rows, out_xp_k, dev)
-        if fmt == 2:
-            out_xp = out_xp[: out_xp.numel() // 3 * 2]
+        out_xp = xp_alloc(n_rows, out_xp_k, dev, planes=3 if fmt == 1 else 2)
     if out_xp is not None:
         out_xp_k = n_out if out_xp_k is None else out_xp_k
         _req(out_xp, torch.int16, "out_xp")
@@ -798,12 +799,12 @@ def ca_pwd_js(ref_ca: torch.Tensor, pred_ca: torch.Tensor, offset: int = 3, n_bi
 
 
 def unpack_planes(xp: torch.Tensor, n_rows: int, k: int, bf16: bool = False) -> torch.Tensor:
-    """XP -> fp32 [n_rows, k] (x_h + x_l of the f16 planes, or h + m + l of bf16 planes; for tests and debugging)."""
+    """XP -> fp32 [n_rows, k] (x_h + x_l of the f16 pair planes, or h + m + l of bf16 planes; for tests and debugging)."""
     KS = k // 16
     if bf16:
         fr = xp.view(torch.bfloat16).reshape(-1, KS, 3, 2, 32, 8).float().sum(2)    # [RT, KS, g, m, j]
     else:
-        fr = xp.view(torch.float16).reshape(-1, KS, 3, 2, 32, 8).float()[:, :, :2].sum(2)
+        fr = xp.view(torch.float16).reshape(-1, KS, 2, 2, 32, 8).float().sum(2)
     ks = torch.arange(KS)[:, None, None]
     g = torch.arange(2)[None, :, None]
     j = torch.arange(8)[None, None, :]
