@@ -608,7 +608,7 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
     {
         row_set(cur.ra);
         for (int i = threadIdx.x; i < 512; i += 256)
-            s_vec[i] = i < 128 ? b2[i] : (i < 256 ? b3[i - 128] : (i < 384 ? gamma[i - 256] : beta[i - 384]));
+            s_vec[i] = i < 128 ? kWS * b2[i] : (i < 256 ? kWS * b3[i - 128] : (i < 384 ? gamma[i - 256] : beta[i - 384]));   // biases x 32 (accumulator scale)
         if (PROJ && threadIdx.x < 64) s_vec[512 + threadIdx.x] = proj_b[threadIdx.x];
         cp_store_a(0);
         cp_load_a(1);
@@ -633,10 +633,9 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
     // on it, and interleaved with them by sched_group_barrier.
     auto pin_frag = [&](f16x8 (&x)[2]) { asm volatile("" : "+v"(x[0]), "+v"(x[1])); };
     // accumulator start = bias (registers 4 rq + q of tile t <-> channel 32 t + 8 rq + 4 h + q)
-    auto bias16 = [&](const float* vec, int t) -> f32x16 {   // 32 x bias (the accumulators carry 32 x the layer output)
+    auto bias16 = [&](const float* vec, int t) -> f32x16 {   // (s_vec holds 32 x bias: the accumulators carry 32 x the layer output)
         const float4 b0 = ldg4(vec, 4 * t, h), b1 = ldg4(vec, 4 * t + 1, h), b2v = ldg4(vec, 4 * t + 2, h), b3v = ldg4(vec, 4 * t + 3, h);
-        return f32x16{kWS * b0.x, kWS * b0.y, kWS * b0.z, kWS * b0.w, kWS * b1.x, kWS * b1.y, kWS * b1.z, kWS * b1.w,
-                      kWS * b2v.x, kWS * b2v.y, kWS * b2v.z, kWS * b2v.w, kWS * b3v.x, kWS * b3v.y, kWS * b3v.z, kWS * b3v.w};
+        return f32x16{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2v.x, b2v.y, b2v.z, b2v.w, b3v.x, b3v.y, b3v.z, b3v.w};
     };
     // layer-2 output (bias already in the accumulator): ReLU + split of k-step k -> layer-3 input planes xp[k]
     auto l2_piece = [&](auto kc) {
