@@ -122,6 +122,37 @@ def test_bf16x3_split_and_stream_layout():
     assert es.numel() * 2 == 4 * 48 * 1024
 
 
+def test_f16x3_weight_split_and_stream_layout():
+    """Host side of the split-f16 kernels (csrc/pair_mlp_f16.hip, node_gemm.hip): the weight pair (W_h, W_l) of 2^5 w recovers w to
+    fp32 rounding over the weights' range (the factor keeps W_l out of f16's subnormals for |w| >= 2^-14), the stream follows the
+    bf16 stream's slot order with 4 fragments per slot, and the gather tables' column blocking is a pure permutation."""
+    from str2str_amd import ops
+
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(96, 64, generator=g) * torch.logspace(-4, 1, 64)        # |w| from 1e-4 to ~30: beyond any trained layer
+    pk = ops.pack_f16x2_layer(w, "chain")                                  # [KS=4, T=3, 2, 64, 8]
+    assert pk.shape == (4, 3, 2, 64, 8) and pk.dtype == torch.float16
+    ref = ops.pack_bf16x3_layer(w, "chain", _fp32_fragments=True)           # the same fragments in fp32
+    rec = (pk[:, :, 0].double() + pk[:, :, 1].double()) / 32.0
+    err = (rec - ref.double()).abs()
+    assert (err <= 2.0 ** -23 * ref.double().abs() + 2.0 ** -30).all(), float((err / ref.abs().clamp_min(1e-30)).max())
+    assert (pk[:, :, 1].float().abs() <= pk[:, :, 0].float().abs() * 2.0 ** -10 + 2.0 ** -24).all()   # W_l is the residue of W_h
+    assert torch.isfinite(pk.float()).all() and float(pk[:, :, 0].float().abs().max()) < 65504
+
+    w1, w2, wf = torch.randn(384, 128, generator=g), torch.randn(384, 384, generator=g), torch.randn(128, 384, generator=g)
+    st = ops.pack_f16x3_stream(w1, w2, wf).view(torch.float16).reshape(240, 4, 64, 8)
+    l1, l2, lf = ops.pack_f16x2_layer(w1), ops.pack_f16x2_layer(w2), ops.pack_f16x2_layer(wf)
+    assert torch.equal(st[0], l1[0:2, 0].reshape(4, 64, 8))             # A_0 slot 0: k-steps 0, 1 of tile 0, [k-step][plane]
+    assert torch.equal(st[8 + 7], l2[1, 2:4].reshape(4, 64, 8))         # B_0 slot (u = 1, pair 1): k-step 1, tiles 2, 3
+    assert torch.equal(st[192 + 2 * 5 + 1], lf[5, 2:4].reshape(4, 64, 8))  # final layer k-step 5, tiles 2, 3
+    assert ops.pack_f16x3_embed_stream(torch.randn(128, 128, generator=g), torch.randn(128, 128, generator=g)).numel() * 2 == 4 * 32 * 1024
+    assert ops.pack_node_weight(torch.randn(256, 320, generator=g), 8).numel() == 256 * 320 * 2
+
+    t = torch.randn(3, 7, 128, generator=g)
+    cb = ops.column_blocked(t)                                             # [3, 32, 7, 4]
+    assert cb.shape == (3, 32, 7, 4) and torch.equal(cb.permute(0, 2, 1, 3).reshape(3, 7, 128), t)
+
+
 def test_rotation_and_rigid_host_types():
     from str2str_amd.common import rotation3d as R3
     from str2str_amd.common.rigid_utils import Rigid, Rotation, quat_multiply, quat_to_rot
