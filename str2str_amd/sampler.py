@@ -197,6 +197,11 @@ def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: flo
     finally:
         if keep_bb is not None:
             net.backbone_in_forward = keep_bb
+    # The split-f16 kernels need activations below f16's 65504: an overflow turns into inf / NaN, and that
+    # must be an error, not a PDB file (one reduction + sync per trajectory chunk)
+    if not bool(torch.isfinite(final["rigids7"]).all()):
+        raise ops.HipLibraryError("non-finite frames at the end of the trajectory: an activation may have exceeded f16's range in the "
+                                  "split-f16 (f16x3) kernels -- rerun with S2S_EDGE_MFMA=bf16x6 S2S_IPA_PATH=planes to check")
     return atom37, final["rigids7"], final["psi"]
 
 
