@@ -165,6 +165,14 @@ int s2s_ipa_attention_f16(const void* q_xp, const void* k_xp, const void* v_vf, 
                              int out_xp_ksteps, int n_samples, int n_res, int n_heads, int c_hidden, int n_qk_points,
                              int n_v_points, int c_pair_z, float inf, float eps, void* stream);
 
+/* s2s_ipa_attention_f16 with ONE WAVE PER QUERY TILE (csrc/ipa_attention_f16w.hip): same operands, same outputs; a workgroup is four
+ * query tiles, a wave runs the whole contraction and owns all ten output tiles (no partial-sum exchange between wave pairs). */
+int s2s_ipa_attention_f16w(const void* q_xp, const void* k_xp, const void* v_vf, const void* qp_xp, const void* kp_xp,
+                             const void* vp_vf, const float* q2, const float* k2, const float* attn_bias, float* logits_out,
+                             float* stats_out, const float* mask, const float* rigids7, float* out, void* out_xp,
+                             int out_xp_ksteps, int n_samples, int n_res, int n_heads, int c_hidden, int n_qk_points,
+                             int n_v_points, int c_pair_z, float inf, float eps, void* stream);
+
 /* The pair term of InvariantPointAttention.forward (src/models/net/ipa.py:253-257):
  *   o_pair[b,i,h,:] = sum_j softmax_j(logits[b,h,i,:])[j] * pair_z[b,i,j,:]
  * from the logits / statistics s2s_ipa_attention stored, streaming pair_z [B,N,N,c_pair_z] once for all heads;

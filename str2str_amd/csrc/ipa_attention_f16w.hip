@@ -1,0 +1,750 @@
+// Invariant Point Attention core on f16 pair operands, ONE WAVE PER QUERY TILE (gfx950; n_res % 32 == 0).
+// The kernel of csrc/ipa_attention_f16.hip (read it and csrc/ipa_attention_planes.hip first) without the wave pairs: with two planes
+// per operand the 18 query fragments of a tile are 144 VGPRs, so a wave owns a whole 32-residue query tile again -- all 18
+// k-steps of S^T and all 10 output tiles -- and a workgroup is four query tiles.  Gone: the partial-sum exchange between the
+// halves, the duplicated logit arithmetic (both waves of a pair evaluated all 16 elements), half of the copy slots and LDS image
+// writes per query (a K / V image now serves four query tiles instead of two).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "geom.h"
+#include "str2str_hip.h"
+
+namespace {
+
+using namespace s2s;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));   // (name kept from the bf16 kernel: a 16 B fragment of eight f16)
+
+__device__ __forceinline__ f32x16 mfma_b16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ void load7(const float* __restrict__ p, Quat<float>& q, Vec3<float>& t) {
+    q.w = p[0]; q.x = p[1]; q.y = p[2]; q.z = p[3];
+    t.x = p[4]; t.y = p[5]; t.z = p[6];
+}
+
+// e^x for x <= ~0 in 6 VALU instructions: v_exp_f32 (2^t, 1 ulp) on t = fl(x log2 e), corrected to first order for the rounding
+// of the product and of the constant (exact residual by FMA), so the argument error does not grow with |x|.  Relative error
+// ~2 ulp; expf() expands to ~12 instructions with many temporaries (the softmax section was the register-pressure peak).
+__device__ __forceinline__ float exp_neg(float x) {
+    const float L2E = 1.44269504088896341f, L2E_LO = 1.92596299112661746e-8f, LN2 = 0.693147180559945309f;
+    const float t = x * L2E;
+    float e = __builtin_fmaf(x, L2E, -t);
+    e = __builtin_fmaf(x, L2E_LO, e);
+    const float r = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(r, e * LN2, r);
+}
+
+__device__ __forceinline__ void split8(const float* v, bf16x8& ph, bf16x8& pl) {   // x_h, x_l
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float xv = v[j];
+        asm volatile("" : "+v"(xv));   // one materialised fp32 value feeds both planes (see node_gemm.hip split8_f16)
+        const _Float16 a_ = (_Float16)xv;
+        ph[j] = a_; pl[j] = (_Float16)(xv - (float)a_);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Point generation (ipa.py:144-171, rigid_utils.py:1107-1120) straight into MFMA fragments.  One workgroup per (row tile of 32
+// residues, head): the 8 + 8 + 12 global-frame points of every residue go through LDS, then 512 (fragment, lane) items are
+// split and stored.  Coordinate k of a point row = 3 p + d (24 of the 32 columns of two k-steps; the rest zero).
+constexpr int PQ = 8, PV = 12;
+
+__global__ void __launch_bounds__(256) ipa_prep_f16w_unused_kernel(const float* __restrict__ rig, const float* __restrict__ qp_lin,
+                                                              const float* __restrict__ kvp_lin, const float* __restrict__ head_w,
+                                                              float q_scale_c1, bf16x8* __restrict__ qp_xp, bf16x8* __restrict__ kp_xp,
+                                                              bf16x8* __restrict__ vp_vf, float* __restrict__ q2, float* __restrict__ k2,
+                                                              int H) {
+    __shared__ float sq[32][33], sk[32][33], sv[32][65];
+    const int tid = threadIdx.x;
+    const int head = blockIdx.x % H;
+    const long long rt = blockIdx.x / H;
+    const float hw = head_w[head];
+    {
+        const int row = tid >> 3, p = tid & 7;
+        const long long r = rt * 32 + row;
+        Quat<float> q; Vec3<float> t;
+        load7(rig + r * 7, q, t);
+        const Mat3<float> R = quat_to_rot<float>(q);
+        const int HPq = H * PQ, HPkv = H * (PQ + PV);
+        const float* ql = qp_lin + r * 3 * HPq;
+        const float* kl = kvp_lin + r * 3 * HPkv;
+        {
+            const int w = head * PQ + p;
+            const Vec3<float> g = rot_vec_mul<float>(R, Vec3<float>{ql[w], ql[HPq + w], ql[2 * HPq + w]});
+            sq[row][3 * p] = g.x + t.x; sq[row][3 * p + 1] = g.y + t.y; sq[row][3 * p + 2] = g.z + t.z;
+            sq[row][24 + p] = 0.f;
+        }
+        {
+            const int c = head * (PQ + PV) + p;
+            const Vec3<float> g = rot_vec_mul<float>(R, Vec3<float>{kl[c], kl[HPkv + c], kl[2 * HPkv + c]});
+            sk[row][3 * p] = g.x + t.x; sk[row][3 * p + 1] = g.y + t.y; sk[row][3 * p + 2] = g.z + t.z;
+            sk[row][24 + p] = 0.f;
+        }
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const int pv = p + 8 * x;  // value-point slot 0..15; slots >= PV are zero padding
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pv < PV) {
+                const int c = head * (PQ + PV) + PQ + pv;
+                const Vec3<float> g = rot_vec_mul<float>(R, Vec3<float>{kl[c], kl[HPkv + c], kl[2 * HPkv + c]});
+                o = make_float4(g.x + t.x, g.y + t.y, g.z + t.z, 0.f);
+            }
+            sv[row][4 * pv] = o.x; sv[row][4 * pv + 1] = o.y; sv[row][4 * pv + 2] = o.z; sv[row][4 * pv + 3] = o.w;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {  // squared norms, fixed summation order
+        const int row = tid & 31;
+        const float (*s)[33] = tid < 32 ? sq : sk;
+        float acc = 0.f;
+#pragma unroll
+        for (int x = 0; x < 24; ++x) acc += s[row][x] * s[row][x];
+        (tid < 32 ? q2 : k2)[(rt * H + head) * 32 + row] = -0.5f * hw * acc;
+    }
+    const float qs = hw / q_scale_c1;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int item = tid + 256 * it;  // 0..127 q, 128..255 k, 256..511 value points
+        const int lane = item & 63, g = lane >> 5, c = lane & 31;
+        float v[8];
+        bf16x8* dst;
+        if (item < 256) {
+            const int ks = (item >> 6) & 1;
+            const bool isq = item < 128;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = isq ? sq[c][16 * ks + 8 * g + j] * qs : sk[c][16 * ks + 8 * g + j];
+            dst = (isq ? qp_xp : kp_xp) + (((rt * H + head) * 2 + ks) * 2) * 64 + lane;
+        } else {
+            const int f = (item - 256) >> 6, ct = f >> 1, u = f & 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = sv[rowmap(8 * u + j, g)][32 * ct + c];
+            dst = vp_vf + ((((rt * H + head) * 2 + ct) * 2 + u) * 2) * 64 + lane;
+        }
+        bf16x8 ph, pl;
+        split8(v, ph, pl);
+        dst[0] = ph; dst[64] = pl;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+struct PlaneArgs {
+    const bf16x8* q_xp; const bf16x8* k_xp; const bf16x8* v_vf;
+    const bf16x8* qp_xp; const bf16x8* kp_xp; const bf16x8* vp_vf;
+    const float* q2; const float* k2;
+    const float* attn_bias;  // [B,H,N,N]
+    float* logits;           // [B,H,N,N] (may alias attn_bias)
+    float* stats;            // [B,H,N,2]
+    const float* mask;       // [B,N]
+    const float* rigids7;    // [B,N,7]
+    float* out;              // [B,N,feat] fp32: only the o_pt columns are written here
+    bf16x8* out_xp;          // packed planes of the [B*N, 16*xp_ksteps] linear_out input: the o columns (k-steps 16 head ..)
+    int xp_ksteps;
+    int B, N, H;
+    float inf, eps;
+    int xcd_remap;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+__device__ __forceinline__ void dma_kib(const bf16x8* src_piece, bf16x8* lds_piece, int lane) {
+    // one 1 KiB fragment: 16 B per lane, destination = wave-uniform base + lane * 16 (LDS-DMA semantics)
+    __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_piece + lane), (lds_ptr_t)lds_piece, 16, 0, 0);
+}
+
+typedef __attribute__((address_space(3))) const bf16x8 lds_frag;
+__device__ __forceinline__ lds_frag* frag_pin(const bf16x8* p) {
+    lds_frag* q = (lds_frag*)p;
+    asm volatile("" : "+v"(q));
+    return q;
+}
+
+// Timeline probe (tools/ipa_planes_probe.py; only in -DS2S_IPA_PROBE=<block> builds)
+#ifdef S2S_IPA_PROBE
+__device__ unsigned long long s2s_ipa8_probe[4][128];
+#define IPROBE(idx) do { if (blockIdx.x == S2S_IPA_PROBE) s2s_ipa8_probe[threadIdx.x >> 6][idx] = __builtin_readcyclecounter(); } while (0)
+#else
+#define IPROBE(idx) do { } while (0)
+#endif
+
+constexpr int KQ = 18;   // k-steps of QK^T: 16 channels + 2 point coordinates
+constexpr int KH = KQ;       // every wave runs the whole contraction
+constexpr int OT = 10;   // output tiles of PV: 8 channels + 2 value points
+constexpr int OH = OT;       // ... and owns all ten output tiles
+constexpr int CT = 8;
+
+// A workgroup = 4 waves = 2 query tiles (32 residues each) x 2 "halves".  The B operands must sit in VGPRs (hipcc allocates
+// MFMA sources there only), and the 18 x 3 query fragments of a tile are 216 of them: a PAIR of waves shares a query tile.
+// Half x holds the query fragments of k-steps 9x .. 9x+8 (108 VGPRs) and computes its half of the contraction of S^T; the
+// halves meet through LDS (added in the same order by both, so both waves see bit-identical logits and maxima); in the second
+// phase half x owns the accumulators of output tiles 5x .. 5x+4 (80 AGPRs).
+//
+// Two phases per work item (sample, head, 64 query residues) instead of an online softmax:
+//   phase 1, key tiles 0 .. NT-1:  S^T -> masked logits -> global (the [B,H,N,N] buffer s2s_ipa_opair reads anyway), row maximum
+//   phase 2, key tiles 0 .. NT-1:  logits back from L2, p = exp(s - max), row sum, O^T += V^T P^T
+// The accumulators are never rescaled (a VALU pass over 80 matrix-core registers per tile, which also dragged the whole
+// register allocation into accvgpr copies), the query fragments are dead in phase 2, and the K images (phase 1) and V images
+// (phase 2) do not coexist in LDS: one stream of images through two 60 KiB buffers, image g in buffer g & 1.  The logit
+// arithmetic of tile t-1 rides between the MFMAs of tile t, the exp / split of tile t+1 between those of tile t (one wave per
+// SIMD: nothing else fills the matrix pipe's shadow).
+//
+// Image g goes global -> VGPR (one step before it is written) -> LDS (one step before it is read), 14 / 15 pieces of 1 KiB per
+// wave, one "copy slot" (ds_write of a piece + re-load of its register) per few MFMAs.  LDS-DMA (global_load_lds_dwordx4) would
+// need no registers but costs the issuing wave ~150 cycles per piece on this part -- as much per key tile as the tile's MFMAs.
+// Every VMEM operation of the loops is UNCONDITIONAL (a piece that does not exist re-loads / re-stores piece 12): vmcnt
+// counts in order, and a load issued on one side of a branch makes hipcc fall back to s_waitcnt vmcnt(0) at every older use.
+//
+// Workgroups are persistent: the image stream runs across work items (images 2 NT, 2 NT + 1 of an item are images 0, 1 of the
+// next one), so only the first item of a workgroup pays the cold start (14 k cycles = 13 % of an item before this).
+struct PlaneStage {
+    bf16x8 img[2][OT * 2 * 2 * 64];   // 2 x 40 KiB: K image [k-step 18][plane 2][lane] (36 KiB) or V image [tile 10][u][plane 2][lane]
+    float4 xs[2][4][4][64];           // 32 KiB: partial S^T, [tile parity][wave][r / 4][lane]
+    __attribute__((aligned(16))) float k2[4][32];                  // per-key scalars of key tile t in slot t % 4 (written two tiles ahead, read one tile late)
+    __attribute__((aligned(16))) float km[4][32];
+};
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// 16 B load that bypasses the (non-coherent) vector L1 (cache policy sc0 | sc1): the logits were stored by the partner wave, to
+// lines this CU read as attention bias a moment ago.
+__device__ __forceinline__ f32x4v load_l2(__amdgpu_buffer_rsrc_t rsrc, int byte_offset) {
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_offset, 0, 17);
+    return __builtin_bit_cast(f32x4v, r);
+}
+
+__global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
+    __shared__ __attribute__((aligned(16))) PlaneStage st;
+    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = 0;   // (one wave per query tile: the pair logic of the parent kernel degenerates)
+    const int N = a.N, H = a.H;
+    const int NT = N / 32;                        // key tiles = row tiles per sample
+    const int n_qb = (NT + 3) / 4;
+    const int n_items = a.B * H * n_qb;
+    const float c1 = sqrtf(1.0f / (3 * 256));
+    const float c2 = sqrtf(1.0f / 3);
+
+    struct Item { int b, head, qb; };
+    auto decode = [&](int item) -> Item {
+        // Workgroup w runs on XCD w % 8 (observed dispatch order; a speed assumption only) and gridDim.x is a multiple of 8: give
+        // every XCD (private L2) a contiguous range of logical ids, so the query blocks of one (sample, head) -- which read the
+        // same K / V images -- run side by side on one XCD.
+        int bid = item;
+        if (a.xcd_remap) bid = (bid & 7) * (n_items >> 3) + (bid >> 3);
+        Item it;
+        it.qb = bid % n_qb; bid /= n_qb;
+        it.head = bid % H;
+        it.b = bid / H;
+        return it;
+    };
+    int item = blockIdx.x;
+    Item cur = decode(item);
+    Item nxt = item + (int)gridDim.x < n_items ? decode(item + (int)gridDim.x) : cur;
+
+    // ---- the image stream of an item: g < NT: K image of key tile g (48 pieces of k_xp + 6 of kp_xp); g < 2 NT: V image of tile
+    // g - NT (48 of v_vf + 12 of vp_vf); g = 2 NT, 2 NT + 1: images 0, 1 of the next item.  Piece p of this wave: p < 12: piece
+    // wave + 4 p of the first array, else piece wave + 4 (p - 12) of the second.  All of this is wave-uniform (scalar).
+    auto piece_ok = [&](int gg, int p) -> bool {   // K images have 36 pieces (9 per wave), V images 40 (10 per wave)
+        return gg >= NT || p < 9;
+    };
+    // sources as buffer resources over the whole arrays (the host checks that they are < 4 GiB): the per-piece offset is a scalar,
+    // the per-lane part (lane * 16) one constant VGPR -- no vector address arithmetic in a copy slot
+    const long long n_rt = (long long)a.B * NT;
+    const __amdgpu_buffer_rsrc_t r_k = __builtin_amdgcn_make_buffer_rsrc((void*)a.k_xp, 0, (int)(n_rt * 16 * H * 2048), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_kp = __builtin_amdgcn_make_buffer_rsrc((void*)a.kp_xp, 0, (int)(n_rt * H * 4096), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_v = __builtin_amdgcn_make_buffer_rsrc((void*)a.v_vf, 0, (int)(n_rt * H * 32768), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_vp = __builtin_amdgcn_make_buffer_rsrc((void*)a.vp_vf, 0, (int)(n_rt * H * 8192), 0x00020000);
+    const int lane16 = lane * 16;
+    // piece p of this wave: p < 8: piece wave + 4 p of the first array (32 KiB), else piece wave + 4 (p - 8) of the second
+    auto piece_load = [&](int g, int p) -> bf16x8 {
+        const bool nx = g >= 2 * NT;
+        const int gg = nx ? g - 2 * NT : g;
+        const int bb = nx ? nxt.b : cur.b, hh = nx ? nxt.head : cur.head;
+        const bool isk = __builtin_amdgcn_readfirstlane(gg < NT);   // (everything here is wave-uniform; keep it on the SALU even
+        const unsigned rt = (unsigned)(bb * NT + (isk ? gg : gg - NT));      //  when the allocator parked an input in a VGPR)
+        const int pm = __builtin_amdgcn_readfirstlane(piece_ok(gg, p) ? p : 8);
+        u32x4 r;
+        if (p < 8) {
+            const unsigned off = (isk ? (rt * (16 * H) + 16 * hh) * 2 : (rt * H + hh) * 32) * 1024u + (wave + 4 * pm) * 1024u;
+            r = __builtin_amdgcn_raw_buffer_load_b128(isk ? r_k : r_v, lane16, __builtin_amdgcn_readfirstlane((int)off), 0);
+        } else {
+            const unsigned off = (rt * H + hh) * (isk ? 4u : 8u) * 1024u + (wave + 4 * (pm - 8)) * 1024u;
+            r = __builtin_amdgcn_raw_buffer_load_b128(isk ? r_kp : r_vp, lane16, __builtin_amdgcn_readfirstlane((int)off), 0);
+        }
+        return __builtin_bit_cast(bf16x8, r);
+    };
+    // cold start only (LDS-DMA wants a flat address)
+    auto piece_src = [&](int g, int p) -> const bf16x8* {
+        const bool isk = g < NT;
+        const long long rt = (long long)cur.b * NT + (isk ? g : g - NT);
+        const int pm = piece_ok(g, p) ? p : 8;
+        if (pm < 8)
+            return (isk ? a.k_xp + ((rt * (16 * H) + 16 * cur.head) * 2) * 64 : a.v_vf + ((rt * H + cur.head) * 32) * 64) + (wave + 4 * pm) * 64;
+        return (isk ? a.kp_xp + ((rt * H + cur.head) * 4) * 64 : a.vp_vf + ((rt * H + cur.head) * 8) * 64) + (wave + 4 * (pm - 8)) * 64;
+    };
+    auto piece_dst = [&](int g, int p) -> bf16x8* {
+        const int gg = g >= 2 * NT ? g - 2 * NT : g;
+        const int pm = piece_ok(gg, p) ? p : 8;
+        return st.img[g & 1] + (pm < 8 ? wave + 4 * pm : 32 + wave + 4 * (pm - 8)) * 64;
+    };
+    bf16x8 stg[10];
+    auto stage_load = [&](int g, int p) { stg[p] = piece_load(g, p); };
+    // one copy slot: piece p of image g leaves its register for LDS, the register is refilled with piece p of image g + 1
+    auto stage_slot = [&](int g, int p) {
+        if (p < 10) {
+            piece_dst(g, p)[lane] = stg[p];
+            stage_load(g + 1, p);
+        }
+    };
+    // per-key scalars of a key tile (k2 and the key mask, 32 floats each) reach LDS slot t & 3 two steps before tile t's logits
+    // are formed; the value is loaded a step before it is stored (waves 2, 3 store; every wave loads: no conditional VMEM).
+    auto small_load = [&](const Item& it, int t) -> float {
+        const int tc = min(t, NT - 1);
+        return (wave & 1) ? a.k2[(((long long)it.b * NT + tc) * H + it.head) * 32 + c] : a.mask[(long long)it.b * N + tc * 32 + c];
+    };
+    auto small_store = [&](int t, float v) {
+        if (wave >= 2 && lane < 32 && t < NT) ((wave & 1) ? st.k2 : st.km)[t & 3][lane] = v;
+    };
+    float sm_val;
+
+    // ---- cold start: image 0 straight into LDS, image 1 into the staging registers
+    IPROBE(126);
+#pragma unroll
+    for (int p = 0; p < 9; ++p)
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(piece_src(0, p) + lane), (lds_ptr_t)piece_dst(0, p), 16, 0, 0);
+#pragma unroll
+    for (int p = 0; p < 10; ++p) stage_load(1, p);
+    small_store(0, small_load(cur, 0));
+    small_store(1, small_load(cur, 1));
+    sm_val = small_load(cur, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    IPROBE(127);
+
+    // ---- per-item state of a lane; the query fragments, scalars and the first bias tile of the NEXT item are fetched before the
+    // epilogue of the current one (the registers are free there and the epilogue covers the HBM latency)
+    struct LaneItem { long long rt_q, row_i, brow0; int i; float q2, mask; };
+    auto lane_item = [&](const Item& it) -> LaneItem {
+        const int qt = it.qb * 4 + wave;             // this wave's query tile within the sample
+        // odd tile count: the second pair of the last workgroup has no tile of its own; it repeats the first pair's (identical
+        // values to identical addresses) so that no memory operation is conditional
+        const int qtc = qt < NT ? qt : NT - 1;
+        LaneItem L;
+        L.rt_q = (long long)it.b * NT + qtc;
+        L.i = qtc * 32 + c;
+        L.row_i = (long long)it.b * N + L.i;
+        L.brow0 = (((long long)it.b * H + it.head) * N + L.i) * N + 4 * h;
+        L.q2 = a.q2[(L.rt_q * H + it.head) * 32 + c];
+        L.mask = a.mask[L.row_i];
+        return L;
+    };
+    bf16x8 qf[KH][2];
+    float4 bias_cur[4], bias_prev[4];
+    // this wave's query fragments (B operands): k-steps 9 half .. 9 half + 8 of [16 of q_xp | 2 of qp_xp], three planes each
+    auto load_queries = [&](const Item& it, const LaneItem& L) {
+        const bf16x8* qs = a.q_xp + ((L.rt_q * (16 * H) + 16 * it.head) * 2) * 64;
+        const bf16x8* ps = a.qp_xp + ((L.rt_q * H + it.head) * 4) * 64;
+#pragma unroll
+        for (int x = 0; x < KH; ++x) {
+            const int ks = KH * half + x;   // wave-uniform
+#pragma unroll
+            for (int p = 0; p < 2; ++p) qf[x][p] = (ks < 16 ? qs + (ks * 2 + p) * 64 : ps + ((ks - 16) * 2 + p) * 64)[lane];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bias_cur[g] = *reinterpret_cast<const float4*>(a.attn_bias + L.brow0 + 8 * g);
+    };
+    LaneItem Lc = lane_item(cur);
+    load_queries(cur, Lc);
+    float sm_n0, sm_n1, sm_n2;   // the next item's per-key scalars of tiles 0 .. 2
+#ifdef S2S_IPA_PROBE
+    int probe_item = 0;
+#endif
+    for (;;) {
+#ifdef S2S_IPA_PROBE
+    if (probe_item < 16) IPROBE(100 + probe_item);
+    ++probe_item;
+#endif
+    const int b = cur.b, head = cur.head;
+    const long long rt_q = Lc.rt_q, row_i = Lc.row_i, brow0 = Lc.brow0;
+    const int i = Lc.i;
+    const float q2_i = Lc.q2, mask_i = Lc.mask;
+    float m_run = -INFINITY;
+
+    // =========================================================== phase 1: logits and row maxima
+    // Software pipeline: the logit arithmetic of tile t-1 (VALU + LDS reads) is issued between the MFMAs of tile t, one element
+    // per two MFMAs, so it runs in the shadow of the matrix pipe (one wave per SIMD: nothing else would fill it).
+    // this (sample, head)'s [N, N] logit slab as a buffer resource: 32-bit offsets, cache policy on the instruction
+    const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.logits + ((long long)b * H + head) * N * N), 0,
+                                                                           N * N * 4, 0x00020000);
+    const int loff0 = (i * N + 4 * h) * 4;
+    f32x4v lg[4], lg1[4];   // logits of the tile whose probabilities are formed next (and of tile 1 across the phase change)
+    float tmax = -INFINITY;
+    float4 k2g, kmg;   // per-key scalars of the 4 keys 8g + 4h .. of the element group being evaluated
+    auto logit_elem = [&](int tp, int r, const float4 (&xa)[4], const float4 (&xb)[4], float (&sl)[16]) {
+        const int g = r >> 2, e = r & 3;
+        if (e == 0) {
+            k2g = *reinterpret_cast<const float4*>(&st.k2[tp & 3][8 * g + 4 * h]);
+            kmg = *reinterpret_cast<const float4*>(&st.km[tp & 3][8 * g + 4 * h]);
+        }
+        const float sa = e == 0 ? xa[g].x : (e == 1 ? xa[g].y : (e == 2 ? xa[g].z : xa[g].w));
+        const float sb = e == 0 ? xb[g].x : (e == 1 ? xb[g].y : (e == 2 ? xb[g].z : xb[g].w));
+        const float bv = e == 0 ? bias_prev[g].x : (e == 1 ? bias_prev[g].y : (e == 2 ? bias_prev[g].z : bias_prev[g].w));
+        const float k2v = e == 0 ? k2g.x : (e == 1 ? k2g.y : (e == 2 ? k2g.z : k2g.w));
+        const float kmv = e == 0 ? kmg.x : (e == 1 ? kmg.y : (e == 2 ? kmg.z : kmg.w));
+        float x = (sa + sb) * c1 + c2 * bv;
+        x = x + (q2_i + k2v);
+        x = x + a.inf * (mask_i * kmv - 1.0f);
+        sl[r] = x;
+        tmax = fmaxf(tmax, x);
+        if (r == 15) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                *reinterpret_cast<float4*>(a.logits + brow0 + tp * 32 + 8 * k) = make_float4(sl[4 * k], sl[4 * k + 1], sl[4 * k + 2], sl[4 * k + 3]);
+        }
+    };
+    auto step1 = [&](int t, auto have_c, auto prev_c, auto flush_c) {
+        constexpr bool have = decltype(have_c)::value, prev = decltype(prev_c)::value, flush = decltype(flush_c)::value;
+        const int par = t & 1;
+        IPROBE(6 * t + 0);
+        // partial sums of tile t-1 (both halves, added in the order half 0 + half 1 by both waves)
+        float4 xa[4], xb[4];
+        if constexpr (prev) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { xa[g] = st.xs[par ^ 1][wave][g][lane]; xb[g] = make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias_prev[g] = bias_cur[g];
+        }
+        // this lane's 16 bias values of tile t (keys 32 t + 8 g + 4 h + e): one 128 B line per (query, tile)
+        if constexpr (have && prev) {   // (tile 0's came with the query fragments)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bias_cur[g] = *reinterpret_cast<const float4*>(a.attn_bias + brow0 + t * 32 + 8 * g);
+        }
+        float sl[16];
+        f32x16 S0, S1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S0[r] = 0.f, S1[r] = 0.f;
+        if constexpr (have) {
+            // ---------------- this wave's half of S^T = K . Q^T (+ point cross term): 54 MFMAs on two accumulation chains
+            const bf16x8* k_half = st.img[par] + KH * half * 128 + lane;
+            bf16x8 kf[2][2];
+            lds_frag* kp = frag_pin(k_half);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) kf[0][p] = kp[p * 64];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int x = 0; x < KH; ++x) {
+                if (x + 1 < KH) {
+                    lds_frag* kn = frag_pin(k_half + (x + 1) * 128);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) kf[(x + 1) & 1][p] = kn[p * 64];
+                }
+                const bf16x8 (&k)[2] = kf[x & 1];
+                const bf16x8 (&q)[2] = qf[x];
+                // copy slots 2x, 2x+1 (ten in all): image t + 1 -> LDS (its buffer was released by the barrier of tile t - 1),
+                // image t + 2 -> registers; two logit elements of tile t - 1 per k-step
+                S0 = mfma_b16(k[1], q[0], S0); S1 = mfma_b16(k[0], q[1], S1);   // k_l q_h, k_h q_l
+                if (prev && 2 * x < 16) logit_elem(t - 1, 2 * x, xa, xb, sl);   // (same scheduling region as the MFMA pair)
+                stage_slot(t + 1, 2 * x);
+                __builtin_amdgcn_sched_barrier(0);
+                if (x & 1) S1 = mfma_b16(k[0], q[0], S1); else S0 = mfma_b16(k[0], q[0], S0);   // k_h q_h, chains alternate
+                if (prev && 2 * x + 1 < 16) logit_elem(t - 1, 2 * x + 1, xa, xb, sl);
+                stage_slot(t + 1, 2 * x + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            IPROBE(6 * t + 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                st.xs[par][wave][g][lane] = make_float4(S0[4 * g] + S1[4 * g], S0[4 * g + 1] + S1[4 * g + 1],
+                                                        S0[4 * g + 2] + S1[4 * g + 2], S0[4 * g + 3] + S1[4 * g + 3]);
+        } else {
+            // The logits of tiles 0 and 1 were stored in steps 1 and 2 and flushed (vmcnt(0) of every wave + barrier) by the last
+            // regular step when NT >= 3: fetch them now, under this step's work -- read after the phase change they cost two
+            // serial HBM latencies (~10 k cycles per item).
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                lg[g] = load_l2(lrsrc, loff0 + 32 * g);
+                lg1[g] = load_l2(lrsrc, loff0 + min(1, NT - 1) * 128 + 32 * g);
+            }
+#pragma unroll
+            for (int p = 0; p < 10; ++p) stage_slot(t + 1, p);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) logit_elem(t - 1, r, xa, xb, sl);   // the last tile's logits: nothing left to hide them under
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and they must have reached L2 before phase 2 reads them back
+        }
+        if constexpr (flush) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // logits stored so far have reached L2
+        IPROBE(6 * t + 2);
+        __syncthreads();                                   // partial sums and image t + 1 visible; buffer t & 1 released
+        IPROBE(6 * t + 3);
+        if constexpr (have) { small_store(t + 2, sm_val); sm_val = small_load(cur, t + 3); }
+        IPROBE(6 * t + 4);
+    };
+    step1(0, std::true_type{}, std::false_type{}, std::false_type{});
+    for (int t = 1; t + 1 < NT; ++t) step1(t, std::true_type{}, std::true_type{}, std::false_type{});
+    if (NT > 1) step1(NT - 1, std::true_type{}, std::true_type{}, std::true_type{});
+    step1(NT, std::false_type{}, std::true_type{}, std::false_type{});
+    m_run = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    // images NT (= V(0)) and NT + 1 are in flight; the last tile's logits have reached L2 (vmcnt(0) + barrier above)
+    IPROBE(120);
+
+    // =========================================================== phase 2: probabilities and value aggregation
+    // Software pipeline again: exp + split of tile t+1 between the MFMAs of tile t.
+    f32x16 O[OH];
+#pragma unroll
+    for (int t = 0; t < OH; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
+    float l_run = 0.f;
+    if (NT < 3) {   // too few steps for the early fetch to be ordered behind the stores: read tiles 0, 1 again
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            lg[g] = load_l2(lrsrc, loff0 + 32 * g);
+            lg1[g] = load_l2(lrsrc, loff0 + min(1, NT - 1) * 128 + 32 * g);
+        }
+    }
+    bf16x8 pc[2][2], pn[2][2];   // planes (h, l) of 2^10 P^T of the current / next tile: [k-step u][plane]
+    float pe[16];
+    auto p_elem = [&](int r, bool pin) {   // probability of element r of the tile whose logits sit in lg
+        float x = lg[r >> 2][r & 3];
+        // pin: the value becomes known HERE (an opaque asm with a memory clobber, sandwiched between this slot's LDS stores), so the
+        // exp / split arithmetic stays between the MFMAs it is written next to -- hipcc otherwise collects it at the tail of the
+        // previous step, in front of the barrier, where nothing hides it (~1 k cycles per step)
+        if (pin) asm volatile("" : "+v"(x) :: "memory");
+        pe[r] = exp_neg(x - m_run);
+        l_run += pe[r];
+        if (pin) asm volatile("" : "+v"(pe[r]), "+v"(l_run) :: "memory");   // ... and is complete here (no sinking to the loop tail)
+    };
+#pragma unroll
+    for (int r = 0; r < 16; ++r) p_elem(r, false);
+    {
+        float ps[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ps[r] = pe[r] * 1024.0f;
+        split8(ps, pc[0][0], pc[0][1]);
+        split8(ps + 8, pc[1][0], pc[1][1]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) lg[g] = lg1[g];
+    auto step2 = [&](int t, auto more_c, auto first_c) {
+        constexpr bool more = decltype(more_c)::value, first = decltype(first_c)::value;
+        IPROBE(60 + 6 * t + 0);
+        if constexpr (!first) __syncthreads();               // V(t) visible; every wave is done with V(t - 1)
+        IPROBE(60 + 6 * t + 1);
+        // ---------------- O^T += V^T . P^T for this wave's five output tiles
+        const bf16x8* v_half = st.img[(NT + t) & 1] + OH * half * 256 + lane;
+        auto load_v = [&](int x, bf16x8 (&d)[2][2]) {
+            lds_frag* pa = frag_pin(v_half + x * 256);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) d[u][p] = pa[(u * 2 + p) * 64];
+        };
+        bf16x8 va[3][2][2], vb[3][2][2];   // fragments of the tile groups (0,1) (5,6) / (2,3,4) (7,8,9), alternately
+        load_v(0, va[0]);
+        load_v(1, va[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        // product order of a k-step u (small terms first): (V plane, P plane) = (l,h) (h,l) (h,h)
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+        // The VALU work for the NEXT tile's probabilities is spread over this tile's 24 MFMA groups (6 per tile group): exp of
+        // element gi in groups 0 .. 15, the split of element pair j in group 9 + 2j, copy slots in groups 0 .. 9, the logits of
+        // tile t + 2 requested in group 16 (lg is dead by then); the next tile group's fragments are requested in this one's first groups.
+        auto split_pair = [&](auto jc) {   // elements 2j, 2j+1 of 2^10 pe -> element pair (j & 3) of the planes of k-step j >> 2
+            constexpr int j = decltype(jc)::value;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float v = pe[2 * j + q] * 1024.0f;
+                asm volatile("" : "+v"(v));
+                const _Float16 a_ = (_Float16)v;
+                pn[j >> 2][0][2 * (j & 3) + q] = a_; pn[j >> 2][1][2 * (j & 3) + q] = (_Float16)(v - (float)a_);
+            }
+            asm volatile("" : "+v"(pn[j >> 2][0]), "+v"(pn[j >> 2][1]) :: "memory");   // done here, not at the loop tail
+        };
+        auto ride = [&](auto gc) {
+            constexpr int gi = decltype(gc)::value;
+            if constexpr (more) {
+                if constexpr (gi < 16) p_elem(gi, true);
+                if constexpr (gi >= 9 && (gi & 1) && gi <= 23) split_pair(std::integral_constant<int, (gi - 9) / 2>{});
+                if constexpr (gi == 16) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) lg[g] = load_l2(lrsrc, loff0 + min(t + 2, NT - 1) * 128 + 32 * g);
+                }
+            }
+            if constexpr (!first && gi < 10) stage_slot(NT + t + 1, gi);
+            if constexpr (gi == 0) load_v(2, vb[0]);
+            if constexpr (gi == 1) load_v(3, vb[1]);
+            if constexpr (gi == 2) load_v(4, vb[2]);
+            if constexpr (gi == 6) load_v(5, va[0]);      // (group 0's fragments are dead from group index 6 on)
+            if constexpr (gi == 7) load_v(6, va[1]);
+            if constexpr (gi == 12) load_v(7, vb[0]);
+            if constexpr (gi == 13) load_v(8, vb[1]);
+            if constexpr (gi == 14) load_v(9, vb[2]);
+        };
+        auto group = [&](auto g0c, auto n3c, f32x16& o0, f32x16& o1, f32x16& o2, const bf16x8 (&v)[3][2][2]) {
+            constexpr int g0 = decltype(g0c)::value;
+            constexpr bool three = decltype(n3c)::value;
+            f32x16 oa = o0, ob = o1, oc = o2;
+            auto one = [&](auto ic) {
+                constexpr int i = decltype(ic)::value, u = i / 3, k = i % 3;
+                oa = mfma_b16(v[0][u][PA[k]], pc[u][PB[k]], oa); ob = mfma_b16(v[1][u][PA[k]], pc[u][PB[k]], ob);
+                if constexpr (three) oc = mfma_b16(v[2][u][PA[k]], pc[u][PB[k]], oc);
+                ride(std::integral_constant<int, g0 + i>{});   // (same scheduling region as the MFMAs: hipcc interleaves the VALU between them)
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
+            one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{}); one(std::integral_constant<int, 5>{});
+            o0 = oa; o1 = ob;
+            if constexpr (three) o2 = oc;
+        };
+        f32x16 odummy = O[0];
+        group(std::integral_constant<int, 0>{}, std::false_type{}, O[0], O[1], odummy, va);
+        group(std::integral_constant<int, 6>{}, std::true_type{}, O[2], O[3], O[4], vb);
+        group(std::integral_constant<int, 12>{}, std::false_type{}, O[5], O[6], odummy, va);
+        group(std::integral_constant<int, 18>{}, std::true_type{}, O[7], O[8], O[9], vb);
+        if constexpr (more) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) pc[u][p] = pn[u][p];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        IPROBE(60 + 6 * t + 3);
+    };
+    IPROBE(123);
+    if (NT > 1) {
+        step2(0, std::true_type{}, std::true_type{});
+        for (int t = 1; t + 1 < NT; ++t) step2(t, std::true_type{}, std::false_type{});
+        step2(NT - 1, std::false_type{}, std::false_type{});
+    } else {
+        step2(0, std::false_type{}, std::true_type{});
+    }
+    IPROBE(121);
+
+    // ---------------- the next item's query side (unconditionally: after the last item nxt == cur and the values are unused)
+    const bool last = item + (int)gridDim.x >= n_items;
+    const LaneItem Ln = lane_item(nxt);
+    load_queries(nxt, Ln);
+    sm_n0 = small_load(nxt, 0); sm_n1 = small_load(nxt, 1); sm_n2 = small_load(nxt, 2);
+    // ---------------- epilogue
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = (1.0f / l_tot) * (1.0f / 1024.0f);   // (the probabilities went into the products scaled by 2^10)
+    {
+        // o: accumulator registers 8u .. 8u+7 of channel tile T = fragment k-step 16 head + 2T + u of this row tile (chain order)
+        bf16x8* o = a.out_xp + ((rt_q * a.xp_ksteps + 16 * head) * 2) * 64 + lane;
+#pragma unroll
+        for (int x = 0; x < OH; ++x) {
+            const int T = OH * half + x;   // wave-uniform
+            if (T >= CT) continue;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = O[x][8 * u + j] * inv;
+                // this output is an INPUT of the node stream (linear_out, s2s_node_linear): f16 pair planes (x_h, x_l)
+                typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                f16x8 ph, pl;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float xv = v[j];
+                    asm volatile("" : "+v"(xv));   // one materialised fp32 value feeds both planes (see node_gemm.hip split8_f16)
+                    const _Float16 hh = (_Float16)xv;
+                    ph[j] = hh; pl[j] = (_Float16)(xv - (float)hh);
+                }
+                bf16x8* q = o + ((2 * T + u) * 2) * 64;
+                q[0] = ph; q[64] = pl;
+            }
+        }
+    }
+    {
+        // frame of residue i: R = quat_to_rot(q) (rigid_utils.py:187-207), o_pt = R^T (x - t) (:1122-1133)
+        const int feat = H * (256 + 4 * PV + 32);
+        const float* f = a.rigids7 + row_i * 7;
+        const float qa = f[0], qb_ = f[1], qc = f[2], qd = f[3];
+        const float tx = f[4], ty = f[5], tz = f[6];
+        const float r00 = qa * qa + qb_ * qb_ - qc * qc - qd * qd, r01 = 2 * qb_ * qc - 2 * qa * qd, r02 = 2 * qb_ * qd + 2 * qa * qc;
+        const float r10 = 2 * qb_ * qc + 2 * qa * qd, r11 = qa * qa - qb_ * qb_ + qc * qc - qd * qd, r12 = 2 * qc * qd - 2 * qa * qb_;
+        const float r20 = 2 * qb_ * qd - 2 * qa * qc, r21 = 2 * qc * qd + 2 * qa * qb_, r22 = qa * qa - qb_ * qb_ - qc * qc + qd * qd;
+        float* ox = a.out + row_i * feat + H * 256 + head * PV;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int pt_idx = 8 * t + 2 * rq + h;  // point whose (x,y,z,0) group this lane holds
+                const f32x16& ov = O[CT + t];           // output tiles 8, 9: the value points
+                const float dx = ov[4 * rq + 0] * inv - tx;
+                const float dy = ov[4 * rq + 1] * inv - ty;
+                const float dz = ov[4 * rq + 2] * inv - tz;
+                const float lx = r00 * dx + r10 * dy + r20 * dz;
+                const float ly = r01 * dx + r11 * dy + r21 * dz;
+                const float lz = r02 * dx + r12 * dy + r22 * dz;
+                const float nr = sqrtf(lx * lx + ly * ly + lz * lz + a.eps);
+                if (pt_idx < PV) {
+                    ox[pt_idx] = lx;
+                    ox[H * PV + pt_idx] = ly;
+                    ox[2 * H * PV + pt_idx] = lz;
+                    ox[3 * H * PV + pt_idx] = nr;
+                }
+            }
+    }
+    if (h == 0) {
+        float* st2 = a.stats + ((((long long)b * H + head) * N) + i) * 2;
+        st2[0] = m_run;
+        st2[1] = l_tot;
+    }
+    IPROBE(122);
+
+    // ---------------- next item: its image 0 is already in buffer 0, its image 1 in the staging registers
+    item += (int)gridDim.x;
+    if (last) break;
+    cur = nxt;
+    Lc = Ln;
+    nxt = item + (int)gridDim.x < n_items ? decode(item + (int)gridDim.x) : cur;
+    __syncthreads();   // every wave is done with the last V image (buffer 1) before image 1 of the next item is written there
+    small_store(0, sm_n0);
+    small_store(1, sm_n1);
+    sm_val = sm_n2;
+    __syncthreads();
+    }
+}
+
+}  // namespace
+
+#ifdef S2S_IPA_PROBE
+extern "C" int s2s_debug_read_ipa8_probe(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(s2s_ipa8_probe), sizeof(s2s_ipa8_probe));
+}
+#endif
+
+extern "C" int s2s_ipa_attention_f16w(const void* q_xp, const void* k_xp, const void* v_vf, const void* qp_xp, const void* kp_xp,
+                                        const void* vp_vf, const float* q2, const float* k2, const float* attn_bias,
+                                        float* logits_out, float* stats_out, const float* mask, const float* rigids7, float* out,
+                                        void* out_xp, int out_xp_ksteps, int n_samples, int n_res, int n_heads, int c_hidden,
+                                        int n_qk_points, int n_v_points, int c_pair_z, float inf, float eps, void* stream) {
+    if (n_samples <= 0 || n_res <= 0) return 0;
+    if (c_hidden != 256 || n_qk_points != PQ || n_v_points != PV || c_pair_z != 32 || n_heads < 1 || n_res % 32 ||
+        out_xp_ksteps < 16 * n_heads || !out_xp)
+        return (int)hipErrorInvalidValue;
+    const int n_qb = (n_res + 127) / 128;
+    const long long items = (long long)n_samples * n_heads * n_qb;
+    // the kernel addresses its fragment arrays through 32-bit buffer offsets
+    if ((long long)n_samples * (n_res / 32) * 16 * n_heads * 2048 >= (1ll << 32)) return (int)hipErrorInvalidValue;
+    static const int remap_env = getenv("S2S_IPA_XCD") ? atoi(getenv("S2S_IPA_XCD")) : 1;
+    // persistent workgroups, one per CU (153 KiB of LDS each); a multiple of 8 so that workgroup w stays on XCD w % 8
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return (int)hipErrorUnknown;
+        n_cu = prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : prop.multiProcessorCount;
+    }
+    const long long blocks = items < n_cu ? items : n_cu;
+    PlaneArgs a{(const bf16x8*)q_xp, (const bf16x8*)k_xp, (const bf16x8*)v_vf, (const bf16x8*)qp_xp, (const bf16x8*)kp_xp,
+                (const bf16x8*)vp_vf, q2, k2, attn_bias, logits_out, stats_out, mask, rigids7, out, (bf16x8*)out_xp, out_xp_ksteps,
+                n_samples, n_res, n_heads, inf, eps, (remap_env && items % 8 == 0 && blocks % 8 == 0 && n_qb > 1) ? 1 : 0};
+    hipLaunchKernelGGL(ipa_attention_f16w_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+}

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _lib = None
 _tables_loaded = False
@@ -39,6 +39,7 @@ _SIGNATURES = {
     "s2s_ipa_attention_planes": [_vp] * 15 + [_i] * 8 + [_f, _f, _vp],
     "s2s_ipa_prep_points_f16": [_vp] * 9 + [_ll, _i, _i, _i, _i, _vp],
     "s2s_ipa_attention_f16": [_vp] * 15 + [_i] * 8 + [_f, _f, _vp],
+    "s2s_ipa_attention_f16w": [_vp] * 15 + [_i] * 8 + [_f, _f, _vp],
     "s2s_rigid_compose_update": [_vp] * 4 + [_ll, _vp],
     "s2s_rigid_scale_trans": [_vp, _vp, _ll, _f, _i, _vp],
     "s2s_set_backbone_tables": [_vp] * 4,
@@ -532,7 +533,10 @@ def ipa_attention_planes(q_xp, k_xp, v_vf, points, attn_bias, pair_z, mask, rigi
     stats = torch.empty(B, n_heads, N, 2, device=mask.device, dtype=torch.float32)
 
     def launch():
-        fn = lib.s2s_ipa_attention_f16 if f16 else lib.s2s_ipa_attention_planes
+        if f16:   # S2S_IPA_KERNEL=pair: the wave-pair kernel (s2s_ipa_attention_f16) instead of one wave per query tile
+            fn = lib.s2s_ipa_attention_f16 if os.environ.get("S2S_IPA_KERNEL", "wave") == "pair" else lib.s2s_ipa_attention_f16w
+        else:
+            fn = lib.s2s_ipa_attention_planes
         rc = fn(_p(q_xp), _p(k_xp), _p(v_vf), _p(qp), _p(kp), _p(vp), _p(q2), _p(k2), _p(attn_bias), _p(logits), _p(stats), _p(mask),
                 _p(rigids7), _p(out), _p(out_xp), feat // 16, B, N, n_heads, c_hidden, n_qk, n_v, c_pz, inf, eps, _stream())
         if rc:
