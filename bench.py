@@ -79,7 +79,7 @@ def traffic_from_profiles(pairs, mode):
     """HBM bytes per launch of the dominant kernel.  NOT measured in this run: PMC counters need rocprofv3 around the
     process (separate --pmc passes, tools/pmc_hbm_traffic.sh), so the committed pass at B = 16, N = 256 is scaled by the
     pairs of this launch and labelled as such.  (None, None) if the file is absent."""
-    for name in ("r02l_pmc_hbm_traffic.json", "r02k_pmc_hbm_traffic.json", "r02i_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01i_pmc_hbm_traffic.json"):
+    for name in ("r02m_pmc_hbm_traffic.json", "r02l_pmc_hbm_traffic.json", "r02k_pmc_hbm_traffic.json", "r02i_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01i_pmc_hbm_traffic.json"):
         key = {"bf16x6": "edge_transition_bf16x6", "f16x3": "edge_transition_f16x3"}.get(mode, "edge_transition")
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -293,7 +293,8 @@ def main():
                 "fp32_equivalent_tflops": alg / (et_ms * 1e-3) / 1e12,
                 "fp32_equivalent_vs_fp32_mfma_peak": alg / (et_ms * 1e-3) / MFMA_FP32_PEAK}
             ipa_path = os.environ.get("S2S_IPA_PATH", "f16")
-            ipa_name = {"f16": "s2s_ipa_attention_f16", "planes": "s2s_ipa_attention_planes"}.get(ipa_path, "s2s_ipa_attention")
+            f16_name = "s2s_ipa_attention_f16" if os.environ.get("S2S_IPA_KERNEL", "wave") == "pair" else "s2s_ipa_attention_f16w"
+            ipa_name = {"f16": f16_name, "planes": "s2s_ipa_attention_planes"}.get(ipa_path, "s2s_ipa_attention")
             line["ipa_kernel"] = {"bound": "hbm", "kernel": f"{ipa_name} (n_res % 32 == 0; else s2s_ipa_attention) + s2s_ipa_opair", "mean_launch_ms": ipa_ms,
                                   "launches_timed": ipa_n, "achieved": ipa_bytes / (ipa_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                                   "unit": "GB/s", "frac": ipa_bytes / (ipa_ms * 1e-3) / HBM_PEAK,

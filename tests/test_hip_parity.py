@@ -316,13 +316,14 @@ def test_ipa_vs_oracle(net_rough, B, N):
     check(f"{_test_name()}: rel err", rel(out.cpu().numpy()[valid], ref.numpy()[valid]), 2e-5)
 
 
-@pytest.mark.parametrize("f16", [True, False], ids=["f16", "bf16"])
-def test_ipa_planes_kernel_matches_fp32_operand_kernel(net_rough, f16):
+@pytest.mark.parametrize("f16,kern", [(True, "wave"), (True, "pair"), (False, "pair")], ids=["f16w", "f16pair", "bf16"])
+def test_ipa_planes_kernel_matches_fp32_operand_kernel(net_rough, f16, kern, monkeypatch):
     """The two attention paths side by side on the same inputs (ops level, through the C ABI): s2s_ipa_attention_planes on operands
     pre-split by the GEMM epilogues / the point kernel vs s2s_ipa_attention on the fp32 projections -- o (decoded from the packed
     planes), o_pt and o_pair columns.  Several work items per persistent workgroup chain (B x H x N/64 = 48 items)."""
     from str2str_amd import ops
 
+    monkeypatch.setenv("S2S_IPA_KERNEL", kern)   # f16 operands: one wave per query tile (default) or the wave-pair kernel
     ipa = net_rough.translator.trunk["ipa_1"]
     B, N, H = 3, 64, 8
     M = B * N
@@ -355,7 +356,7 @@ def test_ipa_planes_kernel_matches_fp32_operand_kernel(net_rough, f16):
     got[:, 2048:] = feats.view(M, -1)[:, 2048:]
     valid = mask.reshape(-1).bool()
     for name, sl in (("o", slice(0, 2048)), ("o_pt", slice(2048, 2432)), ("o_pair", slice(2432, 2688))):
-        check(f"ipa {'f16' if f16 else 'bf16'} planes vs fp32-operand kernel, {name}", rel(got[valid][:, sl], ref[valid][:, sl]), 5e-6)
+        check(f"ipa {('f16 ' + kern) if f16 else 'bf16'} planes vs fp32-operand kernel, {name}", rel(got[valid][:, sl], ref[valid][:, sl]), 5e-6)
 
 
 def test_se3_step_golden(diffuser):

@@ -51,8 +51,10 @@ def timeit(name, fn):
 lin = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], M, x["k"], x["n"], x["tg"], **kw)  # noqa: E731
 alg = B * 4 * (9512 * N + 40 * N * N)
 with torch.no_grad():
-    for f16 in (True, False):
-        print(f"{'f16 pair' if f16 else 'bf16 three-way'} planes path  B={B} N={N}")
+    import os
+    for f16, kern in ((True, "wave"), (True, "pair"), (False, "pair")):
+        os.environ["S2S_IPA_KERNEL"] = kern
+        print(f"{'f16 pair' if f16 else 'bf16 three-way'} planes path ({'one wave per query tile' if f16 and kern == 'wave' else 'wave pairs'})  B={B} N={N}")
         tot = 0.0
         fmt = 2 if f16 else 1
         (_, q_xp), t = timeit("q  -> planes", lambda: lin(w["q"], want_f32=False, want_xp=True, xp_format=fmt)); tot += t

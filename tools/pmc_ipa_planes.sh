@@ -12,7 +12,7 @@ done
 python - <<PY
 import csv, glob, json
 B, N = $B, $N
-names = {"ipa_attention_f16_kernel": "ipa_attention_f16", "ipa_attention_planes_kernel": "ipa_attention_planes", "ipa_attention_kernel": "ipa_attention_fp32_operands", "ipa_opair_kernel": "ipa_opair",
+names = {"ipa_attention_f16w_kernel": "ipa_attention_f16w", "ipa_attention_f16_kernel": "ipa_attention_f16", "ipa_attention_planes_kernel": "ipa_attention_planes", "ipa_attention_kernel": "ipa_attention_fp32_operands", "ipa_opair_kernel": "ipa_opair",
          "ipa_prep_planes_kernel": "ipa_prep_points_planes"}
 acc = {v: {"FETCH_SIZE": [], "WRITE_SIZE": []} for v in names.values()}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -30,7 +30,7 @@ for nm, d in acc.items():
         fe, wr = sum(d["FETCH_SIZE"]) / len(d["FETCH_SIZE"]), sum(d["WRITE_SIZE"]) / len(d["WRITE_SIZE"])
         out["kernels"][nm] = {"fetch_bytes": fe, "write_bytes": wr, "hbm_bytes_corrected": 2 * fe + wr}
 k = out["kernels"]
-for path, att in (("f16", "ipa_attention_f16"), ("planes", "ipa_attention_planes"), ("fp32_operands", "ipa_attention_fp32_operands")):
+for path, att in (("f16w", "ipa_attention_f16w"), ("f16", "ipa_attention_f16"), ("planes", "ipa_attention_planes"), ("fp32_operands", "ipa_attention_fp32_operands")):
     if att in k and "ipa_opair" in k:
         tot = k[att]["hbm_bytes_corrected"] + k["ipa_opair"]["hbm_bytes_corrected"]
         out["attention_plus_opair_" + path] = {"hbm_bytes_corrected": tot, "ratio_to_algorithmic": tot / alg}
