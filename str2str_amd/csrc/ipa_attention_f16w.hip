@@ -205,7 +205,6 @@ constexpr int CT = 8;
 // next one), so only the first item of a workgroup pays the cold start (14 k cycles = 13 % of an item before this).
 struct PlaneStage {
     bf16x8 img[2][OT * 2 * 2 * 64];   // 2 x 40 KiB: K image [k-step 18][plane 2][lane] (36 KiB) or V image [tile 10][u][plane 2][lane]
-    float4 xs[2][4][4][64];           // 32 KiB: partial S^T, [tile parity][wave][r / 4][lane]
     __attribute__((aligned(16))) float k2[4][32];                  // per-key scalars of key tile t in slot t % 4 (written two tiles ahead, read one tile late)
     __attribute__((aligned(16))) float km[4][32];
 };
@@ -346,6 +345,7 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
     };
     bf16x8 qf[KH][2];
     float4 bias_cur[4], bias_prev[4];
+    float4 xkeep[4];   // S^T of the previous key tile (accumulator layout), consumed one step later
     // this wave's query fragments (B operands): k-steps 9 half .. 9 half + 8 of [16 of q_xp | 2 of qp_xp], three planes each
     auto load_queries = [&](const Item& it, const LaneItem& L) {
         const bf16x8* qs = a.q_xp + ((L.rt_q * (16 * H) + 16 * it.head) * 2) * 64;
@@ -416,7 +416,7 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
         float4 xa[4], xb[4];
         if constexpr (prev) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { xa[g] = st.xs[par ^ 1][wave][g][lane]; xb[g] = make_float4(0.f, 0.f, 0.f, 0.f); }
+            for (int g = 0; g < 4; ++g) { xa[g] = xkeep[g]; xb[g] = make_float4(0.f, 0.f, 0.f, 0.f); }   // S^T of tile t-1 (this wave's own)
 #pragma unroll
             for (int g = 0; g < 4; ++g) bias_prev[g] = bias_cur[g];
         }
@@ -459,9 +459,9 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
             }
             IPROBE(6 * t + 1);
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                st.xs[par][wave][g][lane] = make_float4(S0[4 * g] + S1[4 * g], S0[4 * g + 1] + S1[4 * g + 1],
-                                                        S0[4 * g + 2] + S1[4 * g + 2], S0[4 * g + 3] + S1[4 * g + 3]);
+            for (int g = 0; g < 4; ++g)   // kept in registers for the next step's logit arithmetic (no exchange between waves here)
+                xkeep[g] = make_float4(S0[4 * g] + S1[4 * g], S0[4 * g + 1] + S1[4 * g + 1],
+                                       S0[4 * g + 2] + S1[4 * g + 2], S0[4 * g + 3] + S1[4 * g + 3]);
         } else {
             // The logits of tiles 0 and 1 were stored in steps 1 and 2 and flushed (vmcnt(0) of every wave + barrier) by the last
             // regular step when NT >= 3: fetch them now, under this step's work -- read after the phase change they cost two
