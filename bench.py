@@ -292,10 +292,9 @@ def main():
                 "algorithmic_flops_per_launch": alg, "executed_mfma_flops_per_launch": executed,
                 "fp32_equivalent_tflops": alg / (et_ms * 1e-3) / 1e12,
                 "fp32_equivalent_vs_fp32_mfma_peak": alg / (et_ms * 1e-3) / MFMA_FP32_PEAK}
-            ipa_path = os.environ.get("S2S_IPA_PATH", "f16")
-            f16_name = "s2s_ipa_attention_f16" if os.environ.get("S2S_IPA_KERNEL", "wave") == "pair" else "s2s_ipa_attention_f16w"
-            ipa_name = {"f16": f16_name, "planes": "s2s_ipa_attention_planes"}.get(ipa_path, "s2s_ipa_attention")
-            line["ipa_kernel"] = {"bound": "hbm", "kernel": f"{ipa_name} (n_res % 32 == 0; else s2s_ipa_attention) + s2s_ipa_opair", "mean_launch_ms": ipa_ms,
+            ipa_path = net.translator.trunk["ipa_0"].ipa_path
+            ipa_name = {"f16": "s2s_ipa_attention_f16w", "planes": "s2s_ipa_attention_planes"}.get(ipa_path, "s2s_ipa_attention")
+            line["ipa_kernel"] = {"bound": "hbm", "kernel": f"{ipa_name} + s2s_ipa_opair", "mean_launch_ms": ipa_ms,
                                   "launches_timed": ipa_n, "achieved": ipa_bytes / (ipa_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                                   "unit": "GB/s", "frac": ipa_bytes / (ipa_ms * 1e-3) / HBM_PEAK,
                                   "algorithmic_bytes_per_launch": ipa_bytes}

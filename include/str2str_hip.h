@@ -152,21 +152,20 @@ int s2s_ipa_attention_planes(const void* q_xp, const void* k_xp, const void* v_v
                              int out_xp_ksteps, int n_samples, int n_res, int n_heads, int c_hidden, int n_qk_points,
                              int n_v_points, int c_pair_z, float inf, float eps, void* stream);
 
-/* The same two entry points on f16 pair operands (csrc/ipa_attention_f16.hip): every operand as (x_h, x_l) f16 planes -- TWO planes
- * per fragment group in all the arrays above -- and three products per block (a_h b_h + a_h b_l + a_l b_h) instead of six: half the
- * matrix instructions and two thirds of the operand bytes.  q_xp / k_xp from s2s_node_linear with out_xp_format 2, v_vf from
- * s2s_node_linear_vfrag with out_format 1.  Same outputs (out_xp: f16 planes of the node stream). */
+/* The DEFAULT attention core: the same two entry points on f16 pair operands (csrc/ipa_attention_f16w.hip): every operand as
+ * (x_h, x_l) f16 planes -- TWO planes per fragment group in all the arrays above -- and three products per block
+ * (a_h b_h + a_h b_l + a_l b_h) instead of six: half the matrix instructions and two thirds of the operand bytes.  One wave per query
+ * tile (a workgroup is four query tiles; a wave runs the whole contraction and owns all ten output tiles).
+ * ANY n_res (ipa.py:183-257 has one code path for every length): with n_pad = n_res rounded up to 32, the fragment arrays, q2 and k2
+ * hold n_pad rows PER SAMPLE (row tile = sample * n_pad/32 + tile):
+ *   q_xp / k_xp from s2s_node_linear (out_xp_format 2) and v_vf from s2s_node_linear_vfrag (out_format 1), both with n_rows =
+ *   n_samples * n_pad and the row map (map_pad = n_pad, map_src = n_res) when n_pad != n_res; points from s2s_ipa_prep_points_f16
+ *   (padded rows: zero points, k2 = -1e9, so a padded key never carries probability -- exactly the un-padded softmax).
+ * attn_bias stays [B,H,n_res,n_res]; when n_pad != n_res logits_out must be a SEPARATE [B,H,n_pad,n_pad] buffer (s2s_ipa_opair:
+ * logits_ld = n_pad); stats_out [B,H,n_res,2], out [B,n_res,feat] and out_xp (row tiles of the flat [B n_res] rows) are not padded. */
 int s2s_ipa_prep_points_f16(const float* rigids7, const float* q_pts_lin, const float* kv_pts_lin, const float* head_w_scaled,
-                               void* qp_xp, void* kp_xp, void* vp_vf, float* q2, float* k2, long long n_frames, int n_heads,
-                               int n_qk_points, int n_v_points, int c_hidden, void* stream);
-int s2s_ipa_attention_f16(const void* q_xp, const void* k_xp, const void* v_vf, const void* qp_xp, const void* kp_xp,
-                             const void* vp_vf, const float* q2, const float* k2, const float* attn_bias, float* logits_out,
-                             float* stats_out, const float* mask, const float* rigids7, float* out, void* out_xp,
-                             int out_xp_ksteps, int n_samples, int n_res, int n_heads, int c_hidden, int n_qk_points,
-                             int n_v_points, int c_pair_z, float inf, float eps, void* stream);
-
-/* s2s_ipa_attention_f16 with ONE WAVE PER QUERY TILE (csrc/ipa_attention_f16w.hip): same operands, same outputs; a workgroup is four
- * query tiles, a wave runs the whole contraction and owns all ten output tiles (no partial-sum exchange between wave pairs). */
+                            void* qp_xp, void* kp_xp, void* vp_vf, float* q2, float* k2, int n_samples, int n_res, int n_heads,
+                            int n_qk_points, int n_v_points, int c_hidden, void* stream);
 int s2s_ipa_attention_f16w(const void* q_xp, const void* k_xp, const void* v_vf, const void* qp_xp, const void* kp_xp,
                              const void* vp_vf, const float* q2, const float* k2, const float* attn_bias, float* logits_out,
                              float* stats_out, const float* mask, const float* rigids7, float* out, void* out_xp,
@@ -176,9 +175,11 @@ int s2s_ipa_attention_f16w(const void* q_xp, const void* k_xp, const void* v_vf,
 /* The pair term of InvariantPointAttention.forward (src/models/net/ipa.py:253-257):
  *   o_pair[b,i,h,:] = sum_j softmax_j(logits[b,h,i,:])[j] * pair_z[b,i,j,:]
  * from the logits / statistics s2s_ipa_attention stored, streaming pair_z [B,N,N,c_pair_z] once for all heads;
- * written to out[(b*N+i)*out_row_stride + out_col_offset + h*c_pair_z + c]  (H = 8, c_pair_z = 32). */
+ * written to out[(b*N+i)*out_row_stride + out_col_offset + h*c_pair_z + c]  (H = 8, c_pair_z = 32).
+ * logits_ld: rows per (sample, head) slab and row stride of ``logits`` ([B,H,ld,ld]; 0 = n_res; the padded length when
+ * s2s_ipa_attention_f16w wrote them for a ragged n_res). */
 int s2s_ipa_opair(const float* logits, const float* stats, const float* pair_z, float* out, int n_samples, int n_res,
-                  int n_heads, int c_pair_z, int out_row_stride, int out_col_offset, void* stream);
+                  int n_heads, int c_pair_z, int out_row_stride, int out_col_offset, int logits_ld, void* stream);
 
 /* ---- Rigid frames ---- */
 
@@ -241,22 +242,25 @@ int s2s_pack_planes(const float* x, long long n_rows, int ld, int col0, int n_co
  *   xp: packed planes of the input [n_rows, k_in]; w_packed: ops.pack_node_weight(W [n_out, k_in], tiles_per_block);
  *   outputs: out_f32[row * out_ld + out_col0 + col] and/or the packed planes of the result as k-steps out_xp_kstep0 .. of an XP
  *   buffer with out_xp_ksteps k-steps (out_xp_format 0 (or 2): f16 pair planes -- the input format of the next layer and of
- *   s2s_ipa_attention_f16; 1: exact three-way bf16 planes, three per k-step, for s2s_ipa_attention_planes).
- *   Any pointer may be NULL to skip that step. */
+ *   s2s_ipa_attention_f16w; 1: exact three-way bf16 planes, three per k-step, for s2s_ipa_attention_planes).
+ *   Any pointer may be NULL to skip that step.
+ *   Row map (map_pad > 0; only with bias / relu / LayerNorm epilogues): n_rows counts OUTPUT rows = n_samples * map_pad, and output
+ *   row (sample, n) reads input row sample * map_src + min(n, map_src - 1) -- the per-sample padding to whole 32-row tiles that
+ *   s2s_ipa_attention_f16w wants of its q / k / v operands for a ragged n_res (map_src = n_res, map_pad = n_res rounded up to 32). */
 int s2s_node_linear(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
                     int tiles_per_block, const float* pre_scale, int relu, const float* pre_mask, const float* residual,
                     int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_mask,
                     float* out_f32, int out_ld, int out_col0, void* out_xp, int out_xp_ksteps, int out_xp_kstep0,
-                    int out_xp_format, void* stream);
+                    int out_xp_format, int map_pad, int map_src, void* stream);
 
 /* The same GEMM with the operands swapped, for a projection whose output is consumed as the A operand of a later product over
  * its ROWS (the value projection of InvariantPointAttention, ipa.py:132-141, consumed by the PV step): the result (+ bias) is
  * stored as bf16x3 MFMA A fragments  out_vf[row tile (32 rows)][head][column tile (32 cols) in head][k-step u (16 rows)][plane]
  * [lane 64][8], element j of lane (column c, half h) = row (r&3) + 8 (r>>2) + 4 h, r = 8 u + j, of the tile.  w_packed as for
  * s2s_node_linear with tiles_per_block = 8.  out_format 0: three bf16 planes (s2s_ipa_attention_planes), 1: f16 pair planes
- * (x_h, x_l), two per fragment group (s2s_ipa_attention_f16). */
+ * (x_h, x_l), two per fragment group (s2s_ipa_attention_f16w).  map_pad / map_src: the row map of s2s_node_linear. */
 int s2s_node_linear_vfrag(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
-                          int tiles_per_head, void* out_vf, int out_format, void* stream);
+                          int tiles_per_head, void* out_vf, int out_format, int map_pad, int map_src, void* stream);
 
 /* Self-attention core of the trunk's TransformerEncoderLayer (src/models/net/ipa.py:312-317,357; torch.nn.MultiheadAttention with
  * d_model = n_heads * head_dim, head_dim = 80): softmax(q k^T / sqrt(head_dim) + key_bias[j]) v per (sample, head), exact fp32 MFMA.

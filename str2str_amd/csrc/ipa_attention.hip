@@ -470,7 +470,8 @@ __global__ void __launch_bounds__(256) ipa_attention_kernel(IpaArgs a) {
 template <int H, int PZ>
 __global__ void __launch_bounds__(256) ipa_opair_kernel(const float* __restrict__ logits, const float* __restrict__ stats,
                                                         const float* __restrict__ pair_z, float* __restrict__ out, int B, int N,
-                                                        int feat, int col0) {
+                                                        int feat, int col0, int LD) {
+    // LD: rows per (sample, head) slab and row stride of the logits ([B,H,LD,LD]; LD = N unless the attention kernel padded them)
     static_assert(H == 8 && PZ == 32, "shape");
     constexpr int CH = 256;  // keys per chunk
     __shared__ __attribute__((aligned(16))) float a_s[4][CH * H];
@@ -498,7 +499,7 @@ __global__ void __launch_bounds__(256) ipa_opair_kernel(const float* __restrict_
         float pr[H][4];
 #pragma unroll
         for (int hd = 0; hd < H; ++hd) {
-            const float* lrow = logits + ((b * H + hd) * N + i) * N + j0 + jl;
+            const float* lrow = logits + ((b * H + hd) * LD + i) * LD + j0 + jl;
             float4 s4 = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
             if (j0 + jl + 3 < N) s4 = *reinterpret_cast<const float4*>(lrow);
             else {
@@ -556,12 +557,13 @@ extern "C" int s2s_debug_read_ipa_probe(void* dst) {
 #endif
 
 extern "C" int s2s_ipa_opair(const float* logits, const float* stats, const float* pair_z, float* out, int n_samples, int n_res,
-                             int n_heads, int c_pair_z, int out_row_stride, int out_col_offset, void* stream) {
+                             int n_heads, int c_pair_z, int out_row_stride, int out_col_offset, int logits_ld, void* stream) {
     if (n_samples <= 0 || n_res <= 0) return 0;
-    if (n_heads != 8 || c_pair_z != 32) return (int)hipErrorInvalidValue;
+    if (logits_ld <= 0) logits_ld = n_res;
+    if (n_heads != 8 || c_pair_z != 32 || logits_ld < n_res) return (int)hipErrorInvalidValue;
     const long long rows = (long long)n_samples * n_res;
     hipLaunchKernelGGL((ipa_opair_kernel<8, 32>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, stats,
-                       pair_z, out, n_samples, n_res, out_row_stride, out_col_offset);
+                       pair_z, out, n_samples, n_res, out_row_stride, out_col_offset, logits_ld);
     return (int)hipGetLastError();
 }
 

@@ -1,9 +1,9 @@
-// Invariant Point Attention core on f16 pair operands, ONE WAVE PER QUERY TILE (gfx950; n_res % 32 == 0).
-// The kernel of csrc/ipa_attention_f16.hip (read it and csrc/ipa_attention_planes.hip first) without the wave pairs: with two planes
-// per operand the 18 query fragments of a tile are 144 VGPRs, so a wave owns a whole 32-residue query tile again -- all 18
-// k-steps of S^T and all 10 output tiles -- and a workgroup is four query tiles.  Gone: the partial-sum exchange between the
-// halves, the duplicated logit arithmetic (both waves of a pair evaluated all 16 elements), half of the copy slots and LDS image
-// writes per query (a K / V image now serves four query tiles instead of two).
+// Invariant Point Attention core on f16 pair operands, ONE WAVE PER QUERY TILE (gfx950), the default attention kernel.
+// Structure (phases, image stream, copy slots, software pipeline) is the one csrc/ipa_attention_planes.hip documents for the
+// range-safe bf16-planes kernel; here every operand is an f16 pair (x_h, x_l), three products per block, and with two planes per
+// operand the 18 query fragments of a tile are 144 VGPRs, so a wave owns a whole 32-residue query tile -- all 18 k-steps of S^T
+// and all 10 output tiles -- and a workgroup is four query tiles: no partial-sum exchange between wave halves, no duplicated logit
+// arithmetic, and a K / V image serves four query tiles.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdlib.h>
@@ -57,19 +57,27 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& ph, bf16x8& pl) {
 // split and stored.  Coordinate k of a point row = 3 p + d (24 of the 32 columns of two k-steps; the rest zero).
 constexpr int PQ = 8, PV = 12;
 
-__global__ void __launch_bounds__(256) ipa_prep_f16w_unused_kernel(const float* __restrict__ rig, const float* __restrict__ qp_lin,
+__global__ void __launch_bounds__(256) ipa_prep_f16_kernel(const float* __restrict__ rig, const float* __restrict__ qp_lin,
                                                               const float* __restrict__ kvp_lin, const float* __restrict__ head_w,
                                                               float q_scale_c1, bf16x8* __restrict__ qp_xp, bf16x8* __restrict__ kp_xp,
                                                               bf16x8* __restrict__ vp_vf, float* __restrict__ q2, float* __restrict__ k2,
-                                                              int H) {
+                                                              int H, int n_res, int n_pad) {
+    // Row tiles are tiles of the PADDED residue range (n_pad = n_res rounded up to 32, per sample): tile rt = sample rt / (n_pad / 32);
+    // residues >= n_res of the last tile are padding: zero points, q2 = 0, k2 = -1e9 (such a key can never carry probability).
     __shared__ float sq[32][33], sk[32][33], sv[32][65];
+    __shared__ int s_pad[32];
     const int tid = threadIdx.x;
     const int head = blockIdx.x % H;
     const long long rt = blockIdx.x / H;
     const float hw = head_w[head];
+    const int tps = n_pad / 32;
     {
         const int row = tid >> 3, p = tid & 7;
-        const long long r = rt * 32 + row;
+        const long long smp = rt / tps;
+        const int n = (int)(rt - smp * tps) * 32 + row;
+        const bool pad = n >= n_res;
+        if (p == 0) s_pad[row] = pad;
+        const long long r = smp * n_res + (pad ? n_res - 1 : n);
         Quat<float> q; Vec3<float> t;
         load7(rig + r * 7, q, t);
         const Mat3<float> R = quat_to_rot<float>(q);
@@ -79,20 +87,20 @@ __global__ void __launch_bounds__(256) ipa_prep_f16w_unused_kernel(const float* 
         {
             const int w = head * PQ + p;
             const Vec3<float> g = rot_vec_mul<float>(R, Vec3<float>{ql[w], ql[HPq + w], ql[2 * HPq + w]});
-            sq[row][3 * p] = g.x + t.x; sq[row][3 * p + 1] = g.y + t.y; sq[row][3 * p + 2] = g.z + t.z;
+            sq[row][3 * p] = pad ? 0.f : g.x + t.x; sq[row][3 * p + 1] = pad ? 0.f : g.y + t.y; sq[row][3 * p + 2] = pad ? 0.f : g.z + t.z;
             sq[row][24 + p] = 0.f;
         }
         {
             const int c = head * (PQ + PV) + p;
             const Vec3<float> g = rot_vec_mul<float>(R, Vec3<float>{kl[c], kl[HPkv + c], kl[2 * HPkv + c]});
-            sk[row][3 * p] = g.x + t.x; sk[row][3 * p + 1] = g.y + t.y; sk[row][3 * p + 2] = g.z + t.z;
+            sk[row][3 * p] = pad ? 0.f : g.x + t.x; sk[row][3 * p + 1] = pad ? 0.f : g.y + t.y; sk[row][3 * p + 2] = pad ? 0.f : g.z + t.z;
             sk[row][24 + p] = 0.f;
         }
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             const int pv = p + 8 * x;  // value-point slot 0..15; slots >= PV are zero padding
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pv < PV) {
+            if (pv < PV && !pad) {
                 const int c = head * (PQ + PV) + PQ + pv;
                 const Vec3<float> g = rot_vec_mul<float>(R, Vec3<float>{kl[c], kl[HPkv + c], kl[2 * HPkv + c]});
                 o = make_float4(g.x + t.x, g.y + t.y, g.z + t.z, 0.f);
@@ -107,7 +115,7 @@ __global__ void __launch_bounds__(256) ipa_prep_f16w_unused_kernel(const float* 
         float acc = 0.f;
 #pragma unroll
         for (int x = 0; x < 24; ++x) acc += s[row][x] * s[row][x];
-        (tid < 32 ? q2 : k2)[(rt * H + head) * 32 + row] = -0.5f * hw * acc;
+        (tid < 32 ? q2 : k2)[(rt * H + head) * 32 + row] = s_pad[row] ? (tid < 32 ? 0.f : -1.0e9f) : -0.5f * hw * acc;
     }
     const float qs = hw / q_scale_c1;
 #pragma unroll
@@ -140,7 +148,7 @@ struct PlaneArgs {
     const bf16x8* qp_xp; const bf16x8* kp_xp; const bf16x8* vp_vf;
     const float* q2; const float* k2;
     const float* attn_bias;  // [B,H,N,N]
-    float* logits;           // [B,H,N,N] (may alias attn_bias)
+    float* logits;           // [B,H,NP,NP] (may alias attn_bias when NP == N)
     float* stats;            // [B,H,N,2]
     const float* mask;       // [B,N]
     const float* rigids7;    // [B,N,7]
@@ -148,6 +156,7 @@ struct PlaneArgs {
     bf16x8* out_xp;          // packed planes of the [B*N, 16*xp_ksteps] linear_out input: the o columns (k-steps 16 head ..)
     int xp_ksteps;
     int B, N, H;
+    int NP;                  // N rounded up to the 32-residue tiles: the fragment arrays, q2 / k2 and the logits use NP rows per sample
     float inf, eps;
     int xcd_remap;
 };
@@ -180,13 +189,10 @@ constexpr int OT = 10;   // output tiles of PV: 8 channels + 2 value points
 constexpr int OH = OT;       // ... and owns all ten output tiles
 constexpr int CT = 8;
 
-// A workgroup = 4 waves = 2 query tiles (32 residues each) x 2 "halves".  The B operands must sit in VGPRs (hipcc allocates
-// MFMA sources there only), and the 18 x 3 query fragments of a tile are 216 of them: a PAIR of waves shares a query tile.
-// Half x holds the query fragments of k-steps 9x .. 9x+8 (108 VGPRs) and computes its half of the contraction of S^T; the
-// halves meet through LDS (added in the same order by both, so both waves see bit-identical logits and maxima); in the second
-// phase half x owns the accumulators of output tiles 5x .. 5x+4 (80 AGPRs).
+// A workgroup = 4 waves = 4 query tiles (32 residues each) of one (sample, head); wave w holds the query fragments of its tile
+// (B operands must sit in VGPRs: hipcc allocates MFMA sources there only) and the accumulators of its ten output tiles.
 //
-// Two phases per work item (sample, head, 64 query residues) instead of an online softmax:
+// Two phases per work item (sample, head, 128 query residues) instead of an online softmax:
 //   phase 1, key tiles 0 .. NT-1:  S^T -> masked logits -> global (the [B,H,N,N] buffer s2s_ipa_opair reads anyway), row maximum
 //   phase 2, key tiles 0 .. NT-1:  logits back from L2, p = exp(s - max), row sum, O^T += V^T P^T
 // The accumulators are never rescaled (a VALU pass over 80 matrix-core registers per tile, which also dragged the whole
@@ -195,10 +201,10 @@ constexpr int CT = 8;
 // arithmetic of tile t-1 rides between the MFMAs of tile t, the exp / split of tile t+1 between those of tile t (one wave per
 // SIMD: nothing else fills the matrix pipe's shadow).
 //
-// Image g goes global -> VGPR (one step before it is written) -> LDS (one step before it is read), 14 / 15 pieces of 1 KiB per
+// Image g goes global -> VGPR (one step before it is written) -> LDS (one step before it is read), 9 / 10 pieces of 1 KiB per
 // wave, one "copy slot" (ds_write of a piece + re-load of its register) per few MFMAs.  LDS-DMA (global_load_lds_dwordx4) would
 // need no registers but costs the issuing wave ~150 cycles per piece on this part -- as much per key tile as the tile's MFMAs.
-// Every VMEM operation of the loops is UNCONDITIONAL (a piece that does not exist re-loads / re-stores piece 12): vmcnt
+// Every VMEM operation of the loops is UNCONDITIONAL (a piece that does not exist re-loads / re-stores piece 8): vmcnt
 // counts in order, and a load issued on one side of a branch makes hipcc fall back to s_waitcnt vmcnt(0) at every older use.
 //
 // Workgroups are persistent: the image stream runs across work items (images 2 NT, 2 NT + 1 of an item are images 0, 1 of the
@@ -218,12 +224,18 @@ __device__ __forceinline__ f32x4v load_l2(__amdgpu_buffer_rsrc_t rsrc, int byte_
     return __builtin_bit_cast(f32x4v, r);
 }
 
+// RAGGED (n_res % 32 != 0): operands arrive in the padded layout (NP = n_res rounded up to 32 rows per sample; padded key rows are
+// finite, their k2 is -1e9, see ipa_prep_f16_kernel), the bias keeps its [B,H,N,N] strides (rows of the last tile may be read past
+// their end: finite neighbours or 0 outside the slab -- the -1e9 of the key decides), the logits go to a SEPARATE [B,H,NP,NP] buffer
+// (a padded row's stores never touch a neighbour), and every result row is written in the real-row layout, padded rows skipped.
+template <bool RAGGED>
 __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
     __shared__ __attribute__((aligned(16))) PlaneStage st;
     const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = 0;   // (one wave per query tile: the pair logic of the parent kernel degenerates)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = a.N, H = a.H;
-    const int NT = N / 32;                        // key tiles = row tiles per sample
+    const int NP = RAGGED ? a.NP : N;             // logits stride / padded rows per sample
+    const int NT = NP / 32;                       // key tiles = row tiles per sample
     const int n_qb = (NT + 3) / 4;
     const int n_items = a.B * H * n_qb;
     const float c1 = sqrtf(1.0f / (3 * 256));
@@ -305,6 +317,11 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
     // are formed; the value is loaded a step before it is stored (waves 2, 3 store; every wave loads: no conditional VMEM).
     auto small_load = [&](const Item& it, int t) -> float {
         const int tc = min(t, NT - 1);
+        if constexpr (RAGGED) {
+            const int kk = tc * 32 + c;
+            const float v = (wave & 1) ? a.k2[(((long long)it.b * NT + tc) * H + it.head) * 32 + c] : a.mask[(long long)it.b * N + min(kk, N - 1)];
+            return ((wave & 1) || kk < N) ? v : 0.f;
+        }
         return (wave & 1) ? a.k2[(((long long)it.b * NT + tc) * H + it.head) * 32 + c] : a.mask[(long long)it.b * N + tc * 32 + c];
     };
     auto small_store = [&](int t, float v) {
@@ -336,28 +353,41 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
         const int qtc = qt < NT ? qt : NT - 1;
         LaneItem L;
         L.rt_q = (long long)it.b * NT + qtc;
-        L.i = qtc * 32 + c;
-        L.row_i = (long long)it.b * N + L.i;
-        L.brow0 = (((long long)it.b * H + it.head) * N + L.i) * N + 4 * h;
+        L.i = qtc * 32 + c;                          // (RAGGED: index in the padded range; >= N for a padded query row)
+        const int ic = RAGGED ? min(L.i, N - 1) : L.i;
+        L.row_i = (long long)it.b * N + ic;
+        L.brow0 = (((long long)it.b * H + it.head) * N + ic) * N + 4 * h;
         L.q2 = a.q2[(L.rt_q * H + it.head) * 32 + c];
         L.mask = a.mask[L.row_i];
+        if constexpr (RAGGED) L.mask = L.i < N ? L.mask : 0.f;
         return L;
     };
     bf16x8 qf[KH][2];
+    // RAGGED: the bias rows are read through a bounds-checked resource (a row of the last key tile runs past its end, the last
+    // row of the array past the allocation) at dword alignment
+    const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.attn_bias, 0, RAGGED ? (int)((long long)a.B * H * N * N * 4) : 0, 0x00020000);
+    auto bias_load = [&](long long brow, int t, int g) -> float4 {
+        if constexpr (RAGGED) {
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(r_bias, (int)(brow * 4) + (t * 32 + 8 * g) * 4, 0, 0);
+            return make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+        } else {
+            return *reinterpret_cast<const float4*>(a.attn_bias + brow + t * 32 + 8 * g);
+        }
+    };
     float4 bias_cur[4], bias_prev[4];
     float4 xkeep[4];   // S^T of the previous key tile (accumulator layout), consumed one step later
-    // this wave's query fragments (B operands): k-steps 9 half .. 9 half + 8 of [16 of q_xp | 2 of qp_xp], three planes each
+    // this wave's query fragments (B operands): the 18 k-steps of [16 of q_xp | 2 of qp_xp], two planes each
     auto load_queries = [&](const Item& it, const LaneItem& L) {
         const bf16x8* qs = a.q_xp + ((L.rt_q * (16 * H) + 16 * it.head) * 2) * 64;
         const bf16x8* ps = a.qp_xp + ((L.rt_q * H + it.head) * 4) * 64;
 #pragma unroll
         for (int x = 0; x < KH; ++x) {
-            const int ks = KH * half + x;   // wave-uniform
+            const int ks = x;
 #pragma unroll
             for (int p = 0; p < 2; ++p) qf[x][p] = (ks < 16 ? qs + (ks * 2 + p) * 64 : ps + ((ks - 16) * 2 + p) * 64)[lane];
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bias_cur[g] = *reinterpret_cast<const float4*>(a.attn_bias + L.brow0 + 8 * g);
+        for (int g = 0; g < 4; ++g) bias_cur[g] = bias_load(L.brow0, 0, g);
     };
     LaneItem Lc = lane_item(cur);
     load_queries(cur, Lc);
@@ -380,9 +410,9 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
     // Software pipeline: the logit arithmetic of tile t-1 (VALU + LDS reads) is issued between the MFMAs of tile t, one element
     // per two MFMAs, so it runs in the shadow of the matrix pipe (one wave per SIMD: nothing else would fill it).
     // this (sample, head)'s [N, N] logit slab as a buffer resource: 32-bit offsets, cache policy on the instruction
-    const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.logits + ((long long)b * H + head) * N * N), 0,
-                                                                           N * N * 4, 0x00020000);
-    const int loff0 = (i * N + 4 * h) * 4;
+    const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.logits + ((long long)b * H + head) * NP * NP), 0,
+                                                                           NP * NP * 4, 0x00020000);
+    const int loff0 = (i * NP + 4 * h) * 4;
     f32x4v lg[4], lg1[4];   // logits of the tile whose probabilities are formed next (and of tile 1 across the phase change)
     float tmax = -INFINITY;
     float4 k2g, kmg;   // per-key scalars of the 4 keys 8g + 4h .. of the element group being evaluated
@@ -404,15 +434,20 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
         tmax = fmaxf(tmax, x);
         if (r == 15) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                *reinterpret_cast<float4*>(a.logits + brow0 + tp * 32 + 8 * k) = make_float4(sl[4 * k], sl[4 * k + 1], sl[4 * k + 2], sl[4 * k + 3]);
+            for (int k = 0; k < 4; ++k) {
+                if constexpr (RAGGED)
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(sl[4 * k]), __float_as_uint(sl[4 * k + 1]), __float_as_uint(sl[4 * k + 2]),
+                                                                 __float_as_uint(sl[4 * k + 3])}, lrsrc, loff0 + tp * 128 + 32 * k, 0, 0);
+                else
+                    *reinterpret_cast<float4*>(a.logits + brow0 + tp * 32 + 8 * k) = make_float4(sl[4 * k], sl[4 * k + 1], sl[4 * k + 2], sl[4 * k + 3]);
+            }
         }
     };
     auto step1 = [&](int t, auto have_c, auto prev_c, auto flush_c) {
         constexpr bool have = decltype(have_c)::value, prev = decltype(prev_c)::value, flush = decltype(flush_c)::value;
         const int par = t & 1;
         IPROBE(6 * t + 0);
-        // partial sums of tile t-1 (both halves, added in the order half 0 + half 1 by both waves)
+        // S^T of tile t-1
         float4 xa[4], xb[4];
         if constexpr (prev) {
 #pragma unroll
@@ -423,15 +458,15 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
         // this lane's 16 bias values of tile t (keys 32 t + 8 g + 4 h + e): one 128 B line per (query, tile)
         if constexpr (have && prev) {   // (tile 0's came with the query fragments)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) bias_cur[g] = *reinterpret_cast<const float4*>(a.attn_bias + brow0 + t * 32 + 8 * g);
+            for (int g = 0; g < 4; ++g) bias_cur[g] = bias_load(brow0, t, g);
         }
         float sl[16];
         f32x16 S0, S1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S0[r] = 0.f, S1[r] = 0.f;
         if constexpr (have) {
-            // ---------------- this wave's half of S^T = K . Q^T (+ point cross term): 54 MFMAs on two accumulation chains
-            const bf16x8* k_half = st.img[par] + KH * half * 128 + lane;
+            // ---------------- S^T = K . Q^T (+ point cross term): 54 MFMAs on two accumulation chains
+            const bf16x8* k_half = st.img[par] + lane;
             bf16x8 kf[2][2];
             lds_frag* kp = frag_pin(k_half);
 #pragma unroll
@@ -536,7 +571,7 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
         if constexpr (!first) __syncthreads();               // V(t) visible; every wave is done with V(t - 1)
         IPROBE(60 + 6 * t + 1);
         // ---------------- O^T += V^T . P^T for this wave's five output tiles
-        const bf16x8* v_half = st.img[(NT + t) & 1] + OH * half * 256 + lane;
+        const bf16x8* v_half = st.img[(NT + t) & 1] + lane;
         auto load_v = [&](int x, bf16x8 (&d)[2][2]) {
             lds_frag* pa = frag_pin(v_half + x * 256);
 #pragma unroll
@@ -634,10 +669,13 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
     const float inv = (1.0f / l_tot) * (1.0f / 1024.0f);   // (the probabilities went into the products scaled by 2^10)
     {
         // o: accumulator registers 8u .. 8u+7 of channel tile T = fragment k-step 16 head + 2T + u of this row tile (chain order)
-        bf16x8* o = a.out_xp + ((rt_q * a.xp_ksteps + 16 * head) * 2) * 64 + lane;
+        // (RAGGED: the output rows are NOT padded -- row_i sits at position row_i & 31 of row tile row_i >> 5 of the [B N] rows)
+        bf16x8* o = RAGGED ? a.out_xp + (((row_i >> 5) * a.xp_ksteps + 16 * head) * 2) * 64 + ((int)(row_i & 31) + 32 * h)
+                           : a.out_xp + ((rt_q * a.xp_ksteps + 16 * head) * 2) * 64 + lane;
+        const bool row_ok = !RAGGED || i < N;
 #pragma unroll
         for (int x = 0; x < OH; ++x) {
-            const int T = OH * half + x;   // wave-uniform
+            const int T = x;
             if (T >= CT) continue;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -655,7 +693,7 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
                     ph[j] = hh; pl[j] = (_Float16)(xv - (float)hh);
                 }
                 bf16x8* q = o + ((2 * T + u) * 2) * 64;
-                q[0] = ph; q[64] = pl;
+                if (row_ok) { q[0] = ph; q[64] = pl; }
             }
         }
     }
@@ -682,7 +720,7 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
                 const float ly = r01 * dx + r11 * dy + r21 * dz;
                 const float lz = r02 * dx + r12 * dy + r22 * dz;
                 const float nr = sqrtf(lx * lx + ly * ly + lz * lz + a.eps);
-                if (pt_idx < PV) {
+                if (pt_idx < PV && (!RAGGED || i < N)) {
                     ox[pt_idx] = lx;
                     ox[H * PV + pt_idx] = ly;
                     ox[2 * H * PV + pt_idx] = lz;
@@ -690,7 +728,7 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
                 }
             }
     }
-    if (h == 0) {
+    if (h == 0 && (!RAGGED || i < N)) {
         float* st2 = a.stats + ((((long long)b * H + head) * N) + i) * 2;
         st2[0] = m_run;
         st2[1] = l_tot;
@@ -719,21 +757,40 @@ extern "C" int s2s_debug_read_ipa8_probe(void* dst) {
 }
 #endif
 
+extern "C" int s2s_ipa_prep_points_f16(const float* rigids7, const float* q_pts_lin, const float* kv_pts_lin,
+                                          const float* head_w_scaled, void* qp_xp, void* kp_xp, void* vp_vf, float* q2, float* k2,
+                                          int n_samples, int n_res, int n_heads, int n_qk_points, int n_v_points, int c_hidden, void* stream) {
+    if (n_samples <= 0 || n_res <= 0) return 0;
+    if (n_qk_points != PQ || n_v_points != PV || c_hidden != 256 || n_heads < 1) return (int)hipErrorInvalidValue;
+    const int n_pad = (n_res + 31) / 32 * 32;
+    const long long blocks = (long long)n_samples * (n_pad / 32) * n_heads;
+    if (blocks >= (1ll << 31)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(ipa_prep_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rigids7, q_pts_lin, kv_pts_lin,
+                       head_w_scaled, sqrtf(1.0f / (3 * c_hidden)), (bf16x8*)qp_xp, (bf16x8*)kp_xp, (bf16x8*)vp_vf, q2, k2, n_heads, n_res,
+                       n_pad);
+    return (int)hipGetLastError();
+}
+
 extern "C" int s2s_ipa_attention_f16w(const void* q_xp, const void* k_xp, const void* v_vf, const void* qp_xp, const void* kp_xp,
                                         const void* vp_vf, const float* q2, const float* k2, const float* attn_bias,
                                         float* logits_out, float* stats_out, const float* mask, const float* rigids7, float* out,
                                         void* out_xp, int out_xp_ksteps, int n_samples, int n_res, int n_heads, int c_hidden,
                                         int n_qk_points, int n_v_points, int c_pair_z, float inf, float eps, void* stream) {
     if (n_samples <= 0 || n_res <= 0) return 0;
-    if (c_hidden != 256 || n_qk_points != PQ || n_v_points != PV || c_pair_z != 32 || n_heads < 1 || n_res % 32 ||
+    if (c_hidden != 256 || n_qk_points != PQ || n_v_points != PV || c_pair_z != 32 || n_heads < 1 ||
         out_xp_ksteps < 16 * n_heads || !out_xp)
         return (int)hipErrorInvalidValue;
-    const int n_qb = (n_res + 127) / 128;
+    const int n_pad = (n_res + 31) / 32 * 32;
+    const bool ragged = n_pad != n_res;
+    // ragged lengths: the logits live in their own [B,H,n_pad,n_pad] buffer (a row padded in place would run into its neighbour)
+    if (ragged && (!logits_out || logits_out == attn_bias)) return (int)hipErrorInvalidValue;
+    const int n_qb = (n_pad + 127) / 128;
     const long long items = (long long)n_samples * n_heads * n_qb;
-    // the kernel addresses its fragment arrays through 32-bit buffer offsets
-    if ((long long)n_samples * (n_res / 32) * 16 * n_heads * 2048 >= (1ll << 32)) return (int)hipErrorInvalidValue;
+    // the kernel addresses its fragment arrays (and, for ragged lengths, the bias array) through 32-bit buffer offsets
+    if ((long long)n_samples * (n_pad / 32) * 16 * n_heads * 2048 >= (1ll << 32)) return (int)hipErrorInvalidValue;
+    if (ragged && (long long)n_samples * n_heads * n_res * n_res * 4 >= (1ll << 31)) return (int)hipErrorInvalidValue;
     static const int remap_env = getenv("S2S_IPA_XCD") ? atoi(getenv("S2S_IPA_XCD")) : 1;
-    // persistent workgroups, one per CU (153 KiB of LDS each); a multiple of 8 so that workgroup w stays on XCD w % 8
+    // persistent workgroups, one per CU (83 KiB of LDS each); a multiple of 8 so that workgroup w stays on XCD w % 8
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -744,7 +801,10 @@ extern "C" int s2s_ipa_attention_f16w(const void* q_xp, const void* k_xp, const 
     const long long blocks = items < n_cu ? items : n_cu;
     PlaneArgs a{(const bf16x8*)q_xp, (const bf16x8*)k_xp, (const bf16x8*)v_vf, (const bf16x8*)qp_xp, (const bf16x8*)kp_xp,
                 (const bf16x8*)vp_vf, q2, k2, attn_bias, logits_out, stats_out, mask, rigids7, out, (bf16x8*)out_xp, out_xp_ksteps,
-                n_samples, n_res, n_heads, inf, eps, (remap_env && items % 8 == 0 && blocks % 8 == 0 && n_qb > 1) ? 1 : 0};
-    hipLaunchKernelGGL(ipa_attention_f16w_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+                n_samples, n_res, n_heads, n_pad, inf, eps, (remap_env && items % 8 == 0 && blocks % 8 == 0 && n_qb > 1) ? 1 : 0};
+    if (ragged)
+        hipLaunchKernelGGL(ipa_attention_f16w_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(ipa_attention_f16w_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     return (int)hipGetLastError();
 }

@@ -106,6 +106,9 @@ struct GemmArgs {
     float ln_eps;
     int xp_bf16;             // out_xp format: 0 (or 2) f16 pair planes, 1 exact three-way bf16 planes (bf16 attention kernel);
                              // VF kernels: 0 = bf16 triples, 1 = f16 pairs
+    int map_pad, map_src;    // map_pad > 0: OUTPUT row r = sample r / map_pad, residue n = r % map_pad reads INPUT row
+                             // sample * map_src + min(n, map_src - 1) of xp: the per-sample padding to whole 32-row tiles the
+                             // attention kernel wants for ragged lengths (padded rows repeat the sample's last row: finite, masked there)
 };
 
 // VF: operands swapped -- Y[row, col] = X . W^T with A = the activation fragment, B = the weight fragment -- so that a lane owns
@@ -155,6 +158,13 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
         }
     };
     const f16x8* xsrc = a.xp + (rtc * KS) * 2 * 64 + lane;
+    if (a.map_pad > 0) {   // gather: this lane's row of the (padded) output comes from another row tile / lane slot of the input
+        const long long orow = rtc * 32 + (lane & 31);
+        const long long smp = orow / a.map_pad;
+        const int n = (int)(orow - smp * a.map_pad);
+        const long long srow = smp * a.map_src + (n < a.map_src ? n : a.map_src - 1);
+        xsrc = a.xp + ((srow >> 5) * KS) * 2 * 64 + ((int)(srow & 31) + 32 * h);
+    }
     f16x8 xa[2], xb[2];  // activation fragments (planes x_h, x_l) of the current / next k-step
     auto x_load = [&](int ks, f16x8 (&x)[2]) {
         ks = ks < KS ? ks : KS - 1;
@@ -430,8 +440,12 @@ extern "C" int s2s_node_linear(const void* xp, const void* w_packed, const float
                                int tiles_per_block, const float* pre_scale, int relu, const float* pre_mask, const float* residual,
                                int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_mask,
                                float* out_f32, int out_ld, int out_col0, void* out_xp, int out_xp_ksteps, int out_xp_kstep0,
-                               int out_xp_format, void* stream) {
+                               int out_xp_format, int map_pad, int map_src, void* stream) {
     if (n_rows <= 0) return 0;
+    // row map (padded output rows): n_rows counts OUTPUT rows; per-row epilogue operands are not mapped
+    if (map_pad < 0 || (map_pad > 0 && (map_src <= 0 || map_src > map_pad || map_pad % 32 || n_rows % map_pad || pre_scale || pre_mask ||
+                                        residual || post_mask)))
+        return (int)hipErrorInvalidValue;
     const int TG = tiles_per_block;
     if (!xp || !w_packed || k_in <= 0 || k_in % 32 || n_out <= 0 || n_out % (32 * TG) || (!out_f32 && !out_xp))
         return (int)hipErrorInvalidValue;
@@ -443,7 +457,7 @@ extern "C" int s2s_node_linear(const void* xp, const void* w_packed, const float
     if (out_xp_format < 0 || out_xp_format > 2) return (int)hipErrorInvalidValue;
     GemmArgs a{(const f16x8*)xp, (const char*)w_packed, bias, pre_scale, pre_mask, residual, ln_gamma, ln_beta, post_mask, out_f32,
                (f16x8*)out_xp, nullptr, 0, n_rows, k_in / 16, ncb, residual_ld, out_ld, out_col0, out_xp_ksteps, out_xp_kstep0, relu, ln_eps,
-               out_xp_format};
+               out_xp_format, map_pad, map_src};
     hipStream_t st = (hipStream_t)stream;
     switch (TG) {
         case 1: return launch_gemm<1>(a, st);
@@ -458,13 +472,15 @@ extern "C" int s2s_node_linear(const void* xp, const void* w_packed, const float
 }
 
 extern "C" int s2s_node_linear_vfrag(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
-                                     int tiles_per_head, void* out_vf, int out_format, void* stream) {
+                                     int tiles_per_head, void* out_vf, int out_format, int map_pad, int map_src, void* stream) {
     if (n_rows <= 0) return 0;
     constexpr int TG = 8;
+    if (map_pad < 0 || (map_pad > 0 && (map_src <= 0 || map_src > map_pad || map_pad % 32 || n_rows % map_pad))) return (int)hipErrorInvalidValue;
     if (!xp || !w_packed || !out_vf || k_in <= 0 || k_in % 32 || n_out <= 0 || n_out % (32 * TG) || tiles_per_head <= 0 ||
         (n_out / 32) % tiles_per_head)
         return (int)hipErrorInvalidValue;
     GemmArgs a{(const f16x8*)xp, (const char*)w_packed, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-               (bf16x8*)out_vf, tiles_per_head, n_rows, k_in / 16, n_out / (32 * TG), 0, 0, 0, 0, 0, 0, 0.f, out_format ? 1 : 0};
+               (bf16x8*)out_vf, tiles_per_head, n_rows, k_in / 16, n_out / (32 * TG), 0, 0, 0, 0, 0, 0, 0.f, out_format ? 1 : 0, map_pad,
+               map_src};
     return launch_gemm_w<TG, 4, true>(a, (hipStream_t)stream);
 }

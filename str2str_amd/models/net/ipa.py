@@ -3,12 +3,16 @@
 Interface, constructor arguments and ``state_dict`` keys follow the reference's
 ``src/models/net/ipa.py`` (InvariantPointAttention :34-268, TranslationIPA :271-387).  Point frames,
 pair projections (linear_b / down_z), logits, softmax, o / o_pt / o_pair are the HIP launches
-``s2s_ipa_prep_points``, ``s2s_pair_project`` (normally fused into the producer of z) and ``s2s_ipa_attention``.
+``s2s_ipa_prep_points_f16``, ``s2s_pair_project`` (normally fused into the producer of z), ``s2s_ipa_attention_f16w`` and
+``s2s_ipa_opair`` -- for every chain length (operands padded per sample to the kernel's 32-residue tiles).  ``S2S_IPA_PATH``
+(read once, at construction) selects the alternatives: ``planes`` = the range-safe three-way bf16 operand kernel (lengths that are
+multiples of 32; others fall through to ``f32``), ``f32`` = the exact fp32-operand kernel (``s2s_ipa_attention``, any length).
 Every dense layer of the node stream (q / kv / point projections, linear_out, skip_embed, the transformer's
 projections and feed-forward, trunk.linear, NodeTransition, BackboneUpdate, the per-node parts of EdgeTransition, the
-torsion head) runs on ``s2s_node_linear`` (csrc/node_gemm.hip: split-bf16 MFMA, activations travelling as packed bf16x3
-planes) with bias / ReLU / mask / residual / LayerNorm fused into its epilogue -- ``TranslationIPA._forward_fused``.
-``S2S_NODE_PATH=blas`` keeps the layer-by-layer torch evaluation (same parameters) for A/B measurements.
+torsion head) runs on ``s2s_node_linear`` (csrc/node_gemm.hip: split-f16 MFMA, activations travelling as packed f16 pair
+planes) with bias / ReLU / mask / residual / LayerNorm fused into its epilogue -- ``TranslationIPA.forward``.
+No BLAS / SDPA call is left in this module (the round-2 layer-by-layer A/B path was removed; tools/node_gemm_bench.py compares
+the GEMM kernel with rocBLAS directly).
 """
 from __future__ import annotations
 
@@ -43,6 +47,9 @@ class InvariantPointAttention(nn.Module):
         self.linear_out = Linear(no_heads * (c_z // 4 + c_hidden + no_v_points * 4), c_s, init="final")
         self.softmax = nn.Softmax(dim=-1)
         self.softplus = nn.Softplus()
+        self.ipa_path = os.environ.get("S2S_IPA_PATH", "f16")   # f16 (default) | planes | f32, fixed at construction
+        if self.ipa_path not in ("f16", "planes", "f32"):
+            raise ValueError(f"S2S_IPA_PATH={self.ipa_path!r}: expected f16, planes or f32")
         self._cache = ParamCache()
         self._packs = ParamCache()
 
@@ -83,27 +90,36 @@ class InvariantPointAttention(nn.Module):
         return self._packs.get([p for lin in (self.linear_q, self.linear_kv, self.linear_q_points, self.linear_kv_points,
                                               self.linear_out) for p in (lin.weight, lin.bias)], build)
 
-    @staticmethod
-    def use_planes(n_res: int, n_rows: int = 0) -> bool:
-        """The pre-split (planes) attention kernel serves lengths that are multiples of its 32-residue tiles (and fragment
-        arrays below 4 GiB: it addresses them through 32-bit buffer offsets)."""
-        return n_res % 32 == 0 and n_rows * 12288 < (1 << 32) and os.environ.get("S2S_IPA_PATH", "f16") != "f32"
+    def use_planes(self, n_res: int, n_rows: int = 0) -> bool:
+        """Does the pre-split operand path serve this call?  The kernels are built for the reference configuration (c_hidden 256,
+        8 / 12 points, c_z/4 = 32, 8 heads) and address their fragment arrays through 32-bit buffer offsets (< 4 GiB); the f16
+        kernel takes any length, the bf16 planes kernel multiples of 32."""
+        if self.ipa_path == "f32" or (self.ipa_path == "planes" and n_res % 32):
+            return False
+        shape_ok = (self.c_hidden == 256 and self.no_qk_points == 8 and self.no_v_points == 12 and self.c_z // 4 == 32
+                    and self.no_heads == 8)
+        rows_pad = (n_rows // max(n_res, 1)) * ops.padded_len(n_res)
+        return shape_ok and rows_pad * 12288 < (1 << 32) and (n_res % 32 == 0 or n_rows * n_res * 32 < (1 << 31))
 
     def attention_planes(self, s_xp, B: int, N: int, r7, mask, pair_proj):
         """Projections -> points -> attention core on pre-split operands.  s_xp: packed planes of s [B*N, c_s].
         -> packed planes of linear_out's input [B*N, H*(c_hidden + 4 Pv + c_z/4)]"""
         w, d, M, H = self.node_packs(), self._derived(), B * N, self.no_heads
-        lin = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], M, x["k"], x["n"], x["tg"], **kw)  # noqa: E731
-        # attention operands: f16 pair planes (S2S_IPA_PATH=f16, default: s2s_ipa_attention_f16, three products per block) or
-        # exact three-way bf16 planes (S2S_IPA_PATH=planes: s2s_ipa_attention_planes, six products)
-        f16 = os.environ.get("S2S_IPA_PATH", "f16") == "f16"
+        f16 = self.ipa_path == "f16"
+        NP = ops.padded_len(N)
+        # a ragged length: the q / k / v operands are produced straight into the per-sample padded row layout of the kernel
+        rmap, Mo = ((NP, N), B * NP) if NP != N else (None, M)
+        lin = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], Mo, x["k"], x["n"], x["tg"], row_map=rmap, **kw)  # noqa: E731
+        # attention operands: f16 pair planes (s2s_ipa_attention_f16w, three products per block) or exact three-way bf16 planes
+        # (S2S_IPA_PATH=planes: s2s_ipa_attention_planes, six products)
         fmt = 0 if f16 else 1
         _, q_xp = lin(w["q"], want_f32=False, want_xp=True, xp_format=fmt)
         _, k_xp = lin(w["k"], want_f32=False, want_xp=True, xp_format=fmt)
-        v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, w["v"]["k"], w["v"]["n"], self.c_hidden // 32, f16=f16)
-        qp, _ = lin(w["qp"])
-        kvp, _ = lin(w["kvp"])
-        pts = ops.ipa_prep_points_planes(r7, qp, kvp, d["hw"], H, self.no_qk_points, self.no_v_points, self.c_hidden, f16=f16)
+        v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], Mo, w["v"]["k"], w["v"]["n"], self.c_hidden // 32, f16=f16,
+                                     row_map=rmap)
+        qp, _ = ops.node_linear(s_xp, w["qp"]["w"], w["qp"]["b"], M, w["qp"]["k"], w["qp"]["n"], w["qp"]["tg"])
+        kvp, _ = ops.node_linear(s_xp, w["kvp"]["w"], w["kvp"]["b"], M, w["kvp"]["k"], w["kvp"]["n"], w["kvp"]["tg"])
+        pts = ops.ipa_prep_points_planes(r7.view(B, N, 7), qp, kvp, d["hw"], H, self.no_qk_points, self.no_v_points, self.c_hidden, f16=f16)
         attn_bias, pair_z = pair_proj
         feats, feats_xp = ops.ipa_attention_planes(q_xp, k_xp, v_vf, pts, attn_bias, pair_z, mask, r7, H, self.c_hidden,
                                                    self.no_qk_points, self.no_v_points, self.c_z // 4, self.inf, self.eps,
@@ -112,6 +128,26 @@ class InvariantPointAttention(nn.Module):
         f2 = feats.view(M, -1)
         ops.pack_planes(f2, col0=c0, n_cols=f2.shape[1] - c0, out=feats_xp, out_k=f2.shape[1], k0=c0)
         return feats_xp
+
+    def attention_f32(self, s_xp, B: int, N: int, r7, mask, pair_proj):
+        """The same on the exact fp32-operand kernel (s2s_ipa_attention: any length, any magnitude) -> packed planes of
+        linear_out's input."""
+        w, d, M, H = self.node_packs(), self._derived(), B * N, self.no_heads
+        lin = lambda x: ops.node_linear(s_xp, x["w"], x["b"], M, x["k"], x["n"], x["tg"])[0]  # noqa: E731
+        q, kv, qp, kvp = lin(w["q"]), lin(w["kv"]), lin(w["qp"]), lin(w["kvp"])
+        q_pts, k_pts, v_pts = ops.ipa_prep_points(r7.view(B, N, 7), qp.view(B, N, -1), kvp.view(B, N, -1), H, self.no_qk_points,
+                                                  self.no_v_points)
+        attn_bias, pair_z = pair_proj
+        feats = ops.ipa_attention(q.view(B, N, H, -1), kv.view(B, N, H, -1), q_pts, k_pts, v_pts, attn_bias, pair_z, mask, r7,
+                                  d["hw"], H, self.c_hidden, self.no_qk_points, self.no_v_points, self.c_z // 4, self.inf,
+                                  self.eps, logits_inplace=True)
+        return ops.pack_planes(feats.view(M, -1))
+
+    def attention(self, s_xp, B: int, N: int, r7, mask, pair_proj):
+        """Attention core of the block on the configured kernel (see the module docstring)."""
+        if self.use_planes(N, B * N):
+            return self.attention_planes(s_xp, B, N, r7, mask, pair_proj)
+        return self.attention_f32(s_xp, B, N, r7, mask, pair_proj)
 
     def pair_proj_weights(self):
         """(packed [linear_b; down_z] weight, bias64, the same matrix as one bf16x3 weight stage): what a pair-stream
@@ -131,59 +167,12 @@ class InvariantPointAttention(nn.Module):
         d = self._derived()
         r7 = (_rigids7 if _rigids7 is not None else r.to_tensor_7()).type(torch.float32).contiguous()
         mask = mask.type(torch.float32).contiguous()
-        if self.use_planes(s.shape[1], s.shape[0] * s.shape[1]) and self.c_hidden == 256:
-            B, N = s.shape[:2]
-            pp = _pair_proj if _pair_proj is not None else ops.pair_project(z.contiguous(), d["wp"], d["b64"])
-            feats_xp = self.attention_planes(ops.pack_planes(s.reshape(B * N, -1).float().contiguous()), B, N, r7, mask, pp)
-            w = self.node_packs()["out"]
-            out, _ = ops.node_linear(feats_xp, w["w"], w["b"], B * N, w["k"], w["n"], w["tg"])
-            return out.view(B, N, -1)
-        q = self.linear_q(s)
-        kv = self.linear_kv(s)
-        q_pts, k_pts, v_pts = ops.ipa_prep_points(r7, self.linear_q_points(s).contiguous(),
-                                                  self.linear_kv_points(s).contiguous(), self.no_heads,
-                                                  self.no_qk_points, self.no_v_points)
-        attn_bias, pair_z = _pair_proj if _pair_proj is not None else ops.pair_project(z.contiguous(), d["wp"], d["b64"])
-        feats = ops.ipa_attention(q.contiguous(), kv.contiguous(), q_pts, k_pts, v_pts, attn_bias, pair_z, mask, r7,
-                                  d["hw"], self.no_heads, self.c_hidden, self.no_qk_points, self.no_v_points,
-                                  self.c_z // 4, self.inf, self.eps, logits_inplace=True)
-        return self.linear_out(feats)
-
-
-def encoder_forward(enc: nn.TransformerEncoder, x: torch.Tensor, key_padding_float: torch.Tensor,
-                    exact_padding: bool = False) -> torch.Tensor:
-    """The 2-layer post-norm ``nn.TransformerEncoder`` of the trunk (reference ipa.py:312-317,357)
-    evaluated with explicit ops on its own parameters.  x is batch-first [B,N,D] here; the FLOAT
-    key-padding mask (1 - node_mask) is ADDED to the logits, as PyTorch does for float masks
-    — a no-op for the all-ones masks of every reference run.  ``exact_padding`` instead removes padded keys
-    (-inf), which is what a mixed-length padded batch needs to reproduce each chain's un-padded run."""
-    B, N, D = x.shape
-    if exact_padding:
-        key_padding_float = torch.where(key_padding_float > 0, float("-inf"), 0.0).to(x.dtype)
-    for layer in enc.layers:
-        att = layer.self_attn
-        h = att.num_heads
-        dh = D // h
-        qkv = F.linear(x, att.in_proj_weight, att.in_proj_bias).view(B, N, 3, h, dh)
-        q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
-        bias = key_padding_float[:, None, None, :].expand(B, h, N, N)
-        sa = F.scaled_dot_product_attention(q, k, v, attn_mask=bias)
-        sa = att.out_proj(sa.transpose(1, 2).reshape(B, N, D))
-        x = layer.norm1(x + sa)
-        ff = layer.linear2(F.relu(layer.linear1(x)))
-        x = layer.norm2(x + ff)
-    return x
-
-
-def encoder_attention(qkv: torch.Tensor, key_padding_float: torch.Tensor, exact_padding: bool = False) -> torch.Tensor:
-    """Self-attention core of one encoder layer on the projected [B,N,3,h,dh] tensor -> [B,N,h*dh] (same mask semantics as
-    ``encoder_forward``)."""
-    B, N = qkv.shape[:2]
-    if exact_padding:
-        key_padding_float = torch.where(key_padding_float > 0, float("-inf"), 0.0).to(qkv.dtype)
-    q, k, v = qkv[:, :, 0].transpose(1, 2), qkv[:, :, 1].transpose(1, 2), qkv[:, :, 2].transpose(1, 2)
-    bias = key_padding_float[:, None, None, :].expand(B, q.shape[1], N, N)
-    return F.scaled_dot_product_attention(q, k, v, attn_mask=bias).transpose(1, 2).reshape(B, N, -1).contiguous()
+        B, N = s.shape[:2]
+        pp = _pair_proj if _pair_proj is not None else ops.pair_project(z.contiguous(), d["wp"], d["b64"])
+        feats_xp = self.attention(ops.pack_planes(s.reshape(B * N, -1).float().contiguous()), B, N, r7, mask, pp)
+        w = self.node_packs()["out"]
+        out, _ = ops.node_linear(feats_xp, w["w"], w["b"], B * N, w["k"], w["n"], w["tg"])
+        return out.view(B, N, -1)
 
 
 class TranslationIPA(nn.Module):
@@ -214,7 +203,11 @@ class TranslationIPA(nn.Module):
                                                                     edge_embed_out=c_z)
         self.torsion_pred = TorsionAngleHead(c_s, 1)
         self._wcache = ParamCache()
-        self.exact_padding = False  # see encoder_forward; set by the mixed-length sampler
+        # Padding semantics of the encoder layers.  False = the reference's: the FLOAT key-padding mask (1 - node_mask) is ADDED to
+        # the logits, as PyTorch does for float masks -- a no-op for the all-ones masks of every reference
+        # run.  True (set by the mixed-length sampler) removes padded keys (-inf), which is what a padded batch needs to
+        # reproduce each chain's un-padded run.
+        self.exact_padding = False
         self.fuse_pair_projection = True  # producers of z also emit the next IPA block's linear_b / down_z
 
     # ------------------------------------------------------------------ packed weights of the fused node path
@@ -261,11 +254,6 @@ class TranslationIPA(nn.Module):
         """reference :331-387.  Frames travel as one [B,N,7] tensor between the fused kernels."""
         if not node_embed.is_cuda:
             raise ops.HipLibraryError("TranslationIPA runs on the HIP device only (no CPU fallback)")
-        if os.environ.get("S2S_NODE_PATH", "fused") == "blas":
-            return self._forward_blas(node_embed, edge_embed, batch, _first_proj)
-        return self._forward_fused(node_embed, edge_embed, batch, _first_proj)
-
-    def _forward_fused(self, node_embed, edge_embed, batch, _first_proj=None) -> dict:
         T, W = self.trunk, self._node_weights()
         B, N, C = node_embed.shape
         M = B * N
@@ -296,19 +284,7 @@ class TranslationIPA(nn.Module):
             # ---- InvariantPointAttention (:100-268): projections -> points -> attention core -> linear_out (+mask, +residual, LN)
             attn_bias, pair_z = proj if proj is not None else ops.pair_project(edge_embed.contiguous(), d["wp"], d["b64"])
             proj = None
-            if ipa.use_planes(N, M):
-                feats_xp = ipa.attention_planes(s_xp, B, N, curr7, node_mask, (attn_bias, pair_z))
-            else:
-                q, _ = lin(s_xp, w["q"])
-                kv, _ = lin(s_xp, w["kv"])
-                qp, _ = lin(s_xp, w["qp"])
-                kvp, _ = lin(s_xp, w["kvp"])
-                q_pts, k_pts, v_pts = ops.ipa_prep_points(curr7, qp.view(B, N, -1), kvp.view(B, N, -1), ipa.no_heads,
-                                                          ipa.no_qk_points, ipa.no_v_points)
-                feats = ops.ipa_attention(q.view(B, N, ipa.no_heads, -1), kv.view(B, N, ipa.no_heads, -1), q_pts, k_pts, v_pts,
-                                          attn_bias, pair_z, node_mask, curr7, d["hw"], ipa.no_heads, ipa.c_hidden,
-                                          ipa.no_qk_points, ipa.no_v_points, ipa.c_z // 4, ipa.inf, ipa.eps, logits_inplace=True)
-                feats_xp = ops.pack_planes(feats.view(M, -1))
+            feats_xp = ipa.attention(s_xp, B, N, curr7, node_mask, (attn_bias, pair_z))
             ln = T[f"ipa_ln_{b}"]
             x_f32 = torch.empty(M, D, device=dev, dtype=torch.float32)     # [node_embed | skip_embed(init)] (:356)
             x_xp = ops.xp_alloc(M, D, dev)
@@ -347,43 +323,6 @@ class TranslationIPA(nn.Module):
         _, t2 = lin(t1, wt["l2"], residual=s_f32, want_f32=False, want_xp=True)
         u = lin(t2, wt["fin"])[0][:, :2].reshape(B, N, 2)
         psi = u / torch.sqrt(torch.clamp(torch.sum(u**2, dim=-1, keepdim=True), min=self.torsion_pred.eps))
-        out7 = ops.rigid_scale_trans(curr7, self.coordinate_scaling, divide=True)
-        return {
-            "in_rigids": Rigid.from_tensor_7(init7),
-            "out_rigids": Rigid(Rotation(quats=out7[..., :4], normalize_quats=False), out7[..., 4:]),
-            "out_rigids7": out7,
-            "psi": psi,
-        }
-
-    def _forward_blas(self, node_embed: torch.Tensor, edge_embed: torch.Tensor, batch: dict, _first_proj=None) -> dict:
-        """Layer-by-layer evaluation with torch's dense ops (rocBLAS fp32) on the same parameters: the A/B baseline."""
-        T = self.trunk
-        node_mask = batch["residue_mask"].type(torch.float).contiguous()
-        diffuse_mask = ((1 - batch["fixed_mask"].type(torch.float)) * node_mask).contiguous()
-        init7 = batch["rigids_t"].type(torch.float).contiguous()
-        curr7 = ops.rigid_scale_trans(init7, self.coordinate_scaling, divide=False)
-        init_node = node_embed
-        pad = 1.0 - node_mask
-        proj = _first_proj
-        for b in range(self.num_blocks):
-            ipa_embed = T[f"ipa_{b}"](node_embed, edge_embed, None, node_mask, _rigids7=curr7, _pair_proj=proj)
-            proj = None
-            ipa_embed = ipa_embed * node_mask[..., None]
-            node_embed = T[f"ipa_ln_{b}"](node_embed + ipa_embed)
-            cat = torch.cat([node_embed, T[f"skip_embed_{b}"](init_node)], dim=-1)
-            tr = encoder_forward(T[f"transformer_{b}"], cat, pad, self.exact_padding)
-            node_embed = node_embed + T[f"linear_{b}"](tr)
-            node_embed = T[f"node_transition_{b}"](node_embed)
-            node_embed = node_embed * node_mask[..., None]
-            upd = T[f"bb_update_{b}"](node_embed * diffuse_mask[..., None]).contiguous()
-            curr7 = ops.rigid_compose_update(curr7, upd, diffuse_mask)
-            if b < self.num_blocks - 1:
-                if self.fuse_pair_projection:
-                    edge_embed, *proj = T[f"edge_transition_{b}"](node_embed, edge_embed, edge_mask_1d=node_mask,
-                                                                 next_proj=T[f"ipa_{b + 1}"].pair_proj_weights())
-                else:
-                    edge_embed = T[f"edge_transition_{b}"](node_embed, edge_embed, edge_mask_1d=node_mask)
-        psi = self.torsion_pred(node_embed)
         out7 = ops.rigid_scale_trans(curr7, self.coordinate_scaling, divide=True)
         return {
             "in_rigids": Rigid.from_tensor_7(init7),

@@ -70,6 +70,10 @@ class ParamCache:
             self._key = key
         return self._val
 
+    def pinned(self):
+        """The cached value (a captured HIP graph keeps it alive beyond the next rebuild; sampler._GraphedNet)."""
+        return self._val
+
 
 class NodeTransition(nn.Module):
     def __init__(self, dim: int):

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _lib = None
 _tables_loaded = False
@@ -34,11 +34,10 @@ _SIGNATURES = {
     "s2s_pair_project": [_vp] * 5 + [_i, _i, _vp],
     "s2s_ipa_prep_points": [_vp] * 6 + [_ll, _i, _i, _i, _i, _vp],
     "s2s_ipa_attention": [_vp] * 12 + [_i, _i, _i, _i, _i, _i, _i, _f, _f, _vp],
-    "s2s_ipa_opair": [_vp] * 4 + [_i, _i, _i, _i, _i, _i, _vp],
+    "s2s_ipa_opair": [_vp] * 4 + [_i, _i, _i, _i, _i, _i, _i, _vp],
     "s2s_ipa_prep_points_planes": [_vp] * 9 + [_ll, _i, _i, _i, _i, _vp],
     "s2s_ipa_attention_planes": [_vp] * 15 + [_i] * 8 + [_f, _f, _vp],
-    "s2s_ipa_prep_points_f16": [_vp] * 9 + [_ll, _i, _i, _i, _i, _vp],
-    "s2s_ipa_attention_f16": [_vp] * 15 + [_i] * 8 + [_f, _f, _vp],
+    "s2s_ipa_prep_points_f16": [_vp] * 9 + [_i, _i, _i, _i, _i, _i, _vp],
     "s2s_ipa_attention_f16w": [_vp] * 15 + [_i] * 8 + [_f, _f, _vp],
     "s2s_rigid_compose_update": [_vp] * 4 + [_ll, _vp],
     "s2s_rigid_scale_trans": [_vp, _vp, _ll, _f, _i, _vp],
@@ -47,8 +46,8 @@ _SIGNATURES = {
     "s2s_se3_step": [_vp] * 12 + [_i, _i, _d, _d, _i, _i, _d, _vp],
     "s2s_forward_marginal": [_vp] * 7 + [_i, _vp, _vp, _f, _vp, _i, _i, _vp],
     "s2s_pack_planes": [_vp, _ll, _i, _i, _i, _vp, _i, _i, _vp, _vp],
-    "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
-    "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp],
+    "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _i, _i, _vp],
     "s2s_encoder_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "s2s_ca_sample_stats": [_vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
     "s2s_ca_pwd_js": [_vp, _i, _vp, _i, _i, _i, _i, _d, _vp, _vp],
@@ -480,21 +479,31 @@ def ipa_attention(q, kv, q_pts, k_pts, v_pts, attn_bias, pair_z, mask, rigids7, 
         if rc:
             return rc
         return lib.s2s_ipa_opair(_p(logits), _p(stats), _p(pair_z), _p(out), B, N, n_heads, c_pz, feat,
-                                 n_heads * (c_hidden + 4 * n_v), _stream())
+                                 n_heads * (c_hidden + 4 * n_v), N, _stream())
 
     _check(_timed("s2s_ipa_attention", launch), "s2s_ipa_attention/s2s_ipa_opair")
     return out
 
 
+def padded_len(n_res: int) -> int:
+    """n_res rounded up to the attention kernels' 32-residue tiles."""
+    return (n_res + 31) // 32 * 32
+
+
 def ipa_prep_points_planes(rigids7, q_pts_lin, kv_pts_lin, head_w_scaled, n_heads=8, n_qk=8, n_v=12, c_hidden=256, f16=False):
-    """Global-frame points of a block as MFMA fragments + the squared-norm terms of the logits (s2s_ipa_prep_points_planes, or
-    s2s_ipa_prep_points_f16 with two f16 planes per fragment group).  B*N must be a multiple of 32.  -> (qp_xp, kp_xp, vp_vf, q2, k2)"""
+    """Global-frame points of a block as MFMA fragments + the squared-norm terms of the logits.  ``f16`` (default path,
+    s2s_ipa_prep_points_f16): two f16 planes per fragment group, ANY n_res -- the arrays hold padded_len(n_res) rows per sample
+    (padded rows: zero points, k2 = -1e9).  Otherwise s2s_ipa_prep_points_planes (three bf16 planes; B*N a multiple of 32).
+    rigids7 [B,N,7].  -> (qp_xp, kp_xp, vp_vf, q2, k2)"""
     lib = load_library()
     _req(rigids7, name="rigids7"); _req(q_pts_lin, name="q_pts_lin"); _req(kv_pts_lin, name="kv_pts_lin")
     _req(head_w_scaled, name="head_w")
-    M = rigids7.numel() // 7
+    if rigids7.ndim != 3:
+        raise HipLibraryError("ipa_prep_points_planes: rigids7 must be [B,N,7]")
+    B, N = rigids7.shape[:2]
+    M = B * (padded_len(N) if f16 else N)
     if M % 32:
-        raise HipLibraryError("ipa_prep_points_planes: the number of frames must be a multiple of 32")
+        raise HipLibraryError("ipa_prep_points_planes: the number of frames must be a multiple of 32 (bf16 planes kernel)")
     dev, rt = rigids7.device, M // 32
     npl = 2 if f16 else 3
     qp = torch.empty(rt * n_heads * 2 * npl * 64 * 8, dtype=torch.int16, device=dev)
@@ -502,17 +511,23 @@ def ipa_prep_points_planes(rigids7, q_pts_lin, kv_pts_lin, head_w_scaled, n_head
     vp = torch.empty(rt * n_heads * 4 * npl * 64 * 8, dtype=torch.int16, device=dev)
     q2 = torch.empty(rt, n_heads, 32, dtype=torch.float32, device=dev)
     k2 = torch.empty_like(q2)
-    fn = lib.s2s_ipa_prep_points_f16 if f16 else lib.s2s_ipa_prep_points_planes
-    _check(fn(_p(rigids7), _p(q_pts_lin), _p(kv_pts_lin), _p(head_w_scaled), _p(qp), _p(kp), _p(vp), _p(q2), _p(k2), M, n_heads, n_qk,
-              n_v, c_hidden, _stream()), "s2s_ipa_prep_points_planes/_f16")
+    if f16:
+        rc = lib.s2s_ipa_prep_points_f16(_p(rigids7), _p(q_pts_lin), _p(kv_pts_lin), _p(head_w_scaled), _p(qp), _p(kp), _p(vp), _p(q2),
+                                         _p(k2), B, N, n_heads, n_qk, n_v, c_hidden, _stream())
+    else:
+        rc = lib.s2s_ipa_prep_points_planes(_p(rigids7), _p(q_pts_lin), _p(kv_pts_lin), _p(head_w_scaled), _p(qp), _p(kp), _p(vp),
+                                            _p(q2), _p(k2), M, n_heads, n_qk, n_v, c_hidden, _stream())
+    _check(rc, "s2s_ipa_prep_points_planes/_f16")
     return qp, kp, vp, q2, k2
 
 
 def ipa_attention_planes(q_xp, k_xp, v_vf, points, attn_bias, pair_z, mask, rigids7, n_heads=8, c_hidden=256, n_qk=8, n_v=12,
                          c_pz=32, inf=1e5, eps=1e-8, logits_inplace=False, f16=False):
-    """Attention core on pre-split operands + pair term (n_res % 32 == 0).  ``points`` = ipa_prep_points_planes(...).
-    ``f16``: every operand as f16 pair planes (s2s_ipa_attention_f16; q/k from node_linear(xp_format=2), v from
-    node_linear_vfrag(f16=True), points from ipa_prep_points_planes(f16=True)) instead of three-way bf16 planes.
+    """Attention core on pre-split operands + pair term.  ``points`` = ipa_prep_points_planes(...).
+    ``f16`` (default path, s2s_ipa_attention_f16w): every operand as f16 pair planes, ANY n_res -- for a ragged length the operand
+    arrays hold padded_len(n_res) rows per sample (q/k from node_linear(xp_format=2, row_map=...), v from
+    node_linear_vfrag(f16=True, row_map=...)) and the logits get their own padded buffer.  Otherwise the range-safe three-way bf16
+    planes kernel (s2s_ipa_attention_planes, n_res % 32 == 0).
     -> (feats fp32 [B,N,feat] with the o_pt / o_pair columns valid, feats_xp packed planes with the o columns valid); the
     caller packs columns H*c_hidden.. of ``feats`` into ``feats_xp`` (ops.pack_planes) to complete linear_out's input."""
     lib = load_library()
@@ -522,29 +537,34 @@ def ipa_attention_planes(q_xp, k_xp, v_vf, points, attn_bias, pair_z, mask, rigi
         _req(t, name=n)
     for n, t in (("q_xp", q_xp), ("k_xp", k_xp), ("v_vf", v_vf), ("qp_xp", qp), ("kp_xp", kp), ("vp_vf", vp)):
         _req(t, torch.int16, n)
-    if N % 32:
-        raise HipLibraryError("ipa_attention_planes: n_res must be a multiple of 32 (use ipa_attention)")
+    NP = padded_len(N)
+    if N % 32 and not f16:
+        raise HipLibraryError("ipa_attention_planes: the bf16 planes kernel needs n_res % 32 == 0 (use ipa_attention)")
     if attn_bias.shape != (B, n_heads, N, N) or pair_z.shape != (B, N, N, c_pz):
         raise HipLibraryError("ipa_attention_planes: attn_bias must be [B,H,N,N] and pair_z [B,N,N,c_pz]")
+    npl = 2 if f16 else 3
+    if q_xp.numel() != B * NP * n_heads * c_hidden * npl or v_vf.numel() != q_xp.numel() or q2.numel() != B * NP * n_heads:
+        raise HipLibraryError("ipa_attention_planes: operand arrays do not hold padded_len(n_res) rows per sample")
     feat = n_heads * (c_hidden + 4 * n_v + c_pz)
     out = torch.empty(B, N, feat, device=mask.device, dtype=torch.float32)
     out_xp = xp_alloc(B * N, feat, mask.device)
-    logits = attn_bias if logits_inplace else torch.empty_like(attn_bias)
+    if NP != N:
+        logits = torch.empty(B, n_heads, NP, NP, device=mask.device, dtype=torch.float32)
+    else:
+        logits = attn_bias if logits_inplace else torch.empty_like(attn_bias)
     stats = torch.empty(B, n_heads, N, 2, device=mask.device, dtype=torch.float32)
+    name = "s2s_ipa_attention_f16w" if f16 else "s2s_ipa_attention_planes"
 
     def launch():
-        if f16:   # S2S_IPA_KERNEL=pair: the wave-pair kernel (s2s_ipa_attention_f16) instead of one wave per query tile
-            fn = lib.s2s_ipa_attention_f16 if os.environ.get("S2S_IPA_KERNEL", "wave") == "pair" else lib.s2s_ipa_attention_f16w
-        else:
-            fn = lib.s2s_ipa_attention_planes
+        fn = lib.s2s_ipa_attention_f16w if f16 else lib.s2s_ipa_attention_planes
         rc = fn(_p(q_xp), _p(k_xp), _p(v_vf), _p(qp), _p(kp), _p(vp), _p(q2), _p(k2), _p(attn_bias), _p(logits), _p(stats), _p(mask),
                 _p(rigids7), _p(out), _p(out_xp), feat // 16, B, N, n_heads, c_hidden, n_qk, n_v, c_pz, inf, eps, _stream())
         if rc:
             return rc
         return lib.s2s_ipa_opair(_p(logits), _p(stats), _p(pair_z), _p(out), B, N, n_heads, c_pz, feat,
-                                 n_heads * (c_hidden + 4 * n_v), _stream())
+                                 n_heads * (c_hidden + 4 * n_v), NP, _stream())
 
-    _check(_timed("s2s_ipa_attention", launch), "s2s_ipa_attention_planes/s2s_ipa_opair")
+    _check(_timed("s2s_ipa_attention", launch), name + "/s2s_ipa_opair")
     return out, out_xp
 
 
@@ -705,20 +725,25 @@ def pack_planes(x2d: torch.Tensor, col0: int = 0, n_cols: Optional[int] = None, 
 
 def node_linear(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles: int, *, pre_scale=None, relu=False, pre_mask=None,
                 residual=None, ln=None, post_mask=None, out_f32=None, out_col0: int = 0, want_f32=True, out_xp=None,
-                out_xp_k: Optional[int] = None, out_xp_k0: int = 0, want_xp=False, xp_bf16=False, xp_format: Optional[int] = None):
+                out_xp_k: Optional[int] = None, out_xp_k0: int = 0, want_xp=False, xp_bf16=False, xp_format: Optional[int] = None,
+                row_map: Optional[tuple] = None):
     """One fused per-node layer (s2s_node_linear).  ``residual`` [n_rows, ld] fp32 (its leading n_out columns are added);
     ``ln`` = (gamma, beta, eps); ``out_f32`` a preallocated [n_rows, ld] buffer written at ``out_col0`` (allocated
     [n_rows, n_out] when ``want_f32``); ``out_xp`` likewise for the packed planes (``xp_bf16``: as exact three-way bf16 planes,
     the operand format of the bf16 attention kernel, instead of the f16 pair planes the node stream and the f16 attention kernel
-    take).  -> (out_f32 or None, out_xp or None)."""
+    take).  ``row_map`` = (n_pad, n_src): ``n_rows`` counts OUTPUT rows = samples * n_pad, output row (sample, n) is computed from
+    input row sample * n_src + min(n, n_src - 1) (per-sample padding to whole 32-row tiles for the attention kernel).
+    -> (out_f32 or None, out_xp or None)."""
     lib = load_library()
     _req(xp, torch.int16, "xp"); _req(wpk, torch.int16, "w_packed")
     dev = xp.device
+    map_pad, map_src = row_map if row_map is not None else (0, 0)
+    in_rows = n_rows // map_pad * map_src if map_pad else n_rows
     for n, t in (("bias", bias), ("pre_scale", pre_scale), ("pre_mask", pre_mask), ("residual", residual), ("post_mask", post_mask)):
         if t is not None:
             _req(t, name=n)
-    if xp.numel() != ((n_rows + 31) // 32) * (k_in // 16) * 1024 or wpk.numel() != n_out * k_in * 2:
-        raise HipLibraryError(f"node_linear: operand sizes do not match M={n_rows} K={k_in} N={n_out}")
+    if xp.numel() != ((in_rows + 31) // 32) * (k_in // 16) * 1024 or wpk.numel() != n_out * k_in * 2:
+        raise HipLibraryError(f"node_linear: operand sizes do not match M={in_rows} K={k_in} N={n_out}")
     if out_f32 is None and want_f32:
         out_f32 = torch.empty(n_rows, n_out, device=dev, dtype=torch.float32)
     if out_f32 is not None:
@@ -738,11 +763,12 @@ def node_linear(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles: int, *
         _p(xp), _p(wpk), _p(bias), n_rows, k_in, n_out, tiles, _p(pre_scale), int(bool(relu)), _p(pre_mask), _p(residual),
         residual.shape[-1] if residual is not None else 0, _p(g), _p(b), float(eps), _p(post_mask), _p(out_f32),
         out_f32.shape[-1] if out_f32 is not None else 0, out_col0, _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16,
-        fmt, _stream())), "s2s_node_linear")
+        fmt, map_pad, map_src, _stream())), "s2s_node_linear")
     return out_f32, out_xp
 
 
-def node_linear_vfrag(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles_per_head: int = 8, out=None, f16: bool = False):
+def node_linear_vfrag(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles_per_head: int = 8, out=None, f16: bool = False,
+                      row_map: Optional[tuple] = None):
     """Projection stored as bf16x3 A fragments over 32-row tiles (s2s_node_linear_vfrag; the value projection of the IPA).
     -> int16 buffer [row tiles][heads][tiles_per_head][2][3][64][8]."""
     lib = load_library()
@@ -753,8 +779,10 @@ def node_linear_vfrag(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles_p
     if out is None:
         out = torch.empty(n_el, dtype=torch.int16, device=xp.device)
     _req(out, torch.int16, "out_vf")
+    map_pad, map_src = row_map if row_map is not None else (0, 0)
     _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_vfrag(_p(xp), _p(wpk), _p(bias), n_rows, k_in, n_out, tiles_per_head,
-                                                                       _p(out), int(bool(f16)), _stream())), "s2s_node_linear_vfrag")
+                                                                       _p(out), int(bool(f16)), map_pad, map_src, _stream())),
+           "s2s_node_linear_vfrag")
     return out
 
 

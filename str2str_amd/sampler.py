@@ -29,10 +29,10 @@ from .common.rigid_utils import Rigid
 
 _REPEAT_KEYS = ("aatype", "residue_mask", "fixed_mask", "residue_idx", "torsion_angles_sin_cos")
 _log = logging.getLogger("str2str_amd.sampler")
-# A network evaluation is ~330 kernel launches.  For tiny chunks (<= 64 Ki pairs, e.g. 64 replicas of a 20-residue peptide) the
-# GPU finishes them faster than the host can issue them, so the evaluation is captured once into a HIP graph and replayed
-# every step: 1.7x there, bit-identical output; larger chunks are GPU-bound (the host already runs ahead) and capture would
-# only add its three warm-up evaluations (measured 0.92-0.97x).  S2S_HIP_GRAPH=0 / 1 forces eager / graph.
+# A network evaluation is ~165 kernel launches (profiles/r02m_eval_sequence.md).  For tiny chunks (<= 64 Ki pairs, e.g. 64 replicas
+# of a 20-residue peptide) the GPU finishes them faster than the host can issue them, so the evaluation is captured once into a
+# HIP graph and replayed every step: 1.7x there, bit-identical output; larger chunks are GPU-bound (the host already runs ahead)
+# and capture would only add its three warm-up evaluations (measured 0.92-0.97x).  S2S_HIP_GRAPH=0 / 1 forces eager / graph.
 _GRAPH_MAX_PAIRS = 1 << 16
 _GRAPH_MIN_STEPS = 16
 
@@ -53,12 +53,44 @@ class _GraphedNet:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = net(self.feats, as_tensor_7=False)
+        # The captured kernels hold raw pointers to every tensor the evaluation read.  Those allocated INSIDE the capture live in the
+        # graph's private pool; the ones built by the warm-up outside it must be kept alive by THIS object, because their only other
+        # owner is a single-slot cache that the next evaluation of another shape overwrites: the embedder's per-target tables
+        # (relative-position table, its column-blocked copy, positional node image, device residue indices) and the packed /
+        # derived weights of the modules' parameter caches.
+        self._pinned = _graph_read_tensors(net)
 
     def __call__(self, feats):
         for k in ("rigids_t", "sc_ca_t", "t_emb"):
             self.feats[k].copy_(feats[k])
         self.graph.replay()
         return self.out
+
+
+def _graph_read_tensors(net):
+    """Every tensor held by a replaceable cache slot of the network's modules (index tables of the embedder, ParamCache entries)."""
+    from .models.net.layers import ParamCache
+
+    def tensors(x, out):
+        if torch.is_tensor(x):
+            out.append(x)
+        elif isinstance(x, dict):
+            for v in x.values():
+                tensors(v, out)
+        elif isinstance(x, (list, tuple)):
+            for v in x:
+                tensors(v, out)
+        return out
+
+    keep = []
+    for m in net.modules():
+        for name in ("_idx_val", "_rel_cb", "_idx_src", "node_embed_xp"):
+            if hasattr(m, name):
+                tensors(getattr(m, name), keep)
+        for v in vars(m).values():
+            if isinstance(v, ParamCache):
+                tensors(v.pinned(), keep)
+    return keep
 
 
 _GRAPH_CACHE = {}   # (net id, parameter versions, b, N, feature bytes) -> _GraphedNet; a few entries (one per chunk shape)
@@ -75,9 +107,10 @@ def _graph_key(net, feats, b, N):
             continue  # per-step inputs are copied into the static buffers at every replay
         h.update(k.encode()); h.update(str(tuple(v.shape)).encode()); h.update(v.detach().cpu().numpy().tobytes())
     tr = getattr(net, "translator", None)
-    modes = tuple(sorted({getattr(m, "mfma_mode") for m in net.modules() if hasattr(m, "mfma_mode")}))  # which kernels were captured
-    return (id(net), sum(p._version for p in net.parameters()), b, N, bool(getattr(tr, "exact_padding", False)), modes,
-            os.environ.get("S2S_IPA_PATH", "f16"), h.hexdigest())
+    # which kernels were captured: the arithmetic / kernel selectors of the modules
+    modes = tuple(sorted({(a, str(getattr(m, a))) for m in net.modules() for a in ("mfma_mode", "ipa_path", "range_safe") if hasattr(m, a)}))
+    return (id(net), sum(p._version for p in net.parameters()), b, N, bool(getattr(tr, "exact_padding", False)),
+            bool(getattr(tr, "fuse_pair_projection", False)), modes, h.hexdigest())
 
 
 def _maybe_graph(net, feats, b, N, trace, n_steps):

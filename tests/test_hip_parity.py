@@ -291,18 +291,8 @@ def test_ipa_golden(net_rough):
     check(f"{_test_name()}: rel err", rel(out.cpu().numpy()[valid], g["out"][valid]), 2e-5)
 
 
-# N % 32 == 0 runs the planes kernel (csrc/ipa_attention_planes.hip): 32 / 64 = one / two key tiles (the short-stream paths of the
-# two-phase pipeline), 96 = odd tile count (a wave pair without a tile of its own),
-# 256 / 512 = the BASELINE lengths, (3, 64) = several work items per persistent workgroup chain; the other lengths run the
-# fp32-operand kernel (N = 300: ragged last tile, three query blocks, two chunks in s2s_ipa_opair)
-@pytest.mark.parametrize("B,N", [(1, 7), (2, 32), (2, 40), (1, 96), (3, 64), (1, 256), (1, 300), (1, 512)])
-def test_ipa_vs_oracle(net_rough, B, N):
-    from oracle import geometry as OG
-    from oracle import net as ON
-    from str2str_amd.common.rigid_utils import Rigid
-
-    sd = synth_sd(0, 0.02)
-    g = torch.Generator().manual_seed(200 + N)
+def _ipa_case(B, N, seed_off=200):
+    g = torch.Generator().manual_seed(seed_off + N)
     s = torch.randn(B, N, 256, generator=g)
     z = torch.randn(B, N, N, 128, generator=g)
     q = torch.randn(B, N, 4, generator=g)
@@ -310,23 +300,78 @@ def test_ipa_vs_oracle(net_rough, B, N):
     mask = torch.ones(B, N)
     if N > 8:
         mask[-1, -3:] = 0
+    return s, z, r7, mask
+
+
+class _ipa_path:
+    """Run a block on another attention kernel (InvariantPointAttention.ipa_path is fixed at construction from S2S_IPA_PATH)."""
+
+    def __init__(self, net, path):
+        self.mods = [m for m in net.modules() if hasattr(m, "ipa_path")]
+        self.path = path
+
+    def __enter__(self):
+        self.prev = [m.ipa_path for m in self.mods]
+        for m in self.mods:
+            m.ipa_path = self.path
+
+    def __exit__(self, *exc):
+        for m, v in zip(self.mods, self.prev):
+            m.ipa_path = v
+
+
+# Every length runs the default f16 kernel (csrc/ipa_attention_f16w.hip).  32 / 64 = one / two key tiles (the short-stream paths of
+# the two-phase pipeline), 96 = odd tile count (a wave without a tile of its own), 256 / 512 = the BASELINE lengths, (3, 64) =
+# several work items per persistent workgroup chain; 7 / 37 / 40 / 73 / 300 = ragged lengths (operands padded per sample to whole
+# tiles: a single partial tile, a partial second tile, samples whose rows straddle row tiles of the flat [B N] layout, three query
+# blocks + two chunks in s2s_ipa_opair)
+@pytest.mark.parametrize("B,N", [(1, 7), (2, 32), (3, 37), (2, 40), (2, 73), (1, 96), (3, 64), (1, 256), (1, 300), (1, 512)])
+def test_ipa_vs_oracle(net_rough, B, N):
+    from oracle import geometry as OG
+    from oracle import net as ON
+    from str2str_amd.common.rigid_utils import Rigid
+
+    sd = synth_sd(0, 0.02)
+    s, z, r7, mask = _ipa_case(B, N)
     ref = ON.ipa(sd, "translator.trunk.ipa_2", s, z, OG.Frames.from_tensor_7(r7), mask)
-    out = net_rough.translator.trunk["ipa_2"](s.to(DEV), z.to(DEV), Rigid.from_tensor_7(r7.to(DEV)), mask.to(DEV))
+    ipa = net_rough.translator.trunk["ipa_2"]
+    assert ipa.ipa_path == "f16" and ipa.use_planes(N, B * N)
+    out = ipa(s.to(DEV), z.to(DEV), Rigid.from_tensor_7(r7.to(DEV)), mask.to(DEV))
     valid = mask.bool().numpy()
     check(f"{_test_name()}: rel err", rel(out.cpu().numpy()[valid], ref.numpy()[valid]), 2e-5)
 
 
-@pytest.mark.parametrize("f16,kern", [(True, "wave"), (True, "pair"), (False, "pair")], ids=["f16w", "f16pair", "bf16"])
-def test_ipa_planes_kernel_matches_fp32_operand_kernel(net_rough, f16, kern, monkeypatch):
-    """The two attention paths side by side on the same inputs (ops level, through the C ABI): s2s_ipa_attention_planes on operands
-    pre-split by the GEMM epilogues / the point kernel vs s2s_ipa_attention on the fp32 projections -- o (decoded from the packed
-    planes), o_pt and o_pair columns.  Several work items per persistent workgroup chain (B x H x N/64 = 48 items)."""
+@pytest.mark.parametrize("path,B,N", [("f32", 2, 40), ("f32", 1, 300), ("f32", 3, 64), ("planes", 1, 96), ("planes", 3, 64)])
+def test_ipa_alternative_kernels_vs_oracle(net_rough, path, B, N):
+    """The exact fp32-operand kernel (any length) and the range-safe bf16 planes kernel (multiples of 32) against the oracle."""
+    from oracle import geometry as OG
+    from oracle import net as ON
+    from str2str_amd.common.rigid_utils import Rigid
+
+    sd = synth_sd(0, 0.02)
+    s, z, r7, mask = _ipa_case(B, N)
+    ref = ON.ipa(sd, "translator.trunk.ipa_2", s, z, OG.Frames.from_tensor_7(r7), mask)
+    ipa = net_rough.translator.trunk["ipa_2"]
+    with _ipa_path(net_rough, path):
+        assert ipa.use_planes(N, B * N) == (path == "planes")
+        out = ipa(s.to(DEV), z.to(DEV), Rigid.from_tensor_7(r7.to(DEV)), mask.to(DEV))
+    valid = mask.bool().numpy()
+    check(f"{_test_name()}: rel err", rel(out.cpu().numpy()[valid], ref.numpy()[valid]), 2e-5)
+
+
+@pytest.mark.parametrize("f16,N", [(True, 64), (True, 75), (True, 20), (False, 64)], ids=["f16w", "f16w-ragged75", "f16w-ragged20", "bf16"])
+def test_ipa_planes_kernel_matches_fp32_operand_kernel(net_rough, f16, N):
+    """The attention paths side by side on the same inputs (ops level, through the C ABI): the pre-split operand kernels
+    (s2s_ipa_attention_f16w / s2s_ipa_attention_planes, operands from the GEMM epilogues / the point kernel; ragged lengths through
+    the per-sample padded row map) vs s2s_ipa_attention on the fp32 projections -- o (decoded from the packed planes), o_pt and
+    o_pair columns.  Several work items per persistent workgroup chain."""
     from str2str_amd import ops
 
-    monkeypatch.setenv("S2S_IPA_KERNEL", kern)   # f16 operands: one wave per query tile (default) or the wave-pair kernel
     ipa = net_rough.translator.trunk["ipa_1"]
-    B, N, H = 3, 64, 8
+    B, H = 3, 8
     M = B * N
+    NP = ops.padded_len(N)
+    rmap, Mo = ((NP, N), B * NP) if NP != N else (None, M)
     g = torch.Generator().manual_seed(11)
     s = torch.randn(M, 256, generator=g).to(DEV)
     q4 = torch.randn(B, N, 4, generator=g)
@@ -340,14 +385,17 @@ def test_ipa_planes_kernel_matches_fp32_operand_kernel(net_rough, f16, kern, mon
         w, d = ipa.node_packs(), ipa._derived()
         s_xp = ops.pack_planes(s)
         lin = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], M, x["k"], x["n"], x["tg"], **kw)  # noqa: E731
+        linp = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], Mo, x["k"], x["n"], x["tg"], row_map=rmap, **kw)  # noqa: E731
         fmt = 2 if f16 else 1
-        _, q_xp = lin(w["q"], want_f32=False, want_xp=True, xp_format=fmt)
-        _, k_xp = lin(w["k"], want_f32=False, want_xp=True, xp_format=fmt)
-        v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, 256, 2048, 8, f16=f16)
+        _, q_xp = linp(w["q"], want_f32=False, want_xp=True, xp_format=fmt)
+        _, k_xp = linp(w["k"], want_f32=False, want_xp=True, xp_format=fmt)
+        v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], Mo, 256, 2048, 8, f16=f16, row_map=rmap)
         qp, _ = lin(w["qp"])
         kvp, _ = lin(w["kvp"])
         pts = ops.ipa_prep_points_planes(r7, qp, kvp, d["hw"], f16=f16)
-        feats, fxp = ops.ipa_attention_planes(q_xp, k_xp, v_vf, pts, bias, pz, mask, r7, f16=f16)
+        bias_in = bias.clone()
+        feats, fxp = ops.ipa_attention_planes(q_xp, k_xp, v_vf, pts, bias_in, pz, mask, r7, f16=f16)
+        assert torch.equal(bias_in, bias)   # not in place unless asked
         q, _ = lin(w["q"])
         kv, _ = lin(w["kv"])
         q_pts, k_pts, v_pts = ops.ipa_prep_points(r7, qp.view(B, N, -1), kvp.view(B, N, -1), 8, 8, 12)
@@ -355,8 +403,9 @@ def test_ipa_planes_kernel_matches_fp32_operand_kernel(net_rough, f16, kern, mon
     got = ops.unpack_planes(fxp, M, 2688)
     got[:, 2048:] = feats.view(M, -1)[:, 2048:]
     valid = mask.reshape(-1).bool()
+    assert torch.isfinite(got[valid]).all()
     for name, sl in (("o", slice(0, 2048)), ("o_pt", slice(2048, 2432)), ("o_pair", slice(2432, 2688))):
-        check(f"ipa {('f16 ' + kern) if f16 else 'bf16'} planes vs fp32-operand kernel, {name}", rel(got[valid][:, sl], ref[valid][:, sl]), 5e-6)
+        check(f"ipa {'f16w' if f16 else 'bf16'} planes N={N} vs fp32-operand kernel, {name}", rel(got[valid][:, sl], ref[valid][:, sl]), 5e-6)
 
 
 def test_se3_step_golden(diffuser):
@@ -573,6 +622,35 @@ def test_hip_graph_replay_is_bit_identical(net_smooth, diffuser, monkeypatch):
         torch.manual_seed(11)
         outs[mode] = forward_backward(net_smooth, diffuser, feats, rig0, 1.0, num_timesteps=6, device=DEV).clone()
     assert torch.isfinite(outs["1"]).all() and torch.equal(outs["0"], outs["1"])
+
+
+def test_hip_graph_cache_survives_other_shapes(net_smooth, diffuser, monkeypatch):
+    """A cached graph is replayed after evaluations of OTHER shapes / targets rebuilt the embedder's per-target tables (the default
+    config's chunks of 64 + 36 replicas do exactly this every t_delta): capture A, capture B, churn the allocator, replay A --
+    still the eager result, bit for bit.  (The captured kernels read those tables through raw pointers; the graph object owns them.)"""
+    from str2str_amd import sampler
+    from str2str_amd.common.rigid_utils import Rigid
+    from str2str_amd.synth import synth_chain
+
+    def run(N, B, seed, mode):
+        monkeypatch.setenv("S2S_HIP_GRAPH", mode)
+        feats = synth_chain(N)
+        feats["residue_idx"] = feats["residue_idx"] + 3 * N      # another residue numbering per target: other tables
+        rig0 = Rigid.from_tensor_4x4(feats["rigidgroups_gt_frames"][..., 0, :, :].repeat(B, 1, 1, 1))
+        torch.manual_seed(seed)
+        return sampler.forward_backward(net_smooth, diffuser, feats, rig0, 1.0, num_timesteps=5, device=DEV).clone()
+
+    sampler._GRAPH_CACHE.clear()
+    eager_a, eager_b = run(20, 3, 1, "0"), run(13, 2, 2, "0")
+    a1 = run(20, 3, 1, "1")
+    b1 = run(13, 2, 2, "1")          # frees / replaces the single-slot tables shape A was captured with
+    assert len(sampler._GRAPH_CACHE) == 2
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 18,), float("nan"), device=DEV) for _ in range(64)]   # whatever was freed gets overwritten
+    a2 = run(20, 3, 1, "1")          # cache hit: replays graph A
+    del junk
+    assert len(sampler._GRAPH_CACHE) == 2
+    assert torch.equal(a1, eager_a) and torch.equal(b1, eager_b) and torch.equal(a2, eager_a)
 
 def test_cfg4_shape_n512_kernels_agree_and_shard(net_smooth, diffuser):
     """BASELINE configs[3] shape (N = 512; the oracle is too slow there): size-independent properties instead.

@@ -49,17 +49,18 @@ def timeit(name, fn):
 
 
 lin = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], M, x["k"], x["n"], x["tg"], **kw)  # noqa: E731
+NP = ops.padded_len(N)
+rmap, Mo = ((NP, N), B * NP) if NP != N else (None, M)
+linp = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], Mo, x["k"], x["n"], x["tg"], row_map=rmap, **kw)  # noqa: E731
 alg = B * 4 * (9512 * N + 40 * N * N)
 with torch.no_grad():
-    import os
-    for f16, kern in ((True, "wave"), (True, "pair"), (False, "pair")):
-        os.environ["S2S_IPA_KERNEL"] = kern
-        print(f"{'f16 pair' if f16 else 'bf16 three-way'} planes path ({'one wave per query tile' if f16 and kern == 'wave' else 'wave pairs'})  B={B} N={N}")
+    for f16 in ((True, False) if N % 32 == 0 else (True,)):
+        print(f"{'f16 pair (s2s_ipa_attention_f16w)' if f16 else 'bf16 three-way (s2s_ipa_attention_planes)'} operand path  B={B} N={N} (padded {NP})")
         tot = 0.0
         fmt = 2 if f16 else 1
-        (_, q_xp), t = timeit("q  -> planes", lambda: lin(w["q"], want_f32=False, want_xp=True, xp_format=fmt)); tot += t
-        (_, k_xp), t = timeit("k  -> planes", lambda: lin(w["k"], want_f32=False, want_xp=True, xp_format=fmt)); tot += t
-        v_vf, t = timeit("v  -> A fragments", lambda: ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, 256, 2048, 8, f16=f16)); tot += t
+        (_, q_xp), t = timeit("q  -> planes", lambda: linp(w["q"], want_f32=False, want_xp=True, xp_format=fmt)); tot += t
+        (_, k_xp), t = timeit("k  -> planes", lambda: linp(w["k"], want_f32=False, want_xp=True, xp_format=fmt)); tot += t
+        v_vf, t = timeit("v  -> A fragments", lambda: ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], Mo, 256, 2048, 8, f16=f16, row_map=rmap)); tot += t
         (qp, _), t = timeit("q points (linear)", lambda: lin(w["qp"])); tot += t
         (kvp, _), t = timeit("kv points (linear)", lambda: lin(w["kvp"])); tot += t
         pts, t = timeit("points -> fragments", lambda: ops.ipa_prep_points_planes(r7, qp, kvp, d["hw"], f16=f16)); tot += t
