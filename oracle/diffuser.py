@@ -237,13 +237,15 @@ class FrameDiffuser:
 # ------------------------------------------------------------------ diffusion_module.py:260-334
 def forward_backward(net_fn, diffuser: FrameDiffuser, feats: dict, rigids_0: Frames, t_delta: float, *,
                      num_timesteps: int, min_t: float = 0.01, noise_scale: float = 1.0,
-                     probability_flow: bool = True, self_conditioning: bool = True, trace: Optional[list] = None):
+                     probability_flow: bool = True, self_conditioning: bool = True, trace: Optional[list] = None,
+                     rigids_t_init: Optional[torch.Tensor] = None):
     """The sampler closure of DiffusionLitModule.predict_step (diffusion_module.py:260-334).
 
     ``feats`` holds the B-repeated aatype / residue_mask / fixed_mask / residue_idx /
     torsion_angles_sin_cos (:269-272).  ``net_fn(batch) -> dict(rigids=Frames, psi=...)``.
     Returns atom37 [B,N,37,3] float32 numpy.  If ``trace`` is a list, every step appends
-    dict(t, rigids_t(in), x0(7), psi, rigids_next(7)).
+    dict(t, rigids_t(in), x0(7), psi, rigids_next(7)).  ``rigids_t_init`` [B,N,7] replaces the forward-marginal draw (a fixture's
+    noised frames: the loop alone).
     """
     from .geometry import compute_backbone
 
@@ -253,7 +255,9 @@ def forward_backward(net_fn, diffuser: FrameDiffuser, feats: dict, rigids_0: Fra
     dt = 1.0 / n
     ts = np.linspace(min_t, T, n)[::-1]
     f = dict(feats)
-    if t_delta > 0:
+    if rigids_t_init is not None:
+        rigids_t = rigids_t_init.clone()
+    elif t_delta > 0:
         rigids_t = diffuser.forward_marginal(rigids_0, t_delta * torch.ones(B), diffuse_mask=f["residue_mask"])
     else:
         rigids_t = diffuser.sample_prior(rigids_0.trans.shape[:-1])

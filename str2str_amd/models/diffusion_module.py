@@ -108,6 +108,7 @@ class DiffusionLitModule(_Base):
         kw = dict(num_timesteps=inf.num_timesteps, min_t=inf.min_t, noise_scale=inf.noise_scale,
                   probability_flow=inf.probability_flow, self_conditioning=self_cond, device=device, rng=self.rng_mode)
         saved = []
+        self.last_samples = {}   # t_delta -> atom37 [n_replica, N, 37, 3] device tensor of the last target (rank 0; programmatic callers)
         for t_delta in delta_range:
             gt4 = batch["rigidgroups_gt_frames"][..., 0, :, :].clone()
             mine = []
@@ -122,6 +123,7 @@ class DiffusionLitModule(_Base):
             if distributed:
                 a37 = gather_replicas(a37, n_replica)   # ONE collective per (target, t_delta)
             if shard[0] == 0:
+                self.last_samples[float(t_delta)] = a37
                 t_dir = os.path.join(output_dir, f"{t_delta}")
                 os.makedirs(t_dir, exist_ok=True)
                 saved.append(atom37_to_pdb(atom_positions=a37.cpu().numpy(),

@@ -33,7 +33,13 @@ def _is_final(key: str) -> bool:
 
 
 def synth_state_dict(manifest: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 0,
-                     sigma_final: float = 0.02) -> Dict[str, torch.Tensor]:
+                     sigma_final: float = 0.02, style: str = "init", dense_gain: float = 2.0) -> Dict[str, torch.Tensor]:
+    """``style="trained_like"`` keeps the same draws but gives them the magnitudes a trained checkpoint typically has and a fresh
+    initialisation does not: LayerNorm gains log-normal in [0.1, 10], dense weights ``dense_gain`` x the fan-in scale, biases
+    0.1 -- hidden activations of several hundred to a few thousand (the regime that matters for the f16x3 kernels' range)."""
+    if style not in ("init", "trained_like"):
+        raise ValueError(style)
+    tl = style == "trained_like"
     g = torch.Generator().manual_seed(int(seed))
     out = {}
     for key, shape in sorted((k, tuple(s)) for k, s in manifest):
@@ -41,11 +47,11 @@ def synth_state_dict(manifest: Iterable[Tuple[str, Tuple[int, ...]]], seed: int 
         if key.endswith("head_weights"):
             v = 0.541324854612918 + 0.1 * r
         elif len(shape) == 2:
-            v = r * (sigma_final if _is_final(key) else math.sqrt(1.0 / shape[1]))
+            v = r * (sigma_final if _is_final(key) else math.sqrt(1.0 / shape[1]) * (dense_gain if tl else 1.0))
         elif key.endswith(".weight"):  # 1-D weight == LayerNorm gain
-            v = 1.0 + 0.05 * r
+            v = torch.exp(0.9 * r).clamp(0.1, 10.0) if tl else 1.0 + 0.05 * r
         else:  # biases (Linear and LayerNorm)
-            v = r * (sigma_final if _is_final(key) else 0.02)
+            v = r * (sigma_final if _is_final(key) else (0.1 if tl else 0.02))
         out[key] = v.contiguous()
     return out
 

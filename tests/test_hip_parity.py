@@ -1,10 +1,11 @@
 """HIP path (through the C ABI) vs the reference-generated golden fixtures and vs the CPU oracle on
 the same seeded inputs.  Needs a real MI355X: every test is marked ``gpu``.
 
-Tolerances (float32 path; the reference itself is float32):
-  per-op            <= 2e-5 relative to the output scale (1e-6 for the pure geometry kernels)
-  one network eval  <= 5e-4 absolute on frames (same bound the oracle meets against the reference)
-  free-running trajectory with contractive weights: backbone RMSD <= 1e-4 Angstrom (north star)
+Tolerances (float32 path; the reference itself is float32).  Every bound is at most ~5x the margin achieved on an MI355X
+(profiles/parity_margins.json), so a regression of one order of magnitude fails:
+  per-op            <= 5e-6 relative to the output scale (1e-6 for the pure geometry kernels)
+  one network eval  <= 1e-4 absolute on frames (the oracle itself meets the reference at 2e-4)
+  free-running trajectory with contractive weights: backbone RMSD <= 1e-4 Angstrom (north star; achieved <= 3.4e-5)
 """
 import numpy as np
 import pytest
@@ -164,7 +165,7 @@ def test_edge_transition_golden(net_rough, mode):
     finally:
         for m, v in prev:
             m.mfma_mode = v
-    check(f"{_test_name()}: rel err", rel(out, g["out"]), 2e-5)
+    check(f"{_test_name()}: rel err", rel(out, g["out"]), 5e-6)
 
 
 def test_edge_transition_split_bf16_is_fp32_equivalent(net_rough):
@@ -216,7 +217,7 @@ def test_edge_transition_vs_oracle(net_rough, B, N, mode):
     finally:
         for m, v in prev:
             m.mfma_mode = v
-    check(f"{_test_name()}: rel err", rel(out, ref), 2e-5)
+    check(f"{_test_name()}: rel err", rel(out, ref), 5e-6)
 
 
 @pytest.mark.parametrize("mode", ["bf16x6", "f16x3", "f32"])
@@ -235,7 +236,7 @@ def test_edge_embed_golden(net_rough, mode):
             m.mfma_mode = v
     assert torch.equal(edge, edge2)
     assert rel(bias, ipa0.linear_b(edge).permute(0, 3, 1, 2)) < 2e-5 and rel(pz, ipa0.down_z(edge)) < 2e-5
-    check(f"{_test_name()}: rel err", rel(node, g["node"]), 2e-5)
+    check(f"{_test_name()}: rel err", rel(node, g["node"]), 5e-6)
     d = np.abs(edge.cpu().numpy() - g["edge"]).max(-1)
     # a pair whose CA distance sits within 1 ulp of a distogram edge may legitimately land in the
     # neighbouring bin (SURVEY.md §7 "discontinuities"): allow none here except the constructed edge pair
@@ -288,7 +289,7 @@ def test_ipa_golden(net_rough):
     ipa = net_rough.translator.trunk["ipa_0"]
     out = ipa(T(g["s"]).to(DEV), T(g["z"]).to(DEV), Rigid.from_tensor_7(T(g["rigids7"]).to(DEV)), T(g["mask"]).to(DEV))
     valid = T(g["mask"]).bool().numpy()
-    check(f"{_test_name()}: rel err", rel(out.cpu().numpy()[valid], g["out"][valid]), 2e-5)
+    check(f"{_test_name()}: rel err", rel(out.cpu().numpy()[valid], g["out"][valid]), 5e-6)
 
 
 def _ipa_case(B, N, seed_off=200):
@@ -338,7 +339,7 @@ def test_ipa_vs_oracle(net_rough, B, N):
     assert ipa.ipa_path == "f16" and ipa.use_planes(N, B * N)
     out = ipa(s.to(DEV), z.to(DEV), Rigid.from_tensor_7(r7.to(DEV)), mask.to(DEV))
     valid = mask.bool().numpy()
-    check(f"{_test_name()}: rel err", rel(out.cpu().numpy()[valid], ref.numpy()[valid]), 2e-5)
+    check(f"{_test_name()}: rel err", rel(out.cpu().numpy()[valid], ref.numpy()[valid]), 5e-6)
 
 
 @pytest.mark.parametrize("path,B,N", [("f32", 2, 40), ("f32", 1, 300), ("f32", 3, 64), ("planes", 1, 96), ("planes", 3, 64)])
@@ -356,7 +357,7 @@ def test_ipa_alternative_kernels_vs_oracle(net_rough, path, B, N):
         assert ipa.use_planes(N, B * N) == (path == "planes")
         out = ipa(s.to(DEV), z.to(DEV), Rigid.from_tensor_7(r7.to(DEV)), mask.to(DEV))
     valid = mask.bool().numpy()
-    check(f"{_test_name()}: rel err", rel(out.cpu().numpy()[valid], ref.numpy()[valid]), 2e-5)
+    check(f"{_test_name()}: rel err", rel(out.cpu().numpy()[valid], ref.numpy()[valid]), 5e-6)
 
 
 @pytest.mark.parametrize("f16,N", [(True, 64), (True, 75), (True, 20), (False, 64)], ids=["f16w", "f16w-ragged75", "f16w-ragged20", "bf16"])
@@ -405,7 +406,7 @@ def test_ipa_planes_kernel_matches_fp32_operand_kernel(net_rough, f16, N):
     valid = mask.reshape(-1).bool()
     assert torch.isfinite(got[valid]).all()
     for name, sl in (("o", slice(0, 2048)), ("o_pt", slice(2048, 2432)), ("o_pair", slice(2432, 2688))):
-        check(f"ipa {'f16w' if f16 else 'bf16'} planes N={N} vs fp32-operand kernel, {name}", rel(got[valid][:, sl], ref[valid][:, sl]), 5e-6)
+        check(f"ipa {'f16w' if f16 else 'bf16'} planes N={N} vs fp32-operand kernel, {name}", rel(got[valid][:, sl], ref[valid][:, sl]), 3.5e-6)
 
 
 def test_se3_step_golden(diffuser):
@@ -465,12 +466,13 @@ def _batch(g, dev):
 
 
 def test_denoising_net_golden(net_rough):
-    for tag in ("b1n10", "b2n16", "b1n256"):  # b1n256: the bench shape (one reference evaluation at N = 256)
+    # b1n256 / b1n512: one reference evaluation at the BASELINE configs[1] / configs[3] lengths
+    for tag in ("b1n10", "b2n16", "b1n256", "b1n512"):
         g = golden(f"net_{tag}.npz")
         out = net_rough(_batch(g, DEV))
-        check(f"net golden {tag}: max |frames - reference|", maxdiff(out["rigids"].to_tensor_7().cpu(), g["rigids7"]), 5e-4)
-        check(f"net golden {tag}: max |psi - reference|", maxdiff(out["psi"].cpu(), g["psi"]), 5e-4)
-        check(f"net golden {tag}: max |backbone atoms - reference| (A)", maxdiff(out["atom37"].cpu()[..., :5, :], g["atom37"]), 1e-3)
+        check(f"net golden {tag}: max |frames - reference|", maxdiff(out["rigids"].to_tensor_7().cpu(), g["rigids7"]), 1e-4)
+        check(f"net golden {tag}: max |psi - reference|", maxdiff(out["psi"].cpu(), g["psi"]), 3e-5)
+        check(f"net golden {tag}: max |backbone atoms - reference| (A)", maxdiff(out["atom37"].cpu()[..., :5, :], g["atom37"]), 1.2e-4)
         assert float(out["atom37"][..., 5:, :].abs().max()) == 0
 
 
@@ -487,7 +489,7 @@ def test_teacher_forced_trajectory(net_rough, diffuser):
     dt = float(g["dt"])
     mask = f["residue_mask"].float().contiguous()
     worst_x0 = worst_next = 0.0
-    n_good = 0
+    n_good = n_total = 0
     for i, t in enumerate(g["ts"]):
         f["t"] = torch.full((B,), float(t), dtype=torch.float32)
         f["rigids_t"] = T(g["rigids_t"][i]).to(DEV)
@@ -502,13 +504,18 @@ def test_teacher_forced_trajectory(net_rough, diffuser):
             assert rel(tsc, g["trans_score"][i]) < 1e-5
             # frames of residues whose rotation score is well conditioned in the reference's own float32
             n_good += int(good.sum())
+            n_total += int(good.size)
             if good.any():
                 worst_next = max(worst_next, maxdiff(nxt.cpu()[T(good)], g["next7"][i][good]))
             # translations do not depend on the rotation score at all
             assert maxdiff(nxt.cpu()[..., 4:], g["next7"][i][..., 4:]) < 2e-5
-    check("teacher-forced: worst |x0 - reference| over 20 steps", worst_x0, 1e-3)
+    check("teacher-forced: worst |x0 - reference| over 20 steps", worst_x0, 1.2e-4)
+    # how much of the trajectory the next-frame check covers (the rest: residues where the bound above proves the reference's own
+    # float32 rotation score is rounding noise; their TRANSLATIONS are still checked, two lines up)
+    record_margin(f"teacher-forced: well-conditioned residue-steps checked for next frames: {n_good} of {n_total} (fraction NOT checked)",
+                  1.0 - n_good / max(n_total, 1), 1.0)
     assert n_good > 100, n_good
-    check("teacher-forced: worst |next frames - reference| on well-conditioned residues", worst_next, 2e-5)
+    check("teacher-forced: worst |next frames - reference| on well-conditioned residues", worst_next, 4e-6)
 
 
 @pytest.mark.parametrize("mode", ["bf16x6", "f32"])
@@ -680,12 +687,13 @@ def test_cfg4_shape_n512_kernels_agree_and_shard(net_smooth, diffuser):
         parts.append(forward_backward(net_smooth, diffuser, feats, rig0, 0.5, num_timesteps=2 * S, device=DEV, shard=(r, 2)).cpu().numpy())
     assert backbone_rmsd(np.concatenate(parts)[..., :5, :], outs["bf16x6"][..., :5, :]) < 5e-5
 
-@pytest.mark.parametrize("tag", ["n16_s20", "n12_prior", "n24_delta", "cfg1_n64_s20", "n256_s5", "n256_s100"])
+@pytest.mark.parametrize("tag", ["n16_s20", "n12_prior", "n24_delta", "cfg1_n64_s20", "n256_s5", "n256_s100", "n512_s10"])
 def test_free_running_trajectory_rmsd(net_smooth, diffuser, tag):
     """Same input, same seed, contractive synthetic weights: backbone RMSD vs the reference <= 1e-4 A.
     n256_s100 is the HEADLINE workload as the reference itself runs it (BASELINE configs[1]: 256 residues, 100 denoise
     steps + the self-conditioning evaluation, B = 2 replicas): final coordinates AND the frames entering steps 25 / 50 / 75 /
-    99 are compared, so a divergence would be located, not just detected."""
+    99 are compared, so a divergence would be located, not just detected.  n512_s10 = BASELINE configs[3]'s chain length (N = 512,
+    10 + 1 evaluations, B = 1) on the default f16x3 arithmetic."""
     from str2str_amd.common.rigid_utils import Rigid
     from str2str_amd.sampler import forward_backward
     from str2str_amd.synth import synth_chain
@@ -814,6 +822,76 @@ def test_predict_step_entry_writes_reference_layout(tmp_path, monkeypatch):
     assert 0.0 <= float(mean["val_clash"]) <= 1.0 and 0.0 <= float(mean["js_pwd"]) <= 1.0
 
 
+def test_cfg3_science2011_all_targets_vs_reference(tmp_path, monkeypatch):
+    """BASELINE configs[2]: every one of the 12 Science2011 targets (10 ... 80 residues, all ragged for the 32-residue tiles) from its
+    PDB file through the Hydra config, the datamodule / featuriser and ``predict_step`` (3 replicas, t_delta 0.5, 10 + 1
+    evaluations) -- against the REFERENCE's run of the same target under the same seed (tests/golden/make_golden_configs.py --cfg3:
+    the reference's own ProteinFeatureTransform + its predict_step control flow).  Device tensors at RMSD < 1e-4 A; the written
+    multi-MODEL PDB text at its 3-decimal resolution."""
+    import os
+
+    from conftest import GOLDEN, ROOT
+    from str2str_amd.synth import synth_state_dict
+    from str2str_amd.utils import config as C
+
+    g = golden("cfg3_science2011.npz")
+    monkeypatch.setenv("TEST_DATA", os.path.join(GOLDEN, "pdb"))
+    monkeypatch.setenv("CACHE_DIR", str(tmp_path / "cache"))
+    monkeypatch.setenv("PROJECT_ROOT", str(tmp_path))
+    args = ["task_name=inference", "ckpt_path=null", f"model.inference.n_replica={int(g['B'])}", "model.inference.replica_per_batch=8",
+            f"model.inference.num_timesteps={int(g['num_timesteps'])}", f"model.inference.delta_min={float(g['t_delta'])}",
+            f"model.inference.delta_max={float(g['t_delta'])}", "model.inference.delta_step=0.1", "extras.print_config=false"]
+    cfg = C.compose(os.path.join(ROOT, "configs"), "eval.yaml", args)
+    model = C.instantiate(cfg.model)
+    man = [(k, tuple(v.shape)) for k, v in model.net.state_dict().items()]
+    model.net.load_state_dict(synth_state_dict(man, seed=0, sigma_final=0.002))
+    model = model.to(DEV).eval()
+    batches = C.instantiate(cfg.data).test_dataloader()
+    codes = sorted({k.split("/")[0] for k in g if "/" in k})
+    assert len(batches) == len(codes) == 12
+    seen = set()
+    for batch in batches:
+        code = batch["accession_code"][0]
+        batch = {k: (v.to(DEV) if torch.is_tensor(v) and k != "residue_idx" else v) for k, v in batch.items()}
+        torch.manual_seed(int(g[f"{code}/seed"]))
+        all_dir = model.predict_step(batch, 0)
+        got = model.last_samples[float(g["t_delta"])].cpu().numpy()[..., :5, :]
+        want = g[f"{code}/atom37"]
+        assert got.shape == want.shape, (code, got.shape, want.shape)
+        check(f"cfg3 {code} (N = {want.shape[1]}): backbone RMSD vs the reference (A)", backbone_rmsd(got, want), 1e-4)
+        txt = open(os.path.join(os.path.dirname(all_dir), f"{float(g['t_delta'])}", f"{code}.pdb")).read()
+        assert txt.count("MODEL ") == int(g["B"])
+        xyz = np.array([[float(l[30:38]), float(l[38:46]), float(l[46:54])] for l in txt.split("\n") if l.startswith("ATOM")])
+        aat = batch["aatype"][0].cpu().numpy()
+        keep = np.array([[not (a == 3 and aat[i] == 7) for a in range(5)] for i in range(want.shape[1])])   # GLY has no CB line
+        assert np.abs(xyz - want[:, keep]. reshape(-1, 3)).max() < 1e-3, code
+        seen.add(code)
+    assert seen == set(codes)
+
+
+def test_cfg5_padded_mixed_batch_vs_reference_per_chain(net_smooth, diffuser):
+    """BASELINE configs[4]: chains of different length in ONE padded, masked batch -- each chain against the REFERENCE's own
+    un-padded run of that chain alone (tests/golden/make_golden_configs.py --cfg5: lengths 12, 33 and 71 / 214 / 323 of the seed-5
+    draw; 2 replicas, 4 + 1 evaluations, started from the reference's noised frames).  The reference cannot batch chains
+    (diffusion_module.py:249); exact padding must make the batch equal to its per-chain runs, not just to our own."""
+    from str2str_amd.sampler import plan_mixed_work, sample_mixed_lengths
+    from str2str_amd.synth import synth_chain
+
+    g = golden("cfg5_mixed_lengths.npz")
+    lens = [int(x) for x in g["lens"]]
+    R, S = int(g["R"]), int(g["num_timesteps"])
+    targets = [synth_chain(n, frame_seed=3 + n, aatype_seed=4 + n) for n in lens]
+    inits = [T(g[f"n{n}/first_rigids_t"]) for n in lens]
+    plan = plan_mixed_work(lens, R, 1, launch_floor_ms=1e9)   # everything in one padded batch (n_pad = 323)
+    assert len(plan[0]) == 1 and plan[0][0]["n_pad"] == max(lens)
+    one = sample_mixed_lengths(net_smooth, diffuser, targets, R, float(g["t_delta"]), num_timesteps=S, device=DEV, rigids_t_init=inits, plan=plan)
+    auto = sample_mixed_lengths(net_smooth, diffuser, targets, R, float(g["t_delta"]), num_timesteps=S, device=DEV, rigids_t_init=inits)
+    for k, n in enumerate(lens):
+        for name, res in (("one padded batch", one), ("planner's batches", auto)):
+            got = torch.cat([p for _, p in res[k]]).cpu().numpy()[..., :5, :]
+            check(f"cfg5 N={n} in {name}: backbone RMSD vs the reference's un-padded run (A)", backbone_rmsd(got, g[f"n{n}/atom37"]), 1e-4)
+
+
 def test_mixed_length_padded_batch_equals_unpadded_runs(net_smooth, diffuser):
     """BASELINE configs[4] semantics: chains of different length in padded batches; every chain must equal its own un-padded
     single-chain run (same initial noised frames).  Lengths drawn like the cfg5 workload (U[64, 384], seed 5) plus two short
@@ -844,11 +922,11 @@ def test_mixed_length_padded_batch_equals_unpadded_runs(net_smooth, diffuser):
         alone = alone.cpu().numpy()[..., :5, :]
         (lo, got), = mixed[k]
         assert lo == 0 and got.shape == (R, lens[k], 37, 3)
-        check(f"mixed-length padded batch vs un-padded run, N={lens[k]} (RMSD, A)", backbone_rmsd(got.cpu().numpy()[..., :5, :], alone), 1e-4)
+        check(f"mixed-length padded batch vs un-padded run, N={lens[k]} (RMSD, A)", backbone_rmsd(got.cpu().numpy()[..., :5, :], alone), 1.5e-5)
         parts = sorted(halves[0][k] + halves[1][k], key=lambda x: x[0])
         both = torch.cat([p for _, p in parts]).cpu().numpy()[..., :5, :]
         assert [lo for lo, _ in parts] == [0, 1] and both.shape[0] == R
-        check(f"mixed-length 2-rank plan vs un-padded run, N={lens[k]} (RMSD, A)", backbone_rmsd(both, alone), 1e-4)
+        check(f"mixed-length 2-rank plan vs un-padded run, N={lens[k]} (RMSD, A)", backbone_rmsd(both, alone), 1.5e-5)
 
 
 def _q_sign_free(a, b):
@@ -870,11 +948,11 @@ def test_forward_marginal_device_reproduces_reference_draws(diffuser):
     torch.manual_seed(int(g["seed_fm"]))
     noise = (torch.randn(B, N, 3), torch.rand(B, N), torch.randn(B, N, 3))
     got = diffuser.forward_marginal_device(gt4.to(DEV), float(g["t_delta"]), mask.to(DEV), noise=noise)
-    check("forward marginal (device) vs reference frames", _q_sign_free(got.cpu().numpy(), g["rigids_t"]), 2e-5)
+    check("forward marginal (device) vs reference frames", _q_sign_free(got.cpu().numpy(), g["rigids_t"]), 2e-6)
     torch.manual_seed(int(g["seed_prior"]))
     noise = (torch.randn(B, N, 3), torch.rand(B, N), torch.randn(B, N, 3))
     got = diffuser.forward_marginal_device(None, None, shape=(B, N), noise=noise)
-    check("prior sample (device) vs reference frames", _q_sign_free(got.cpu().numpy(), g["prior"]), 2e-5)
+    check("prior sample (device) vs reference frames", _q_sign_free(got.cpu().numpy(), g["prior"]), 1.2e-6)
     # host path of this build on fresh draws == device path on the same draws (larger sample, all four t regimes)
     rig0 = Rigid.from_tensor_4x4(gt4[:1].repeat(64, 1, 1, 1))
     for td in (0.05, 0.35, 1.0):
@@ -883,7 +961,7 @@ def test_forward_marginal_device_reproduces_reference_draws(diffuser):
         torch.manual_seed(5)
         noise = (torch.randn(64, N, 3), torch.rand(64, N), torch.randn(64, N, 3))
         dev = diffuser.forward_marginal_device(rig0.to_tensor_4x4().to(DEV), td, noise=noise)
-        check(f"forward marginal device vs host, t={td}", _q_sign_free(dev.cpu().numpy(), host.numpy()), 2e-5)
+        check(f"forward marginal device vs host, t={td}", _q_sign_free(dev.cpu().numpy(), host.numpy()), 3e-6)
 
 
 def test_forward_marginal_device_distribution(diffuser):
@@ -1065,12 +1143,12 @@ def test_encoder_attention_vs_torch(net_rough, B, N):
 
     # float mask: added to the logits (what the reference's call does with src_key_padding_mask = 1 - mask)
     ref = ref_enc(x.double().transpose(0, 1), src_key_padding_mask=pad.double()).transpose(0, 1)
-    check(f"encoder (float mask) B{B} N{N}", rel(run(pad.contiguous()), ref), 5e-6)
+    check(f"encoder (float mask) B{B} N{N}", rel(run(pad.contiguous()), ref), 2e-6)
     # exact padding: padded keys removed (bool mask in torch)
     ref = ref_enc(x.double().transpose(0, 1), src_key_padding_mask=pad.bool()).transpose(0, 1)
     got = run(torch.where(pad > 0, float("-inf"), 0.0).contiguous())
     valid = mask.bool().numpy()
-    check(f"encoder (exact padding) B{B} N{N}", rel(got.cpu().numpy()[valid], ref.cpu().numpy()[valid]), 5e-6)
+    check(f"encoder (exact padding) B{B} N{N}", rel(got.cpu().numpy()[valid], ref.cpu().numpy()[valid]), 2e-6)
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
@@ -1089,5 +1167,5 @@ def test_ensemble_metrics_match_reference(tag):
     ch = ops.ca_pwd_js(torch.as_tensor(d["target"]).to(DEV), torch.as_tensor(d["pred"]).to(DEV)).cpu().numpy()
     check(f"js_pwd per-channel vs reference [{tag}]", float(np.abs(ch - g[f"{tag}_js_pwd_channels"]).max()), 1e-12)
     assert M.js_pwd(d)["pred"] == float(g[f"{tag}_js_pwd"]) and M.js_pwd(d)["target"] == 0.0
-    check(f"radius of gyration vs reference [{tag}]", float(np.abs(M.radius_of_gyration(d["pred"]) - g[f"{tag}_rg_pred"]).max()), 2e-5)
+    check(f"radius of gyration vs reference [{tag}]", float(np.abs(M.radius_of_gyration(d["pred"]) - g[f"{tag}_rg_pred"]).max()), 1.5e-6)
     check(f"js_rg vs reference [{tag}]", abs(M.js_rg(d)["pred"] - float(g[f"{tag}_js_rg"])), 2.1e-3)
