@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 FLOPS_PER_PAIR_ET = 491520          # 2*(128*384 + 384*384 + 384*128) fp32 multiply-adds x2
 MFMA_FP32_PEAK = 157.3e12           # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
-MFMA_BF16_PEAK = 2500e12            # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
+MFMA_F16_PEAK = 2500e12             # dense f16 / bf16 MFMA (v_mfma_f32_32x32x16_f16), /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK = 8e12
 METRIC = "sampled conformations/sec (whole node), 256-res chain, 100 denoise steps"
 
@@ -80,7 +80,7 @@ def traffic_from_profiles(pairs, mode):
     process (separate --pmc passes, tools/pmc_hbm_traffic.sh), so the committed pass at B = 16, N = 256 is scaled by the
     pairs of this launch and labelled as such.  (None, None) if the file is absent."""
     for name in ("r02m_pmc_hbm_traffic.json", "r02l_pmc_hbm_traffic.json", "r02k_pmc_hbm_traffic.json", "r02i_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01i_pmc_hbm_traffic.json"):
-        key = {"bf16x6": "edge_transition_bf16x6", "f16x3": "edge_transition_f16x3"}.get(mode, "edge_transition")
+        key = {"f16x3": "edge_transition_f16x3"}.get(mode, "edge_transition")
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 return json.load(f)["kernels"][key]["bytes_per_pair_corrected"] * pairs, f"profiles/{name} (PMC pass at B=16, N=256, scaled per pair)"
@@ -260,16 +260,18 @@ def main():
     if rank == 0:
         assert res is not None and torch.isfinite(res).all()
         total = a.steps * per_rank * world
-        mode = net.translator.trunk["edge_transition_0"].mfma_mode
+        from str2str_amd.arith import net_arith
+
+        mode = net_arith(net)
         line = {
             "metric": METRIC if a.config == "cfg2" else f"sampled conformations/sec (whole node), BASELINE {a.config}",
             "value": total / elapsed, "unit": "conformations/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f32": "f32", "bf16x6": "f32 (pair MLP on exact 3-way bf16 split MFMA, fp32 accumulate)",
+            "dtype": {"f32": "f32",
                       "f16x3": "f32 (matrix products on 2-way f16 split MFMA 'f16x3': 3 products per block, fp32 accumulate, fp32-equivalent)"}[mode],
             "data": "synthetic",
             "config": {"workload": workload, "n_res": N, "replicas_per_gpu": B, "denoise_steps": S,
-                       "parallelism": f"replica-shard x{world}", "edge_mfma_mode": mode, "rng": a.rng,
+                       "parallelism": f"replica-shard x{world}", "arith": mode, "range_fallback": bool(getattr(net, "range_fallback", False)), "rng": a.rng,
                        "step_definition": "one replica chunk (cfg3: all 12 targets; cfg5: the rank's plan) sampled end to end incl. gather + D2H"},
             "distributed": {"backend": (dist.get_backend() if world > 1 else None), "world_size": world,
                             "per_rank_conformations_per_s": [a.steps * per_rank / float(x.item()) for x in per_rank_s]},
@@ -278,22 +280,20 @@ def main():
         if a.config in ("cfg2", "cfg4") and et_n:
             pairs = pairs_main
             alg = pairs * FLOPS_PER_PAIR_ET                       # fp32 multiply-add flops the operator needs
-            executed = alg * {"bf16x6": 6, "f16x3": 3}.get(mode, 1)   # low-precision products executed per fp32 product
-            peak = MFMA_FP32_PEAK if mode == "f32" else MFMA_BF16_PEAK  # f16 and bf16 MFMA share the dense peak
+            executed = alg * {"f16x3": 3}.get(mode, 1)   # 16-bit products executed per fp32 product
+            peak = MFMA_FP32_PEAK if mode == "f32" else MFMA_F16_PEAK
             ach = executed / (et_ms * 1e-3)
             traffic, traffic_src = traffic_from_profiles(pairs, mode)
             ipa_bytes = B * 4 * (9512 * N + 40 * N * N)
             line["roofline"] = {
                 "bound": "mfma",
-                "kernel": "s2s_edge_transition" + {"bf16x6": "_bf16x6 (edge_transition_bf16_kernel)",
-                                                   "f16x3": "_f16x3 (edge_transition_f16_kernel)"}.get(mode, " (edge_transition_kernel)"),
+                "kernel": "s2s_edge_transition" + {"f16x3": "_f16x3 (edge_transition_f16_kernel)"}.get(mode, " (edge_transition_kernel)"),
                 "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
                 "traffic": traffic, "traffic_source": traffic_src, "launches_timed": et_n, "mean_launch_ms": et_ms,
                 "algorithmic_flops_per_launch": alg, "executed_mfma_flops_per_launch": executed,
                 "fp32_equivalent_tflops": alg / (et_ms * 1e-3) / 1e12,
                 "fp32_equivalent_vs_fp32_mfma_peak": alg / (et_ms * 1e-3) / MFMA_FP32_PEAK}
-            ipa_path = net.translator.trunk["ipa_0"].ipa_path
-            ipa_name = {"f16": "s2s_ipa_attention_f16w", "planes": "s2s_ipa_attention_planes"}.get(ipa_path, "s2s_ipa_attention")
+            ipa_name = {"f16x3": "s2s_ipa_attention_f16w"}.get(mode, "s2s_ipa_attention")
             line["ipa_kernel"] = {"bound": "hbm", "kernel": f"{ipa_name} + s2s_ipa_opair", "mean_launch_ms": ipa_ms,
                                   "launches_timed": ipa_n, "achieved": ipa_bytes / (ipa_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                                   "unit": "GB/s", "frac": ipa_bytes / (ipa_ms * 1e-3) / HBM_PEAK,

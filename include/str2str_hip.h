@@ -25,6 +25,16 @@ extern "C" {
 /* Library ABI version (bumped on any signature change). */
 int s2s_abi_version(void);
 
+/* Arithmetic.  Every matrix product of the path exists in two forms behind the same operator contract:
+ *   "f16x3" (default): operands split into f16 pairs, three products per block on the 16-bit matrix cores, fp32 accumulation --
+ *           fp32-equivalent in precision, but an activation must stay below f16's 65504;
+ *   "f32":  exact fp32 MFMA, no range limit (s2s_edge_transition, s2s_edge_embed, s2s_ipa_attention, s2s_node_linear_f32,
+ *           s2s_encoder_attention): the reference arithmetic and the automatic fallback.
+ * Range guard: every f16x3 kernel keeps a running maximum of the values it splits and ORs a bit into the device word registered
+ * here when that maximum reaches 2^15 or is not finite (bits: 1 node GEMM, 2 pack_planes, 4 edge transition, 8 edge embedding,
+ * 16 IPA points, 32 encoder attention).  The caller clears / reads the word (no kernel waits for it); NULL disables the reports. */
+int s2s_set_range_flag(int* device_word);
+
 /* ---- Pair-stream MLPs (fp32 MFMA).  Weight blobs are "packed" for the kernels' lane order:
  *      packed[((s4*T + t)*64 + lane)*4 + q] = W[32*t + (lane & 31)][8*s4 + 4*(lane >> 5) + q]
  *      for W [32*T, 8*S4] row-major (str2str_amd.ops.pack_weight does this).  s2s_edge_transition takes the
@@ -44,23 +54,15 @@ int s2s_edge_transition(const float* edge, const float* node_ab, const float* no
                         int n_res, float ln_eps, const float* proj_w_packed, const float* proj_bias_cat64,
                         float* proj_attn_bias, float* proj_pair_z, void* stream);
 
-/* The same operator on split-bf16 MFMA ("bf16x6": every fp32 operand split exactly into three bf16 planes, six
- * plane-pair products per MFMA block, fp32 accumulation; the dropped products are below one fp32 rounding, i.e.
- * fp32-equivalent) at 2.67x fewer matrix-core cycles.  weight_stream: 30 stages x 48 KiB of bf16 A fragments in the
- * kernel's slot order (ops.pack_bf16x3_stream; the order is part of the ABI version).
+/* The same operator on split-f16 MFMA ("f16x3", csrc/pair_mlp_f16.hip; the default): every fp32 operand as two f16 numbers (11 + 11
+ * bits + the residue's sign = fp32's 24), products w_h x_h + w_h x_l + w_l x_h with the weights stored as the split of 2^5 w (2^-5
+ * back in the epilogues), fp32 accumulation -- three matrix instructions per block, the dropped w_l x_l below one fp32 rounding.
+ * Activations must stay below f16's 65504 (range guard above).  weight_stream: 30 (+1 with the fused projection) stages x 32 KiB
+ * of f16 A fragments (W_h, W_l) in slot order (ops.pack_f16x3_stream, ops.pack_f16x2_layer for the projection stage; the order is
+ * part of the ABI version).
  *   Optional fused epilogue (proj_attn_bias != NULL): the NEXT IPA block's linear_b / down_z (see s2s_pair_project);
  *   the stream then carries a 31st stage with the chain-packed 64x128 [linear_b; down_z; 0] matrix, proj_bias_cat64 [64];
  *   outputs proj_attn_bias [B,8,N,N] (head-major) and proj_pair_z [B,N,N,32]. */
-int s2s_edge_transition_bf16x6(const float* edge, const float* node_ab, const float* node_p, const void* weight_stream,
-                               const float* b2, const float* bf, const float* ln_gamma, const float* ln_beta,
-                               const float* mask, float* out, int n_samples, int n_res, float ln_eps,
-                               const float* proj_bias_cat64, float* proj_attn_bias, float* proj_pair_z, void* stream);
-
-/* The same operator on split-f16 MFMA ("f16x3", csrc/pair_mlp_f16.hip): every fp32 operand as two f16 numbers (11 + 11 bits + the
- * residue's sign = fp32's 24), products w_h x_h + w_h x_l + w_l x_h with the weights stored as the split of 2^5 w (2^-5 back in the epilogues), fp32
- * accumulation -- three matrix instructions per block instead of six, the dropped w_l x_l below one fp32 rounding as in bf16x6.
- * Activations must stay below f16's 65504.  weight_stream: 30 (+1 with the fused projection) stages x 32 KiB of f16 A fragments
- * (W_h, W_ls) in slot order (ops.pack_f16x3_stream, ops.pack_f16x2_layer for the projection stage). */
 int s2s_edge_transition_f16x3(const float* edge, const float* node_ab, const float* node_p, const void* weight_stream,
                               const float* b2, const float* bf, const float* ln_gamma, const float* ln_beta,
                               const float* mask, float* out, int n_samples, int n_res, float ln_eps,
@@ -80,23 +82,14 @@ int s2s_edge_embed(const float* node_a, const float* node_b, const float* rel_ta
                    float ln_eps, const float* proj_w_packed, const float* proj_bias_cat64, float* proj_attn_bias,
                    float* proj_pair_z, void* stream);
 
-/* The same operator on split-bf16 MFMA (fp32-equivalent, see s2s_edge_transition_bf16x6).  weight_stream: 4 stages x 48 KiB
- * (W2 | W3, chain-packed bf16x3 fragments in slot order: ops.pack_bf16x3_embed_stream) + a 5th stage with the
- * [linear_b; down_z; 0] matrix when the fused projection is requested (proj_attn_bias != NULL).
+/* The edge embedding on split-f16 MFMA (see s2s_edge_transition_f16x3; the default).  weight_stream: 4 stages x 32 KiB (W2 | W3,
+ * chain-packed (W_h, W_l) fragments in slot order: ops.pack_f16x3_embed_stream) + a 5th stage with the [linear_b; down_z; 0]
+ * matrix when the fused projection is requested (proj_attn_bias != NULL).
  *   Layout difference to s2s_edge_embed: node_b, rel_table and bin_table are COLUMN-BLOCKED --
  *   node_b [B][32][N][4], rel_table [32][n_rel][4], bin_table [32][n_bins][4], element [c][row][q] = channel 4c + q of that row
  *   (ops.column_blocked) -- so that the gathers of neighbouring pairs share cache lines; node_a stays [B,N,128];
  *   bin_lower must ascend (torch.linspace), n_bins <= 32.  Pair indices are 32-bit inside a launch: the entry point splits the
  *   samples over several launches when B*N*N >= 2^31 (N*N itself and n_rel*512 must stay below 2^31 / 2^32). */
-int s2s_edge_embed_bf16x6(const float* node_a, const float* node_b, const float* rel_table, const float* bin_table,
-                          const float* bin_lower, const long long* residue_idx, const float* ca_xyz,
-                          const void* weight_stream, const float* b2, const float* b3, const float* ln_gamma,
-                          const float* ln_beta, const float* mask, float* out, int n_samples, int n_res, int rel_offset,
-                          int n_rel, int n_bins, float ln_eps, const float* proj_bias_cat64, float* proj_attn_bias,
-                          float* proj_pair_z, void* stream);
-
-/* The edge embedding on split-f16 MFMA (see s2s_edge_transition_f16x3): arguments and table layouts of s2s_edge_embed_bf16x6,
- * weight_stream = 4 (+1) stages x 32 KiB of (W_h, W_ls) fragments (ops.pack_f16x3_embed_stream). */
 int s2s_edge_embed_f16x3(const float* node_a, const float* node_b, const float* rel_table, const float* bin_table,
                          const float* bin_lower, const long long* residue_idx, const float* ca_xyz,
                          const void* weight_stream, const float* b2, const float* b3, const float* ln_gamma,
@@ -133,34 +126,22 @@ int s2s_ipa_attention(const float* q, const float* kv, const float* q_pts, const
                       const float* head_w_scaled, float* out, int n_samples, int n_res, int n_heads, int c_hidden,
                       int n_qk_points, int n_v_points, int c_pair_z, float inf, float eps, void* stream);
 
-/* The same two operators for n_res % 32 == 0 on operands that are ALREADY exact bf16x3 splits in MFMA fragment order
- * (csrc/ipa_attention_planes.hip): q_xp / k_xp = packed planes [M/32][16 H][3][64][8] of the q and k projections (out_xp of
- * s2s_node_linear with linear_q and the k rows of linear_kv), v_vf = s2s_node_linear_vfrag of the v rows of linear_kv.
- * s2s_ipa_prep_points_planes (ipa.py:144-171) writes the global-frame points as fragments: qp_xp [M/32][H][2][3][64][8] (query
- * points x head_w_scaled[h] / sqrt(1/(3 c_hidden))), kp_xp (key points), vp_vf [M/32][H][2][2][3][64][8] (value points as
- * (x,y,z,0) groups), and q2 / k2 [M/32][H][32] = -1/2 head_w_scaled[h] |points|^2: the point term of the logits (ipa.py:191-205)
+/* The DEFAULT attention core (csrc/ipa_attention_f16w.hip), on operands that are ALREADY split into f16 pairs (x_h, x_l) in MFMA
+ * fragment order: q_xp / k_xp = packed planes [rows/32][16 H][2][64][8] of the q and k projections (out_xp of s2s_node_linear with
+ * linear_q and the k rows of linear_kv), v_vf = s2s_node_linear_vfrag of the v rows of linear_kv.
+ * s2s_ipa_prep_points_f16 (ipa.py:144-171) writes the global-frame points as fragments: qp_xp [rows/32][H][2][2][64][8] (query
+ * points x head_w_scaled[h] / sqrt(1/(3 c_hidden))), kp_xp (key points), vp_vf [rows/32][H][2][2][2][64][8] (value points as
+ * (x,y,z,0) groups), and q2 / k2 [rows/32][H][32] = -1/2 head_w_scaled[h] |points|^2: the point term of the logits (ipa.py:191-205)
  * is evaluated as  w q.k - w/2 |q|^2 - w/2 |k|^2  with the cross term on the matrix cores.
- * s2s_ipa_attention_planes: out [B,N,feat] receives only the o_pt columns (H*c_hidden ..); the o columns are written as packed
- * planes (k-steps 16 h .. 16 h + 15 of an activation with out_xp_ksteps k-steps per row: the input of linear_out);
- * logits_out / stats_out as s2s_ipa_attention (consumed by s2s_ipa_opair). */
-int s2s_ipa_prep_points_planes(const float* rigids7, const float* q_pts_lin, const float* kv_pts_lin, const float* head_w_scaled,
-                               void* qp_xp, void* kp_xp, void* vp_vf, float* q2, float* k2, long long n_frames, int n_heads,
-                               int n_qk_points, int n_v_points, int c_hidden, void* stream);
-int s2s_ipa_attention_planes(const void* q_xp, const void* k_xp, const void* v_vf, const void* qp_xp, const void* kp_xp,
-                             const void* vp_vf, const float* q2, const float* k2, const float* attn_bias, float* logits_out,
-                             float* stats_out, const float* mask, const float* rigids7, float* out, void* out_xp,
-                             int out_xp_ksteps, int n_samples, int n_res, int n_heads, int c_hidden, int n_qk_points,
-                             int n_v_points, int c_pair_z, float inf, float eps, void* stream);
-
-/* The DEFAULT attention core: the same two entry points on f16 pair operands (csrc/ipa_attention_f16w.hip): every operand as
- * (x_h, x_l) f16 planes -- TWO planes per fragment group in all the arrays above -- and three products per block
- * (a_h b_h + a_h b_l + a_l b_h) instead of six: half the matrix instructions and two thirds of the operand bytes.  One wave per query
- * tile (a workgroup is four query tiles; a wave runs the whole contraction and owns all ten output tiles).
+ * s2s_ipa_attention_f16w: three products per block (a_h b_h + a_h b_l + a_l b_h), one wave per query tile (a workgroup is four
+ * query tiles; a wave runs the whole contraction and owns all ten output tiles).  out [B,N,feat] receives only the o_pt columns
+ * (H*c_hidden ..); the o columns are written as packed planes (k-steps 16 h .. 16 h + 15 of an activation with out_xp_ksteps
+ * k-steps per row: the input of linear_out); logits_out / stats_out as s2s_ipa_attention (consumed by s2s_ipa_opair).
  * ANY n_res (ipa.py:183-257 has one code path for every length): with n_pad = n_res rounded up to 32, the fragment arrays, q2 and k2
  * hold n_pad rows PER SAMPLE (row tile = sample * n_pad/32 + tile):
- *   q_xp / k_xp from s2s_node_linear (out_xp_format 2) and v_vf from s2s_node_linear_vfrag (out_format 1), both with n_rows =
- *   n_samples * n_pad and the row map (map_pad = n_pad, map_src = n_res) when n_pad != n_res; points from s2s_ipa_prep_points_f16
- *   (padded rows: zero points, k2 = -1e9, so a padded key never carries probability -- exactly the un-padded softmax).
+ *   q_xp / k_xp from s2s_node_linear and v_vf from s2s_node_linear_vfrag, both with n_rows = n_samples * n_pad and the row map
+ *   (map_pad = n_pad, map_src = n_res) when n_pad != n_res; points from s2s_ipa_prep_points_f16 (padded rows: zero points,
+ *   k2 = -1e9, so a padded key never carries probability -- exactly the un-padded softmax).
  * attn_bias stays [B,H,n_res,n_res]; when n_pad != n_res logits_out must be a SEPARATE [B,H,n_pad,n_pad] buffer (s2s_ipa_opair:
  * logits_ld = n_pad); stats_out [B,H,n_res,2], out [B,n_res,feat] and out_xp (row tiles of the flat [B n_res] rows) are not padded. */
 int s2s_ipa_prep_points_f16(const float* rigids7, const float* q_pts_lin, const float* kv_pts_lin, const float* head_w_scaled,
@@ -225,9 +206,8 @@ int s2s_se3_step(const float* x0_7, const float* xt_7, const float* mask, const 
  * Activations travel between these layers as PACKED PLANES ("XP"): for X [M, K],
  *   XP[rt = row/32][ks = K/16][plane 2][lane 64][8] f16, lane = 32 g + (row & 31),
  *   element j = plane of X[row][32 (ks>>1) + (r&3) + 8 (r>>2) + 4 g], r = 8 (ks&1) + j;
- * planes = the f16 pair (x_h = rn16(x), x_l = rn16(x - x_h)); the f16 attention kernel takes the same planes; the bf16 attention
- * kernel takes exact three-way bf16 planes (h, m, l), three per k-step (out_xp_format = 1).  Rows past M inside the last row tile
- * are zero. */
+ * planes = the f16 pair (x_h = rn16(x), x_l = rn16(x - x_h)); the attention kernel takes the same planes.  Rows past M inside the
+ * last row tile are zero. */
 
 /* fp32 row-major x [n_rows, ld], columns col0 .. col0 + n_cols (n_cols % 32 == 0), optionally scaled per row, -> k-steps
  * xp_kstep0 .. of an XP buffer holding xp_ksteps k-steps (concatenation along K = k-step ranges). */
@@ -241,8 +221,7 @@ int s2s_pack_planes(const float* x, long long n_rows, int ld, int col0, int n_co
  *     columns (gamma/beta given; needs n_out == 32 * tiles_per_block);  v *= post_mask[row]
  *   xp: packed planes of the input [n_rows, k_in]; w_packed: ops.pack_node_weight(W [n_out, k_in], tiles_per_block);
  *   outputs: out_f32[row * out_ld + out_col0 + col] and/or the packed planes of the result as k-steps out_xp_kstep0 .. of an XP
- *   buffer with out_xp_ksteps k-steps (out_xp_format 0 (or 2): f16 pair planes -- the input format of the next layer and of
- *   s2s_ipa_attention_f16w; 1: exact three-way bf16 planes, three per k-step, for s2s_ipa_attention_planes).
+ *   buffer with out_xp_ksteps k-steps (the input format of the next layer and of s2s_ipa_attention_f16w).
  *   Any pointer may be NULL to skip that step.
  *   Row map (map_pad > 0; only with bias / relu / LayerNorm epilogues): n_rows counts OUTPUT rows = n_samples * map_pad, and output
  *   row (sample, n) reads input row sample * map_src + min(n, map_src - 1) -- the per-sample padding to whole 32-row tiles that
@@ -251,16 +230,23 @@ int s2s_node_linear(const void* xp, const void* w_packed, const float* bias, lon
                     int tiles_per_block, const float* pre_scale, int relu, const float* pre_mask, const float* residual,
                     int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_mask,
                     float* out_f32, int out_ld, int out_col0, void* out_xp, int out_xp_ksteps, int out_xp_kstep0,
-                    int out_xp_format, int map_pad, int map_src, void* stream);
+                    int map_pad, int map_src, void* stream);
+
+/* The same layer, same epilogue, on EXACT fp32 MFMA: x fp32 row-major [n_rows, x_ld] (its first k_in columns, k_in % 8 == 0),
+ * w_packed = ops.pack_node_weight_f32(W, tiles_per_block): [n_out/(32 TG)][k_in/8][TG][64][4] fp32 in the pack_weight lane order,
+ * out_f32 required.  No planes, no range limit: the node stream of the "f32" arithmetic. */
+int s2s_node_linear_f32(const float* x, int x_ld, const float* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
+                        int tiles_per_block, const float* pre_scale, int relu, const float* pre_mask, const float* residual,
+                        int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_mask,
+                        float* out_f32, int out_ld, int out_col0, void* stream);
 
 /* The same GEMM with the operands swapped, for a projection whose output is consumed as the A operand of a later product over
  * its ROWS (the value projection of InvariantPointAttention, ipa.py:132-141, consumed by the PV step): the result (+ bias) is
- * stored as bf16x3 MFMA A fragments  out_vf[row tile (32 rows)][head][column tile (32 cols) in head][k-step u (16 rows)][plane]
- * [lane 64][8], element j of lane (column c, half h) = row (r&3) + 8 (r>>2) + 4 h, r = 8 u + j, of the tile.  w_packed as for
- * s2s_node_linear with tiles_per_block = 8.  out_format 0: three bf16 planes (s2s_ipa_attention_planes), 1: f16 pair planes
- * (x_h, x_l), two per fragment group (s2s_ipa_attention_f16w).  map_pad / map_src: the row map of s2s_node_linear. */
+ * stored as MFMA A fragments of f16 pairs  out_vf[row tile (32 rows)][head][column tile (32 cols) in head][k-step u (16 rows)]
+ * [plane 2][lane 64][8], element j of lane (column c, half h) = row (r&3) + 8 (r>>2) + 4 h, r = 8 u + j, of the tile.  w_packed as
+ * for s2s_node_linear with tiles_per_block = 8.  map_pad / map_src: the row map of s2s_node_linear. */
 int s2s_node_linear_vfrag(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
-                          int tiles_per_head, void* out_vf, int out_format, int map_pad, int map_src, void* stream);
+                          int tiles_per_head, void* out_vf, int map_pad, int map_src, void* stream);
 
 /* Self-attention core of the trunk's TransformerEncoderLayer (src/models/net/ipa.py:312-317,357; torch.nn.MultiheadAttention with
  * d_model = n_heads * head_dim, head_dim = 80): softmax(q k^T / sqrt(head_dim) + key_bias[j]) v per (sample, head), exact fp32 MFMA.

@@ -32,10 +32,8 @@ UNITS = {
     "ensemble_metrics.hip": ["-ffp-contract=off"],
     # the MFMA chains are fully unrolled on purpose (accumulator tiles must be statically indexed)
     "pair_mlp.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
-    "pair_mlp_bf16.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
     "pair_mlp_f16.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
     "ipa_attention.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
-    "ipa_attention_planes.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
     "ipa_attention_f16w.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
     "node_gemm.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
     # contraction off: the packed-plane output must be the exact split of the SAME rounded value the fp32 output stores

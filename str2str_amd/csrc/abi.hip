@@ -1,3 +1,14 @@
-// ABI version of libstr2str_hip.so (include/str2str_hip.h).
+// ABI version of libstr2str_hip.so (include/str2str_hip.h) and the library-wide range flag (range_flag.h).
+#include "range_flag.h"
 #include "str2str_hip.h"
-extern "C" int s2s_abi_version(void) { return 15; }
+
+namespace s2s {
+int* g_range_flag = nullptr;
+}
+
+extern "C" int s2s_abi_version(void) { return 16; }
+
+extern "C" int s2s_set_range_flag(int* device_word) {
+    s2s::g_range_flag = device_word;
+    return 0;
+}

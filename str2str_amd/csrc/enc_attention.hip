@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include "range_flag.h"
 #include "str2str_hip.h"
 
 namespace {
@@ -28,7 +29,7 @@ __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >>
 
 template <int DH>
 __global__ void __launch_bounds__(256) enc_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ key_bias,
-                                                            float* __restrict__ out_f32, bf16x8* __restrict__ out_xp, int B, int N,
+                                                            float* __restrict__ out_f32, bf16x8* __restrict__ out_xp, int* range_flag, int B, int N,
                                                             int heads, float scale) {
     static_assert(DH == 80, "built for the reference configuration (d_model 320, 4 heads)");
     constexpr int KSd = DH + 4;          // padded LDS row stride (floats): conflict-free ds_read_b128 of the key rows
@@ -168,6 +169,7 @@ __global__ void __launch_bounds__(256) enc_attention_kernel(const float* __restr
         // packed planes of the [B*N, D] result: fragment (row tile, k-step 5 head + 2t + u, plane, lane 32 h + row % 32)
         const int KS = D / 16;
         bf16x8* o = out_xp + (((row >> 5) * KS + (DH / 16) * head) * 2) * 64 + 32 * h + (int)(row & 31);
+        float amax = 0.f;   // range guard (range_flag.h)
 #pragma unroll
         for (int t = 0; t < CT; ++t)
 #pragma unroll
@@ -179,6 +181,7 @@ __global__ void __launch_bounds__(256) enc_attention_kernel(const float* __restr
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     float v = O[t][8 * u + j] * inv;
+                    amax = s2s::range_max(amax, v);
                     asm volatile("" : "+v"(v));   // one materialised fp32 value feeds both planes (see node_gemm.hip split8_f16)
                     const _Float16 a_ = (_Float16)v;
                     ph[j] = a_; pl[j] = (_Float16)(v - (float)a_);
@@ -186,6 +189,7 @@ __global__ void __launch_bounds__(256) enc_attention_kernel(const float* __restr
                 bf16x8* q = o + ((2 * t + u) * 2) * 64;
                 q[0] = __builtin_bit_cast(bf16x8, ph); q[64] = __builtin_bit_cast(bf16x8, pl);
             }
+        s2s::range_report(range_flag, amax, s2s::kRangeEncoderAttention);
     }
 }
 
@@ -197,6 +201,6 @@ extern "C" int s2s_encoder_attention(const float* qkv, const float* key_bias, fl
     if (!qkv || (!out_f32 && !out_xp) || head_dim != 80 || n_heads < 1 || (n_heads * head_dim) % 32) return (int)hipErrorInvalidValue;
     const long long blocks = (long long)n_samples * n_heads * ((n_res + 127) / 128);
     hipLaunchKernelGGL((enc_attention_kernel<80>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, qkv, key_bias, out_f32,
-                       (bf16x8*)out_xp, n_samples, n_res, n_heads, 1.0f / sqrtf((float)head_dim));
+                       (bf16x8*)out_xp, s2s::g_range_flag, n_samples, n_res, n_heads, 1.0f / sqrtf((float)head_dim));
     return (int)hipGetLastError();
 }

@@ -1,9 +1,25 @@
-// Invariant Point Attention core on f16 pair operands, ONE WAVE PER QUERY TILE (gfx950), the default attention kernel.
-// Structure (phases, image stream, copy slots, software pipeline) is the one csrc/ipa_attention_planes.hip documents for the
-// range-safe bf16-planes kernel; here every operand is an f16 pair (x_h, x_l), three products per block, and with two planes per
-// operand the 18 query fragments of a tile are 144 VGPRs, so a wave owns a whole 32-residue query tile -- all 18 k-steps of S^T
-// and all 10 output tiles -- and a workgroup is four query tiles: no partial-sum exchange between wave halves, no duplicated logit
-// arithmetic, and a K / V image serves four query tiles.
+// Invariant Point Attention core on f16 pair operands, ONE WAVE PER QUERY TILE (gfx950): the default attention kernel, any length.
+// Reference: InvariantPointAttention.forward, src/models/net/ipa.py:183-257 (same operator as csrc/ipa_attention.hip, the exact
+// fp32-operand kernel, which documents the MFMA orientation and the pair-term split).
+//
+// Every matrix operand arrives ALREADY split into f16 pairs (x_h, x_l) in MFMA fragment order, written by the epilogues of the
+// producing GEMMs (csrc/node_gemm.hip) and by the point kernel below, so this kernel contains no operand split except the 16
+// probabilities of a key tile, and all products run on v_mfma_f32_32x32x16_f16 (a_h b_h + a_h b_l + a_l b_h, fp32 accumulate =
+// fp32-equivalent):
+//   S^T[j, i]  = K[j, :] . Q[i, :]  + K'pts[j, :] . Q'pts[i, :]     18 k-steps: 16 of the head's channels + 2 of point coordinates
+//   O^T[c, i] += V^T[c, j] P^T[j, i]                                10 output tiles: 8 of channels + 2 of (x, y, z, 0) value points
+// The point term  -1/2 w_h sum_p |q_ip - k_jp|^2  =  w_h q.k  - 1/2 w_h |q_i|^2 - 1/2 w_h |k_j|^2 : the cross term rides in the
+// QK^T accumulator (the query points are pre-scaled by w_h / c1, c1 = sqrt(1/(3C)) the scalar-logit scale), the two squared
+// norms are per-residue fp32 scalars from the point kernel.  (ipa_attention.hip forms explicit differences on the VALU; the
+// expansion costs ~1e-6 absolute in a logit at protein coordinates / 10 -- see DESIGN.md -- and removes 900 VALU
+// instructions per key tile.)
+//   q_xp, k_xp : packed planes [row tile][16 H k-steps][2][64][8] of the q / k projections (s2s_node_linear out_xp)
+//   v_vf       : [row tile][H][8 col tiles][2][2][64][8] A fragments of the v projection (s2s_node_linear_vfrag)
+//   qp_xp, kp_xp [row tile][H][2][2][64][8], vp_vf [row tile][H][2][2][2][64][8], q2 / k2 [row tile][H][32]: the point kernel
+// With two planes per operand the 18 query fragments of a tile are 144 VGPRs, so a wave owns a whole 32-residue query tile -- all
+// 18 k-steps of S^T and all 10 output tiles -- and a workgroup is four query tiles of one (sample, head): no partial-sum exchange,
+// and a K / V image (36 / 40 KiB, contiguous in HBM) serves four query tiles.  The head output leaves as packed planes of
+// linear_out's input (the accumulator registers ARE its fragments).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdlib.h>
@@ -11,6 +27,7 @@
 #include <type_traits>
 
 #include "geom.h"
+#include "range_flag.h"
 #include "str2str_hip.h"
 
 namespace {
@@ -18,9 +35,9 @@ namespace {
 using namespace s2s;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));   // (name kept from the bf16 kernel: a 16 B fragment of eight f16)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));   // a 16 B fragment
 
-__device__ __forceinline__ f32x16 mfma_b16(bf16x8 a, bf16x8 b, f32x16 c) {
+__device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -41,7 +58,7 @@ __device__ __forceinline__ float exp_neg(float x) {
     return __builtin_fmaf(r, e * LN2, r);
 }
 
-__device__ __forceinline__ void split8(const float* v, bf16x8& ph, bf16x8& pl) {   // x_h, x_l
+__device__ __forceinline__ void split8(const float* v, f16x8& ph, f16x8& pl) {   // x_h, x_l
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         float xv = v[j];
@@ -59,9 +76,9 @@ constexpr int PQ = 8, PV = 12;
 
 __global__ void __launch_bounds__(256) ipa_prep_f16_kernel(const float* __restrict__ rig, const float* __restrict__ qp_lin,
                                                               const float* __restrict__ kvp_lin, const float* __restrict__ head_w,
-                                                              float q_scale_c1, bf16x8* __restrict__ qp_xp, bf16x8* __restrict__ kp_xp,
-                                                              bf16x8* __restrict__ vp_vf, float* __restrict__ q2, float* __restrict__ k2,
-                                                              int H, int n_res, int n_pad) {
+                                                              float q_scale_c1, f16x8* __restrict__ qp_xp, f16x8* __restrict__ kp_xp,
+                                                              f16x8* __restrict__ vp_vf, float* __restrict__ q2, float* __restrict__ k2,
+                                                              int H, int n_res, int n_pad, int* range_flag) {
     // Row tiles are tiles of the PADDED residue range (n_pad = n_res rounded up to 32, per sample): tile rt = sample rt / (n_pad / 32);
     // residues >= n_res of the last tile are padding: zero points, q2 = 0, k2 = -1e9 (such a key can never carry probability).
     __shared__ float sq[32][33], sk[32][33], sv[32][65];
@@ -118,12 +135,13 @@ __global__ void __launch_bounds__(256) ipa_prep_f16_kernel(const float* __restri
         (tid < 32 ? q2 : k2)[(rt * H + head) * 32 + row] = s_pad[row] ? (tid < 32 ? 0.f : -1.0e9f) : -0.5f * hw * acc;
     }
     const float qs = hw / q_scale_c1;
+    float amax = 0.f;   // range guard (range_flag.h): the point coordinates are split into f16 planes here
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int item = tid + 256 * it;  // 0..127 q, 128..255 k, 256..511 value points
         const int lane = item & 63, g = lane >> 5, c = lane & 31;
         float v[8];
-        bf16x8* dst;
+        f16x8* dst;
         if (item < 256) {
             const int ks = (item >> 6) & 1;
             const bool isq = item < 128;
@@ -136,16 +154,19 @@ __global__ void __launch_bounds__(256) ipa_prep_f16_kernel(const float* __restri
             for (int j = 0; j < 8; ++j) v[j] = sv[rowmap(8 * u + j, g)][32 * ct + c];
             dst = vp_vf + ((((rt * H + head) * 2 + ct) * 2 + u) * 2) * 64 + lane;
         }
-        bf16x8 ph, pl;
+        f16x8 ph, pl;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = s2s::range_max(amax, v[j]);
         split8(v, ph, pl);
         dst[0] = ph; dst[64] = pl;
     }
+    s2s::range_report(range_flag, amax, s2s::kRangeIpaPoints);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
 struct PlaneArgs {
-    const bf16x8* q_xp; const bf16x8* k_xp; const bf16x8* v_vf;
-    const bf16x8* qp_xp; const bf16x8* kp_xp; const bf16x8* vp_vf;
+    const f16x8* q_xp; const f16x8* k_xp; const f16x8* v_vf;
+    const f16x8* qp_xp; const f16x8* kp_xp; const f16x8* vp_vf;
     const float* q2; const float* k2;
     const float* attn_bias;  // [B,H,N,N]
     float* logits;           // [B,H,NP,NP] (may alias attn_bias when NP == N)
@@ -153,7 +174,7 @@ struct PlaneArgs {
     const float* mask;       // [B,N]
     const float* rigids7;    // [B,N,7]
     float* out;              // [B,N,feat] fp32: only the o_pt columns are written here
-    bf16x8* out_xp;          // packed planes of the [B*N, 16*xp_ksteps] linear_out input: the o columns (k-steps 16 head ..)
+    f16x8* out_xp;          // packed planes of the [B*N, 16*xp_ksteps] linear_out input: the o columns (k-steps 16 head ..)
     int xp_ksteps;
     int B, N, H;
     int NP;                  // N rounded up to the 32-residue tiles: the fragment arrays, q2 / k2 and the logits use NP rows per sample
@@ -163,19 +184,19 @@ struct PlaneArgs {
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-__device__ __forceinline__ void dma_kib(const bf16x8* src_piece, bf16x8* lds_piece, int lane) {
+__device__ __forceinline__ void dma_kib(const f16x8* src_piece, f16x8* lds_piece, int lane) {
     // one 1 KiB fragment: 16 B per lane, destination = wave-uniform base + lane * 16 (LDS-DMA semantics)
     __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src_piece + lane), (lds_ptr_t)lds_piece, 16, 0, 0);
 }
 
-typedef __attribute__((address_space(3))) const bf16x8 lds_frag;
-__device__ __forceinline__ lds_frag* frag_pin(const bf16x8* p) {
+typedef __attribute__((address_space(3))) const f16x8 lds_frag;
+__device__ __forceinline__ lds_frag* frag_pin(const f16x8* p) {
     lds_frag* q = (lds_frag*)p;
     asm volatile("" : "+v"(q));
     return q;
 }
 
-// Timeline probe (tools/ipa_planes_probe.py; only in -DS2S_IPA_PROBE=<block> builds)
+// Timeline probe (tools/ipa_f16w_probe.py; only in -DS2S_IPA_PROBE=<block> builds)
 #ifdef S2S_IPA_PROBE
 __device__ unsigned long long s2s_ipa8_probe[4][128];
 #define IPROBE(idx) do { if (blockIdx.x == S2S_IPA_PROBE) s2s_ipa8_probe[threadIdx.x >> 6][idx] = __builtin_readcyclecounter(); } while (0)
@@ -210,7 +231,7 @@ constexpr int CT = 8;
 // Workgroups are persistent: the image stream runs across work items (images 2 NT, 2 NT + 1 of an item are images 0, 1 of the
 // next one), so only the first item of a workgroup pays the cold start (14 k cycles = 13 % of an item before this).
 struct PlaneStage {
-    bf16x8 img[2][OT * 2 * 2 * 64];   // 2 x 40 KiB: K image [k-step 18][plane 2][lane] (36 KiB) or V image [tile 10][u][plane 2][lane]
+    f16x8 img[2][OT * 2 * 2 * 64];   // 2 x 40 KiB: K image [k-step 18][plane 2][lane] (36 KiB) or V image [tile 10][u][plane 2][lane]
     __attribute__((aligned(16))) float k2[4][32];                  // per-key scalars of key tile t in slot t % 4 (written two tiles ahead, read one tile late)
     __attribute__((aligned(16))) float km[4][32];
 };
@@ -273,7 +294,7 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
     const __amdgpu_buffer_rsrc_t r_vp = __builtin_amdgcn_make_buffer_rsrc((void*)a.vp_vf, 0, (int)(n_rt * H * 8192), 0x00020000);
     const int lane16 = lane * 16;
     // piece p of this wave: p < 8: piece wave + 4 p of the first array (32 KiB), else piece wave + 4 (p - 8) of the second
-    auto piece_load = [&](int g, int p) -> bf16x8 {
+    auto piece_load = [&](int g, int p) -> f16x8 {
         const bool nx = g >= 2 * NT;
         const int gg = nx ? g - 2 * NT : g;
         const int bb = nx ? nxt.b : cur.b, hh = nx ? nxt.head : cur.head;
@@ -288,10 +309,10 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
             const unsigned off = (rt * H + hh) * (isk ? 4u : 8u) * 1024u + (wave + 4 * (pm - 8)) * 1024u;
             r = __builtin_amdgcn_raw_buffer_load_b128(isk ? r_kp : r_vp, lane16, __builtin_amdgcn_readfirstlane((int)off), 0);
         }
-        return __builtin_bit_cast(bf16x8, r);
+        return __builtin_bit_cast(f16x8, r);
     };
     // cold start only (LDS-DMA wants a flat address)
-    auto piece_src = [&](int g, int p) -> const bf16x8* {
+    auto piece_src = [&](int g, int p) -> const f16x8* {
         const bool isk = g < NT;
         const long long rt = (long long)cur.b * NT + (isk ? g : g - NT);
         const int pm = piece_ok(g, p) ? p : 8;
@@ -299,12 +320,12 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
             return (isk ? a.k_xp + ((rt * (16 * H) + 16 * cur.head) * 2) * 64 : a.v_vf + ((rt * H + cur.head) * 32) * 64) + (wave + 4 * pm) * 64;
         return (isk ? a.kp_xp + ((rt * H + cur.head) * 4) * 64 : a.vp_vf + ((rt * H + cur.head) * 8) * 64) + (wave + 4 * (pm - 8)) * 64;
     };
-    auto piece_dst = [&](int g, int p) -> bf16x8* {
+    auto piece_dst = [&](int g, int p) -> f16x8* {
         const int gg = g >= 2 * NT ? g - 2 * NT : g;
         const int pm = piece_ok(gg, p) ? p : 8;
         return st.img[g & 1] + (pm < 8 ? wave + 4 * pm : 32 + wave + 4 * (pm - 8)) * 64;
     };
-    bf16x8 stg[10];
+    f16x8 stg[10];
     auto stage_load = [&](int g, int p) { stg[p] = piece_load(g, p); };
     // one copy slot: piece p of image g leaves its register for LDS, the register is refilled with piece p of image g + 1
     auto stage_slot = [&](int g, int p) {
@@ -362,7 +383,7 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
         if constexpr (RAGGED) L.mask = L.i < N ? L.mask : 0.f;
         return L;
     };
-    bf16x8 qf[KH][2];
+    f16x8 qf[KH][2];
     // RAGGED: the bias rows are read through a bounds-checked resource (a row of the last key tile runs past its end, the last
     // row of the array past the allocation) at dword alignment
     const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.attn_bias, 0, RAGGED ? (int)((long long)a.B * H * N * N * 4) : 0, 0x00020000);
@@ -378,8 +399,8 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
     float4 xkeep[4];   // S^T of the previous key tile (accumulator layout), consumed one step later
     // this wave's query fragments (B operands): the 18 k-steps of [16 of q_xp | 2 of qp_xp], two planes each
     auto load_queries = [&](const Item& it, const LaneItem& L) {
-        const bf16x8* qs = a.q_xp + ((L.rt_q * (16 * H) + 16 * it.head) * 2) * 64;
-        const bf16x8* ps = a.qp_xp + ((L.rt_q * H + it.head) * 4) * 64;
+        const f16x8* qs = a.q_xp + ((L.rt_q * (16 * H) + 16 * it.head) * 2) * 64;
+        const f16x8* ps = a.qp_xp + ((L.rt_q * H + it.head) * 4) * 64;
 #pragma unroll
         for (int x = 0; x < KH; ++x) {
             const int ks = x;
@@ -466,8 +487,8 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
         for (int r = 0; r < 16; ++r) S0[r] = 0.f, S1[r] = 0.f;
         if constexpr (have) {
             // ---------------- S^T = K . Q^T (+ point cross term): 54 MFMAs on two accumulation chains
-            const bf16x8* k_half = st.img[par] + lane;
-            bf16x8 kf[2][2];
+            const f16x8* k_half = st.img[par] + lane;
+            f16x8 kf[2][2];
             lds_frag* kp = frag_pin(k_half);
 #pragma unroll
             for (int p = 0; p < 2; ++p) kf[0][p] = kp[p * 64];
@@ -479,15 +500,15 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
 #pragma unroll
                     for (int p = 0; p < 2; ++p) kf[(x + 1) & 1][p] = kn[p * 64];
                 }
-                const bf16x8 (&k)[2] = kf[x & 1];
-                const bf16x8 (&q)[2] = qf[x];
+                const f16x8 (&k)[2] = kf[x & 1];
+                const f16x8 (&q)[2] = qf[x];
                 // copy slots 2x, 2x+1 (ten in all): image t + 1 -> LDS (its buffer was released by the barrier of tile t - 1),
                 // image t + 2 -> registers; two logit elements of tile t - 1 per k-step
-                S0 = mfma_b16(k[1], q[0], S0); S1 = mfma_b16(k[0], q[1], S1);   // k_l q_h, k_h q_l
+                S0 = mfma_f16(k[1], q[0], S0); S1 = mfma_f16(k[0], q[1], S1);   // k_l q_h, k_h q_l
                 if (prev && 2 * x < 16) logit_elem(t - 1, 2 * x, xa, xb, sl);   // (same scheduling region as the MFMA pair)
                 stage_slot(t + 1, 2 * x);
                 __builtin_amdgcn_sched_barrier(0);
-                if (x & 1) S1 = mfma_b16(k[0], q[0], S1); else S0 = mfma_b16(k[0], q[0], S0);   // k_h q_h, chains alternate
+                if (x & 1) S1 = mfma_f16(k[0], q[0], S1); else S0 = mfma_f16(k[0], q[0], S0);   // k_h q_h, chains alternate
                 if (prev && 2 * x + 1 < 16) logit_elem(t - 1, 2 * x + 1, xa, xb, sl);
                 stage_slot(t + 1, 2 * x + 1);
                 __builtin_amdgcn_sched_barrier(0);
@@ -542,7 +563,7 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
             lg1[g] = load_l2(lrsrc, loff0 + min(1, NT - 1) * 128 + 32 * g);
         }
     }
-    bf16x8 pc[2][2], pn[2][2];   // planes (h, l) of 2^10 P^T of the current / next tile: [k-step u][plane]
+    f16x8 pc[2][2], pn[2][2];   // planes (h, l) of 2^10 P^T of the current / next tile: [k-step u][plane]
     float pe[16];
     auto p_elem = [&](int r, bool pin) {   // probability of element r of the tile whose logits sit in lg
         float x = lg[r >> 2][r & 3];
@@ -571,15 +592,15 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
         if constexpr (!first) __syncthreads();               // V(t) visible; every wave is done with V(t - 1)
         IPROBE(60 + 6 * t + 1);
         // ---------------- O^T += V^T . P^T for this wave's five output tiles
-        const bf16x8* v_half = st.img[(NT + t) & 1] + lane;
-        auto load_v = [&](int x, bf16x8 (&d)[2][2]) {
+        const f16x8* v_half = st.img[(NT + t) & 1] + lane;
+        auto load_v = [&](int x, f16x8 (&d)[2][2]) {
             lds_frag* pa = frag_pin(v_half + x * 256);
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int p = 0; p < 2; ++p) d[u][p] = pa[(u * 2 + p) * 64];
         };
-        bf16x8 va[3][2][2], vb[3][2][2];   // fragments of the tile groups (0,1) (5,6) / (2,3,4) (7,8,9), alternately
+        f16x8 va[3][2][2], vb[3][2][2];   // fragments of the tile groups (0,1) (5,6) / (2,3,4) (7,8,9), alternately
         load_v(0, va[0]);
         load_v(1, va[1]);
         __builtin_amdgcn_sched_barrier(0);
@@ -619,14 +640,14 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
             if constexpr (gi == 13) load_v(8, vb[1]);
             if constexpr (gi == 14) load_v(9, vb[2]);
         };
-        auto group = [&](auto g0c, auto n3c, f32x16& o0, f32x16& o1, f32x16& o2, const bf16x8 (&v)[3][2][2]) {
+        auto group = [&](auto g0c, auto n3c, f32x16& o0, f32x16& o1, f32x16& o2, const f16x8 (&v)[3][2][2]) {
             constexpr int g0 = decltype(g0c)::value;
             constexpr bool three = decltype(n3c)::value;
             f32x16 oa = o0, ob = o1, oc = o2;
             auto one = [&](auto ic) {
                 constexpr int i = decltype(ic)::value, u = i / 3, k = i % 3;
-                oa = mfma_b16(v[0][u][PA[k]], pc[u][PB[k]], oa); ob = mfma_b16(v[1][u][PA[k]], pc[u][PB[k]], ob);
-                if constexpr (three) oc = mfma_b16(v[2][u][PA[k]], pc[u][PB[k]], oc);
+                oa = mfma_f16(v[0][u][PA[k]], pc[u][PB[k]], oa); ob = mfma_f16(v[1][u][PA[k]], pc[u][PB[k]], ob);
+                if constexpr (three) oc = mfma_f16(v[2][u][PA[k]], pc[u][PB[k]], oc);
                 ride(std::integral_constant<int, g0 + i>{});   // (same scheduling region as the MFMAs: hipcc interleaves the VALU between them)
                 __builtin_amdgcn_sched_barrier(0);
             };
@@ -670,7 +691,7 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
     {
         // o: accumulator registers 8u .. 8u+7 of channel tile T = fragment k-step 16 head + 2T + u of this row tile (chain order)
         // (RAGGED: the output rows are NOT padded -- row_i sits at position row_i & 31 of row tile row_i >> 5 of the [B N] rows)
-        bf16x8* o = RAGGED ? a.out_xp + (((row_i >> 5) * a.xp_ksteps + 16 * head) * 2) * 64 + ((int)(row_i & 31) + 32 * h)
+        f16x8* o = RAGGED ? a.out_xp + (((row_i >> 5) * a.xp_ksteps + 16 * head) * 2) * 64 + ((int)(row_i & 31) + 32 * h)
                            : a.out_xp + ((rt_q * a.xp_ksteps + 16 * head) * 2) * 64 + lane;
         const bool row_ok = !RAGGED || i < N;
 #pragma unroll
@@ -683,7 +704,6 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = O[x][8 * u + j] * inv;
                 // this output is an INPUT of the node stream (linear_out, s2s_node_linear): f16 pair planes (x_h, x_l)
-                typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
                 f16x8 ph, pl;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -692,7 +712,7 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
                     const _Float16 hh = (_Float16)xv;
                     ph[j] = hh; pl[j] = (_Float16)(xv - (float)hh);
                 }
-                bf16x8* q = o + ((2 * T + u) * 2) * 64;
+                f16x8* q = o + ((2 * T + u) * 2) * 64;
                 if (row_ok) { q[0] = ph; q[64] = pl; }
             }
         }
@@ -766,8 +786,8 @@ extern "C" int s2s_ipa_prep_points_f16(const float* rigids7, const float* q_pts_
     const long long blocks = (long long)n_samples * (n_pad / 32) * n_heads;
     if (blocks >= (1ll << 31)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(ipa_prep_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rigids7, q_pts_lin, kv_pts_lin,
-                       head_w_scaled, sqrtf(1.0f / (3 * c_hidden)), (bf16x8*)qp_xp, (bf16x8*)kp_xp, (bf16x8*)vp_vf, q2, k2, n_heads, n_res,
-                       n_pad);
+                       head_w_scaled, sqrtf(1.0f / (3 * c_hidden)), (f16x8*)qp_xp, (f16x8*)kp_xp, (f16x8*)vp_vf, q2, k2, n_heads, n_res,
+                       n_pad, s2s::g_range_flag);
     return (int)hipGetLastError();
 }
 
@@ -799,8 +819,8 @@ extern "C" int s2s_ipa_attention_f16w(const void* q_xp, const void* k_xp, const 
         n_cu = prop.multiProcessorCount >= 8 ? prop.multiProcessorCount / 8 * 8 : prop.multiProcessorCount;
     }
     const long long blocks = items < n_cu ? items : n_cu;
-    PlaneArgs a{(const bf16x8*)q_xp, (const bf16x8*)k_xp, (const bf16x8*)v_vf, (const bf16x8*)qp_xp, (const bf16x8*)kp_xp,
-                (const bf16x8*)vp_vf, q2, k2, attn_bias, logits_out, stats_out, mask, rigids7, out, (bf16x8*)out_xp, out_xp_ksteps,
+    PlaneArgs a{(const f16x8*)q_xp, (const f16x8*)k_xp, (const f16x8*)v_vf, (const f16x8*)qp_xp, (const f16x8*)kp_xp,
+                (const f16x8*)vp_vf, q2, k2, attn_bias, logits_out, stats_out, mask, rigids7, out, (f16x8*)out_xp, out_xp_ksteps,
                 n_samples, n_res, n_heads, n_pad, inf, eps, (remap_env && items % 8 == 0 && blocks % 8 == 0 && n_qb > 1) ? 1 : 0};
     if (ragged)
         hipLaunchKernelGGL(ipa_attention_f16w_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);

@@ -16,9 +16,12 @@
 // Planes of the node stream: the f16 pair (x_h = rn16(x), x_l = rn16(x - x_h)), TWO planes per k-step; a product keeps
 //     W_h x_h + W_h x_l + W_l x_h,   (W_h, W_l) = the same split of 2^5 w   (the factor keeps W_l in f16's normal range)
 // -- 3 MFMAs and 2 weight fragments per (k-step, tile); what is dropped (w_l x_l) is below one fp32 rounding; the accumulators
-// carry 32 x the output and the 2^-5 rides in the epilogue's first multiply-add.  The f16 attention kernel takes the same pair
-// planes (q / k projections); the bf16 attention kernel wants exact three-way bf16 planes (h, m, l): out_xp_format = 1 writes
-// those instead.  Weights are packed on the host in chain order (ops.pack_node_weight): [col block][k-step][tile][2][lane][8].
+// carry 32 x the output and the 2^-5 rides in the epilogue's first multiply-add.  The attention kernel takes the same pair
+// planes (q / k projections).  Weights are packed on the host in chain order (ops.pack_node_weight):
+// [col block][k-step][tile][2][lane][8].  Values written as planes feed the range guard (range_flag.h).
+//
+// s2s_node_linear_f32 (bottom of this file) is the same layer with the same epilogue on exact fp32 MFMA, fp32 row-major in and
+// out: the node stream of the range-safe / exact mode (S2S_ARITH=f32; the sampler's fallback when the range guard fires).
 //
 // Per workgroup: 4 waves x 32 rows, TG output tiles of 32 columns (TG x 16 accumulator registers per lane), one weight stage
 // (one k-step: TG tiles x 2 planes = 2 TG KiB) per barrier, two workgroups per CU.  Per (k-step, tile): 2 ds_read_b128 + 3
@@ -28,13 +31,15 @@
 
 #include <cstdlib>
 
+#include "range_flag.h"
 #include "str2str_hip.h"
 
 namespace {
 
+using s2s::range_max;
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
@@ -42,18 +47,6 @@ __device__ __forceinline__ f32x16 mfma_f16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
-
-// exact 3-way split of 8 fp32 values into bf16 planes (round-to-nearest residues)
-__device__ __forceinline__ void split8(const float* v, bf16x8& ph, bf16x8& pm, bf16x8& pl) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const __bf16 a = (__bf16)v[j];
-        const float r1 = v[j] - (float)a;
-        const __bf16 b = (__bf16)r1;
-        const float r2 = r1 - (float)b;
-        ph[j] = a; pm[j] = b; pl[j] = (__bf16)r2;
-    }
-}
 
 constexpr float kInvWS = 1.0f / 32.0f;   // weights are packed as the split of 2^5 w: accumulators carry 32 x the output
 
@@ -70,23 +63,18 @@ __device__ __forceinline__ void split8_f16(const float* v, f16x8& ph, f16x8& pl)
         ph[j] = a; pl[j] = (_Float16)(xv - (float)a);
     }
 }
-// 8 values -> 16 B plane fragments 64 fragments apart: format 1 = exact three-way bf16 planes (three per k-step), otherwise the
-// f16 pair (x_h, x_l) (two per k-step) -- the caller's k-step stride follows
-__device__ __forceinline__ void store_planes(f16x8* q, const float* v, int fmt) {
-    if (fmt == 1) {
-        bf16x8 ph, pm, pl;
-        split8(v, ph, pm, pl);
-        q[0] = __builtin_bit_cast(f16x8, ph); q[64] = __builtin_bit_cast(f16x8, pm); q[128] = __builtin_bit_cast(f16x8, pl);
-    } else {
-        f16x8 ph, pl;
-        split8_f16(v, ph, pl);
-        q[0] = ph; q[64] = pl;
-    }
+// 8 values -> the two 16 B plane fragments (x_h, x_l), 64 fragments apart; the values feed the caller's range maximum
+__device__ __forceinline__ void store_planes(f16x8* q, const float* v, float& amax) {
+    f16x8 ph, pl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = range_max(amax, v[j]);
+    split8_f16(v, ph, pl);
+    q[0] = ph; q[64] = pl;
 }
 
 struct GemmArgs {
-    const f16x8* xp;         // packed activation planes [RT][KS][2][64] fragments (f16 pair)
-    const char* wpk;         // packed weights [n_col_blocks][KS][TG][2][64][8] f16: (W_h, W_l) of 32 w
+    const f16x8* xp;         // packed activation planes [RT][KS][2][64] fragments (f16 pair); fp32 kernel: const float* [M, x_ld]
+    const char* wpk;         // packed weights [n_col_blocks][KS][TG][2][64][8] f16: (W_h, W_l) of 32 w; fp32 kernel: [ncb][K/8][TG][64][4] fp32
     const float* bias;       // [Nout] or NULL
     const float* pre_scale;  // [M] or NULL: acc *= pre_scale[row] before the bias (input rows were to be scaled)
     const float* pre_mask;   // [M] or NULL: (acc + bias) *= pre_mask[row]
@@ -96,7 +84,7 @@ struct GemmArgs {
     const float* post_mask;  // [M] or NULL: applied last
     float* out_f32;          // [M, out_ld] (columns out_col0 + ...) or NULL
     f16x8* out_xp;           // packed planes of the output as a K' = 16 * xp_KS wide activation, at k-step offset xp_ks0, or NULL
-    bf16x8* out_vf;          // VF kernels only (exact three-way bf16 planes: the attention kernel's PV operands): the output as A fragments of a [32 rows x 32 columns] x 2 k-step tiling (see below)
+    f16x8* out_vf;           // VF kernels only (the attention kernel's PV operands): the output as A fragments of a [32 rows x 32 columns] x 2 k-step tiling (see below)
     int vf_tiles_per_head;   // column tiles (of 32) per head
     long long M;
     int KS;                  // K / 16 (even)
@@ -104,18 +92,113 @@ struct GemmArgs {
     int res_ld, out_ld, out_col0, xp_KS, xp_ks0;
     int relu;
     float ln_eps;
-    int xp_bf16;             // out_xp format: 0 (or 2) f16 pair planes, 1 exact three-way bf16 planes (bf16 attention kernel);
-                             // VF kernels: 0 = bf16 triples, 1 = f16 pairs
+    int x_ld;                // fp32 kernel: row stride of x
+    int* range_flag;         // range guard word (range_flag.h) or NULL
     int map_pad, map_src;    // map_pad > 0: OUTPUT row r = sample r / map_pad, residue n = r % map_pad reads INPUT row
                              // sample * map_src + min(n, map_src - 1) of xp: the per-sample padding to whole 32-row tiles the
                              // attention kernel wants for ragged lengths (padded rows repeat the sample's last row: finite, masked there)
 };
 
+// Epilogue shared by the f16x3 and the fp32 kernel.  Lane (row m = lane & 31, half h): register r of tile t = column
+// 32 t + (r&3) + 8 (r>>2) + 4 h.   v = acc * ps + bias;  relu;  v *= pre_mask[row];  v += residual;  LayerNorm;  v *= post_mask[row]
+template <int TG>
+__device__ __forceinline__ void node_epilogue(f32x16 (&acc)[TG], const GemmArgs& a, long long rt, long long n_rt, int lane, int cb,
+                                              float ps) {
+    const int h = lane >> 5;
+    const long long row = rt * 32 + (lane & 31);
+    const bool valid = rt < n_rt && row < a.M;
+    const long long rowc = valid ? row : a.M - 1;
+    const float pm = a.pre_mask ? a.pre_mask[rowc] : 1.0f;
+    const int col_base = cb * TG * 32;
+    #pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int c0 = col_base + 32 * t + 8 * rq + 4 * h;
+            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + c0);
+            float v[4] = {acc[t][4 * rq + 0] * ps + b.x, acc[t][4 * rq + 1] * ps + b.y, acc[t][4 * rq + 2] * ps + b.z,
+                          acc[t][4 * rq + 3] * ps + b.w};
+            if (a.relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= pm;
+            if (a.residual) {
+                const float4 rr = *reinterpret_cast<const float4*>(a.residual + rowc * a.res_ld + c0);
+                v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][4 * rq + e] = v[e];
+        }
+    if (a.ln_gamma) {  // LayerNorm over the TG*32 columns of the row (half here, half in lane ^ 32)
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum += acc[t][r];
+        const float mean = xhalf_sum(sum) * (1.0f / (TG * 32));
+        float var = 0.f;
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = acc[t][r] - mean;
+                var += d * d;
+            }
+        const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / (TG * 32)) + a.ln_eps);
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int c0 = col_base + 32 * t + 8 * rq + 4 * h;
+                const float4 g = *reinterpret_cast<const float4*>(a.ln_gamma + c0), be = *reinterpret_cast<const float4*>(a.ln_beta + c0);
+                acc[t][4 * rq + 0] = (acc[t][4 * rq + 0] - mean) * rstd * g.x + be.x;
+                acc[t][4 * rq + 1] = (acc[t][4 * rq + 1] - mean) * rstd * g.y + be.y;
+                acc[t][4 * rq + 2] = (acc[t][4 * rq + 2] - mean) * rstd * g.z + be.z;
+                acc[t][4 * rq + 3] = (acc[t][4 * rq + 3] - mean) * rstd * g.w + be.w;
+            }
+    }
+    if (a.post_mask) {
+        const float q = a.post_mask[rowc];
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] *= q;
+    }
+    if (a.out_f32 && valid) {
+        float* o = a.out_f32 + row * a.out_ld + a.out_col0 + col_base;
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                *reinterpret_cast<float4*>(o + 32 * t + 8 * rq + 4 * h) =
+                    make_float4(acc[t][4 * rq + 0], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]);
+    }
+    if (a.out_xp && rt < n_rt) {
+        // the accumulator layout is the next layer's B-operand layout: k-step 2 (cb TG + t) + u = registers 8u .. 8u+7 of tile t.
+        // Rows past M inside the last row tile are written as zeros (they are read, never stored, by the consumer).
+        float amax = 0.f;
+        f16x8* o = a.out_xp + ((rt * a.xp_KS + a.xp_ks0 + 2 * (cb * TG)) * 2) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = valid ? acc[t][8 * u + j] : 0.f;
+                store_planes(o + ((2 * t + u) * 2) * 64, v, amax);
+            }
+        s2s::range_report(a.range_flag, amax, s2s::kRangeNodeGemm);
+    }
+}
+
 // VF: operands swapped -- Y[row, col] = X . W^T with A = the activation fragment, B = the weight fragment -- so that a lane owns
 // one OUTPUT COLUMN and 16 rows (accumulator register r <-> row (r&3) + 8 (r>>2) + 4 h of the 32-row tile): registers 8u .. 8u+7
 // are then exactly the A fragment (k-step u) of a later  Z^T[col, i] += Y^T[col, row] P^T[row, i]  product over the rows, i.e. of
 // the attention's PV step with rows = keys (csrc/ipa_attention.hip).  The epilogue adds the bias, splits and stores them as
-//   out_vf[row tile][head][column tile in head][k-step u][plane 3][lane 64][8]   (bf16; 1 KiB per (u, plane), lane-linear)
+//   out_vf[row tile][head][column tile in head][k-step u][plane 2][lane 64][8]   (f16 pairs; 1 KiB per (u, plane), lane-linear)
 template <int TG, int WAVES, bool VF>
 __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
     // One weight stage = ONE k-step (TG tiles x 2 planes = 2 TG KiB), double buffered: 4 TG KiB of LDS and <= 256 registers, so
@@ -213,10 +296,8 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
     };
 
     const long long row = rt * 32 + (lane & 31);
-    const bool valid = rt < n_rt && row < a.M;
-    const long long rowc = valid ? row : a.M - 1;
+    const long long rowc = (rt < n_rt && row < a.M) ? row : a.M - 1;
     const float ps = (a.pre_scale ? a.pre_scale[rowc] : 1.0f) * kInvWS;   // (the accumulators carry 32 x the product)
-    const float pm = a.pre_mask ? a.pre_mask[rowc] : 1.0f;
 
     const int cb = blockIdx.y;
 #pragma unroll
@@ -261,7 +342,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
     }
 #endif
 
-    const int col_base = cb * TG * 32;
+    float amax = 0.f;   // range guard: largest magnitude written as planes
     if constexpr (VF) {
         // lane (column c = lane & 31 of tile t, half h): register r = row (r&3) + 8 (r>>2) + 4 h of the wave's row tile
         if (rt < n_rt) {
@@ -269,9 +350,8 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
             for (int t = 0; t < TG; ++t) {
                 const int T = cb * TG + t;
                 const float bv = a.bias ? a.bias[32 * T + (lane & 31)] : 0.f;
-                const int vpl = a.xp_bf16 ? 2 : 3;   // planes per fragment group
-                bf16x8* o = a.out_vf + ((((rt * (a.n_col_blocks * TG / a.vf_tiles_per_head) + T / a.vf_tiles_per_head) * a.vf_tiles_per_head +
-                                          T % a.vf_tiles_per_head) * 2) * vpl) * 64 + lane;
+                f16x8* o = a.out_vf + ((((rt * (a.n_col_blocks * TG / a.vf_tiles_per_head) + T / a.vf_tiles_per_head) * a.vf_tiles_per_head +
+                                         T % a.vf_tiles_per_head) * 2) * 2) * 64 + lane;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     float v[8];
@@ -280,108 +360,21 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
                         const int r = 8 * u + j;
                         v[j] = (rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < a.M) ? __builtin_fmaf(acc[t][r], kInvWS, bv) : 0.f;
                     }
-                    if (a.xp_bf16) {   // f16 pair (x_h, x_l): operands of s2s_ipa_attention_f16
-                        f16x8 ph, pl;
-                        split8_f16(v, ph, pl);
-                        o[(u * 2) * 64] = __builtin_bit_cast(bf16x8, ph); o[(u * 2 + 1) * 64] = __builtin_bit_cast(bf16x8, pl);
-                    } else {
-                        bf16x8 ph, pmid, pl;
-                        split8(v, ph, pmid, pl);
-                        o[(u * 3) * 64] = ph; o[(u * 3 + 1) * 64] = pmid; o[(u * 3 + 2) * 64] = pl;
-                    }
+                    store_planes(o + (u * 2) * 64, v, amax);
                 }
             }
         }
+        s2s::range_report(a.range_flag, amax, s2s::kRangeNodeGemm);
         return;
     }
-    // ---------------- epilogue.  Lane (row m = lane & 31, half h): register r of tile t = column 32 t + (r&3) + 8 (r>>2) + 4 h
-#pragma unroll
-    for (int t = 0; t < TG; ++t)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const int c0 = col_base + 32 * t + 8 * rq + 4 * h;
-            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + c0);
-            float v[4] = {acc[t][4 * rq + 0] * ps + b.x, acc[t][4 * rq + 1] * ps + b.y, acc[t][4 * rq + 2] * ps + b.z,
-                          acc[t][4 * rq + 3] * ps + b.w};
-            if (a.relu) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= pm;
-            if (a.residual) {
-                const float4 rr = *reinterpret_cast<const float4*>(a.residual + rowc * a.res_ld + c0);
-                v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t][4 * rq + e] = v[e];
-        }
-    if (a.ln_gamma) {  // LayerNorm over the TG*32 columns of the row (half here, half in lane ^ 32)
-        float sum = 0.f;
-#pragma unroll
-        for (int t = 0; t < TG; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sum += acc[t][r];
-        const float mean = xhalf_sum(sum) * (1.0f / (TG * 32));
-        float var = 0.f;
-#pragma unroll
-        for (int t = 0; t < TG; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float d = acc[t][r] - mean;
-                var += d * d;
-            }
-        const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / (TG * 32)) + a.ln_eps);
-#pragma unroll
-        for (int t = 0; t < TG; ++t)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int c0 = col_base + 32 * t + 8 * rq + 4 * h;
-                const float4 g = *reinterpret_cast<const float4*>(a.ln_gamma + c0), be = *reinterpret_cast<const float4*>(a.ln_beta + c0);
-                acc[t][4 * rq + 0] = (acc[t][4 * rq + 0] - mean) * rstd * g.x + be.x;
-                acc[t][4 * rq + 1] = (acc[t][4 * rq + 1] - mean) * rstd * g.y + be.y;
-                acc[t][4 * rq + 2] = (acc[t][4 * rq + 2] - mean) * rstd * g.z + be.z;
-                acc[t][4 * rq + 3] = (acc[t][4 * rq + 3] - mean) * rstd * g.w + be.w;
-            }
-    }
-    if (a.post_mask) {
-        const float q = a.post_mask[rowc];
-#pragma unroll
-        for (int t = 0; t < TG; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] *= q;
-    }
-    if (a.out_f32 && valid) {
-        float* o = a.out_f32 + row * a.out_ld + a.out_col0 + col_base;
-#pragma unroll
-        for (int t = 0; t < TG; ++t)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq)
-                *reinterpret_cast<float4*>(o + 32 * t + 8 * rq + 4 * h) =
-                    make_float4(acc[t][4 * rq + 0], acc[t][4 * rq + 1], acc[t][4 * rq + 2], acc[t][4 * rq + 3]);
-    }
-    if (a.out_xp && rt < n_rt) {
-        // the accumulator layout is the next layer's B-operand layout: k-step 2 (cb TG + t) + u = registers 8u .. 8u+7 of tile t.
-        // Rows past M inside the last row tile are written as zeros (they are read, never stored, by the consumer).
-        const int fmt = a.xp_bf16, npl = fmt == 1 ? 3 : 2;
-        f16x8* o = a.out_xp + ((rt * a.xp_KS + a.xp_ks0 + 2 * (cb * TG)) * npl) * 64 + lane;
-#pragma unroll
-        for (int t = 0; t < TG; ++t)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float v[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = valid ? acc[t][8 * u + j] : 0.f;
-                store_planes(o + ((2 * t + u) * npl) * 64, v, fmt);
-            }
-    }
+    node_epilogue<TG>(acc, a, rt, n_rt, lane, cb, ps);
 }
 
 // fp32 row-major [M, ld] (columns col0 .. col0 + 16 KS) -> packed planes at k-step offset ks0 of an XP buffer with xp_KS k-steps.
-// One wave per (row tile, k-step): lane (row m, half g) gathers its 8 chain-ordered channels (two float4), splits, stores 3 x 16 B.
+// One wave per (row tile, k-step): lane (row m, half g) gathers its 8 chain-ordered channels (two float4), splits, stores 2 x 16 B.
 __global__ void __launch_bounds__(256) pack_planes_kernel(const float* __restrict__ x, long long M, int ld, int col0, int KS,
-                                                          f16x8* __restrict__ xp, int xp_KS, int ks0, const float* __restrict__ row_scale) {
+                                                          f16x8* __restrict__ xp, int xp_KS, int ks0, const float* __restrict__ row_scale,
+                                                          int* range_flag) {
     const int lane = threadIdx.x & 63, g = lane >> 5;
     const long long unit = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long n_rt = (M + 31) / 32;
@@ -398,7 +391,56 @@ __global__ void __launch_bounds__(256) pack_planes_kernel(const float* __restric
         v[0] = lo.x * sc; v[1] = lo.y * sc; v[2] = lo.z * sc; v[3] = lo.w * sc;
         v[4] = hi.x * sc; v[5] = hi.y * sc; v[6] = hi.z * sc; v[7] = hi.w * sc;
     }
-    store_planes(xp + ((rt * xp_KS + ks0 + ks) * 2) * 64 + lane, v, 0);
+    float amax = 0.f;
+    store_planes(xp + ((rt * xp_KS + ks0 + ks) * 2) * 64 + lane, v, amax);
+    s2s::range_report(range_flag, amax, s2s::kRangePackPlanes);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The same layer on EXACT fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 row-major in and out: no planes, no range limit.  One wave =
+// 32 rows x TG output tiles; per group of 8 input channels a lane (row m, half h) loads X[m][8 j + 4 h .. + 3] and, per tile, the
+// packed weight float4 W[32 t + m][8 j + 4 h .. + 3] (pack_weight order of csrc/pair_mlp.hip: MFMA i of the group contracts the
+// channel pair (8 j + i, 8 j + 4 + i)); weights come straight from L2 (this is the fallback path: simplicity over the last 2x).
+template <int TG>
+__global__ void __launch_bounds__(256) node_gemm_f32_kernel(GemmArgs a) {
+    const int lane = threadIdx.x & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long rt = (long long)blockIdx.x * 4 + wave;
+    const long long n_rt = (a.M + 31) / 32;
+    const int cb = blockIdx.y;
+    const long long row = rt * 32 + (lane & 31);
+    const long long rowc = (rt < n_rt && row < a.M) ? row : a.M - 1;
+    const int S4 = a.KS;   // groups of 8 input channels
+    const float* xr = reinterpret_cast<const float*>(a.xp) + rowc * a.x_ld + 4 * h;
+    const float4* w = reinterpret_cast<const float4*>(a.wpk) + ((long long)cb * S4 * TG) * 64 + lane;
+    f32x16 acc[TG];
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float4 xv = *reinterpret_cast<const float4*>(xr);
+    for (int j = 0; j < S4; ++j) {
+        const float4 xn = *reinterpret_cast<const float4*>(xr + 8 * (j + 1 < S4 ? j + 1 : j));
+        const float4* wj = w + (long long)j * TG * 64;
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+            const float4 wv = wj[t * 64];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.x, xv.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.y, xv.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.z, xv.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv.w, xv.w, acc[t], 0, 0, 0);
+        }
+        xv = xn;
+    }
+    const float ps = a.pre_scale ? a.pre_scale[rowc] : 1.0f;
+    node_epilogue<TG>(acc, a, rt, n_rt, lane, cb, ps);
+}
+
+template <int TG>
+int launch_gemm_f32(const GemmArgs& a, hipStream_t stream) {
+    const long long n_rt = (a.M + 31) / 32;
+    hipLaunchKernelGGL((node_gemm_f32_kernel<TG>), dim3((unsigned)((n_rt + 3) / 4), (unsigned)a.n_col_blocks), dim3(256), 0, stream, a);
+    return (int)hipGetLastError();
 }
 
 template <int TG, int WAVES, bool VF = false>
@@ -432,32 +474,38 @@ extern "C" int s2s_pack_planes(const float* x, long long n_rows, int ld, int col
     const int KS = n_cols / 16;
     const long long units = ((n_rows + 31) / 32) * KS;
     hipLaunchKernelGGL(pack_planes_kernel, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n_rows, ld, col0, KS,
-                       (f16x8*)xp, xp_ksteps, xp_kstep0, row_scale);
+                       (f16x8*)xp, xp_ksteps, xp_kstep0, row_scale, s2s::g_range_flag);
     return (int)hipGetLastError();
+}
+
+static int check_epilogue(int n_out, int TG, const float* ln_gamma, const float* ln_beta, const float* out_f32, int out_ld, int out_col0,
+                          const float* residual, int residual_ld) {
+    if (n_out <= 0 || TG <= 0 || n_out % (32 * TG)) return 1;
+    if ((ln_gamma != nullptr) != (ln_beta != nullptr) || (ln_gamma && n_out != 32 * TG)) return 1;
+    if (out_f32 && (out_ld % 4 || out_col0 % 4)) return 1;
+    if (residual && residual_ld % 4) return 1;
+    return 0;
 }
 
 extern "C" int s2s_node_linear(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
                                int tiles_per_block, const float* pre_scale, int relu, const float* pre_mask, const float* residual,
                                int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_mask,
                                float* out_f32, int out_ld, int out_col0, void* out_xp, int out_xp_ksteps, int out_xp_kstep0,
-                               int out_xp_format, int map_pad, int map_src, void* stream) {
+                               int map_pad, int map_src, void* stream) {
     if (n_rows <= 0) return 0;
     // row map (padded output rows): n_rows counts OUTPUT rows; per-row epilogue operands are not mapped
     if (map_pad < 0 || (map_pad > 0 && (map_src <= 0 || map_src > map_pad || map_pad % 32 || n_rows % map_pad || pre_scale || pre_mask ||
                                         residual || post_mask)))
         return (int)hipErrorInvalidValue;
     const int TG = tiles_per_block;
-    if (!xp || !w_packed || k_in <= 0 || k_in % 32 || n_out <= 0 || n_out % (32 * TG) || (!out_f32 && !out_xp))
+    if (!xp || !w_packed || k_in <= 0 || k_in % 32 || (!out_f32 && !out_xp) ||
+        check_epilogue(n_out, TG, ln_gamma, ln_beta, out_f32, out_ld, out_col0, residual, residual_ld))
         return (int)hipErrorInvalidValue;
     const int ncb = n_out / (32 * TG);
-    if ((ln_gamma != nullptr) != (ln_beta != nullptr) || (ln_gamma && ncb != 1)) return (int)hipErrorInvalidValue;
-    if (out_f32 && (out_ld % 4 || out_col0 % 4)) return (int)hipErrorInvalidValue;
-    if (residual && residual_ld % 4) return (int)hipErrorInvalidValue;
     if (out_xp && (out_xp_kstep0 < 0 || out_xp_kstep0 % 2 || out_xp_kstep0 + n_out / 16 > out_xp_ksteps)) return (int)hipErrorInvalidValue;
-    if (out_xp_format < 0 || out_xp_format > 2) return (int)hipErrorInvalidValue;
     GemmArgs a{(const f16x8*)xp, (const char*)w_packed, bias, pre_scale, pre_mask, residual, ln_gamma, ln_beta, post_mask, out_f32,
                (f16x8*)out_xp, nullptr, 0, n_rows, k_in / 16, ncb, residual_ld, out_ld, out_col0, out_xp_ksteps, out_xp_kstep0, relu, ln_eps,
-               out_xp_format, map_pad, map_src};
+               0, s2s::g_range_flag, map_pad, map_src};
     hipStream_t st = (hipStream_t)stream;
     switch (TG) {
         case 1: return launch_gemm<1>(a, st);
@@ -471,8 +519,32 @@ extern "C" int s2s_node_linear(const void* xp, const void* w_packed, const float
     }
 }
 
+extern "C" int s2s_node_linear_f32(const float* x, int x_ld, const float* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
+                                   int tiles_per_block, const float* pre_scale, int relu, const float* pre_mask, const float* residual,
+                                   int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps, const float* post_mask,
+                                   float* out_f32, int out_ld, int out_col0, void* stream) {
+    if (n_rows <= 0) return 0;
+    const int TG = tiles_per_block;
+    if (!x || !w_packed || !out_f32 || k_in <= 0 || k_in % 8 || x_ld % 4 || x_ld < k_in ||
+        check_epilogue(n_out, TG, ln_gamma, ln_beta, out_f32, out_ld, out_col0, residual, residual_ld))
+        return (int)hipErrorInvalidValue;
+    GemmArgs a{(const f16x8*)x, (const char*)w_packed, bias, pre_scale, pre_mask, residual, ln_gamma, ln_beta, post_mask, out_f32,
+               nullptr, nullptr, 0, n_rows, k_in / 8, n_out / (32 * TG), residual_ld, out_ld, out_col0, 0, 0, relu, ln_eps, x_ld, nullptr, 0, 0};
+    hipStream_t st = (hipStream_t)stream;
+    switch (TG) {
+        case 1: return launch_gemm_f32<1>(a, st);
+        case 2: return launch_gemm_f32<2>(a, st);
+        case 4: return launch_gemm_f32<4>(a, st);
+        case 5: return launch_gemm_f32<5>(a, st);
+        case 6: return launch_gemm_f32<6>(a, st);
+        case 8: return launch_gemm_f32<8>(a, st);
+        case 10: return launch_gemm_f32<10>(a, st);
+        default: return (int)hipErrorInvalidValue;
+    }
+}
+
 extern "C" int s2s_node_linear_vfrag(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
-                                     int tiles_per_head, void* out_vf, int out_format, int map_pad, int map_src, void* stream) {
+                                     int tiles_per_head, void* out_vf, int map_pad, int map_src, void* stream) {
     if (n_rows <= 0) return 0;
     constexpr int TG = 8;
     if (map_pad < 0 || (map_pad > 0 && (map_src <= 0 || map_src > map_pad || map_pad % 32 || n_rows % map_pad))) return (int)hipErrorInvalidValue;
@@ -480,7 +552,7 @@ extern "C" int s2s_node_linear_vfrag(const void* xp, const void* w_packed, const
         (n_out / 32) % tiles_per_head)
         return (int)hipErrorInvalidValue;
     GemmArgs a{(const f16x8*)xp, (const char*)w_packed, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-               (bf16x8*)out_vf, tiles_per_head, n_rows, k_in / 16, n_out / (32 * TG), 0, 0, 0, 0, 0, 0, 0.f, out_format ? 1 : 0, map_pad,
+               (f16x8*)out_vf, tiles_per_head, n_rows, k_in / 16, n_out / (32 * TG), 0, 0, 0, 0, 0, 0, 0.f, 0, s2s::g_range_flag, map_pad,
                map_src};
     return launch_gemm_w<TG, 4, true>(a, (hipStream_t)stream);
 }

@@ -1,21 +1,46 @@
-// EdgeTransition on split-f16 MFMA ("f16x3"): the schedule of csrc/pair_mlp_bf16.hip (same slots, phases, weight pipe, persistent
-// workgroups -- read its header first) with HALF the matrix instructions per slot and TWO THIRDS of the weight fragments.
+// EdgeTransition / edge embedding on split-f16 MFMA ("f16x3"): fp32-equivalent accuracy on the 16-bit matrix cores, the DEFAULT
+// arithmetic of the pair stream.  Same operators and contracts as s2s_edge_transition / s2s_edge_embed (csrc/pair_mlp.hip, the
+// exact fp32-MFMA kernels; reference EdgeTransition.forward, src/models/net/layers.py:170-185 + mask ipa.py:372, and
+// EmbeddingModule.forward, denoising_ipa.py:137-158).
 //
-// Every fp32 operand is split into two f16 numbers  x = x_h + x_l (+ <= 2^-24 |x|),  x_h = rn16(x), x_l = rn16(x - x_h)  --
-// 11 + 11 significant bits plus the sign of the residue, i.e. fp32's 24 -- and a product keeps  w_h x_h + w_h x_l + w_l x_h  (the
-// dropped w_l x_l is below one fp32 rounding of the product, like the plane pairs bf16x6 drops) on v_mfma_f32_32x32x16_f16 with
-// fp32 accumulation: 3 MFMAs per (k-step, tile) instead of 6.  f16's narrow exponent is handled by one exact power-of-two scaling:
-// the weight side stores the split of 2^5 w,  W_h = rn16(32 w), W_l = rn16(32 w - W_h)  (so that the small part stays in f16's
-// normal range; 2 A fragments per (k-step, tile), 4 KiB per slot, 32 KiB stages, 0.94 MB stream), the activation side two plane
-// registers  x_h, x_l,  the products are  W_h x_h + W_h x_l + W_l x_h  and the accumulators carry 32 x the layer output: the
-// factor 2^-5 rides in the multiply-add that adds the bias / seeds in every epilogue (LayerNorm, scale invariant, runs on the
-// scaled values with 1024 eps).  A value of x_l below f16's normal range (|x| < 0.25) is rounded to 2^-25 absolute --
-// 1.7e-8 rms on an O(1) output, under fp32's own rounding; activations must stay below f16's 65504 (they are LayerNorm
-// outputs and one hidden layer away from them).  The parity suite runs this mode against the same oracle and tolerances.
+// Arithmetic.  Every fp32 operand is split into two f16 numbers  x = x_h + x_l (+ <= 2^-24 |x|),  x_h = rn16(x), x_l = rn16(x - x_h)
+// -- 11 + 11 significant bits plus the sign of the residue, i.e. fp32's 24 -- and a product keeps  w_h x_h + w_h x_l + w_l x_h  (the
+// dropped w_l x_l is below one fp32 rounding of the product) on v_mfma_f32_32x32x16_f16 with fp32 accumulation: 3 MFMAs per
+// (k-step, tile).  f16's narrow exponent is handled by one exact power-of-two scaling: the weight side stores the split of 2^5 w,
+// W_h = rn16(32 w), W_l = rn16(32 w - W_h)  (so that the small part stays in f16's normal range; 2 A fragments per (k-step, tile),
+// 4 KiB per slot, 32 KiB stages, 0.94 MB stream), the activation side two plane registers x_h, x_l, and the accumulators carry
+// 32 x the layer output: the factor 2^-5 rides in the multiply-add that adds the bias / seeds in every epilogue (LayerNorm, scale
+// invariant, runs on the scaled values with 1024 eps).  A value of x_l below f16's normal range (|x| < 0.25) is rounded to 2^-25
+// absolute -- 1.7e-8 rms on an O(1) output, under fp32's own rounding.
+// RANGE: activations must stay below f16's 65504.  Every activation that is split here feeds a running maximum; a tile whose
+// maximum reaches 2^15 (or is not finite) raises the library's range flag (range_flag.h), and the sampler re-runs that chunk on the
+// exact fp32 kernels (str2str_amd/sampler.py) -- an overflow is neither silent nor an error.  Weights with |32 w| >= 65504 are
+// refused at pack time (ops.pack_f16x2_layer).
+//
+// Schedule.  One wave owns 32 pairs; the 4 waves of a workgroup share the weight stream (30 stages of 32 KiB, double buffered in
+// LDS).  A stage is 8 SLOTS of 6 MFMAs / 4 A fragments.  Per pair tile (240 slots):
+//   A_t  (4 slots)  layer-1 output tile t (32 of the 384 hidden channels) over the 8 k-steps of the 128 edge channels;
+//                   the edge row is split once into 8 x 2 f16 plane registers, so A_t is pure MFMA work.
+//   B_t  (12 slots) layer-2 k-steps 2t, 2t+1 (= the 32 channels of a1 tile t) into all 12 output tiles; the 192
+//                   layer-2 accumulators stay resident, a1 is never materialised beyond two tiles.
+//   order: A_0 A_1 | B_0 A_2 | B_1 A_3 | ... | B_9 A_11 | B_10 B_11 | final layer (48 slots, k-step major).
+//   The ReLU + per-node seeds + split of a1 tile t (VALU) runs under A_{t+1}; the final layer's input (ReLU + residual +
+//   split) is produced block-wise (8 k-steps) in three exposed steps -- hiding it under the final layer's own MFMAs measured
+//   slower.  Every activation is split exactly once (microbenchmark tools/ubench/mfma_fill.hip: at most 5 independent VALU issue
+//   slots hide under one 32-cycle MFMA, a dependent one or a v_accvgpr_read costs 8 cycles, one v_pk_add_f32 costs 18).
+//   C->B chaining as in pair_mlp.hip: element j of lane (pair, g) in k-step 2t'+u is accumulator register 8u+j of
+//   tile t' (row 32t' + (r&3) + 8(r>>2) + 4g); the host packs A fragments in that k order (ops.pack_f16x3_stream).
+//   Weight pipe: this wave's quarter of the next stage travels global -> VGPR -> LDS in two halves, each loaded (buffer
+//   loads: SGPR base + constant lane offset) five slots before it is stored; the workgroup barrier sits at the top
+//   of the last slot of a stage, after which the next stage's first fragments are fetched one slot ahead.
+//   Workgroups are persistent (one per CU); the next tile's edge row, seeds and weight stages are prefetched under the
+//   last final-layer block.  With the fused projection (PROJ) the stream has a 31st stage and the two LDS buffers swap
+//   roles after every tile (odd stage count).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
 
+#include "range_flag.h"
 #include "str2str_hip.h"
 
 namespace {
@@ -66,14 +91,16 @@ constexpr SlotDesc slot_desc(int s) {
 
 #define S2S_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-// PROJ: the next IPA block's linear_b / down_z fused as a 31st weight stage (see pair_mlp_bf16.hip)
+// PROJ: also emit the NEXT IPA block's linear_b / down_z (ipa.py:177,253) of the pair vector just produced -- one more
+// weight stage (64 x 128 Wcat, chain-packed), 8 more slots on the LayerNorm output while it is still in registers,
+// attention bias written head-major [B,8,N,N], pair_z [B,N,N,32].  Saves the 512 B/pair re-read of z by s2s_pair_project.
 template <bool PROJ>
 __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     const float* __restrict__ edge, const float* __restrict__ node_ab, const float* __restrict__ node_p,
     const char* __restrict__ wblob, const float* __restrict__ b2, const float* __restrict__ bf,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask,
     float* __restrict__ out, long long M, int N, float ln_eps, const float* __restrict__ proj_b,
-    float* __restrict__ proj_bias_out, float* __restrict__ proj_pz_out) {
+    float* __restrict__ proj_bias_out, float* __restrict__ proj_pz_out, int* __restrict__ range_flag) {
     constexpr int kStages = kStagesBase + (PROJ ? 1 : 0);
     constexpr int kSlots = 8 * kStages;
     __shared__ __attribute__((aligned(16))) char s_w[2][kStageBytes];
@@ -114,33 +141,43 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     cp_load_b(0);
 
     // ---- persistent workgroup: tiles of 128 pairs (32 per wave) blockIdx.x, blockIdx.x + gridDim.x, ...
+    // Per-pair context as four 32-bit indices (the launcher keeps 8 M below 2^32): the row pointers are re-formed where they are
+    // used (one v_mad_u64_u32 each) instead of living in twelve address registers through the whole tile -- this kernel sits at the
+    // 512-register limit, and one more long-lived VGPR costs hundreds of spills.
     struct PairCtx {
-        const float *erow, *arow, *brow, *npi, *npj;
-        float* orow;
-        long long p, boff;  // flat pair index; offset of head 0 of this pair in a head-major [B,8,N,N] tensor
+        unsigned p, bi, bj, boff;  // flat pair index; flat node rows of i and j; offset of head 0 of this pair in a head-major [B,8,N,N] tensor
         float em;
         bool valid;
     };
+    const unsigned NNu = (unsigned)N * (unsigned)N;
     const long long NN = (long long)N * N;
+    // division by N through floor(2^32 / N) (quotient short by at most one for x < 2^31; a 64-bit division is ~100 VALU instructions)
+    const unsigned n_magic = N >= 2 ? (unsigned)((1ull << 32) / (unsigned)N) : 0u;
+    auto div_n = [&](unsigned x, unsigned& q, unsigned& r) {
+        q = N >= 2 ? __umulhi(x, n_magic) : x;
+        r = x - q * (unsigned)N;
+        const bool fix = r >= (unsigned)N;
+        q = fix ? q + 1 : q;
+        r = fix ? r - (unsigned)N : r;
+    };
     auto setup = [&](long long wg_tile) -> PairCtx {
-        long long p = (wg_tile * 4 + wave) * 32 + (lane & 31);
+        long long pl = (wg_tile * 4 + wave) * 32 + (lane & 31);
         PairCtx c;
-        c.valid = p < M;
-        if (!c.valid) p = M - 1;  // waves / lanes past the end run on the last pair and store nothing
-        const long long bb = p / NN;
-        const long long rem = p - bb * NN;
-        const long long bi = bb * N + rem / N, bj = bb * N + rem % N;
-        c.erow = edge + p * 128;
-        c.arow = node_ab + bi * 768;        // A_i + b1, 384 channels
-        c.brow = node_ab + bj * 768 + 384;  // B_j
-        c.npi = node_p + bi * 128;
-        c.npj = node_p + bj * 128;
-        c.orow = out + p * 128;
+        c.valid = pl < M;
+        if (!c.valid) pl = M - 1;  // waves / lanes past the end run on the last pair and store nothing
+        const unsigned p = (unsigned)pl;
+        // p = (bb N + i) N + j:  flat row bi = p / N,  j = p - bi N,  bb = bi / N
+        unsigned bi, j, bb, i;
+        div_n(p, bi, j);
+        div_n(bi, bb, i);
         c.p = p;
-        c.boff = p + 7 * bb * NN;
-        c.em = mask ? mask[bi] * mask[bj] : 1.0f;
+        c.bi = bi;
+        c.bj = bb * (unsigned)N + j;
+        c.boff = p + 7u * bb * NNu;
+        c.em = mask ? mask[bi] * mask[c.bj] : 1.0f;
         return c;
     };
+    auto erow_of = [&](const PairCtx& c) -> const float* { return edge + (unsigned long long)c.p * 128u; };
     const long long n_wt = (M + 127) / 128;
     long long wt = blockIdx.x;
     PairCtx cur = setup(wt);
@@ -149,20 +186,25 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     //      2t+u is channel 32t + 8(2u + (j>>2)) + 4h + (j&3): the accumulator layout of a 128-channel block (register 8u+j of
     //      tile t), so the exact sum of the three planes later serves as the residual row of block 0 without a second read.
     f16x8 xpl[8][2];
-    // planes (x_h, x_l, x_hs = 2^-5 x_h), see the header
+    float amax = 0.f;   // range guard (range_flag.h): running maximum of every value that is split into f16 planes
+    // planes (x_h, x_l), see the header
     auto split4 = [&](const float (&x)[4], f16x8& ph, f16x8& pm, int at) {
+        float xv[4] = {x[0], x[1], x[2], x[3]};
+        // one materialised fp32 value feeds both planes (see node_gemm.hip split8_f16) and the range maximum; the maximum is
+        // opaque to the compiler on purpose (as an fmaxf chain it cost this kernel 300 spilled registers)
+        asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]));
+        asm volatile("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|"
+                     : "+v"(amax) : "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float xv = x[j];
-            asm volatile("" : "+v"(xv));   // one materialised fp32 value feeds both planes (see node_gemm.hip split8_f16)
-            const _Float16 a = (_Float16)xv;
-            ph[at + j] = a; pm[at + j] = (_Float16)(xv - (float)a);
+            const _Float16 a = (_Float16)xv[j];
+            ph[at + j] = a; pm[at + j] = (_Float16)(xv[j] - (float)a);
         }
     };
     {
         float4 xv[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) xv[i] = ldg4(cur.erow, i, h);  // accumulator ("chain") channel order, see xpl
+        for (int i = 0; i < 16; ++i) xv[i] = ldg4(erow_of(cur), i, h);  // accumulator ("chain") channel order, see xpl
         for (int i = threadIdx.x; i < 768; i += 256)
             s_vec[i] = i < 384 ? b2[i] : (i < 512 ? bf[i - 384] : (i < 640 ? gamma[i - 512] : beta[i - 640]));
         if (PROJ && threadIdx.x < 64) s_vec[768 + threadIdx.x] = proj_b[threadIdx.x];
@@ -184,7 +226,9 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     auto seeds_load = [&](const PairCtx& c, int t) {  // C layout of tile t: register 4rq + e = channel 32t + 8rq + 4h + e
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-            const float4 x = ldg4(c.arow + 32 * t, rq, h), y = ldg4(c.brow + 32 * t, rq, h);
+            // A_i + b1 (384 channels) and B_j of the per-node first-layer halves [B,N,768]
+            const float4 x = ldg4(node_ab + (unsigned long long)c.bi * 768u + 32 * t, rq, h);
+            const float4 y = ldg4(node_ab + (unsigned long long)c.bj * 768u + 384 + 32 * t, rq, h);
             sa[4 * rq + 0] = x.x; sa[4 * rq + 1] = x.y; sa[4 * rq + 2] = x.z; sa[4 * rq + 3] = x.w;
             sb[4 * rq + 0] = y.x; sb[4 * rq + 1] = y.y; sb[4 * rq + 2] = y.z; sb[4 * rq + 3] = y.w;
         }
@@ -246,7 +290,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             var += dd * dd;
         }
     const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / 128) + ln_eps * (kWS * kWS));
-    float* orow = cur.orow;
+    float* orow = out + (unsigned long long)cur.p * 128u;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -290,7 +334,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         if constexpr (s == 224) {
             nxt = setup(has_next ? wt_next : wt);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) xv[i] = ldg4(nxt.erow, i, h);
+            for (int i = 0; i < 16; ++i) xv[i] = ldg4(erow_of(nxt), i, h);
         }
         if constexpr (s == 236) seeds_load(nxt, 0);
         // seeds of a1 tile t+1 are fetched late in B_t (they are consumed under A_{t+2}, or right after B_10 for tile 11)
@@ -384,7 +428,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
                                         fmaxf(__builtin_fmaf(a[4 * rq + 3], kInvWS, bq.w), 0.f) + rs[16 * t + 4 * rq + 3]};
                     split4(x, xpl[2 * t + (rq >> 1)][0], xpl[2 * t + (rq >> 1)][1], 4 * (rq & 1));
                 }
-            if constexpr (pb < 2) row_load(pb == 0 ? cur.npi : cur.npj);  // lands under the next 16 slots
+            if constexpr (pb < 2) row_load(node_p + (unsigned long long)(pb == 0 ? cur.bi : cur.bj) * 128u);  // lands under the next 16 slots
         }
     });
 
@@ -393,7 +437,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         // rows 0..7 (+ bias) -> attention bias, head-major; rows 8..39 -> pair_z channel row - 8 (same map as pair_mlp.hip)
         if (cur.valid) {
             const float4 b0 = ldg4(s_vec + 768, 0, h);
-            float* o = proj_bias_out + cur.boff + 4 * h * NN;
+            float* o = proj_bias_out + ((unsigned long long)cur.boff + 4 * h * NN);
             o[0] = __builtin_fmaf(pq[0][0], kInvWS, b0.x);
             o[NN] = __builtin_fmaf(pq[0][1], kInvWS, b0.y);
             o[2 * NN] = __builtin_fmaf(pq[0][2], kInvWS, b0.z);
@@ -402,7 +446,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             for (int g = 1; g <= 4; ++g) {
                 const int t = g >> 2, rq = g & 3;
                 const float4 bq = ldg4(s_vec + 768, g, h);
-                *reinterpret_cast<float4*>(proj_pz_out + cur.p * 32 + 8 * (g - 1) + 4 * h) =
+                *reinterpret_cast<float4*>(proj_pz_out + (unsigned long long)cur.p * 32u + 8 * (g - 1) + 4 * h) =
                     make_float4(__builtin_fmaf(pq[t][4 * rq + 0], kInvWS, bq.x), __builtin_fmaf(pq[t][4 * rq + 1], kInvWS, bq.y),
                                 __builtin_fmaf(pq[t][4 * rq + 2], kInvWS, bq.z), __builtin_fmaf(pq[t][4 * rq + 3], kInvWS, bq.w));
             }
@@ -419,12 +463,16 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         lds_image[1] = sw;
     }
     }  // persistent tile loop
+    s2s::range_report(range_flag, amax, s2s::kRangeEdgeTransition);
 }
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// Edge embedding on split-f16 MFMA: the kernel of csrc/pair_mlp_bf16.hip (edge_embed_bf16_kernel: gathers, slot schedule, pinned
-// VALU pieces -- documented there) with the f16x3 products and 32 KiB weight stages (W2 | W3 | [linear_b; down_z]).
+// Edge embedding on split-f16 MFMA: same operator and contract as s2s_edge_embed (csrc/pair_mlp.hip; reference
+// EmbeddingModule.forward edge branch, denoising_ipa.py:137-158).  The first Linear(120 -> 128) is a sum of four gathered
+// rows (+ ReLU); the two 128 x 128 layers, LayerNorm and (PROJ) the first IPA block's linear_b / down_z run as f16x3 slots
+// exactly like the edge transition above: 5 weight stages of 32 KiB (W2 | W3 | [linear_b; down_z]), 40 slots of 6 MFMAs per
+// 32-pair tile, persistent workgroups; the NEXT tile's rows are gathered and split under the current tile's MFMAs.
 template <bool PROJ>
 __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
     const float* __restrict__ node_a, const float* __restrict__ node_b, const float* __restrict__ rel_tab,
@@ -432,7 +480,7 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
     const float* __restrict__ ca, const char* __restrict__ wblob, const float* __restrict__ b2, const float* __restrict__ b3,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask, float* __restrict__ out,
     long long M, int N, int rel_off, int n_rel, int n_bins, float ln_eps, const float* __restrict__ proj_b,
-    float* __restrict__ proj_bias_out, float* __restrict__ proj_pz_out) {
+    float* __restrict__ proj_bias_out, float* __restrict__ proj_pz_out, int* __restrict__ range_flag) {
     constexpr int kStages = PROJ ? 5 : 4;
     constexpr int kSlots = 8 * kStages;
     __shared__ __attribute__((aligned(16))) char s_w[2][kStageBytes];
@@ -556,13 +604,18 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
         c.em = mask ? r.mi * r.mj : 1.0f;
         return c;
     };
+    float amax = 0.f;   // range guard (range_flag.h)
     auto split4 = [&](const float (&x)[4], f16x8& ph, f16x8& pm, int at) {  // planes (x_h, x_l)
+        float xv[4] = {x[0], x[1], x[2], x[3]};
+        // one materialised fp32 value feeds both planes (see node_gemm.hip split8_f16) and the range maximum; the maximum is
+        // opaque to the compiler on purpose (as an fmaxf chain it cost this kernel 300 spilled registers)
+        asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]));
+        asm volatile("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|"
+                     : "+v"(amax) : "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float xv = x[j];
-            asm volatile("" : "+v"(xv));   // one materialised fp32 value feeds both planes (see node_gemm.hip split8_f16)
-            const _Float16 a = (_Float16)xv;
-            ph[at + j] = a; pm[at + j] = (_Float16)(xv - (float)a);
+            const _Float16 a = (_Float16)xv[j];
+            ph[at + j] = a; pm[at + j] = (_Float16)(xv[j] - (float)a);
         }
     };
     // first-layer sum in accumulator layout: g1[4G + q] = channel 8G + 4h + q, built row by row (same association as the
@@ -835,6 +888,7 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
         lds_image[1] = sw;
     }
     }  // persistent tile loop
+    s2s::range_report(range_flag, amax, s2s::kRangeEdgeEmbed);
 }
 
 
@@ -845,24 +899,39 @@ extern "C" int s2s_edge_transition_f16x3(const float* edge, const float* node_ab
                                          const float* ln_gamma, const float* ln_beta, const float* mask, float* out,
                                          int n_samples, int n_res, float ln_eps, const float* proj_bias_cat64,
                                          float* proj_attn_bias, float* proj_pair_z, void* stream) {
-    const long long M = (long long)n_samples * n_res * n_res;
-    if (M <= 0) return 0;
-    const long long wg_tiles = (M + 127) / 128;
+    if (n_samples <= 0 || n_res <= 0) return 0;
+    const long long NN = (long long)n_res * n_res;
+    // 32-bit pair / head-major indices inside a launch (8 M < 2^32): split the samples over several launches when needed
+    const char* cap_env = getenv("S2S_ET_MAX_PAIRS");   // test hook: a smaller per-launch pair budget exercises the split
+    long long cap = cap_env ? atoll(cap_env) : 0;
+    if (cap <= 0 || cap > (1ll << 29) - 1) cap = (1ll << 29) - 1;
+    const long long chunk = cap / NN;
+    if (chunk < 1) return (int)hipErrorInvalidValue;
     static int n_cu = 0;  // persistent workgroups, one per CU
     if (n_cu == 0) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
             n_cu = 256;
     }
-    const long long grid = wg_tiles < n_cu ? wg_tiles : n_cu;
-    if (proj_attn_bias)
-        hipLaunchKernelGGL(edge_transition_f16_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, edge, node_ab,
-                           node_p, (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mask, out, M, n_res, ln_eps,
-                           proj_bias_cat64, proj_attn_bias, proj_pair_z);
-    else
-        hipLaunchKernelGGL(edge_transition_f16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, edge, node_ab,
-                           node_p, (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mask, out, M, n_res, ln_eps,
-                           (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    for (long long b0 = 0; b0 < n_samples; b0 += chunk) {
+        const long long nb = n_samples - b0 < chunk ? n_samples - b0 : chunk;
+        const long long M = nb * NN, rows0 = b0 * n_res;
+        const long long wg_tiles = (M + 127) / 128;
+        const long long grid = wg_tiles < n_cu ? wg_tiles : n_cu;
+        const float* e = edge + b0 * NN * 128;
+        const float* nab = node_ab + rows0 * 768;
+        const float* np = node_p + rows0 * 128;
+        const float* mk = mask ? mask + rows0 : nullptr;
+        float* o = out + b0 * NN * 128;
+        if (proj_attn_bias)
+            hipLaunchKernelGGL(edge_transition_f16_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, e, nab, np,
+                               (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mk, o, M, n_res, ln_eps, proj_bias_cat64,
+                               proj_attn_bias + b0 * 8 * NN, proj_pair_z + b0 * NN * 32, s2s::g_range_flag);
+        else
+            hipLaunchKernelGGL(edge_transition_f16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, e, nab, np,
+                               (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mk, o, M, n_res, ln_eps, (const float*)nullptr,
+                               (float*)nullptr, (float*)nullptr, s2s::g_range_flag);
+    }
     return (int)hipGetLastError();
 }
 
@@ -902,12 +971,12 @@ extern "C" int s2s_edge_embed_f16x3(const float* node_a, const float* node_b, co
             hipLaunchKernelGGL(edge_embed_f16_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, na, nbp,
                                rel_table, bin_table, bin_lower, ridx, cap, (const char*)weight_stream, b2, b3, ln_gamma, ln_beta,
                                mk, o, M, n_res, rel_offset, n_rel, n_bins, ln_eps, proj_bias_cat64,
-                               proj_attn_bias + b0 * 8 * NN, proj_pair_z + b0 * NN * 32);
+                               proj_attn_bias + b0 * 8 * NN, proj_pair_z + b0 * NN * 32, s2s::g_range_flag);
         else
             hipLaunchKernelGGL(edge_embed_f16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, na, nbp,
                                rel_table, bin_table, bin_lower, ridx, cap, (const char*)weight_stream, b2, b3, ln_gamma, ln_beta,
                                mk, o, M, n_res, rel_offset, n_rel, n_bins, ln_eps, (const float*)nullptr, (float*)nullptr,
-                               (float*)nullptr);
+                               (float*)nullptr, s2s::g_range_flag);
     }
     return (int)hipGetLastError();
 }

@@ -13,13 +13,12 @@ import math
 from functools import partial
 from typing import Optional
 
-import os
-
 import torch
 import torch.nn.functional as F
 from torch import nn
 
 from ... import ops
+from ...arith import default_arith
 from ...common.all_atom import compute_backbone
 from ...common.rigid_utils import Rigid
 from .ipa import TranslationIPA  # noqa: F401  (re-exported like the reference module)
@@ -44,13 +43,6 @@ def get_timestep_embedding(timesteps: torch.Tensor, embedding_dim: int, max_len:
     return emb
 
 
-def _pack_node(lin: nn.Linear) -> dict:
-    """A whole-row nn.Linear in the layout of s2s_node_linear (csrc/node_gemm.hip)."""
-    n, k = lin.weight.shape
-    tg = ops.node_tiles(n, whole_row=True)
-    return {"w": ops.pack_node_weight(lin.weight.float(), tg), "b": lin.bias.float().contiguous(), "n": n, "k": k, "tg": tg}
-
-
 class EmbeddingModule(nn.Module):
     def __init__(self, init_embed_size: int, node_embed_size: int, edge_embed_size: int, num_bins: int = 22,
                  min_bin: float = 1e-5, max_bin: float = 20.0, self_conditioning: bool = True):
@@ -73,15 +65,13 @@ class EmbeddingModule(nn.Module):
         self.position_embed = partial(get_positional_embedding, embedding_dim=pos_embed_size)
         self._dims = (init_embed_size, num_bins, float(min_bin), float(max_bin), edge_embed_size)
         self._wcache = ParamCache()
+        self._w16cache = ParamCache()
         self._proj_cache = ParamCache()
-        self._proj_cache_f16 = ParamCache()
-        # pair-stream MLP arithmetic: "f16x3" (two-way f16 split MFMA, default), "bf16x6" (three-way bf16 split MFMA; both
-        # fp32-equivalent) or "f32" (exact fp32 MFMA) -- see EdgeTransition in layers.py
-        self.mfma_mode = os.environ.get("S2S_EDGE_MFMA", "f16x3")
+        self.arith = default_arith()   # "f16x3" (split-f16 MFMA, default) | "f32" (exact fp32 MFMA): see str2str_amd/arith.py
         self._idx_key = None
         self._idx_val = None
         self._idx_src = None
-        self.node_embed_xp = None   # packed planes of the last node embedding (read by the trunk instead of re-packing)
+        self.node_embed_act = None  # the last node embedding in the node stream's activation format (read by the trunk)
 
     # ---- derived tensors
     def _weights(self):
@@ -103,15 +93,14 @@ class EmbeddingModule(nn.Module):
                 "wn_t": wn[:, :ie].contiguous(), "wn_f": wn[:, ie].contiguous(), "wn_pos": wn[:, t1:t1 + ie].contiguous(),
                 "bn0": n0.bias.float().contiguous(),
                 "w2p": ops.pack_weight(e2.weight.float()), "w3p": ops.pack_weight(e4.weight.float()),
-                "node_mlp": [_pack_node(self.node_embed[2]), _pack_node(self.node_embed[4])],
-                "wstream": ops.pack_bf16x3_embed_stream(e2.weight.float(), e4.weight.float()),
-                "wstream_f16": ops.pack_f16x3_embed_stream(e2.weight.float(), e4.weight.float()),
+                "node_mlp": [ops.pack_node_layer(self.node_embed[2].weight, self.node_embed[2].bias, True),
+                             ops.pack_node_layer(self.node_embed[4].weight, self.node_embed[4].bias, True)],
             }
             if self.self_conditioning:
                 out["bin_tab"] = w0[:, 2 * t1 + ie:2 * t1 + ie + nb].t().contiguous()
             else:  # no distogram columns: a single zero row that is never selected (ca = 0 -> no bin)
                 out["bin_tab"] = w0.new_zeros(1, w0.shape[0])
-            out["bin_tab_cb"] = ops.column_blocked(out["bin_tab"])  # gather layout of the split-bf16 kernel
+            out["bin_tab_cb"] = ops.column_blocked(out["bin_tab"])  # gather layout of the split-f16 kernel
             out["bin_lower"] = torch.linspace(self._dims[2], self._dims[3], nb).to(w0.device)
             return out
 
@@ -174,35 +163,31 @@ class EmbeddingModule(nn.Module):
         # what the trunk's first projections and every skip_embed read
         M = B * L
         nw = w["node_mlp"]
-        _, h2 = ops.node_linear(ops.pack_planes(h.reshape(M, -1).contiguous()), nw[0]["w"], nw[0]["b"], M, nw[0]["k"], nw[0]["n"],
-                                nw[0]["tg"], relu=True, want_f32=False, want_xp=True)
-        node_embed, self.node_embed_xp = ops.node_linear(h2, nw[1]["w"], nw[1]["b"], M, nw[1]["k"], nw[1]["n"], nw[1]["tg"],
-                                                         ln=(ne[5].weight, ne[5].bias, ne[5].eps),
+        f16 = self.arith == "f16x3"
+        _, h2 = ops.node_apply(ops.to_act(h.reshape(M, -1).contiguous(), self.arith), nw[0], M, relu=True, want_f32=False, want_xp=True)
+        node_embed, self.node_embed_act = ops.node_apply(h2, nw[1], M, ln=(ne[5].weight, ne[5].bias, ne[5].eps),
                                                          post_mask=None if mask is None else mask.reshape(M), want_xp=True)
         node_embed = node_embed.view(B, L, -1)
         node_a = (tl(w["w_row_t"], w["b0"])[:, None, :] + fixed * w["w_row_f"]).expand(B, L, -1).contiguous()
-        if self.mfma_mode != "f32":  # column part straight in the kernel's gather layout [B, 32 chunks, L, 4]
+        if f16:  # column part straight in the kernel's gather layout [B, 32 chunks, L, 4]
             node_b = (tl(w["w_col_t"]).view(-1, 32, 1, 4) + fixed[:, None] * w["w_col_f"].view(1, 32, 1, 4)).expand(B, 32, L, 4).contiguous()
         else:
             node_b = (tl(w["w_col_t"])[:, None, :] + fixed * w["w_col_f"]).expand(B, L, -1).contiguous()
         ca = self_conditioning_ca.to(dev).float().contiguous() if self.self_conditioning else t_emb.new_zeros(B, L, 3)
         e2, e4, ln = self.edge_embed[2], self.edge_embed[4], self.edge_embed[5]
-        if self.mfma_mode != "f32":
-            f16 = self.mfma_mode == "f16x3"
-            ws = w["wstream_f16"] if f16 else w["wstream"]
+        if f16:
+            e2w, e4w = e2.weight, e4.weight
+            ws = self._w16cache.get([e2w, e4w], lambda: ops.pack_f16x3_embed_stream(e2w.float(), e4w.float()))
             proj = None
             if next_proj is not None:  # 5-stage stream: W2 | W3 | the first IPA block's projection stage
-                pw = next_proj[3] if f16 else next_proj[2]
-                cache = self._proj_cache_f16 if f16 else self._proj_cache   # one slot per mode (captured HIP graphs keep the pointer)
-                stream = cache.get([ws, pw], lambda: torch.cat([ws, pw]))
-                proj = (stream, next_proj[1])
-            fn = ops.edge_embed_f16x3 if f16 else ops.edge_embed_bf16x6
-            edge_embed = fn(node_a, node_b, self._rel_cb, w["bin_tab_cb"], w["bin_lower"], idx_dev, ca, ws, e2.bias, e4.bias,
-                            ln.weight, ln.bias, mask, span, ln.eps, proj=proj, column_blocked_tables=True)
+                stream = self._proj_cache.get([ws, next_proj["wp_f16x2"]], lambda: torch.cat([ws, next_proj["wp_f16x2"]]))
+                proj = (stream, next_proj["b64"])
+            edge_embed = ops.edge_embed_f16x3(node_a, node_b, self._rel_cb, w["bin_tab_cb"], w["bin_lower"], idx_dev, ca, ws, e2.bias,
+                                              e4.bias, ln.weight, ln.bias, mask, span, ln.eps, proj=proj, column_blocked_tables=True)
         else:
             edge_embed = ops.edge_embed(node_a, node_b, rel_tab, w["bin_tab"], w["bin_lower"], idx_dev, ca, w["w2p"],
                                         w["w3p"], e2.bias, e4.bias, ln.weight, ln.bias, mask, span, ln.eps,
-                                        proj=None if next_proj is None else next_proj[:2])
+                                        proj=None if next_proj is None else (next_proj["wp"], next_proj["b64"]))
         if next_proj is not None:
             edge_embed, *proj = edge_embed
             return node_embed, edge_embed, tuple(proj)
@@ -232,7 +217,7 @@ class DenoisingNet(nn.Module):
         tb = dict(batch)
         tb["residue_mask"], tb["fixed_mask"] = node_mask, fixed_mask
         tb["rigids_t"] = batch["rigids_t"].to(dev)
-        tb["_node_embed_xp"] = getattr(self.embedder, "node_embed_xp", None)
+        tb["_node_embed_act"] = getattr(self.embedder, "node_embed_act", None)
         model_out = self.translator(node_embed, edge_embed, tb, **({"_first_proj": emb[2]} if fuse else {}))
         gt_psi = batch["torsion_angles_sin_cos"].to(dev)[..., 2, :]
         psi_pred = gt_psi * fixed_mask[..., None] + model_out["psi"] * (1 - fixed_mask[..., None])

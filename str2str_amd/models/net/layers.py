@@ -3,8 +3,10 @@
 Same constructor arguments, parameter names and shapes as the reference's
 ``src/models/net/layers.py`` (Linear :64-124, NodeTransition :128-145, EdgeTransition :148-185,
 TorsionAngleHead :188-213, BackboneUpdate :216-241) so a reference checkpoint loads unchanged.
-Per-node (N-linear) layers are dense projections on the GPU BLAS (fp32 MFMA GEMMs); the N x N
-``EdgeTransition`` runs the fused fp32-MFMA kernel ``s2s_edge_transition`` (csrc/pair_mlp.hip).
+In the sampling path every layer here is evaluated by the fused node kernels (``ops.node_apply``, called from
+``TranslationIPA.forward`` on the packed parameters) and the N x N ``EdgeTransition`` by ``s2s_edge_transition_f16x3`` (or the exact
+fp32 ``s2s_edge_transition``, see str2str_amd/arith.py); the plain ``forward`` methods of the small per-node modules are the
+reference's module API (torch ops), kept for callers outside the sampler.
 """
 from __future__ import annotations
 
@@ -17,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ... import ops
+from ...arith import default_arith
 
 
 def _trunc_normal_(w: torch.Tensor, scale: float):
@@ -106,71 +109,76 @@ class EdgeTransition(nn.Module):
         self.layer_norm = nn.LayerNorm(edge_embed_out)
         self._shape = (edge_embed_in, bias_embed_size, hidden, edge_embed_out, num_layers)
         self._cache = ParamCache()
-        self._proj_cache = ParamCache()
-        self._proj_cache_f16 = ParamCache()   # one slot per arithmetic mode: a captured HIP graph keeps pointing at its stream
-        # "f16x3" (default): two-way f16 split of both operands (11 + 11 bits + sign = fp32's 24), three products per block with
-        # exact 2^+-5 scalings of the small factors, fp32 accumulation (csrc/pair_mlp_f16.hip): 1.65x faster than
-        # "bf16x6": exact 3-way bf16 split, six plane-pair products (csrc/pair_mlp_bf16.hip), which is 1.6x faster than
-        # "f32": v_mfma_f32_32x32x2_f32 (csrc/pair_mlp.hip).  All three pass the same parity suite.
-        self.mfma_mode = os.environ.get("S2S_EDGE_MFMA", "f16x3")
-        # "f16x3": two-way f16 split, three products per block (csrc/pair_mlp_f16.hip); the embedder treats it as "bf16x6".
-        if self.mfma_mode not in ("bf16x6", "f16x3", "f32"):
-            raise ValueError(f"S2S_EDGE_MFMA={self.mfma_mode!r}: expected 'bf16x6', 'f16x3' or 'f32'")
+        self._cache32 = ParamCache()
+        self._proj_cache = ParamCache()   # (a captured HIP graph keeps pointing at its stream: sampler._GraphedNet pins it)
+        self._node_cache = ParamCache()
+        self.arith = default_arith()      # "f16x3" (csrc/pair_mlp_f16.hip) | "f32" (csrc/pair_mlp.hip): see str2str_amd/arith.py
 
     def _packed(self):
+        """Weight stream of the split-f16 kernel."""
         w1, w2, wf = self.trunk[0], self.trunk[2], self.final_layer
+        ce = self._shape[0]
+        return self._cache.get([w1.weight, w2.weight, wf.weight], lambda: {
+            "wstream_f16": ops.pack_f16x3_stream(w1.weight[:, :ce].float(), w2.weight.float(), wf.weight.float())})
+
+    def _packed_f32(self):
+        w1, w2, wf = self.trunk[0], self.trunk[2], self.final_layer
+        ce = self._shape[0]
+        return self._cache32.get([w1.weight, w2.weight, wf.weight], lambda: {
+            "w1p": ops.pack_weight(w1.weight[:, :ce].float(), tile_major=True),
+            "w2p": ops.pack_weight(w2.weight.float(), tile_major=True),
+            "wfp": ops.pack_weight(wf.weight.float(), tile_major=True)})
+
+    def node_layers(self):
+        """The per-node parts as node-stream layers: n' = initial_embed(node) and the node halves of layer 1 applied to it,
+        [W1[:, ce:ce+cb] n' + b1 | W1[:, ce+cb:] n']."""
+        w1, ie = self.trunk[0], self.initial_embed
 
         def build():
-            ce = self._shape[0]
-            return {
-                "w1p": ops.pack_weight(w1.weight[:, :ce].float(), tile_major=True),
-                "w2p": ops.pack_weight(w2.weight.float(), tile_major=True),
-                "wfp": ops.pack_weight(wf.weight.float(), tile_major=True),
-                # node halves of layer 1: [W1[:, ce:ce+cb] ; W1[:, ce+cb:]] applied to n' (+ b1 on the row part)
-                "wstream": ops.pack_bf16x3_stream(w1.weight[:, :ce].float(), w2.weight.float(), wf.weight.float()),
-                "wstream_f16": ops.pack_f16x3_stream(w1.weight[:, :ce].float(), w2.weight.float(), wf.weight.float()),
-                "w_ab": torch.cat([w1.weight[:, ce:ce + self._shape[1]], w1.weight[:, ce + self._shape[1]:]], dim=0).float().contiguous(),
-                "b_ab": torch.cat([w1.bias, torch.zeros_like(w1.bias)]).float().contiguous(),
-            }
+            ce, cb = self._shape[0], self._shape[1]
+            w_ab = torch.cat([w1.weight[:, ce:ce + cb], w1.weight[:, ce + cb:]], dim=0).float().contiguous()
+            b_ab = torch.cat([w1.bias, torch.zeros_like(w1.bias)]).float().contiguous()
+            return {"init": ops.pack_node_layer(ie.weight, ie.bias), "ab": ops.pack_node_layer(w_ab, b_ab)}
 
-        return self._cache.get([w1.weight, w1.bias, w2.weight, wf.weight], build)
+        return self._node_cache.get([w1.weight, w1.bias, ie.weight, ie.bias], build)
+
+    def node_parts(self, s_act, n_rows: int):
+        """-> (n' [M,128] fp32, node_ab [M,768] fp32) from the node activations (packed planes or fp32, see ops.node_apply)."""
+        nl = self.node_layers()
+        n_p, n_pa = ops.node_apply(s_act, nl["init"], n_rows, want_xp=True)
+        node_ab, _ = ops.node_apply(n_pa, nl["ab"], n_rows)
+        return n_p, node_ab
 
     def forward(self, node_embed: torch.Tensor, edge_embed: torch.Tensor, edge_mask_1d: Optional[torch.Tensor] = None,
                 next_proj=None):
         """edge_embed [B,N,N,c_z] -> [B,N,N,c_z].  ``edge_mask_1d`` (node mask [B,N]) optionally fuses
         the caller's ``* edge_mask[..., None]`` (reference ipa.py:372) into the kernel epilogue; ``next_proj``
-        = (packed [linear_b; down_z], bias64) of the NEXT IPA block additionally returns its (attn_bias, pair_z)."""
-        n_p = self.initial_embed(node_embed).contiguous()
-        node_ab = F.linear(n_p, self._packed()["w_ab"], self._packed()["b_ab"]).contiguous()
-        return self.pair_mlp(edge_embed, node_ab, n_p, edge_mask_1d, next_proj)
+        = InvariantPointAttention.pair_proj_weights() of the NEXT IPA block additionally returns its (attn_bias, pair_z)."""
+        B, N = node_embed.shape[:2]
+        n_p, node_ab = self.node_parts(ops.to_act(node_embed.reshape(B * N, -1).float().contiguous(), self.arith), B * N)
+        return self.pair_mlp(edge_embed, node_ab.view(B, N, -1), n_p.view(B, N, -1), edge_mask_1d, next_proj)
 
     def pair_mlp(self, edge_embed, node_ab, n_p, edge_mask_1d=None, next_proj=None):
         """The N x N part given the per-node vectors n' = initial_embed(node) [B,N,128] and
-        node_ab = [W1[:,128:256] n' + b1 | W1[:,256:] n'] [B,N,768] (computed by the fused node path or by ``forward``)."""
+        node_ab = [W1[:,128:256] n' + b1 | W1[:,256:] n'] [B,N,768] (``node_parts``)."""
         if self._shape != (128, 128, 384, 128, 2):
             raise ops.HipLibraryError(f"EdgeTransition kernel is built for c_z=128, c_s=256 (got {self._shape})")
-        pk = self._packed()
         mask = None if edge_mask_1d is None else edge_mask_1d.type(torch.float32).contiguous()
-        if self.mfma_mode == "f16x3":
+        if self.arith == "f16x3":
+            pk = self._packed()
             proj = None
-            if next_proj is not None:
-                stream = self._proj_cache_f16.get([pk["wstream_f16"], next_proj[3]], lambda: torch.cat([pk["wstream_f16"], next_proj[3]]))
-                proj = (stream, next_proj[1])
+            if next_proj is not None:  # 31-stage stream: this layer's 30 stages + the next block's projection stage
+                stream = self._proj_cache.get([pk["wstream_f16"], next_proj["wp_f16x2"]],
+                                              lambda: torch.cat([pk["wstream_f16"], next_proj["wp_f16x2"]]))
+                proj = (stream, next_proj["b64"])
             return ops.edge_transition_f16x3(edge_embed.contiguous(), node_ab, n_p, pk["wstream_f16"], self.trunk[2].bias,
                                              self.final_layer.bias, self.layer_norm.weight, self.layer_norm.bias, mask,
                                              self.layer_norm.eps, proj=proj)
-        if self.mfma_mode == "bf16x6":
-            proj = None
-            if next_proj is not None:  # 31-stage stream: this layer's 30 stages + the next block's projection stage
-                stream = self._proj_cache.get([pk["wstream"], next_proj[2]], lambda: torch.cat([pk["wstream"], next_proj[2]]))
-                proj = (stream, next_proj[1])
-            return ops.edge_transition_bf16x6(edge_embed.contiguous(), node_ab, n_p, pk["wstream"], self.trunk[2].bias,
-                                              self.final_layer.bias, self.layer_norm.weight, self.layer_norm.bias, mask,
-                                              self.layer_norm.eps, proj=proj)
+        pk = self._packed_f32()
         return ops.edge_transition(edge_embed.contiguous(), node_ab, n_p, pk["w1p"], pk["w2p"], pk["wfp"],
                                    self.trunk[2].bias, self.final_layer.bias, self.layer_norm.weight,
                                    self.layer_norm.bias, mask, self.layer_norm.eps,
-                                   proj=None if next_proj is None else next_proj[:2])
+                                   proj=None if next_proj is None else (next_proj["wp"], next_proj["b64"]))
 
 
 class TorsionAngleHead(nn.Module):

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _lib = None
 _tables_loaded = False
@@ -25,18 +25,15 @@ _vp, _i, _f, _d, _ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_d
 
 _SIGNATURES = {
     "s2s_abi_version": [],
+    "s2s_set_range_flag": [_vp],
     "s2s_edge_transition": [_vp] * 12 + [_i, _i, _f, _vp, _vp, _vp, _vp, _vp],
-    "s2s_edge_transition_bf16x6": [_vp] * 10 + [_i, _i, _f, _vp, _vp, _vp, _vp],
     "s2s_edge_transition_f16x3": [_vp] * 10 + [_i, _i, _f, _vp, _vp, _vp, _vp],
     "s2s_edge_embed": [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
-    "s2s_edge_embed_bf16x6": [_vp] * 14 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "s2s_edge_embed_f16x3": [_vp] * 14 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "s2s_pair_project": [_vp] * 5 + [_i, _i, _vp],
     "s2s_ipa_prep_points": [_vp] * 6 + [_ll, _i, _i, _i, _i, _vp],
     "s2s_ipa_attention": [_vp] * 12 + [_i, _i, _i, _i, _i, _i, _i, _f, _f, _vp],
     "s2s_ipa_opair": [_vp] * 4 + [_i, _i, _i, _i, _i, _i, _i, _vp],
-    "s2s_ipa_prep_points_planes": [_vp] * 9 + [_ll, _i, _i, _i, _i, _vp],
-    "s2s_ipa_attention_planes": [_vp] * 15 + [_i] * 8 + [_f, _f, _vp],
     "s2s_ipa_prep_points_f16": [_vp] * 9 + [_i, _i, _i, _i, _i, _i, _vp],
     "s2s_ipa_attention_f16w": [_vp] * 15 + [_i] * 8 + [_f, _f, _vp],
     "s2s_rigid_compose_update": [_vp] * 4 + [_ll, _vp],
@@ -46,8 +43,9 @@ _SIGNATURES = {
     "s2s_se3_step": [_vp] * 12 + [_i, _i, _d, _d, _i, _i, _d, _vp],
     "s2s_forward_marginal": [_vp] * 7 + [_i, _vp, _vp, _f, _vp, _i, _i, _vp],
     "s2s_pack_planes": [_vp, _ll, _i, _i, _i, _vp, _i, _i, _vp, _vp],
-    "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp],
-    "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _i, _i, _vp],
+    "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
+    "s2s_node_linear_f32": [_vp, _i, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
+    "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _i, _vp],
     "s2s_encoder_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "s2s_ca_sample_stats": [_vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
     "s2s_ca_pwd_js": [_vp, _i, _vp, _i, _i, _i, _i, _d, _vp, _vp],
@@ -61,6 +59,10 @@ EXPORTS = tuple(_SIGNATURES)
 
 class HipLibraryError(RuntimeError):
     pass
+
+
+class WeightRangeError(HipLibraryError):
+    """A weight does not fit the f16x3 packing (|32 w| >= 65504)."""
 
 
 class KernelTimer:
@@ -122,6 +124,36 @@ def load_library(path: Optional[str] = None):
     return lib
 
 
+# ------------------------------------------------------------------------------------------ range guard of the f16x3 kernels
+_range_flag = None   # one int32 device word, owned here for the life of the process (captured HIP graphs hold its address)
+RANGE_BITS = {1: "node GEMM", 2: "pack_planes", 4: "edge transition", 8: "edge embedding", 16: "IPA points", 32: "encoder attention"}
+
+
+def range_flag() -> torch.Tensor:
+    """The device word the split-f16 kernels OR a bit into when a value they split into f16 planes reaches 2^15 (half of f16's
+    largest finite number) or is not finite (csrc/range_flag.h).  Registered with the library on first use."""
+    global _range_flag
+    if _range_flag is None:
+        if not torch.cuda.is_available():
+            raise HipLibraryError("the range flag lives on the HIP device")
+        _range_flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _check(load_library().s2s_set_range_flag(_p(_range_flag)), "s2s_set_range_flag")
+    return _range_flag
+
+
+def range_flag_reset():
+    range_flag().zero_()
+
+
+def range_flag_read() -> int:
+    """Synchronising read of the flag word (0 = every f16x3 launch since the last reset stayed in range)."""
+    return int(range_flag().item())
+
+
+def range_flag_names(bits: int) -> str:
+    return ", ".join(n for b, n in RANGE_BITS.items() if bits & b) or "none"
+
+
 def _check(rc: int, what: str):
     if rc != 0:
         raise HipLibraryError(f"{what} failed with hipError_t {rc}")
@@ -161,18 +193,9 @@ def pack_weight(w: torch.Tensor, tile_major: bool = False) -> torch.Tensor:
     return w.reshape(t, 32, s4, 2, 4).permute(*perm).contiguous().reshape(-1)
 
 
-def split_bf16x3(w: torch.Tensor):
-    """Exact three-way bf16 split x = h + m + l (round-to-nearest residues)."""
-    h = w.to(torch.bfloat16)
-    r1 = w - h.float()
-    m = r1.to(torch.bfloat16)
-    l = (r1 - m.float()).to(torch.bfloat16)
-    return h, m, l
-
-
-def pack_bf16x3_layer(w: torch.Tensor, kind: str, _fp32_fragments: bool = False) -> torch.Tensor:
-    """[Mout, K] fp32 -> bf16 fragments [K/16 k-steps][Mout/32 tiles][3 planes][64 lanes][8] for
-    v_mfma_f32_32x32x16_bf16 A operands.  Element j of lane (m, g) in k-step ks is W[32t+m][k(ks,g,j)] with
+def fragment_order(w: torch.Tensor, kind: str) -> torch.Tensor:
+    """[Mout, K] fp32 -> fp32 values in MFMA A-fragment order [K/16 k-steps][Mout/32 tiles][64 lanes][8] (v_mfma_f32_32x32x16_*).
+    Element j of lane (m, g) in k-step ks is W[32t+m][k(ks,g,j)] with
       kind "row"  : k = 16*ks + 8*g + j                                   (B operand read from a memory row)
       kind "chain": k = 32*t' + (r&3) + 8*(r>>2) + 4*g, t' = ks>>1, r = 8*(ks&1) + j   (B operand = accumulator
                     registers of the previous layer in MFMA C layout)."""
@@ -191,47 +214,30 @@ def pack_bf16x3_layer(w: torch.Tensor, kind: str, _fp32_fragments: bool = False)
     else:
         raise ValueError(kind)
     wg = w.float()[:, lab.to(w.device)]  # [Mout, KS, 2, 8]
-    wg = wg.reshape(T, 32, KS, 2, 8).permute(2, 0, 3, 1, 4).reshape(KS, T, 64, 8)  # lane = 32*g + m
-    if _fp32_fragments:
-        return wg.contiguous()
-    planes = torch.stack(split_bf16x3(wg), dim=2)  # [KS, T, 3, 64, 8]
-    return planes.contiguous()
-
-
-def pack_bf16x3_stream(w1_edge: torch.Tensor, w2: torch.Tensor, wf: torch.Tensor) -> torch.Tensor:
-    """The weight stream of s2s_edge_transition_bf16x6 as int16: 240 slots of 6 fragments (6 KiB; 8 slots = one 48 KiB
-    stage) in the kernel's consumption order (csrc/pair_mlp_bf16.hip):
-      A_t (4 slots): layer-1 output tile t, k-step pairs (2s, 2s+1), fragments [k-step][plane];
-      B_t (12 slots): layer-2 k-steps 2t + u (u = 0, 1) x output tile pairs 0..5, fragments [tile][plane];
-      F  (48 slots): final layer k-steps 0..23 x tile pairs 0..1;
-    order  A_0 A_1 | B_0 A_2 | B_1 A_3 | ... | B_9 A_11 | B_10 B_11 | F."""
-    l1 = pack_bf16x3_layer(w1_edge, "chain")  # [8, 12, 3, 64, 8]  (the kernel reads the edge row in accumulator order)
-    l2 = pack_bf16x3_layer(w2, "chain")       # [24, 12, 3, 64, 8]
-    lf = pack_bf16x3_layer(wf, "chain")       # [24, 4, 3, 64, 8]
-    A = lambda t: l1[:, t]                    # [8 k-steps, 3, 64, 8]
-    B = lambda t: l2[2 * t:2 * t + 2]         # [2 k-steps, 12 tiles, 3, 64, 8]
-    pieces = [A(0), A(1)]
-    for t in range(10):
-        pieces += [B(t), A(t + 2)]
-    pieces += [B(10), B(11), lf]
-    blob = torch.cat([x.contiguous().reshape(-1) for x in pieces]).view(torch.int16).contiguous()
-    assert blob.numel() * 2 == 30 * 48 * 1024, blob.numel()
-    return blob
+    return wg.reshape(T, 32, KS, 2, 8).permute(2, 0, 3, 1, 4).reshape(KS, T, 64, 8).contiguous()  # lane = 32*g + m
 
 
 def pack_f16x2_layer(w: torch.Tensor, kind: str = "chain") -> torch.Tensor:
-    """[Mout, K] fp32 -> f16 fragments [K/16][Mout/32][2 planes (W_h, W_ls)][64][8] for v_mfma_f32_32x32x16_f16 A operands
-    (lane / element order of ``pack_bf16x3_layer``): the f16 pair split of 2^5 w,  W_h = rn16(32 w),  W_l = rn16(32 w - W_h)  --
-    the power of two keeps W_l in f16's normal range; the kernels take 2^-5 back in their epilogues (csrc/pair_mlp_f16.hip)."""
-    planes = pack_bf16x3_layer(w, kind, _fp32_fragments=True) * 32.0  # [KS, T, 64, 8] fp32 in fragment order
+    """[Mout, K] fp32 -> f16 fragments [K/16][Mout/32][2 planes (W_h, W_l)][64][8] for v_mfma_f32_32x32x16_f16 A operands
+    (lane / element order of ``fragment_order``): the f16 pair split of 2^5 w,  W_h = rn16(32 w),  W_l = rn16(32 w - W_h)  --
+    the power of two keeps W_l in f16's normal range; the kernels take 2^-5 back in their epilogues (csrc/pair_mlp_f16.hip).
+    A weight with |32 w| beyond f16's range cannot be packed: ``WeightRangeError`` (the modules then run on the fp32 kernels)."""
+    wmax = float(w.detach().abs().max()) if w.numel() else 0.0
+    if not (32.0 * wmax < 65504.0):
+        raise WeightRangeError(f"|w| up to {wmax:.4g}: 32 w does not fit f16 (f16x3 weight packing)")
+    planes = fragment_order(w, kind) * 32.0  # [KS, T, 64, 8] fp32 in fragment order
     h = planes.to(torch.float16)
     ls = (planes - h.float()).to(torch.float16)
     return torch.stack([h, ls], dim=2).contiguous()
 
 
 def pack_f16x3_stream(w1_edge: torch.Tensor, w2: torch.Tensor, wf: torch.Tensor) -> torch.Tensor:
-    """The weight stream of s2s_edge_transition_f16x3 as int16: the slot order of ``pack_bf16x3_stream`` with 4 fragments per
-    slot ((W_h, W_ls) of two (k-step, tile) units; 8 slots = one 32 KiB stage, 30 stages)."""
+    """The weight stream of s2s_edge_transition_f16x3 as int16: 240 slots of 4 fragments ((W_h, W_l) of two (k-step, tile) units;
+    8 slots = one 32 KiB stage, 30 stages) in the kernel's consumption order (csrc/pair_mlp_f16.hip):
+      A_t (4 slots): layer-1 output tile t, k-step pairs (2s, 2s+1), fragments [k-step][plane];
+      B_t (12 slots): layer-2 k-steps 2t + u (u = 0, 1) x output tile pairs 0..5, fragments [tile][plane];
+      F  (48 slots): final layer k-steps 0..23 x tile pairs 0..1;
+    order  A_0 A_1 | B_0 A_2 | B_1 A_3 | ... | B_9 A_11 | B_10 B_11 | F."""
     l1, l2, lf = pack_f16x2_layer(w1_edge), pack_f16x2_layer(w2), pack_f16x2_layer(wf)
     A = lambda t: l1[:, t]
     B = lambda t: l2[2 * t:2 * t + 2]
@@ -246,8 +252,9 @@ def pack_f16x3_stream(w1_edge: torch.Tensor, w2: torch.Tensor, wf: torch.Tensor)
 
 # ------------------------------------------------------------------------------------------ ops
 def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps=1e-5, out=None, proj=None):
-    """EdgeTransition on split-f16 MFMA (three products per block instead of bf16x6's six; csrc/pair_mlp_f16.hip); contract
-    of ``edge_transition_bf16x6`` with 32 KiB stages (``pack_f16x3_stream`` + the next block's ``pack_f16x2_layer`` stage)."""
+    """EdgeTransition on split-f16 MFMA (fp32-equivalent accuracy; csrc/pair_mlp_f16.hip); same contract as ``edge_transition``.
+    ``proj`` = (31-stage stream = this layer's 30 stages (``pack_f16x3_stream``) + the next IPA block's projection stage
+    (``pack_f16x2_layer``), bias64) also returns that block's (attn_bias [B,8,N,N], pair_z [B,N,N,32])."""
     lib = load_library()
     B, N = edge.shape[0], edge.shape[1]
     _req(edge, name="edge")
@@ -270,41 +277,10 @@ def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, m
         out = torch.empty_like(edge)
     elif out.data_ptr() == edge.data_ptr():
         raise HipLibraryError("edge_transition: out may not alias edge")
+    range_flag()
     _check(_timed("s2s_edge_transition", lambda: lib.s2s_edge_transition_f16x3(
         _p(edge), _p(node_ab), _p(node_p), _p(wstream), _p(b2), _p(bf), _p(gamma), _p(beta), _p(mask), _p(out), B, N,
         ln_eps, _p(pb), _p(pbias), _p(ppz), _stream())), "s2s_edge_transition_f16x3")
-    return out if proj is None else (out, pbias, ppz)
-
-
-def edge_transition_bf16x6(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps=1e-5, out=None, proj=None):
-    """EdgeTransition on split-bf16 MFMA (fp32-equivalent accuracy); same contract as ``edge_transition``.
-    ``proj`` = (31-stage stream = this layer's 30 stages + the next IPA block's projection stage, bias64) also
-    returns that block's (attn_bias [B,8,N,N], pair_z [B,N,N,32])."""
-    lib = load_library()
-    B, N = edge.shape[0], edge.shape[1]
-    _req(edge, name="edge")
-    if edge.shape != (B, N, N, 128) or node_ab.shape != (B, N, 768) or node_p.shape != (B, N, 128):
-        raise HipLibraryError("edge_transition_bf16x6: bad shapes")
-    for n, t in (("node_ab", node_ab), ("node_p", node_p), ("b2", b2), ("bf", bf), ("gamma", gamma), ("beta", beta)):
-        _req(t, name=n)
-    pb = pbias = ppz = None
-    if proj is not None:
-        wstream, pb = proj
-        _req(pb, name="proj.b64")
-        pbias = torch.empty(B, 8, N, N, device=edge.device, dtype=torch.float32)
-        ppz = torch.empty(B, N, N, 32, device=edge.device, dtype=torch.float32)
-    _req(wstream, torch.int16, "wstream")
-    if wstream.numel() * 2 != (31 if proj is not None else 30) * 48 * 1024:
-        raise HipLibraryError("edge_transition_bf16x6: weight stream has the wrong number of stages")
-    if mask is not None:
-        _req(mask, name="mask")
-    if out is None:
-        out = torch.empty_like(edge)
-    elif out.data_ptr() == edge.data_ptr():
-        raise HipLibraryError("edge_transition: out may not alias edge")
-    _check(_timed("s2s_edge_transition", lambda: lib.s2s_edge_transition_bf16x6(
-        _p(edge), _p(node_ab), _p(node_p), _p(wstream), _p(b2), _p(bf), _p(gamma), _p(beta), _p(mask), _p(out), B, N,
-        ln_eps, _p(pb), _p(pbias), _p(ppz), _stream())), "s2s_edge_transition_bf16x6")
     return out if proj is None else (out, pbias, ppz)
 
 
@@ -363,24 +339,14 @@ def edge_embed(node_a, node_b, rel_table, bin_table, bin_lower, residue_idx, ca,
     return out if proj is None else (out, pbias, ppz)
 
 
-def pack_bf16x3_embed_stream(w2: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
-    """The 4-stage weight stream of s2s_edge_embed_bf16x6 as int16: layer 2 then layer 3, each [8 k-steps][4 tiles][3 planes]
-    chain-packed = 16 slots of (k-step, tile pair).  A projection stage (``InvariantPointAttention._derived()['wp_bf16x3']``)
-    may be appended as the 5th."""
-    blob = torch.cat([pack_bf16x3_layer(w2, "chain").reshape(-1), pack_bf16x3_layer(w3, "chain").reshape(-1)])
-    blob = blob.view(torch.int16).contiguous()
-    assert blob.numel() * 2 == 4 * 48 * 1024
-    return blob
-
-
 def column_blocked(t: torch.Tensor) -> torch.Tensor:
-    """[..., rows, 128] -> [..., 32, rows, 4]: element [c][row][q] = channel 4c + q (the gather layout of s2s_edge_embed_bf16x6)."""
+    """[..., rows, 128] -> [..., 32, rows, 4]: element [c][row][q] = channel 4c + q (the gather layout of s2s_edge_embed_f16x3)."""
     *lead, rows, ch = t.shape
     return t.reshape(*lead, rows, ch // 4, 4).transpose(-3, -2).contiguous()
 
 
 def pack_f16x3_embed_stream(w2: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
-    """The 4-stage (32 KiB each) weight stream of s2s_edge_embed_f16x3: layer 2 then layer 3, [8 k-steps][4 tiles][(W_h, W_ls)];
+    """The 4-stage (32 KiB each) weight stream of s2s_edge_embed_f16x3: layer 2 then layer 3, [8 k-steps][4 tiles][(W_h, W_l)];
     the projection stage (``InvariantPointAttention._derived()['wp_f16x2']``) may be appended as the 5th."""
     blob = torch.cat([pack_f16x2_layer(w2, "chain").reshape(-1), pack_f16x2_layer(w3, "chain").reshape(-1)])
     blob = blob.view(torch.int16).contiguous()
@@ -388,22 +354,16 @@ def pack_f16x3_embed_stream(w2: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
     return blob
 
 
-def edge_embed_f16x3(*args, **kw):
-    """Edge embedding on split-f16 MFMA (csrc/pair_mlp_f16.hip); arguments of ``edge_embed_bf16x6`` with 32 KiB stages."""
-    return edge_embed_bf16x6(*args, _f16=True, **kw)
-
-
-def edge_embed_bf16x6(node_a, node_b, rel_table, bin_table, bin_lower, residue_idx, ca, wstream, b2, b3, gamma, beta, mask,
-                      rel_offset: int, ln_eps=1e-5, out=None, proj=None, column_blocked_tables=False, _f16=False):
-    """Edge embedding on split-bf16 MFMA; ``proj`` = (5-stage stream, bias64) also returns (attn_bias, pair_z).
+def edge_embed_f16x3(node_a, node_b, rel_table, bin_table, bin_lower, residue_idx, ca, wstream, b2, b3, gamma, beta, mask,
+                     rel_offset: int, ln_eps=1e-5, out=None, proj=None, column_blocked_tables=False):
+    """Edge embedding on split-f16 MFMA (csrc/pair_mlp_f16.hip); ``proj`` = (5-stage stream, bias64) also returns (attn_bias, pair_z).
     node_b / rel_table / bin_table: [.., rows, 128], or already ``column_blocked`` ([.., 32, rows, 4]) with the flag set."""
     lib = load_library()
-    entry, stage_kib = ("s2s_edge_embed_f16x3", 32) if _f16 else ("s2s_edge_embed_bf16x6", 48)
     B, N = node_a.shape[0], node_a.shape[1]
     if not column_blocked_tables:
         node_b, rel_table, bin_table = column_blocked(node_b), column_blocked(rel_table), column_blocked(bin_table)
     if node_b.shape != (B, 32, N, 4) or rel_table.shape[0] != 32 or bin_table.shape[0] != 32:
-        raise HipLibraryError("edge_embed_bf16x6: tables are not column-blocked [.., 32, rows, 4]")
+        raise HipLibraryError("edge_embed_f16x3: tables are not column-blocked [.., 32, rows, 4]")
     for n, t in (("node_a", node_a), ("node_b", node_b), ("rel_table", rel_table), ("bin_table", bin_table),
                  ("bin_lower", bin_lower), ("ca", ca), ("b2", b2), ("b3", b3), ("gamma", gamma), ("beta", beta)):
         _req(t, name=n)
@@ -415,16 +375,17 @@ def edge_embed_bf16x6(node_a, node_b, rel_table, bin_table, bin_lower, residue_i
         pbias = torch.empty(B, 8, N, N, device=node_a.device, dtype=torch.float32)
         ppz = torch.empty(B, N, N, 32, device=node_a.device, dtype=torch.float32)
     _req(wstream, torch.int16, "wstream")
-    if wstream.numel() * 2 != (5 if proj is not None else 4) * stage_kib * 1024:
-        raise HipLibraryError(f"{entry}: weight stream has the wrong number of stages")
+    if wstream.numel() * 2 != (5 if proj is not None else 4) * 32 * 1024:
+        raise HipLibraryError("s2s_edge_embed_f16x3: weight stream has the wrong number of stages")
     if mask is not None:
         _req(mask, name="mask")
     if out is None:
         out = torch.empty(B, N, N, 128, device=node_a.device, dtype=torch.float32)
-    _check(getattr(lib, entry)(_p(node_a), _p(node_b), _p(rel_table), _p(bin_table), _p(bin_lower), _p(residue_idx),
-                               _p(ca), _p(wstream), _p(b2), _p(b3), _p(gamma), _p(beta), _p(mask), _p(out), B, N,
-                               int(rel_offset), rel_table.shape[1], bin_table.shape[1], ln_eps, _p(pb), _p(pbias),
-                               _p(ppz), _stream()), entry)
+    range_flag()
+    _check(_timed("s2s_edge_embed", lambda: lib.s2s_edge_embed_f16x3(
+        _p(node_a), _p(node_b), _p(rel_table), _p(bin_table), _p(bin_lower), _p(residue_idx), _p(ca), _p(wstream), _p(b2), _p(b3),
+        _p(gamma), _p(beta), _p(mask), _p(out), B, N, int(rel_offset), rel_table.shape[1], bin_table.shape[1], ln_eps, _p(pb),
+        _p(pbias), _p(ppz), _stream())), "s2s_edge_embed_f16x3")
     return out if proj is None else (out, pbias, ppz)
 
 
@@ -490,44 +451,33 @@ def padded_len(n_res: int) -> int:
     return (n_res + 31) // 32 * 32
 
 
-def ipa_prep_points_planes(rigids7, q_pts_lin, kv_pts_lin, head_w_scaled, n_heads=8, n_qk=8, n_v=12, c_hidden=256, f16=False):
-    """Global-frame points of a block as MFMA fragments + the squared-norm terms of the logits.  ``f16`` (default path,
-    s2s_ipa_prep_points_f16): two f16 planes per fragment group, ANY n_res -- the arrays hold padded_len(n_res) rows per sample
-    (padded rows: zero points, k2 = -1e9).  Otherwise s2s_ipa_prep_points_planes (three bf16 planes; B*N a multiple of 32).
+def ipa_prep_points_f16(rigids7, q_pts_lin, kv_pts_lin, head_w_scaled, n_heads=8, n_qk=8, n_v=12, c_hidden=256):
+    """Global-frame points of a block as MFMA fragments (two f16 planes per fragment group) + the squared-norm terms of the logits
+    (s2s_ipa_prep_points_f16).  ANY n_res: the arrays hold padded_len(n_res) rows per sample (padded rows: zero points, k2 = -1e9).
     rigids7 [B,N,7].  -> (qp_xp, kp_xp, vp_vf, q2, k2)"""
     lib = load_library()
     _req(rigids7, name="rigids7"); _req(q_pts_lin, name="q_pts_lin"); _req(kv_pts_lin, name="kv_pts_lin")
     _req(head_w_scaled, name="head_w")
     if rigids7.ndim != 3:
-        raise HipLibraryError("ipa_prep_points_planes: rigids7 must be [B,N,7]")
+        raise HipLibraryError("ipa_prep_points_f16: rigids7 must be [B,N,7]")
     B, N = rigids7.shape[:2]
-    M = B * (padded_len(N) if f16 else N)
-    if M % 32:
-        raise HipLibraryError("ipa_prep_points_planes: the number of frames must be a multiple of 32 (bf16 planes kernel)")
-    dev, rt = rigids7.device, M // 32
-    npl = 2 if f16 else 3
-    qp = torch.empty(rt * n_heads * 2 * npl * 64 * 8, dtype=torch.int16, device=dev)
+    dev, rt = rigids7.device, B * padded_len(N) // 32
+    qp = torch.empty(rt * n_heads * 2 * 2 * 64 * 8, dtype=torch.int16, device=dev)
     kp = torch.empty_like(qp)
-    vp = torch.empty(rt * n_heads * 4 * npl * 64 * 8, dtype=torch.int16, device=dev)
+    vp = torch.empty(rt * n_heads * 4 * 2 * 64 * 8, dtype=torch.int16, device=dev)
     q2 = torch.empty(rt, n_heads, 32, dtype=torch.float32, device=dev)
     k2 = torch.empty_like(q2)
-    if f16:
-        rc = lib.s2s_ipa_prep_points_f16(_p(rigids7), _p(q_pts_lin), _p(kv_pts_lin), _p(head_w_scaled), _p(qp), _p(kp), _p(vp), _p(q2),
-                                         _p(k2), B, N, n_heads, n_qk, n_v, c_hidden, _stream())
-    else:
-        rc = lib.s2s_ipa_prep_points_planes(_p(rigids7), _p(q_pts_lin), _p(kv_pts_lin), _p(head_w_scaled), _p(qp), _p(kp), _p(vp),
-                                            _p(q2), _p(k2), M, n_heads, n_qk, n_v, c_hidden, _stream())
-    _check(rc, "s2s_ipa_prep_points_planes/_f16")
+    range_flag()
+    _check(lib.s2s_ipa_prep_points_f16(_p(rigids7), _p(q_pts_lin), _p(kv_pts_lin), _p(head_w_scaled), _p(qp), _p(kp), _p(vp), _p(q2),
+                                       _p(k2), B, N, n_heads, n_qk, n_v, c_hidden, _stream()), "s2s_ipa_prep_points_f16")
     return qp, kp, vp, q2, k2
 
 
-def ipa_attention_planes(q_xp, k_xp, v_vf, points, attn_bias, pair_z, mask, rigids7, n_heads=8, c_hidden=256, n_qk=8, n_v=12,
-                         c_pz=32, inf=1e5, eps=1e-8, logits_inplace=False, f16=False):
-    """Attention core on pre-split operands + pair term.  ``points`` = ipa_prep_points_planes(...).
-    ``f16`` (default path, s2s_ipa_attention_f16w): every operand as f16 pair planes, ANY n_res -- for a ragged length the operand
-    arrays hold padded_len(n_res) rows per sample (q/k from node_linear(xp_format=2, row_map=...), v from
-    node_linear_vfrag(f16=True, row_map=...)) and the logits get their own padded buffer.  Otherwise the range-safe three-way bf16
-    planes kernel (s2s_ipa_attention_planes, n_res % 32 == 0).
+def ipa_attention_f16(q_xp, k_xp, v_vf, points, attn_bias, pair_z, mask, rigids7, n_heads=8, c_hidden=256, n_qk=8, n_v=12,
+                      c_pz=32, inf=1e5, eps=1e-8, logits_inplace=False):
+    """Attention core on pre-split f16 pair operands + pair term (s2s_ipa_attention_f16w + s2s_ipa_opair), ANY n_res.
+    ``points`` = ipa_prep_points_f16(...); for a ragged length the operand arrays hold padded_len(n_res) rows per sample (q/k from
+    node_linear(row_map=...), v from node_linear_vfrag(row_map=...)) and the logits get their own padded buffer.
     -> (feats fp32 [B,N,feat] with the o_pt / o_pair columns valid, feats_xp packed planes with the o columns valid); the
     caller packs columns H*c_hidden.. of ``feats`` into ``feats_xp`` (ops.pack_planes) to complete linear_out's input."""
     lib = load_library()
@@ -538,13 +488,10 @@ def ipa_attention_planes(q_xp, k_xp, v_vf, points, attn_bias, pair_z, mask, rigi
     for n, t in (("q_xp", q_xp), ("k_xp", k_xp), ("v_vf", v_vf), ("qp_xp", qp), ("kp_xp", kp), ("vp_vf", vp)):
         _req(t, torch.int16, n)
     NP = padded_len(N)
-    if N % 32 and not f16:
-        raise HipLibraryError("ipa_attention_planes: the bf16 planes kernel needs n_res % 32 == 0 (use ipa_attention)")
     if attn_bias.shape != (B, n_heads, N, N) or pair_z.shape != (B, N, N, c_pz):
-        raise HipLibraryError("ipa_attention_planes: attn_bias must be [B,H,N,N] and pair_z [B,N,N,c_pz]")
-    npl = 2 if f16 else 3
-    if q_xp.numel() != B * NP * n_heads * c_hidden * npl or v_vf.numel() != q_xp.numel() or q2.numel() != B * NP * n_heads:
-        raise HipLibraryError("ipa_attention_planes: operand arrays do not hold padded_len(n_res) rows per sample")
+        raise HipLibraryError("ipa_attention_f16: attn_bias must be [B,H,N,N] and pair_z [B,N,N,c_pz]")
+    if q_xp.numel() != B * NP * n_heads * c_hidden * 2 or v_vf.numel() != q_xp.numel() or q2.numel() != B * NP * n_heads:
+        raise HipLibraryError("ipa_attention_f16: operand arrays do not hold padded_len(n_res) rows per sample")
     feat = n_heads * (c_hidden + 4 * n_v + c_pz)
     out = torch.empty(B, N, feat, device=mask.device, dtype=torch.float32)
     out_xp = xp_alloc(B * N, feat, mask.device)
@@ -553,18 +500,17 @@ def ipa_attention_planes(q_xp, k_xp, v_vf, points, attn_bias, pair_z, mask, rigi
     else:
         logits = attn_bias if logits_inplace else torch.empty_like(attn_bias)
     stats = torch.empty(B, n_heads, N, 2, device=mask.device, dtype=torch.float32)
-    name = "s2s_ipa_attention_f16w" if f16 else "s2s_ipa_attention_planes"
 
     def launch():
-        fn = lib.s2s_ipa_attention_f16w if f16 else lib.s2s_ipa_attention_planes
-        rc = fn(_p(q_xp), _p(k_xp), _p(v_vf), _p(qp), _p(kp), _p(vp), _p(q2), _p(k2), _p(attn_bias), _p(logits), _p(stats), _p(mask),
-                _p(rigids7), _p(out), _p(out_xp), feat // 16, B, N, n_heads, c_hidden, n_qk, n_v, c_pz, inf, eps, _stream())
+        rc = lib.s2s_ipa_attention_f16w(_p(q_xp), _p(k_xp), _p(v_vf), _p(qp), _p(kp), _p(vp), _p(q2), _p(k2), _p(attn_bias), _p(logits),
+                                        _p(stats), _p(mask), _p(rigids7), _p(out), _p(out_xp), feat // 16, B, N, n_heads, c_hidden,
+                                        n_qk, n_v, c_pz, inf, eps, _stream())
         if rc:
             return rc
         return lib.s2s_ipa_opair(_p(logits), _p(stats), _p(pair_z), _p(out), B, N, n_heads, c_pz, feat,
                                  n_heads * (c_hidden + 4 * n_v), NP, _stream())
 
-    _check(_timed("s2s_ipa_attention", launch), name + "/s2s_ipa_opair")
+    _check(_timed("s2s_ipa_attention", launch), "s2s_ipa_attention_f16w/s2s_ipa_opair")
     return out, out_xp
 
 
@@ -686,7 +632,7 @@ def node_tiles(n_out: int, whole_row: bool = False) -> int:
 
 
 def pack_node_weight(w: torch.Tensor, tiles_per_block: int) -> torch.Tensor:
-    """[n_out, k_in] fp32 -> int16 blob [n_out/(32 TG)][k_in/16][TG][2][64][8] of chain-ordered f16 A fragments (W_h, W_ls)
+    """[n_out, k_in] fp32 -> int16 blob [n_out/(32 TG)][k_in/16][TG][2][64][8] of chain-ordered f16 A fragments (W_h, W_l)
     (s2s_node_linear).  n_out is zero-padded to a multiple of 32 first."""
     n_out, k = w.shape
     pad = (-n_out) % 32
@@ -700,10 +646,54 @@ def pack_node_weight(w: torch.Tensor, tiles_per_block: int) -> torch.Tensor:
     return fr.contiguous().view(torch.int16).reshape(-1)
 
 
-def xp_alloc(n_rows: int, k: int, device, planes: int = 2) -> torch.Tensor:
-    """Packed-plane activation buffer for [n_rows, k] (int16 storage; two f16 planes per k-step for the node stream, three for the
-    bf16 operand format; see include/str2str_hip.h)."""
-    return torch.empty(((n_rows + 31) // 32) * (k // 16) * planes * 64 * 8, dtype=torch.int16, device=device)
+def pack_node_weight_f32(w: torch.Tensor, tiles_per_block: int) -> torch.Tensor:
+    """[n_out, k_in] fp32 -> fp32 blob [n_out/(32 TG)][k_in/8][TG][64][4] in the ``pack_weight`` lane order (s2s_node_linear_f32)."""
+    n_out, k = w.shape
+    pad = (-n_out) % 32
+    if pad:
+        w = torch.cat([w, w.new_zeros(pad, k)], dim=0)
+    if k % 8 or (w.shape[0] // 32) % tiles_per_block:
+        raise ValueError("k_in must be a multiple of 8 and n_out/32 of tiles_per_block")
+    T, S4 = w.shape[0] // 32, k // 8
+    fr = w.float().reshape(T // tiles_per_block, tiles_per_block, 32, S4, 2, 4).permute(0, 3, 1, 4, 2, 5)   # [cb, s4, t, g, m, q]
+    return fr.contiguous().reshape(-1)
+
+
+def pack_node_layer(w: torch.Tensor, bias, whole_row: bool = False) -> dict:
+    """Everything ``node_apply`` needs of one nn.Linear of the node stream: tile grouping, padded bias, and the packed weights of
+    BOTH arithmetics, built on first use ("w": f16x3 fragments, "w32": exact fp32)."""
+    n_out, k = w.shape
+    n_pad = -(-n_out // 32) * 32
+    tg = node_tiles(n_pad, whole_row=whole_row)
+    b = w.new_zeros(n_pad, dtype=torch.float32)
+    if bias is not None:
+        b[:n_out] = bias.detach().float()
+    return _NodeLayer({"b": b.contiguous(), "n": n_pad, "k": k, "tg": tg}, w.detach())
+
+
+class _NodeLayer(dict):
+    def __init__(self, d, w):
+        super().__init__(d)
+        self._w = w
+
+    def __missing__(self, key):
+        if key == "w":
+            self[key] = pack_node_weight(self._w.float(), self["tg"])
+        elif key == "w32":
+            self[key] = pack_node_weight_f32(self._w.float(), self["tg"])
+        else:
+            raise KeyError(key)
+        return self[key]
+
+
+def xp_alloc(n_rows: int, k: int, device) -> torch.Tensor:
+    """Packed-plane activation buffer for [n_rows, k] (int16 storage; two f16 planes per k-step; see include/str2str_hip.h)."""
+    return torch.empty(((n_rows + 31) // 32) * (k // 16) * 2 * 64 * 8, dtype=torch.int16, device=device)
+
+
+def act_alloc(n_rows: int, k: int, device, arith: str) -> torch.Tensor:
+    """Activation buffer of the node stream: packed f16 planes ("f16x3") or fp32 row-major [n_rows, k] ("f32")."""
+    return xp_alloc(n_rows, k, device) if arith == "f16x3" else torch.empty(n_rows, k, device=device, dtype=torch.float32)
 
 
 def pack_planes(x2d: torch.Tensor, col0: int = 0, n_cols: Optional[int] = None, out=None, out_k: Optional[int] = None,
@@ -718,22 +708,25 @@ def pack_planes(x2d: torch.Tensor, col0: int = 0, n_cols: Optional[int] = None, 
         out = xp_alloc(M, out_k, x2d.device)
     if row_scale is not None:
         _req(row_scale, name="row_scale")
+    range_flag()
     _check(lib.s2s_pack_planes(_p(x2d), M, ld, col0, n_cols, _p(out), out_k // 16, k0 // 16, _p(row_scale), _stream()),
            "s2s_pack_planes")
     return out
 
 
+def to_act(x2d: torch.Tensor, arith: str) -> torch.Tensor:
+    """fp32 [M, K] -> the node stream's activation format: packed planes ("f16x3") or the tensor itself ("f32")."""
+    return pack_planes(x2d) if arith == "f16x3" else _req(x2d, name="x")
+
+
 def node_linear(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles: int, *, pre_scale=None, relu=False, pre_mask=None,
                 residual=None, ln=None, post_mask=None, out_f32=None, out_col0: int = 0, want_f32=True, out_xp=None,
-                out_xp_k: Optional[int] = None, out_xp_k0: int = 0, want_xp=False, xp_bf16=False, xp_format: Optional[int] = None,
-                row_map: Optional[tuple] = None):
-    """One fused per-node layer (s2s_node_linear).  ``residual`` [n_rows, ld] fp32 (its leading n_out columns are added);
-    ``ln`` = (gamma, beta, eps); ``out_f32`` a preallocated [n_rows, ld] buffer written at ``out_col0`` (allocated
-    [n_rows, n_out] when ``want_f32``); ``out_xp`` likewise for the packed planes (``xp_bf16``: as exact three-way bf16 planes,
-    the operand format of the bf16 attention kernel, instead of the f16 pair planes the node stream and the f16 attention kernel
-    take).  ``row_map`` = (n_pad, n_src): ``n_rows`` counts OUTPUT rows = samples * n_pad, output row (sample, n) is computed from
-    input row sample * n_src + min(n, n_src - 1) (per-sample padding to whole 32-row tiles for the attention kernel).
-    -> (out_f32 or None, out_xp or None)."""
+                out_xp_k: Optional[int] = None, out_xp_k0: int = 0, want_xp=False, row_map: Optional[tuple] = None):
+    """One fused per-node layer on split-f16 MFMA (s2s_node_linear).  ``residual`` [n_rows, ld] fp32 (its leading n_out columns are
+    added); ``ln`` = (gamma, beta, eps); ``out_f32`` a preallocated [n_rows, ld] buffer written at ``out_col0`` (allocated
+    [n_rows, n_out] when ``want_f32``); ``out_xp`` likewise for the packed planes.  ``row_map`` = (n_pad, n_src): ``n_rows`` counts
+    OUTPUT rows = samples * n_pad, output row (sample, n) is computed from input row sample * n_src + min(n, n_src - 1) (per-sample
+    padding to whole 32-row tiles for the attention kernel).  -> (out_f32 or None, out_xp or None)."""
     lib = load_library()
     _req(xp, torch.int16, "xp"); _req(wpk, torch.int16, "w_packed")
     dev = xp.device
@@ -748,40 +741,85 @@ def node_linear(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles: int, *
         out_f32 = torch.empty(n_rows, n_out, device=dev, dtype=torch.float32)
     if out_f32 is not None:
         _req(out_f32, name="out_f32")
-    fmt = int(xp_format) if xp_format is not None else int(bool(xp_bf16))
-    fmt = 0 if fmt == 2 else fmt   # (2 = "f16 pair planes": since the node stream itself uses them, the same as 0)
     if out_xp is None and want_xp:
         out_xp_k = n_out if out_xp_k is None else out_xp_k
-        out_xp = xp_alloc(n_rows, out_xp_k, dev, planes=3 if fmt == 1 else 2)
+        out_xp = xp_alloc(n_rows, out_xp_k, dev)
     if out_xp is not None:
         out_xp_k = n_out if out_xp_k is None else out_xp_k
         _req(out_xp, torch.int16, "out_xp")
     g, b, eps = ln if ln is not None else (None, None, 0.0)
     if ln is not None:
         _req(g, name="ln.gamma"); _req(b, name="ln.beta")
+    range_flag()
     _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear(
         _p(xp), _p(wpk), _p(bias), n_rows, k_in, n_out, tiles, _p(pre_scale), int(bool(relu)), _p(pre_mask), _p(residual),
         residual.shape[-1] if residual is not None else 0, _p(g), _p(b), float(eps), _p(post_mask), _p(out_f32),
         out_f32.shape[-1] if out_f32 is not None else 0, out_col0, _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16,
-        fmt, map_pad, map_src, _stream())), "s2s_node_linear")
+        map_pad, map_src, _stream())), "s2s_node_linear")
     return out_f32, out_xp
 
 
-def node_linear_vfrag(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles_per_head: int = 8, out=None, f16: bool = False,
+def node_linear_f32(x, wpk32, bias, n_rows: int, k_in: int, n_out: int, tiles: int, *, pre_scale=None, relu=False, pre_mask=None,
+                    residual=None, ln=None, post_mask=None, out=None, out_col0: int = 0):
+    """The same layer on exact fp32 MFMA (s2s_node_linear_f32): x fp32 [n_rows, ld >= k_in], ``wpk32`` = pack_node_weight_f32;
+    -> out fp32 (allocated [n_rows, n_out] unless given: written at ``out_col0``)."""
+    lib = load_library()
+    _req(x, name="x"); _req(wpk32, name="w_packed_f32")
+    if x.ndim != 2 or x.shape[0] != n_rows or x.shape[1] < k_in or wpk32.numel() != n_out * k_in:
+        raise HipLibraryError(f"node_linear_f32: operand sizes do not match M={n_rows} K={k_in} N={n_out}")
+    for n, t in (("bias", bias), ("pre_scale", pre_scale), ("pre_mask", pre_mask), ("residual", residual), ("post_mask", post_mask)):
+        if t is not None:
+            _req(t, name=n)
+    if out is None:
+        out = torch.empty(n_rows, n_out, device=x.device, dtype=torch.float32)
+    _req(out, name="out")
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    if ln is not None:
+        _req(g, name="ln.gamma"); _req(b, name="ln.beta")
+    _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_f32(
+        _p(x), x.shape[1], _p(wpk32), _p(bias), n_rows, k_in, n_out, tiles, _p(pre_scale), int(bool(relu)), _p(pre_mask), _p(residual),
+        residual.shape[-1] if residual is not None else 0, _p(g), _p(b), float(eps), _p(post_mask), _p(out), out.shape[-1], out_col0,
+        _stream())), "s2s_node_linear_f32")
+    return out
+
+
+def node_apply(x, layer: dict, n_rows: int, *, out_f32=None, out_col0: int = 0, want_f32=True, out_xp=None, out_xp_k=None,
+               out_xp_k0: int = 0, want_xp=False, **epilogue):
+    """One layer of the node stream in the arithmetic of its INPUT: ``x`` packed f16 planes (int16) -> s2s_node_linear, ``x`` fp32
+    [n_rows, K] -> s2s_node_linear_f32.  ``layer`` = pack_node_layer(...).  Same calling convention and return value
+    (fp32 output or None, activation-format output or None) in both; in the fp32 arithmetic the two outputs are the same tensor
+    (``out_xp``, an fp32 buffer there, is written at column ``out_xp_k0`` when no ``out_f32`` is given)."""
+    if x.dtype == torch.int16:
+        return node_linear(x, layer["w"], layer["b"], n_rows, layer["k"], layer["n"], layer["tg"], out_f32=out_f32, out_col0=out_col0,
+                           want_f32=want_f32, out_xp=out_xp, out_xp_k=out_xp_k, out_xp_k0=out_xp_k0, want_xp=want_xp, **epilogue)
+    if epilogue.pop("row_map", None) is not None:
+        raise HipLibraryError("node_apply: the row map belongs to the f16 attention operands")
+    if out_f32 is not None:
+        out, col0 = out_f32, out_col0
+        if out_xp is not None and out_xp is not out_f32:
+            raise HipLibraryError("node_apply (fp32): one output buffer")
+    else:
+        out, col0 = out_xp, out_xp_k0
+    y = node_linear_f32(x, layer["w32"], layer["b"], n_rows, layer["k"], layer["n"], layer["tg"], out=out, out_col0=col0, **epilogue)
+    return y, y
+
+
+def node_linear_vfrag(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles_per_head: int = 8, out=None,
                       row_map: Optional[tuple] = None):
-    """Projection stored as bf16x3 A fragments over 32-row tiles (s2s_node_linear_vfrag; the value projection of the IPA).
-    -> int16 buffer [row tiles][heads][tiles_per_head][2][3][64][8]."""
+    """Projection stored as MFMA A fragments of f16 pairs over 32-row tiles (s2s_node_linear_vfrag; the value projection of the IPA).
+    -> int16 buffer [row tiles][heads][tiles_per_head][2][2][64][8]."""
     lib = load_library()
     _req(xp, torch.int16, "xp"); _req(wpk, torch.int16, "w_packed")
     if bias is not None:
         _req(bias, name="bias")
-    n_el = ((n_rows + 31) // 32) * (n_out // 32) * 2 * (2 if f16 else 3) * 64 * 8   # f16: pair planes (x_h, x_l)
+    n_el = ((n_rows + 31) // 32) * (n_out // 32) * 2 * 2 * 64 * 8
     if out is None:
         out = torch.empty(n_el, dtype=torch.int16, device=xp.device)
     _req(out, torch.int16, "out_vf")
     map_pad, map_src = row_map if row_map is not None else (0, 0)
+    range_flag()
     _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_vfrag(_p(xp), _p(wpk), _p(bias), n_rows, k_in, n_out, tiles_per_head,
-                                                                       _p(out), int(bool(f16)), map_pad, map_src, _stream())),
+                                                                       _p(out), map_pad, map_src, _stream())),
            "s2s_node_linear_vfrag")
     return out
 
@@ -800,6 +838,8 @@ def encoder_attention(qkv: torch.Tensor, key_bias: Optional[torch.Tensor], n_sam
         _req(key_bias, name="key_bias")
     out = torch.empty(M, D, device=qkv.device, dtype=torch.float32) if want_f32 else None
     oxp = xp_alloc(M, D, qkv.device) if want_xp else None
+    if want_xp:
+        range_flag()
     _check(_timed("s2s_encoder_attention", lambda: lib.s2s_encoder_attention(_p(qkv), _p(key_bias), _p(out), _p(oxp), n_samples, n_res,
                                                                              n_heads, D // n_heads, _stream())), "s2s_encoder_attention")
     return out, oxp
@@ -830,13 +870,10 @@ def ca_pwd_js(ref_ca: torch.Tensor, pred_ca: torch.Tensor, offset: int = 3, n_bi
     return out
 
 
-def unpack_planes(xp: torch.Tensor, n_rows: int, k: int, bf16: bool = False) -> torch.Tensor:
-    """XP -> fp32 [n_rows, k] (x_h + x_l of the f16 pair planes, or h + m + l of bf16 planes; for tests and debugging)."""
+def unpack_planes(xp: torch.Tensor, n_rows: int, k: int) -> torch.Tensor:
+    """XP -> fp32 [n_rows, k] (x_h + x_l of the f16 pair planes; for tests and debugging)."""
     KS = k // 16
-    if bf16:
-        fr = xp.view(torch.bfloat16).reshape(-1, KS, 3, 2, 32, 8).float().sum(2)    # [RT, KS, g, m, j]
-    else:
-        fr = xp.view(torch.float16).reshape(-1, KS, 2, 2, 32, 8).float().sum(2)
+    fr = xp.view(torch.float16).reshape(-1, KS, 2, 2, 32, 8).float().sum(2)    # [RT, KS, g, m, j]
     ks = torch.arange(KS)[:, None, None]
     g = torch.arange(2)[None, :, None]
     j = torch.arange(8)[None, None, :]
@@ -926,13 +963,13 @@ def register_torch_ops():
         "edge_transition(Tensor edge, Tensor node_ab, Tensor node_p, Tensor w1p, Tensor w2p, Tensor wfp, Tensor b2, "
         "Tensor bf, Tensor gamma, Tensor beta, Tensor? mask, float ln_eps) -> Tensor":
             lambda *a: edge_transition(*a),
-        "edge_transition_bf16x6(Tensor edge, Tensor node_ab, Tensor node_p, Tensor wstream, Tensor b2, Tensor bf, "
+        "edge_transition_f16x3(Tensor edge, Tensor node_ab, Tensor node_p, Tensor wstream, Tensor b2, Tensor bf, "
         "Tensor gamma, Tensor beta, Tensor? mask, float ln_eps) -> Tensor":
-            lambda *a: edge_transition_bf16x6(*a),
-        "edge_embed_bf16x6(Tensor node_a, Tensor node_b, Tensor rel_table, Tensor bin_table, Tensor bin_lower, "
+            lambda *a: edge_transition_f16x3(*a),
+        "edge_embed_f16x3(Tensor node_a, Tensor node_b, Tensor rel_table, Tensor bin_table, Tensor bin_lower, "
         "Tensor residue_idx, Tensor ca, Tensor wstream, Tensor b2, Tensor b3, Tensor gamma, Tensor beta, Tensor? mask, "
         "int rel_offset, float ln_eps) -> Tensor":
-            lambda *a: edge_embed_bf16x6(*a),
+            lambda *a: edge_embed_f16x3(*a),
         "pair_project(Tensor edge, Tensor wp, Tensor bias64) -> (Tensor, Tensor)": lambda *a: pair_project(*a),
         "se3_step(Tensor x0_7, Tensor xt_7, Tensor mask, Tensor diffuse_mask, Tensor params8, float dt) -> Tensor":
             lambda x0, xt, m, dm, p8, dt: se3_step(x0, xt, m, dm, p8, dt)[0],

@@ -9,6 +9,9 @@ x0 prediction itself.  Differences in HOW:
     trajectory; the loop body is network forward -> ONE fused SE(3) kernel, with no device->host sync;
   * the backbone projection runs once at the end (the reference recomputes it every forward and
     throws the result away, denoising_ipa.py:197-201);
+  * the default arithmetic (split-f16 matrix products, str2str_amd/arith.py) has f16's RANGE: its kernels raise a device flag
+    when a value they split reaches 2^15; the flag is read once per chunk, where the loop synchronises anyway, and a flagged
+    chunk is re-run from its starting frames (same noise) on the exact fp32 kernels -- after which the network stays there;
   * replicas can be sharded over ranks (``shard=(rank, world)``): noise for the WHOLE chunk is drawn
     on every rank from the same host generator state and sliced, so the union over ranks equals the
     single-process result sample for sample ("parity" RNG mode).  ``rng="device"`` instead draws
@@ -24,6 +27,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .arith import net_arith, use_arith
 from .common.all_atom import compute_backbone
 from .common.rigid_utils import Rigid
 
@@ -84,7 +88,7 @@ def _graph_read_tensors(net):
 
     keep = []
     for m in net.modules():
-        for name in ("_idx_val", "_rel_cb", "_idx_src", "node_embed_xp"):
+        for name in ("_idx_val", "_rel_cb", "_idx_src", "node_embed_act"):
             if hasattr(m, name):
                 tensors(getattr(m, name), keep)
         for v in vars(m).values():
@@ -108,7 +112,7 @@ def _graph_key(net, feats, b, N):
         h.update(k.encode()); h.update(str(tuple(v.shape)).encode()); h.update(v.detach().cpu().numpy().tobytes())
     tr = getattr(net, "translator", None)
     # which kernels were captured: the arithmetic / kernel selectors of the modules
-    modes = tuple(sorted({(a, str(getattr(m, a))) for m in net.modules() for a in ("mfma_mode", "ipa_path", "range_safe") if hasattr(m, a)}))
+    modes = tuple(sorted({str(getattr(m, "arith")) for m in net.modules() if hasattr(m, "arith")}))
     return (id(net), sum(p._version for p in net.parameters()), b, N, bool(getattr(tr, "exact_padding", False)),
             bool(getattr(tr, "fuse_pair_projection", False)), modes, h.hexdigest())
 
@@ -175,7 +179,68 @@ def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: flo
     """The loop body of forward_backward over ALREADY EXPANDED per-sample features (every tensor has the
     sample dimension b) starting from the noised frames ``rigids_t`` [b,N,7]: 1 self-conditioning evaluation,
     then per step  network -> fused SE(3) step, last step returns the x0 prediction.  ``host_noise()`` (optional)
-    returns the (z_rot, z_trans) float64 [b,N,3] device tensors of a step or None.  -> (atom37, final rigids7, psi)."""
+    returns the (z_rot, z_trans) float64 [b,N,3] device tensors of a step or None.  -> (atom37, final rigids7, psi).
+
+    Range guard: in the split-f16 arithmetic the pass runs with the library's range flag cleared; if a kernel raised it (an
+    activation reached 2^15 -- f16 tops out at 65504) or the result is not finite, the SAME chunk (same starting frames, same
+    noise) is run again on the exact fp32 kernels, a warning is logged once, and the network stays in fp32 for later chunks
+    (``net.range_fallback``).  One flag read per chunk, at the point where the loop synchronises anyway."""
+    kw = dict(min_t=min_t, noise_scale=noise_scale, probability_flow=probability_flow, self_conditioning=self_conditioning,
+              center_mode=center_mode, trace=trace)
+    if net_arith(net) != "f16x3":
+        out = _denoise_pass(net, diffuser, feats, rigids_t, ts, dt, host_noise=host_noise, **kw)
+        _require_finite(out[1], "fp32")
+        return out
+    if getattr(net, "range_fallback", False):
+        with use_arith(net, "f32"):
+            out = _denoise_pass(net, diffuser, feats, rigids_t, ts, dt, host_noise=host_noise, **kw)
+        _require_finite(out[1], "fp32 (range fallback)")
+        return out
+    device_draws = host_noise is None and not probability_flow
+    rng_state = torch.cuda.get_rng_state(rigids_t.device) if device_draws else None
+    drawn = []
+
+    def recording_noise():
+        z = host_noise()
+        drawn.append(z)
+        return z
+
+    ops.range_flag_reset()
+    try:
+        out = _denoise_pass(net, diffuser, feats, rigids_t, ts, dt, host_noise=recording_noise if host_noise is not None else None, **kw)
+        finite = bool(torch.isfinite(out[1]).all())     # (the synchronisation point of the chunk)
+        bits = ops.range_flag_read()
+        if bits == 0 and finite:
+            return out
+        why = f"an activation left f16's safe range in the split-f16 kernels ({ops.range_flag_names(bits)}{'' if finite else '; non-finite frames'})"
+    except ops.WeightRangeError as e:   # |32 w| >= 65504: the weights themselves cannot be packed for the f16 kernels
+        why = f"a weight does not fit the split-f16 packing ({e})"
+        for _ in range(len(ts) - 1 - len(drawn)):   # keep the host generator where a completed pass leaves it
+            recording_noise() if host_noise is not None else None
+    _log.warning("range guard: %s; re-running this chunk on the exact fp32 kernels and keeping the network there "
+                 "(set S2S_ARITH=f32 to start in fp32)", why)
+    net.range_fallback = True
+    if trace is not None:
+        del trace[:]
+    if rng_state is not None:
+        torch.cuda.set_rng_state(rng_state, rigids_t.device)
+    replay = iter(drawn)
+    with use_arith(net, "f32"):
+        out = _denoise_pass(net, diffuser, feats, rigids_t, ts, dt, host_noise=(lambda: next(replay)) if host_noise is not None else None,
+                            **kw)
+    _require_finite(out[1], "fp32 (range fallback)")
+    return out
+
+
+def _require_finite(rigids7, what):
+    if not bool(torch.isfinite(rigids7).all()):
+        raise ops.HipLibraryError(f"non-finite frames at the end of the trajectory in the {what} arithmetic: the network itself "
+                                  "overflows fp32 on this input (weights / checkpoint?)")
+
+
+def _denoise_pass(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: float, *, min_t: float, noise_scale: float,
+                  probability_flow: bool, self_conditioning: bool, center_mode: int, host_noise, trace: Optional[list]):
+    """One pass of the loop in the network's current arithmetic (see ``denoise_loop``)."""
     device = rigids_t.device
     b, N = rigids_t.shape[:2]
     feats = dict(feats)
@@ -230,11 +295,6 @@ def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: flo
     finally:
         if keep_bb is not None:
             net.backbone_in_forward = keep_bb
-    # The split-f16 kernels need activations below f16's 65504: an overflow turns into inf / NaN, and that
-    # must be an error, not a PDB file (one reduction + sync per trajectory chunk)
-    if not bool(torch.isfinite(final["rigids7"]).all()):
-        raise ops.HipLibraryError("non-finite frames at the end of the trajectory: an activation may have exceeded f16's range in the "
-                                  "split-f16 (f16x3) kernels -- rerun with S2S_EDGE_MFMA=bf16x6 S2S_IPA_PATH=planes to check")
     return atom37, final["rigids7"], final["psi"]
 
 

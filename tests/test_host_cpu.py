@@ -84,55 +84,38 @@ def test_pack_weight_layout():
         assert float(p[s4, t, lane, q]) == want
 
 
-def test_bf16x3_split_and_stream_layout():
-    """Host side of the split-bf16 kernels: the 3-way split is EXACT, fragments sit where the kernels' lanes read them,
-    and the streams follow the slot schedule documented in csrc/pair_mlp_bf16.hip (A_0 A_1 | B_0 A_2 | ... | B_10 B_11 | F)."""
-    from str2str_amd import ops
+def test_f16x3_weight_split_and_stream_layout():
+    """Host side of the split-f16 kernels (csrc/pair_mlp_f16.hip, node_gemm.hip): fragments sit where the kernels' lanes read them,
+    the weight pair (W_h, W_l) of 2^5 w recovers w to fp32 rounding over the weights' range (the factor keeps W_l out of f16's
+    subnormals for |w| >= 2^-14), a weight beyond the packing's range is refused, the stream follows the slot schedule documented
+    in csrc/pair_mlp_f16.hip (A_0 A_1 | B_0 A_2 | ... | B_10 B_11 | F), the fp32 node packing follows pack_weight's lane order, and
+    the gather tables' column blocking is a pure permutation."""
+    import pytest
 
-    g = torch.Generator().manual_seed(0)
-    w = torch.randn(96, 64, generator=g) * torch.logspace(-6, 3, 64)  # wide dynamic range
-    h, m, l = ops.split_bf16x3(w)
-    assert h.dtype == torch.bfloat16 and torch.equal(h.double() + m.double() + l.double(), w.double())
-    assert (m.float().abs() <= h.float().abs() * 2 ** -7 + 1e-38).all()
+    from str2str_amd import ops
 
     # chain order: element j of lane (row m, k-group g) in k-step ks is W[32t + m][32t' + (r&3) + 8(r>>2) + 4g], t' = ks>>1, r = 8(ks&1)+j
     wk = torch.arange(64 * 64, dtype=torch.float32).reshape(64, 64)
-    pk = ops.pack_bf16x3_layer(wk, "chain")  # [KS=4, T=2, 3, 64, 8]
-    assert pk.shape == (4, 2, 3, 64, 8)
+    fo = ops.fragment_order(wk, "chain")  # [KS=4, T=2, 64, 8]
+    assert fo.shape == (4, 2, 64, 8)
     for ks, t, lane, j in [(0, 0, 0, 0), (1, 1, 37, 5), (3, 0, 63, 7), (2, 1, 31, 3)]:
         r = 8 * (ks & 1) + j
         col = 32 * (ks >> 1) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-        want = wk[32 * t + (lane & 31), col]
-        got = pk[ks, t, :, lane, j].float().sum()
-        assert float(got) == float(want), (ks, t, lane, j)
-    prow = ops.pack_bf16x3_layer(wk, "row")
-    assert float(prow[1, 0, :, 40, 2].float().sum()) == float(wk[8, 16 + 8 + 2])
-
-    # edge-transition stream: 30 stages x 8 slots x 6 fragments x (64 lanes x 8 bf16)
-    w1, w2, wf = torch.randn(384, 128, generator=g), torch.randn(384, 384, generator=g), torch.randn(128, 384, generator=g)
-    st = ops.pack_bf16x3_stream(w1, w2, wf).view(torch.bfloat16).reshape(240, 6, 64, 8)
-    l1, l2, lf = ops.pack_bf16x3_layer(w1, "chain"), ops.pack_bf16x3_layer(w2, "chain"), ops.pack_bf16x3_layer(wf, "chain")
-    assert torch.equal(st[0], l1[0:2, 0].reshape(6, 64, 8))            # A_0 slot 0: k-steps 0,1 of tile 0, [k-step][plane]
-    assert torch.equal(st[4 + 3], l1[6:8, 1].reshape(6, 64, 8))        # A_1 slot 3
-    assert torch.equal(st[8 + 7], l2[1, 2:4].reshape(6, 64, 8))        # B_0 slot (u=1, pair 1): k-step 1, tiles 2,3
-    assert torch.equal(st[8 + 12 + 1], l1[2:4, 2].reshape(6, 64, 8))   # A_2 slot 1 follows B_0
-    assert torch.equal(st[168 + 12 + 6], l2[23, 0:2].reshape(6, 64, 8))  # B_11 (u=1, pair 0): k-step 2*11+1
-    assert torch.equal(st[192 + 2 * 5 + 1], lf[5, 2:4].reshape(6, 64, 8))  # final layer k-step 5, tiles 2,3
-    es = ops.pack_bf16x3_embed_stream(torch.randn(128, 128, generator=g), torch.randn(128, 128, generator=g))
-    assert es.numel() * 2 == 4 * 48 * 1024
-
-
-def test_f16x3_weight_split_and_stream_layout():
-    """Host side of the split-f16 kernels (csrc/pair_mlp_f16.hip, node_gemm.hip): the weight pair (W_h, W_l) of 2^5 w recovers w to
-    fp32 rounding over the weights' range (the factor keeps W_l out of f16's subnormals for |w| >= 2^-14), the stream follows the
-    bf16 stream's slot order with 4 fragments per slot, and the gather tables' column blocking is a pure permutation."""
-    from str2str_amd import ops
+        assert float(fo[ks, t, lane, j]) == float(wk[32 * t + (lane & 31), col]), (ks, t, lane, j)
+    assert float(ops.fragment_order(wk, "row")[1, 0, 40, 2]) == float(wk[8, 16 + 8 + 2])
+    with pytest.raises(ops.WeightRangeError):
+        ops.pack_f16x2_layer(torch.full((32, 32), 2048.0))
+    # fp32 node packing [cb][s4][t][lane][q] = W[32 (cb TG + t) + (lane & 31)][8 s4 + 4 (lane >> 5) + q]
+    w32 = torch.arange(128 * 16, dtype=torch.float32).reshape(128, 16)
+    p32 = ops.pack_node_weight_f32(w32, 2).reshape(2, 2, 2, 64, 4)
+    for cb, s4, t, lane, q in [(0, 0, 0, 0, 0), (1, 1, 0, 33, 2), (0, 1, 1, 7, 3), (1, 0, 1, 63, 1)]:
+        assert float(p32[cb, s4, t, lane, q]) == float(w32[32 * (cb * 2 + t) + (lane & 31), 8 * s4 + 4 * (lane >> 5) + q])
 
     g = torch.Generator().manual_seed(1)
     w = torch.randn(96, 64, generator=g) * torch.logspace(-4, 1, 64)        # |w| from 1e-4 to ~30: beyond any trained layer
     pk = ops.pack_f16x2_layer(w, "chain")                                  # [KS=4, T=3, 2, 64, 8]
     assert pk.shape == (4, 3, 2, 64, 8) and pk.dtype == torch.float16
-    ref = ops.pack_bf16x3_layer(w, "chain", _fp32_fragments=True)           # the same fragments in fp32
+    ref = ops.fragment_order(w, "chain")                                   # the same fragments in fp32
     rec = (pk[:, :, 0].double() + pk[:, :, 1].double()) / 32.0
     err = (rec - ref.double()).abs()
     assert (err <= 2.0 ** -23 * ref.double().abs() + 2.0 ** -30).all(), float((err / ref.abs().clamp_min(1e-30)).max())
@@ -143,7 +126,10 @@ def test_f16x3_weight_split_and_stream_layout():
     st = ops.pack_f16x3_stream(w1, w2, wf).view(torch.float16).reshape(240, 4, 64, 8)
     l1, l2, lf = ops.pack_f16x2_layer(w1), ops.pack_f16x2_layer(w2), ops.pack_f16x2_layer(wf)
     assert torch.equal(st[0], l1[0:2, 0].reshape(4, 64, 8))             # A_0 slot 0: k-steps 0, 1 of tile 0, [k-step][plane]
+    assert torch.equal(st[4 + 3], l1[6:8, 1].reshape(4, 64, 8))         # A_1 slot 3
     assert torch.equal(st[8 + 7], l2[1, 2:4].reshape(4, 64, 8))         # B_0 slot (u = 1, pair 1): k-step 1, tiles 2, 3
+    assert torch.equal(st[8 + 12 + 1], l1[2:4, 2].reshape(4, 64, 8))    # A_2 slot 1 follows B_0
+    assert torch.equal(st[168 + 12 + 6], l2[23, 0:2].reshape(4, 64, 8))  # B_11 (u = 1, pair 0): k-step 2*11+1
     assert torch.equal(st[192 + 2 * 5 + 1], lf[5, 2:4].reshape(4, 64, 8))  # final layer k-step 5, tiles 2, 3
     assert ops.pack_f16x3_embed_stream(torch.randn(128, 128, generator=g), torch.randn(128, 128, generator=g)).numel() * 2 == 4 * 32 * 1024
     assert ops.pack_node_weight(torch.randn(256, 320, generator=g), 8).numel() == 256 * 320 * 2

@@ -1,5 +1,5 @@
 """Run only the EdgeTransition kernel (for PMC passes / quick timing).
-    python tools/et_only.py --B 16 --N 256 --mode bf16x6 [--proj]      (--proj: with the fused next-block pair projection)"""
+    python tools/et_only.py --B 16 --N 256 --mode f16x3|f32 [--proj]      (--proj: with the fused next-block pair projection)"""
 import argparse
 import os
 import sys
@@ -12,10 +12,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", type=int, default=16)
 ap.add_argument("--N", type=int, default=256)
 ap.add_argument("--iters", type=int, default=3)
-ap.add_argument("--mode", default="bf16x6")
+ap.add_argument("--mode", default="f16x3", choices=["f16x3", "f32"])
 ap.add_argument("--proj", action="store_true")
 a = ap.parse_args()
-os.environ["S2S_EDGE_MFMA"] = a.mode
+os.environ["S2S_ARITH"] = a.mode
 from str2str_amd.factory import build_synthetic_net  # noqa: E402
 
 net = build_synthetic_net(device="cuda")

@@ -1,5 +1,5 @@
 """Time the node-side of one InvariantPointAttention block (projections -> points -> attention core -> packed linear_out input)
-stage by stage, on the pre-split ("planes") path and on the fp32-operand path (S2S_IPA_PATH=f32 equivalent)."""
+stage by stage, on the pre-split f16 operand path (any length) and on the fp32-operand path (arith "f32")."""
 import argparse
 import os
 import sys
@@ -48,23 +48,22 @@ def timeit(name, fn):
     return out, ms
 
 
-lin = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], M, x["k"], x["n"], x["tg"], **kw)  # noqa: E731
+lin = lambda x, **kw: ops.node_apply(s_xp, x, M, **kw)  # noqa: E731
 NP = ops.padded_len(N)
 rmap, Mo = ((NP, N), B * NP) if NP != N else (None, M)
-linp = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], Mo, x["k"], x["n"], x["tg"], row_map=rmap, **kw)  # noqa: E731
+linp = lambda x, **kw: ops.node_apply(s_xp, x, Mo, row_map=rmap, **kw)  # noqa: E731
 alg = B * 4 * (9512 * N + 40 * N * N)
 with torch.no_grad():
-    for f16 in ((True, False) if N % 32 == 0 else (True,)):
-        print(f"{'f16 pair (s2s_ipa_attention_f16w)' if f16 else 'bf16 three-way (s2s_ipa_attention_planes)'} operand path  B={B} N={N} (padded {NP})")
+    if True:
+        print(f"f16 pair operand path (s2s_ipa_attention_f16w)  B={B} N={N} (padded {NP})")
         tot = 0.0
-        fmt = 2 if f16 else 1
-        (_, q_xp), t = timeit("q  -> planes", lambda: linp(w["q"], want_f32=False, want_xp=True, xp_format=fmt)); tot += t
-        (_, k_xp), t = timeit("k  -> planes", lambda: linp(w["k"], want_f32=False, want_xp=True, xp_format=fmt)); tot += t
-        v_vf, t = timeit("v  -> A fragments", lambda: ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], Mo, 256, 2048, 8, f16=f16, row_map=rmap)); tot += t
+        (_, q_xp), t = timeit("q  -> planes", lambda: linp(w["q"], want_f32=False, want_xp=True)); tot += t
+        (_, k_xp), t = timeit("k  -> planes", lambda: linp(w["k"], want_f32=False, want_xp=True)); tot += t
+        v_vf, t = timeit("v  -> A fragments", lambda: ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], Mo, 256, 2048, 8, row_map=rmap)); tot += t
         (qp, _), t = timeit("q points (linear)", lambda: lin(w["qp"])); tot += t
         (kvp, _), t = timeit("kv points (linear)", lambda: lin(w["kvp"])); tot += t
-        pts, t = timeit("points -> fragments", lambda: ops.ipa_prep_points_planes(r7, qp, kvp, d["hw"], f16=f16)); tot += t
-        (feats, fxp), t_att = timeit("attention + o_pair", lambda: ops.ipa_attention_planes(q_xp, k_xp, v_vf, pts, bias, pz, mask, r7, f16=f16)); tot += t_att
+        pts, t = timeit("points -> fragments", lambda: ops.ipa_prep_points_f16(r7, qp, kvp, d["hw"])); tot += t
+        (feats, fxp), t_att = timeit("attention + o_pair", lambda: ops.ipa_attention_f16(q_xp, k_xp, v_vf, pts, bias, pz, mask, r7)); tot += t_att
         f2 = feats.view(M, -1)
         _, t = timeit("pack o_pt | o_pair", lambda: ops.pack_planes(f2, col0=2048, n_cols=640, out=fxp, out_k=2688, k0=2048)); tot += t
         print(f"  total {tot:.3f} ms; attention + o_pair: algorithmic {alg / t_att / 1e6:.0f} GB/s = {alg / t_att / 1e6 / 80:.1f} % of 8 TB/s")

@@ -1,4 +1,4 @@
-"""Loop only the planes attention launch (for power / clock sampling).  python tools/ipa_loop.py [--seconds 12]"""
+"""Loop only the f16 attention launch pair (for power / clock sampling).  python tools/ipa_loop.py [--seconds 12]"""
 import argparse
 import os
 import sys
@@ -9,7 +9,6 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=12)
-ap.add_argument("--path", default="f16", choices=["f16", "planes"])
 a = ap.parse_args()
 from str2str_amd import ops  # noqa: E402
 from str2str_amd.models.net.ipa import InvariantPointAttention  # noqa: E402
@@ -27,17 +26,16 @@ bias, pz = rn(B, H, N, N), rn(B, N, N, 32)
 mask = torch.ones(B, N, device="cuda")
 s_xp = ops.pack_planes(s)
 w, d = ipa.node_packs(), ipa._derived()
-lin = lambda x, **kw: ops.node_linear(s_xp, x["w"], x["b"], M, x["k"], x["n"], x["tg"], **kw)  # noqa: E731
+lin = lambda x, **kw: ops.node_apply(s_xp, x, M, **kw)  # noqa: E731
 with torch.no_grad():
-    f16 = a.path == "f16"
-    _, q_xp = lin(w["q"], want_f32=False, want_xp=True, xp_format=2 if f16 else 1)
-    _, k_xp = lin(w["k"], want_f32=False, want_xp=True, xp_format=2 if f16 else 1)
-    v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, 256, 2048, 8, f16=f16)
+    _, q_xp = lin(w["q"], want_f32=False, want_xp=True)
+    _, k_xp = lin(w["k"], want_f32=False, want_xp=True)
+    v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], M, 256, 2048, 8)
     qp, _ = lin(w["qp"]); kvp, _ = lin(w["kvp"])
-    pts = ops.ipa_prep_points_planes(r7, qp, kvp, d["hw"], f16=f16)
+    pts = ops.ipa_prep_points_f16(r7, qp, kvp, d["hw"])
     t0 = time.time(); n = 0
     while time.time() - t0 < a.seconds:
         for _ in range(50):
-            ops.ipa_attention_planes(q_xp, k_xp, v_vf, pts, bias, pz, mask, r7, f16=f16)
+            ops.ipa_attention_f16(q_xp, k_xp, v_vf, pts, bias, pz, mask, r7)
         torch.cuda.synchronize(); n += 50
     print(f"{n} launch pairs in {time.time() - t0:.1f} s -> {(time.time() - t0) / n * 1e3:.3f} ms per pair")

@@ -13,9 +13,9 @@ python - <<PY
 import csv, glob, json, collections
 B, N = $B, $N
 pairs = B * N * N
-names = {"edge_transition_bf16": ("edge_transition_bf16x6", 1024), "edge_transition_f16": ("edge_transition_f16x3", 1024),
-         "edge_embed_bf16_kernel": ("edge_embed_bf16x6", 512 + 160), "edge_embed_kernel": ("edge_embed", 512 + 160),
-         "pair_project_kernel": ("pair_project", 672), "ipa_attention_kernel": ("ipa_attention", None),
+names = {"edge_transition_f16": ("edge_transition_f16x3", 1024 + 160), "edge_transition_kernel": ("edge_transition", 1024),
+         "edge_embed_f16_kernel": ("edge_embed_f16x3", 512 + 160), "edge_embed_kernel": ("edge_embed", 512 + 160),
+         "pair_project_kernel": ("pair_project", 672), "ipa_attention_f16w_kernel": ("ipa_attention", None),
          "ipa_opair_kernel": ("ipa_opair", None)}
 acc = {v[0]: {"FETCH_SIZE": [], "WRITE_SIZE": []} for v in names.values()}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
