@@ -62,6 +62,34 @@ __device__ __forceinline__ float4 ldg4(const float* __restrict__ base, int g, in
 }
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
+// Four fp32 values -> elements at .. at + 3 of the plane fragments (x_h, x_l), and into the range maximum (range_flag.h).
+//   x_h = rn16(x):            v_cvt_pk_f16_f32, two values per instruction
+//   x_l = rn16(x - x_h):      the difference is exact in fp32, so ONE fused multiply-add that reads x_h as f16 and rounds to f16
+//                             (v_fma_mixlo / mixhi_f16:  (-x_h) * 1.0 + x) gives the bits of convert-back + subtract + convert
+// = 1.5 VALU instructions per value (hipcc's expansion of the C expression: 3), written as ONE opaque block: both planes come from
+// the same materialised fp32 value (node_gemm.hip split8_f16), the block stays where it is written (the schedule pins VALU pieces
+// under specific MFMAs), and the maximum does not enter the compiler's reasoning (as an fmaxf chain it cost 300 spilled registers).
+typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split4_f16(const float (&x)[4], f16x8& ph, f16x8& pl, int at, float& amax) {
+    unsigned h0, h1, l0, l1;
+    asm volatile(
+        "v_max3_f32 %4, %4, |%5|, |%6|\n\t"
+        "v_cvt_pk_f16_f32 %0, %5, %6\n\t"
+        "v_max3_f32 %4, %4, |%7|, |%8|\n\t"
+        "v_cvt_pk_f16_f32 %1, %7, %8\n\t"
+        "v_fma_mixlo_f16 %2, -%0, 1.0, %5 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, -%1, 1.0, %7 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %2, -%0, 1.0, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %3, -%1, 1.0, %8 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1), "+v"(amax)
+        : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]));
+    u32x4p hv = __builtin_bit_cast(u32x4p, ph), lv = __builtin_bit_cast(u32x4p, pl);
+    hv[at / 2] = h0; hv[at / 2 + 1] = h1;
+    lv[at / 2] = l0; lv[at / 2 + 1] = l1;
+    ph = __builtin_bit_cast(f16x8, hv);
+    pl = __builtin_bit_cast(f16x8, lv);
+}
+
 template <int I> struct IC { static constexpr int value = I; };
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -189,17 +217,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     float amax = 0.f;   // range guard (range_flag.h): running maximum of every value that is split into f16 planes
     // planes (x_h, x_l), see the header
     auto split4 = [&](const float (&x)[4], f16x8& ph, f16x8& pm, int at) {
-        float xv[4] = {x[0], x[1], x[2], x[3]};
-        // one materialised fp32 value feeds both planes (see node_gemm.hip split8_f16) and the range maximum; the maximum is
-        // opaque to the compiler on purpose (as an fmaxf chain it cost this kernel 300 spilled registers)
-        asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]));
-        asm volatile("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|"
-                     : "+v"(amax) : "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const _Float16 a = (_Float16)xv[j];
-            ph[at + j] = a; pm[at + j] = (_Float16)(xv[j] - (float)a);
-        }
+        split4_f16(x, ph, pm, at, amax);
     };
     {
         float4 xv[16];
@@ -606,17 +624,7 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
     };
     float amax = 0.f;   // range guard (range_flag.h)
     auto split4 = [&](const float (&x)[4], f16x8& ph, f16x8& pm, int at) {  // planes (x_h, x_l)
-        float xv[4] = {x[0], x[1], x[2], x[3]};
-        // one materialised fp32 value feeds both planes (see node_gemm.hip split8_f16) and the range maximum; the maximum is
-        // opaque to the compiler on purpose (as an fmaxf chain it cost this kernel 300 spilled registers)
-        asm volatile("" : "+v"(xv[0]), "+v"(xv[1]), "+v"(xv[2]), "+v"(xv[3]));
-        asm volatile("v_max3_f32 %0, %0, |%1|, |%2|\n\tv_max3_f32 %0, %0, |%3|, |%4|"
-                     : "+v"(amax) : "v"(xv[0]), "v"(xv[1]), "v"(xv[2]), "v"(xv[3]));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const _Float16 a = (_Float16)xv[j];
-            ph[at + j] = a; pm[at + j] = (_Float16)(xv[j] - (float)a);
-        }
+        split4_f16(x, ph, pm, at, amax);
     };
     // first-layer sum in accumulator layout: g1[4G + q] = channel 8G + 4h + q, built row by row (same association as the
     // fp32 kernel: ((a + b) + r) + kb*k)

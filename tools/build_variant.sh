@@ -1,13 +1,13 @@
 #!/bin/bash
 # tools/build_variant.sh <name> [extra hipcc flags]: library variant with one differently compiled unit
-# (UNIT=pair_mlp_bf16 by default; e.g. UNIT=ipa_attention tools/build_variant.sh qr0 -DS2S_IPA_QR=0).  Run
+# (UNIT=pair_mlp_f16 by default; e.g. UNIT=ipa_attention tools/build_variant.sh qr0 -DS2S_IPA_QR=0).  Run
 # `python -m str2str_amd.build` first: the other units are linked from its objects.
 N=$1; shift
-U=${UNIT:-pair_mlp_bf16}
+U=${UNIT:-pair_mlp_f16}
 D=str2str_amd/csrc/build
 hipcc -x hip -c str2str_amd/csrc/$U.hip -o $D/${U}_$N.o -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I include -I str2str_amd/csrc -mllvm -pragma-unroll-threshold=10000000 "$@" || exit 1
 OBJS=""
 for u in $(python -c "from str2str_amd.build import UNITS; print(' '.join(k.rsplit('.',1)[0] for k in UNITS))"); do
   if [ $u == $U ]; then OBJS="$OBJS $D/${U}_$N.o"; else OBJS="$OBJS $D/$u.o"; fi
 done
-hipcc -shared -fPIC --offload-arch=gfx950 -o $D/lib_$N.so $OBJS && echo $D/lib_$N.so
+hipcc -shared -fPIC --offload-arch=gfx950 -o $D/ab_$N.so $OBJS && echo $D/ab_$N.so
