@@ -46,7 +46,7 @@ def cpu_model():
     return platform.processor() or "unknown"
 
 
-def cpu_baseline(n_res, denoise_steps, steps_sampled=5, replicas=2):
+def cpu_baseline(n_res, denoise_steps, steps_sampled=20, replicas=2):
     """Oracle on the host cores: (1 self-conditioning forward + `steps_sampled` denoise steps) for
     `replicas` replicas of the same synthetic chain, extrapolated linearly to `denoise_steps` steps."""
     from oracle import diffuser as OD
@@ -79,7 +79,7 @@ def traffic_from_profiles(pairs, mode):
     """HBM bytes per launch of the dominant kernel.  NOT measured in this run: PMC counters need rocprofv3 around the
     process (separate --pmc passes, tools/pmc_hbm_traffic.sh), so the committed pass at B = 16, N = 256 is scaled by the
     pairs of this launch and labelled as such.  (None, None) if the file is absent."""
-    for name in ("r02m_pmc_hbm_traffic.json", "r02l_pmc_hbm_traffic.json", "r02k_pmc_hbm_traffic.json", "r02i_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01i_pmc_hbm_traffic.json"):
+    for name in ("r03_pmc_hbm_traffic.json", "r02m_pmc_hbm_traffic.json", "r02l_pmc_hbm_traffic.json", "r02k_pmc_hbm_traffic.json", "r02i_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01i_pmc_hbm_traffic.json"):
         key = {"f16x3": "edge_transition_f16x3"}.get(mode, "edge_transition")
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
@@ -99,8 +99,9 @@ def main():
     ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU per step")
     ap.add_argument("--denoise-steps", type=int, default=None)
     ap.add_argument("--rng", default="device", choices=["device", "host"], help="noise source (host = reference-order parity mode)")
-    ap.add_argument("--cpu-steps", type=int, default=5, help="denoise steps of the CPU-oracle sample (2 replicas)")
+    ap.add_argument("--cpu-steps", type=int, default=20, help="denoise steps of the CPU-oracle sample (2 replicas; ~100 s of host time at N = 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-table", action="store_true", help="skip the extra (untimed) step that times the kernel families")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -149,6 +150,7 @@ def main():
         workload = (f"configs[{1 if a.config == 'cfg2' else 3}]: single {N}-residue synthetic chain, {B} replicas per GPU x {S} "
                     f"denoise steps (+1 self-conditioning forward), probability-flow ODE, seeded synthetic weights")
         pairs_main = B * N * N
+        eval_pairs, eval_ipa_bytes = B * N * N, B * 4 * (9512 * N + 40 * N * N)   # per network evaluation, summed over the step's chunks
 
         def one_step(seed):
             torch.manual_seed(seed * 1000 + rank)
@@ -176,6 +178,7 @@ def main():
         workload = (f"configs[2]: Science2011 fast-folder set ({len(targets)} targets, N = {sorted(lens)}), {B} replicas each per GPU "
                     f"x {S} denoise steps, one chunk per target, multi-MODEL PDB text written by the native writer")
         pairs_main = B * max(lens) ** 2
+        eval_pairs, eval_ipa_bytes = sum(B * n * n for n in lens), sum(B * 4 * (9512 * n + 40 * n * n) for n in lens)
         out_dir = f"/tmp/s2s_bench_cfg3_{rank}"
         os.makedirs(out_dir, exist_ok=True)
         extra["pdb_write_s"] = 0.0
@@ -210,6 +213,10 @@ def main():
                     f"length-bucketed plan over {plan_world} ranks; every GPU runs one rank's share "
                     f"({per_rank} (chain, replica) items in {len(plan[my])} padded batches)")
         pairs_main = max(sum(hi - lo for _, lo, hi in b["items"]) * b["n_pad"] ** 2 for b in plan[my])
+        my_items = [(lens[k], hi - lo) for b in plan[my] for k, lo, hi in b["items"]]
+        eval_pairs = sum(r * n * n for n, r in my_items)                                   # REAL pairs (padding is overhead, not work)
+        eval_ipa_bytes = sum(r * 4 * (9512 * n + 40 * n * n) for n, r in my_items)
+        extra["padded_pairs_over_real"] = sum(sum(hi - lo for _, lo, hi in b["items"]) * b["n_pad"] ** 2 for b in plan[my]) / max(eval_pairs, 1)
 
         def one_step(seed):
             torch.manual_seed(seed * 1000 + rank)
@@ -256,6 +263,19 @@ def main():
     elapsed = float(el.item())
     et_ms, et_n = kt.mean_ms("s2s_edge_transition") if timed else (float("nan"), 0)
     ipa_ms, ipa_n = kt.mean_ms("s2s_ipa_attention") if timed else (float("nan"), 0)
+    # Kernel-family time table: ONE more step, outside the timed region (per-launch HIP events on the launch stream; they switch the
+    # HIP-graph replay of tiny chunks off, which is why cfg3 / cfg5 do not carry them inside the timed region)
+    fam = ("s2s_edge_transition", "s2s_edge_embed", "s2s_ipa_attention", "s2s_encoder_attention", "s2s_node_linear")
+    table = None
+    if not a.no_kernel_table:   # (every rank runs the step: it contains the job's collectives; rank 0's table is reported)
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        with ops.KernelTimer(*fam) as kp:
+            one_step(999)
+            torch.cuda.synchronize()
+            prof_s = time.perf_counter() - tp0
+            table = {n: dict(zip(("total_ms", "launches"), kp.total_ms(n))) for n in fam}
+        table["step_wall_ms_with_events"] = 1e3 * prof_s
 
     if rank == 0:
         assert res is not None and torch.isfinite(res).all()
@@ -298,6 +318,26 @@ def main():
                                   "launches_timed": ipa_n, "achieved": ipa_bytes / (ipa_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                                   "unit": "GB/s", "frac": ipa_bytes / (ipa_ms * 1e-3) / HBM_PEAK,
                                   "algorithmic_bytes_per_launch": ipa_bytes}
+        if table is not None:
+            line["kernel_times"] = table
+            n_eval = S + 1
+            et, ipa = table["s2s_edge_transition"], table["s2s_ipa_attention"]
+            if a.config in ("cfg3", "cfg5") and et["launches"] and ipa["launches"]:
+                # efficiency statements for the small-protein / mixed-length regimes, on the REAL (unpadded) work of the step:
+                # 3 edge transitions and 4 attention launch pairs per network evaluation
+                alg = 3 * n_eval * eval_pairs * FLOPS_PER_PAIR_ET
+                executed = alg * {"f16x3": 3}.get(mode, 1)
+                peak = MFMA_FP32_PEAK if mode == "f32" else MFMA_F16_PEAK
+                line["roofline"] = {"bound": "mfma", "kernel": "s2s_edge_transition" + ("_f16x3" if mode == "f16x3" else ""),
+                                    "achieved": executed / (et["total_ms"] * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                                    "frac": executed / (et["total_ms"] * 1e-3) / peak, "traffic": None,
+                                    "launches_timed": et["launches"], "total_ms": et["total_ms"],
+                                    "source": "kernel_times (one extra step with per-launch HIP events, HIP graphs off)"}
+                ib = 4 * n_eval * eval_ipa_bytes
+                line["ipa_kernel"] = {"bound": "hbm", "kernel": ("s2s_ipa_attention_f16w" if mode == "f16x3" else "s2s_ipa_attention") + " + s2s_ipa_opair",
+                                      "achieved": ib / (ipa["total_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                                      "frac": ib / (ipa["total_ms"] * 1e-3) / HBM_PEAK, "launches_timed": ipa["launches"],
+                                      "total_ms": ipa["total_ms"], "algorithmic_bytes": ib}
         if world == 1 and not a.no_cpu_baseline and a.config == "cfg2":
             line["cpu_baseline"] = cpu_baseline(N, S, steps_sampled=a.cpu_steps)
         print(json.dumps(line), flush=True)

@@ -2,8 +2,8 @@
 (reference: src/eval.py:102-173).  Composes configs/eval.yaml (hydra if installed, otherwise the built-in
 composer), instantiates datamodule / model / trainer from their `_target_`s, loads the checkpoint with the
 reference's key contract and runs ``trainer.predict``; when ``target_dir`` holds reference ensembles the samples are then
-scored (src/eval.py:47-99) with the device metrics of str2str_amd/metrics (validity, bonding validity, JS-PwD, JS-Rg; JS-TICA
-needs deeptime and is skipped without it) into the reference's tab-separated ``metrics_<tag>_<mmdd-HH-MM>.csv``."""
+scored (src/eval.py:47-99) with the device metrics of str2str_amd/metrics (validity, bonding validity, JS-PwD, JS-TICA, JS-Rg)
+into the reference's tab-separated ``metrics_<tag>_<mmdd-HH-MM>.csv``."""
 import logging
 import os
 import sys
@@ -59,13 +59,8 @@ def evaluate_prediction(pred_dir: str, target_dir: str = None, tag: str = None):
     targets = [d.replace(".pdb", "") for d in os.listdir(target_dir)]
     output_dir = os.path.dirname(os.path.dirname(os.path.abspath(pred_dir)))
     tag = tag if tag is not None else "dev"
-    fns = {"val_clash": metrics.validity, "val_bond": metrics.bonding_validity, "js_pwd": metrics.js_pwd, "js_rg": metrics.js_rg}
-    try:
-        import deeptime  # noqa: F401
-
-        fns["js_tica"] = metrics.js_tica
-    except ImportError:
-        log.warning("deeptime is not installed: js_tica is skipped")
+    fns = {"val_clash": metrics.validity, "val_bond": metrics.bonding_validity, "js_pwd": metrics.js_pwd, "js_rg": metrics.js_rg,
+           "js_tica": metrics.js_tica}   # the reference's five columns, in its order (src/eval.py:64-70)
     eval_res = {k: {} for k in fns}
     for target in targets:
         pred_file = os.path.join(pred_dir, f"{target}.pdb")
@@ -73,7 +68,12 @@ def evaluate_prediction(pred_dir: str, target_dir: str = None, tag: str = None):
             continue
         ca = {"target": extract_backbone_coords(os.path.join(target_dir, f"{target}.pdb")), "pred": extract_backbone_coords(pred_file)}
         for name, fn in fns.items():
-            res = fn(ca, ref_key="target") if name.startswith("js_") else fn(ca)
+            try:
+                res = fn(ca, ref_key="target") if name.startswith("js_") else fn(ca)
+            except (ValueError, NotImplementedError) as e:   # e.g. fewer reference frames than the TICA lag time: the other columns stand
+                log.warning(f"{name} on {target}: {e}")
+                eval_res[name][target] = float("nan")
+                continue
             eval_res[name][target] = res[0]["pred"] if name == "js_tica" else res["pred"]
     df = pd.DataFrame.from_dict(eval_res)
     df.loc["mean"] = np.around(df.mean(), decimals=4)
@@ -106,6 +106,8 @@ def evaluate(cfg):
     if cfg.get("dry_run"):
         log.info(f"dry_run: {len(dataloaders)} target(s) featurised, model + checkpoint ready; not sampling.")
         return None
+    if cfg.get("seed") is not None:   # (an extra key of this build: `seed=7` fixes the host noise stream; every rank seeds alike --
+        torch.manual_seed(int(cfg.get("seed")))   #  the ranks then draw each chunk's noise identically and slice it, see sampler.py)
     log.info("Starting predictions.")
     pred_dir = trainer.predict(model=model, dataloaders=dataloaders, ckpt_path=ckpt_path)[-1]
     log.info(f"Samples written under {pred_dir}.")

@@ -4,8 +4,9 @@ Same function names, arguments and return values (dicts keyed like the input, ro
 ``validity`` (:108-121), ``bonding_validity`` (:124-137), ``js_pwd`` (:140-166) and ``js_rg`` (:203-224).  The N^2 x R work --
 pairwise CA distances, per-channel histograms and Jensen-Shannon distances, clash counts, radii of gyration -- runs in two HIP
 kernels (csrc/ensemble_metrics.hip) straight on the coordinates the sampler just produced (or on arrays read back from PDB
-files); numpy only finishes the O(R) / O(bins) tails.  ``js_tica`` (:169-200) needs deeptime's TICA estimator, which is not a
-dependency of this build: it delegates to deeptime when installed and raises otherwise.
+files); numpy only finishes the O(R) / O(bins) tails.  ``js_tica`` (:169-200): pairwise distances on the device, then the TICA
+projection -- deeptime's estimator when it is installed (the reference's), otherwise the same reversible TICA in numpy (``tica_fit``:
+the histograms span the reference's own range per component, so the score does not depend on a component's scale or sign).
 """
 from __future__ import annotations
 
@@ -45,8 +46,8 @@ def validity(ca_coords_dict, ca_vdw_radius=1.7, allowable_overlap=0.4, k_exclusi
 
 def bonding_validity(ca_coords_dict, ref_key="target", eps=1e-6):
     adj = {k: ops.ca_sample_stats(_dev(v))[1] for k, v in ca_coords_dict.items()}
-    thres = float(adj[ref_key].max()) + 1e-6
-    return {k: np.around(float((a.double() < thres).sum()) / len(a), decimals=4) for k, a in adj.items()}
+    thres = adj[ref_key].max() + 1e-6          # float32 arithmetic, as the reference forms it (metrics.py:133)
+    return {k: np.around(float((a < thres).sum()) / len(a), decimals=4) for k, a in adj.items()}
 
 
 def js_pwd(ca_coords_dict, ref_key="target", n_bins=50, pwd_offset=3, weights=None):
@@ -66,7 +67,8 @@ def radius_of_gyration(coords):
 def js_rg(ca_coords_dict, ref_key="target", n_bins=50, weights=None):
     if weights:
         raise NotImplementedError("per-sample weights are not on the device path")
-    rg = {k: radius_of_gyration(v).astype(np.float32) for k, v in ca_coords_dict.items()}  # the reference's Rg is float32
+    # the reference's Rg is float64 (float32 squared distances x float64 weights, metrics.py:62-78) and so are its histogram edges
+    rg = {k: np.asarray(radius_of_gyration(v), dtype=np.float64) for k, v in ca_coords_dict.items()}
     d_min, d_max = rg[ref_key].min(), rg[ref_key].max()
     binned = {k: np.histogram(v, bins=n_bins, range=(d_min, d_max))[0] + PSEUDO_C for k, v in rg.items()}
     out = {k: np.around(_js(v, binned[ref_key]), decimals=4) for k, v in binned.items() if k != ref_key}
@@ -74,9 +76,57 @@ def js_rg(ca_coords_dict, ref_key="target", n_bins=50, weights=None):
     return out
 
 
+def pairwise_distance_ca(coords, k=1) -> np.ndarray:
+    """reference :38-50: upper-triangular CA distances [B, L (L - k + ...)/2], float32, computed on the device."""
+    x = _dev(coords)
+    d = (x[:, :, None, :] - x[:, None, :, :]).square().sum(-1).sqrt()
+    L = d.shape[-1]
+    row, col = np.triu_indices(L, k=k)
+    return d[:, torch.as_tensor(row, device=d.device), torch.as_tensor(col, device=d.device)].cpu().numpy()
+
+
+def tica_fit(x: np.ndarray, lagtime: int, dim: int = 2, epsilon: float = 1e-6):
+    """Reversible TICA (time-lagged independent component analysis) of a trajectory x [T, D]: the ``dim`` slowest components.
+    Same estimator as deeptime's TICA(dim, lagtime) up to each component's scale and sign: mean and covariances symmetrised over
+    the (x_t, x_{t+lag}) pairs, C00 whitened with a relative eigenvalue cut-off ``epsilon``, symmetric eigenproblem of the whitened
+    time-lagged covariance, components ordered by eigenvalue.  -> (mean [D], projection [D, dim]); transform = (x - mean) @ proj."""
+    x = np.asarray(x, dtype=np.float64)
+    if x.shape[0] <= lagtime:
+        raise ValueError(f"js_tica: {x.shape[0]} frames are not enough for lagtime {lagtime}")
+    x0, xt = x[:-lagtime], x[lagtime:]
+    mean = 0.5 * (x0.mean(0) + xt.mean(0))
+    a, b = x0 - mean, xt - mean
+    n = a.shape[0]
+    c00 = (a.T @ a + b.T @ b) / (2.0 * n)
+    c0t = (a.T @ b + b.T @ a) / (2.0 * n)
+    w, v = np.linalg.eigh(c00)
+    keep = w > epsilon * w.max()
+    white = v[:, keep] / np.sqrt(w[keep])              # [D, r]: white.T C00 white = I
+    lam, u = np.linalg.eigh(white.T @ c0t @ white)
+    order = np.argsort(-lam)[:dim]
+    return mean, white @ u[:, order]
+
+
 def js_tica(ca_coords_dict, ref_key="target", n_bins=50, lagtime=20, return_tic=True, weights=None):
+    """reference :169-200: TICA (2 components, fitted on the reference ensemble's pairwise distances) -> 50-bin histograms over the
+    reference's range per component -> mean Jensen-Shannon distance.  -> results (, projections) like the reference."""
+    if weights:
+        raise NotImplementedError("per-sample weights are not on the device path")
+    ca_pwd = {k: pairwise_distance_ca(v) for k, v in ca_coords_dict.items()}
     try:
-        from deeptime.decomposition import TICA  # noqa: F401
-    except ImportError as e:
-        raise NotImplementedError("js_tica needs deeptime (TICA estimator), which is not a dependency of this build") from e
-    raise NotImplementedError("js_tica: run the reference's src/metrics/metrics.py:169-200 (deeptime is installed)")
+        from deeptime.decomposition import TICA
+
+        tica = TICA(dim=2, lagtime=lagtime).fit(ca_pwd[ref_key]).fetch_model()
+        ca_dr2d = {k: tica.transform(v) for k, v in ca_pwd.items()}
+    except ImportError:
+        mean, proj = tica_fit(ca_pwd[ref_key], lagtime, dim=2)
+        ca_dr2d = {k: (v.astype(np.float64) - mean) @ proj for k, v in ca_pwd.items()}
+    d_min, d_max = ca_dr2d[ref_key].min(axis=0), ca_dr2d[ref_key].max(axis=0)
+    binned = {k: np.stack([np.histogram(v[:, c], bins=n_bins, range=(d_min[c], d_max[c]))[0] + PSEUDO_C for c in range(v.shape[1])], 1)
+              for k, v in ca_dr2d.items()}      # [n_bins, 2]
+    results = {k: np.around(np.mean([_js(v[:, c], binned[ref_key][:, c]) for c in range(v.shape[1])]), decimals=4)
+               for k, v in binned.items() if k != ref_key}
+    results[ref_key] = 0.0
+    if return_tic:
+        return results, ca_dr2d
+    return results

@@ -49,6 +49,8 @@ def gather_replicas(atom37: torch.Tensor, total: int, group=None) -> Optional[to
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     per = -(-total // world)
+    if dist.get_backend(group) == "gloo":   # (CPU collectives: the multi-process tests; RCCL gathers device tensors)
+        atom37 = atom37.cpu()
     pad = atom37.new_zeros((per,) + tuple(atom37.shape[1:]))
     pad[: atom37.shape[0]] = atom37
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None

@@ -87,6 +87,11 @@ class KernelTimer:
         ev = self.events[name]
         return (sum(a.elapsed_time(b) for a, b in ev) / len(ev)) if ev else float("nan"), len(ev)
 
+    def total_ms(self, name):
+        torch.cuda.synchronize()
+        ev = self.events[name]
+        return sum(a.elapsed_time(b) for a, b in ev), len(ev)
+
 
 def _timed(name, launch):
     kt = KernelTimer.active

@@ -23,6 +23,8 @@ class Trainer:
                 "trainer.accelerator=cpu / no HIP device visible: the sampling path runs on MI355X only "
                 "(there is deliberately no CPU fallback; use the reference itself for CPU runs)")
         local = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("S2S_DIST_BACKEND", "nccl") == "gloo":
+            local %= torch.cuda.device_count()
         torch.cuda.set_device(local)
         return torch.device("cuda", local)
 
@@ -32,7 +34,10 @@ class Trainer:
         dev = self._device()
         if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("nccl", device_id=dev)
+            if os.environ.get("S2S_DIST_BACKEND", "nccl") == "gloo":   # TEST hook: several ranks sharing one GPU (RCCL wants one each)
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
         if ckpt_path is not None:  # Lightning-style .ckpt: {'state_dict': {'net.…': tensor}}
             sd = torch.load(ckpt_path, map_location="cpu")["state_dict"]
             # the reference's Lightning Trainer restores strictly; here only `net.*` is part of the sampling path, so

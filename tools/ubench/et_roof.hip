@@ -13,7 +13,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <int LEVEL, int V, int SPS = 8>
+template <int LEVEL, int V, int SPS = 8, int FEAT = 7>
 __global__ void __launch_bounds__(256) k(float* out, unsigned long long* cyc, const char* wblob, int iters) {
     constexpr int kStage = SPS * 4096;   // SPS slots of 4 fragments per stage
     __shared__ __attribute__((aligned(16))) char s_w[2][kStage];
@@ -40,6 +40,7 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* cyc, co
     u32x4 fr[2][4];
     for (int kq = 0; kq < 4; ++kq) fr[0][kq] = fr[1][kq] = ((const lds_frag*)img[0])[64 * kq];
     f32x4 c[2 * kQ];
+    for (int q = 0; q < 2 * kQ; ++q) c[q] = f32x4{1.f, 2.f, 3.f, 4.f};
     float va[8];
     for (int i = 0; i < 8; ++i) va[i] = 1.0f + 1e-3f * (lane + i);
     auto mm = [&](const u32x4& a, const u32x4& bb, f32x16 cc) {
@@ -50,7 +51,7 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* cyc, co
 #pragma unroll
         for (int s = 0; s < 2 * SPS; ++s) {  // two stages
             const int ss = s % SPS, par = (s / SPS) & 1;
-            if constexpr (LEVEL >= 2) {
+            if constexpr (LEVEL >= 2 && (FEAT & 4)) {
                 if (ss == SPS - 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             }
             if constexpr (LEVEL >= 1) {
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* cyc, co
 #pragma unroll
                 for (int kq = 0; kq < 4; ++kq) fr[(s + 1) & 1][kq] = src[64 * kq];
             }
-            if constexpr (LEVEL >= 2) {
+            if constexpr (LEVEL >= 2 && (FEAT & 1)) {
                 if (ss == 0 || ss == SPS / 2) {
                     const int so = ((it * 2 + (s / SPS)) % (30 * 8 / SPS)) * kStage + (ss ? kQ * 1024 : 0);
 #pragma unroll
@@ -78,7 +79,7 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* cyc, co
 #pragma unroll
                 for (int v = 0; v < V; ++v) va[v & 7] = __builtin_fmaf(va[v & 7], 1.0000001f, 1e-7f);
             }
-            if constexpr (LEVEL >= 2) {
+            if constexpr (LEVEL >= 2 && (FEAT & 2)) {
                 if (ss == 1 || ss == SPS / 2 + 1) {
                     lds_char* d = img[par ^ 1] + (wave * (kStage / 4) + (ss == 1 ? 0 : kQ * 1024));
 #pragma unroll
@@ -96,13 +97,13 @@ __global__ void __launch_bounds__(256) k(float* out, unsigned long long* cyc, co
     if (threadIdx.x == 0 && blockIdx.x == 7) cyc[0] = t1 - t0;
 }
 
-template <int LEVEL, int V, int SPS = 8> void run(const char* name, float* out, unsigned long long* cyc, const char* w, int iters) {
-    k<LEVEL, V, SPS><<<256, 256>>>(out, cyc, w, iters);
+template <int LEVEL, int V, int SPS = 8, int FEAT = 7> void run(const char* name, float* out, unsigned long long* cyc, const char* w, int iters) {
+    k<LEVEL, V, SPS, FEAT><<<256, 256>>>(out, cyc, w, iters);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
     const int reps = 30;
-    for (int r = 0; r < reps; ++r) k<LEVEL, V, SPS><<<256, 256>>>(out, cyc, w, iters);   // ~0.5 s: long enough for the power cap to act
+    for (int r = 0; r < reps; ++r) k<LEVEL, V, SPS, FEAT><<<256, 256>>>(out, cyc, w, iters);   // ~0.5 s: long enough for the power cap to act
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
     unsigned long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
@@ -122,8 +123,11 @@ int main() {
         run<3, 16>("3 + 16 VALU per slot", out, cyc, w, 4000);
         run<3, 24>("3 + 24 VALU per slot", out, cyc, w, 4000);
         run<3, 16, 16>("3 + 16 VALU per slot, 16-slot (64 KiB) stages", out, cyc, w, 2000);
-        run<2, 0, 16>("2, 16-slot (64 KiB) stages", out, cyc, w, 2000);
-        run<3, 16, 4>("3 + 16 VALU per slot, 4-slot (16 KiB) stages", out, cyc, w, 8000);
+        run<2, 0, 8, 1>("2 pieces: global loads only", out, cyc, w, 4000);
+        run<2, 0, 8, 2>("2 pieces: LDS stores only", out, cyc, w, 4000);
+        run<2, 0, 8, 4>("2 pieces: barrier only", out, cyc, w, 4000);
+        run<2, 0, 8, 3>("2 pieces: loads + stores, no barrier", out, cyc, w, 4000);
+        run<2, 0, 8, 6>("2 pieces: stores + barrier", out, cyc, w, 4000);
     }
     return 0;
 }
