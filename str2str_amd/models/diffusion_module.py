@@ -26,7 +26,7 @@ import torch
 
 from ..common.pdb_utils import atom37_to_pdb, merge_pdbfiles
 from ..common.rigid_utils import Rigid
-from ..sampler import forward_backward, rank_chunk_slices, shard_range
+from ..sampler import forward_backward, plan_mixed_work, rank_chunk_slices, sample_mixed_lengths, shard_range
 
 try:  # pragma: no cover - depends on the environment
     from lightning import LightningModule as _Base
@@ -134,6 +134,85 @@ class DiffusionLitModule(_Base):
         if shard[0] == 0:
             os.makedirs(all_dir, exist_ok=True)
             merge_pdbfiles(saved, os.path.join(all_dir, f"{accession_code}.pdb"), verbose=False)
+        if distributed:
+            dist.barrier()
+        return all_dir
+
+    @torch.no_grad()
+    def predict_mixed(self, batches) -> str:
+        """ALL targets of a run in length-bucketed, padded, masked batches (BASELINE configs[4]) instead of one ``predict_step`` per
+        target -- ``model.inference.mixed_batch=true``.  The reference cannot do this (it asserts one target per batch,
+        diffusion_module.py:249, and its padding semantics would be wrong for it); here padding is exact (sampler.
+        sample_mixed_lengths), so every chain is sampled as if it ran alone.  Same hyper-parameters, same output tree
+        (``<output_dir>/<t_delta>/<accession>.pdb`` + ``all_delta``).  The (chain, replica block) items are distributed over the
+        ranks by FLOP weight (``plan_mixed_work``); ONE gather of a flat coordinate buffer per t_delta brings them to rank 0.  The
+        noise stream is per (chain, block) -- not the reference's per-target chunk order -- so this is the throughput mode: same
+        distribution, different draws than ``predict_step`` under the same seed."""
+        import torch.distributed as dist
+
+        inf = _ns(self.hparams.inference if not isinstance(self.hparams, dict) else self.hparams["inference"])
+        n_replica = int(inf.n_replica)
+        delta_range = np.around(np.arange(inf.delta_min, inf.delta_max + 1e-5, inf.delta_step), decimals=2)
+        if inf.backward_only:
+            n_replica *= len(delta_range)
+            delta_range = [-1.0]
+        self_cond = bool(inf.self_conditioning) and bool(self.net.embedder.self_conditioning)
+        device = next(self.net.parameters()).device
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        rank, world = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
+        if self.rng_mode == "device" and not getattr(self, "_device_rng_seeded", False):
+            torch.cuda.manual_seed(torch.initial_seed() + 7919 * rank)
+            self._device_rng_seeded = True
+        targets = list(batches)
+        for tg in targets:
+            assert tg["aatype"].shape[0] == 1, "one chain per dataloader batch"
+        lens = [int(tg["aatype"].shape[1]) for tg in targets]
+        plan = plan_mixed_work(lens, n_replica, world)
+        saved = {k: [] for k in range(len(targets))}
+        self.last_samples = {}
+        for t_delta in delta_range:
+            pieces = sample_mixed_lengths(self.net, self.diffuser, targets, n_replica, float(t_delta), num_timesteps=inf.num_timesteps,
+                                          min_t=inf.min_t, noise_scale=inf.noise_scale, probability_flow=inf.probability_flow,
+                                          self_conditioning=self_cond, device=device, shard=(rank, world), rng=self.rng_mode, plan=plan)
+            # this rank's pieces in plan order (chain, replica_lo, replica_hi) -> one flat buffer
+            mine = [(k, lo, p) for k, ps in enumerate(pieces) for lo, p in ps]
+            flat = torch.cat([p.reshape(-1) for _, _, p in mine]) if mine else torch.zeros(0, device=device)
+            per_chain = {k: [] for k in range(len(targets))}
+            if distributed:
+                cpu = dist.get_backend() == "gloo"
+                buf_dev = torch.device("cpu") if cpu else device
+                # every rank can compute every rank's piece list from the plan: sizes are known, only the payload travels
+                layout = [sorted(((k, lo, hi) for b in plan[r] for k, lo, hi in b["items"]), key=lambda x: (x[0], x[1])) for r in range(world)]
+                sizes = [sum((hi - lo) * lens[k] * 37 * 3 for k, lo, hi in layout[r]) for r in range(world)]
+                pad = torch.zeros(max(sizes), device=buf_dev)
+                pad[: flat.numel()] = flat.to(buf_dev)
+                bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+                dist.gather(pad, bufs, dst=0)    # ONE collective per t_delta
+                if rank == 0:
+                    for r in range(world):
+                        o = 0
+                        for k, lo, hi in layout[r]:
+                            n = (hi - lo) * lens[k] * 37 * 3
+                            per_chain[k].append((lo, bufs[r][o:o + n].view(hi - lo, lens[k], 37, 3)))
+                            o += n
+            else:
+                for k, lo, p in mine:
+                    per_chain[k].append((lo, p))
+            if rank == 0:
+                t_dir = os.path.join(inf.output_dir, f"{t_delta}")
+                os.makedirs(t_dir, exist_ok=True)
+                for k, tg in enumerate(targets):
+                    a37 = torch.cat([p for _, p in sorted(per_chain[k], key=lambda x: x[0])], dim=0)
+                    assert a37.shape[0] == n_replica, (a37.shape, n_replica)
+                    code = tg["accession_code"][0]
+                    self.last_samples[(code, float(t_delta))] = a37
+                    extra = {kk: tg[kk][0].detach().cpu().numpy() for kk in ("aatype", "chain_index", "residue_index")}
+                    saved[k].append(atom37_to_pdb(atom_positions=a37.cpu().numpy(), save_to=os.path.join(t_dir, f"{code}.pdb"), **extra))
+        all_dir = os.path.join(inf.output_dir, "all_delta")
+        if rank == 0:
+            os.makedirs(all_dir, exist_ok=True)
+            for k, tg in enumerate(targets):
+                merge_pdbfiles(saved[k], os.path.join(all_dir, f"{tg['accession_code'][0]}.pdb"), verbose=False)
         if distributed:
             dist.barrier()
         return all_dir

@@ -52,7 +52,13 @@ class Trainer:
         ops.load_library()
         model = model.to(dev).eval()
         out = []
+        inf = getattr(getattr(model, "hparams", None), "inference", None)
+        if inf is None and isinstance(getattr(model, "hparams", None), dict):
+            inf = model.hparams.get("inference")
+        mixed = bool((inf.get("mixed_batch", False) if hasattr(inf, "get") else getattr(inf, "mixed_batch", False)) if inf is not None else False)
         with torch.no_grad():
+            if mixed:   # all targets in length-bucketed padded batches (BASELINE configs[4]; model.inference.mixed_batch=true)
+                return [model.predict_mixed(list(dataloaders))]
             for i, batch in enumerate(dataloaders):
                 batch = {k: (v.to(dev) if torch.is_tensor(v) and k != "residue_idx" else v) for k, v in batch.items()}
                 out.append(model.predict_step(batch, i))

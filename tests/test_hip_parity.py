@@ -995,6 +995,63 @@ def test_multirank_entry_points_share_one_gpu(tmp_path):
         assert outs[1][k].count("MODEL ") in (5, 10) and outs[1][k] == outs[2][k], k
 
 
+def test_eval_entry_mixed_batch(tmp_path, monkeypatch):
+    """BASELINE configs[4] through the drop-in entry: ``eval.py ... model.inference.mixed_batch=true`` samples ALL targets in
+    length-bucketed padded batches (DiffusionLitModule.predict_mixed) and writes the reference's output tree; under a fixed seed the
+    files are exactly what ``sampler.sample_mixed_lengths`` returns for the same targets (which the cfg5 fixture test holds to the
+    reference's per-chain runs), and a 2-rank launch writes the same tree."""
+    import os
+    import sys
+
+    from conftest import GOLDEN, ROOT
+    from str2str_amd.sampler import sample_mixed_lengths
+    from str2str_amd.synth import synth_state_dict
+    from str2str_amd.utils import config as C
+
+    monkeypatch.setenv("TEST_DATA", os.path.join(GOLDEN, "pdb"))
+    monkeypatch.setenv("CACHE_DIR", str(tmp_path / "cache"))
+    monkeypatch.setenv("PROJECT_ROOT", str(tmp_path))
+    sys.path.insert(0, ROOT)
+    import eval as entry
+
+    args = ["task_name=inference", "ckpt_path=null", "seed=3", "data.dataset.accession_code_fillter=[CLN025,2JOF,1FME]",
+            "model.inference.mixed_batch=true", "model.inference.n_replica=3", "model.inference.num_timesteps=6",
+            "model.inference.delta_min=0.5", "model.inference.delta_max=0.6", "model.inference.delta_step=0.1",
+            "extras.print_config=false", f"paths.output_dir={tmp_path}/out"]
+    all_dir = entry.main(args)
+    samples = os.path.dirname(all_dir)
+    assert sorted(os.listdir(samples)) == ["0.5", "0.6", "all_delta"]
+    for code, n in (("CLN025", 10), ("2JOF", 20), ("1FME", 28)):
+        txt = open(os.path.join(samples, "0.5", f"{code}.pdb")).read()
+        assert txt.count("MODEL ") == 3 and txt.count(" CA ") == 3 * n
+        assert open(os.path.join(all_dir, f"{code}.pdb")).read().count("MODEL ") == 6
+
+    cfg = C.compose(os.path.join(ROOT, "configs"), "eval.yaml", args)
+    model = C.instantiate(cfg.model)
+    man = [(k, tuple(v.shape)) for k, v in model.net.state_dict().items()]
+    model.net.load_state_dict(synth_state_dict(man, seed=0, sigma_final=0.002))
+    model = model.to(DEV).eval()
+    batches = list(C.instantiate(cfg.data).test_dataloader())
+    torch.manual_seed(3)
+    model.predict_mixed(batches)
+    torch.manual_seed(3)
+    want = sample_mixed_lengths(model.net, model.diffuser, batches, 3, 0.5, num_timesteps=6, device=DEV)
+    for k, b in enumerate(batches):
+        code = b["accession_code"][0]
+        got = model.last_samples[(code, 0.5)]
+        assert torch.isfinite(got).all() and torch.equal(got, torch.cat([p for _, p in want[k]]))
+        xyz = np.array([[float(l[30:38]), float(l[38:46]), float(l[46:54])] for l in
+                        open(os.path.join(samples, "0.5", f"{code}.pdb")).read().split("\n") if l.startswith("ATOM") and l[12:16].strip() == "CA"])
+        assert np.abs(xyz - got.cpu().numpy()[:, :, 1].reshape(-1, 3)).max() < 1e-3     # the CLI run under the same seed wrote these samples
+
+    env = {"S2S_DIST_BACKEND": "gloo", "TEST_DATA": os.path.join(GOLDEN, "pdb"), "CACHE_DIR": str(tmp_path / "cache"),
+           "PROJECT_ROOT": str(tmp_path / "w2")}
+    r = _torchrun(2, ["eval.py"] + args[:-1] + [f"paths.output_dir={tmp_path}/w2/out"], env, ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for code in ("CLN025", "2JOF", "1FME"):
+        assert open(os.path.join(tmp_path, "w2", "out", "samples", "all_delta", f"{code}.pdb")).read().count("MODEL ") == 6
+
+
 def test_cfg3_science2011_all_targets_vs_reference(tmp_path, monkeypatch):
     """BASELINE configs[2]: every one of the 12 Science2011 targets (10 ... 80 residues, all ragged for the 32-residue tiles) from its
     PDB file through the Hydra config, the datamodule / featuriser and ``predict_step`` (3 replicas, t_delta 0.5, 10 + 1
