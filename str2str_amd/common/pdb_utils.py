@@ -97,6 +97,9 @@ def merge_pdbfiles(input, output_file: str, verbose: bool = True) -> None:
         print(f"Merged {len(files)} PDB files into {output_file} with {model_number} models.")
 
 
+_AMINO_ACIDS = frozenset("ALA ARG ASN ASP CYS GLN GLU GLY HIS ILE LEU LYS MET PHE PRO SER THR TRP TYR VAL".split())
+
+
 def extract_backbone_coords(input_path: str, max_n_model: Optional[int] = None) -> np.ndarray:
     """CA coordinates [n_models, L, 3] float32 of a (multi-MODEL) PDB file, a .npy file or a directory of PDB files
     (reference pdb_utils.py:255-317, which goes through biotite; here a fixed-column scan of the ATOM records)."""
@@ -107,15 +110,23 @@ def extract_backbone_coords(input_path: str, max_n_model: Optional[int] = None) 
         coords = np.concatenate([extract_backbone_coords(os.path.join(input_path, f)) for f in os.listdir(input_path)
                                  if f.endswith(".pdb")], axis=0)
     elif input_path.endswith(".pdb"):
-        models, cur = [], []
+        # biotite's reader as the reference calls it (altloc="first", then filter_backbone: amino-acid residues only): the first
+        # alternate location of every (chain, residue number, insertion code), standard residue names
+        models, cur, seen = [], [], set()
         with open(input_path) as fh:
             for ln in fh:
-                if ln.startswith("ATOM") and ln[12:16].strip() == "CA":
-                    cur.append((float(ln[30:38]), float(ln[38:46]), float(ln[46:54])))
+                if ln.startswith("ATOM") and ln[12:16].strip() == "CA" and ln[17:20] in _AMINO_ACIDS:
+                    key = (ln[21], ln[22:27])          # chain id, resSeq + iCode
+                    if key not in seen:                 # later altlocs of a residue already taken are skipped
+                        seen.add(key)
+                        cur.append((float(ln[30:38]), float(ln[38:46]), float(ln[46:54])))
                 elif ln.startswith("ENDMDL"):
-                    models.append(cur); cur = []
+                    models.append(cur); cur, seen = [], set()
         if cur:
             models.append(cur)
+        lens = {len(m) for m in models}
+        if len(lens) > 1:
+            raise ValueError(f"{input_path}: models with different numbers of CA atoms {sorted(lens)} (a truncated last model?)")
         coords = np.asarray(models, dtype=np.float32)
     else:
         raise ValueError(f"Unrecognized input path {input_path}.")
