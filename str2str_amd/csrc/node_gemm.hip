@@ -263,36 +263,34 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
     w_load(1);
     __syncthreads();
 
-    // tiles in pairs (two interleaved accumulators); the fragments of the next pair are fetched before the current pair's MFMAs
-    constexpr int NP = (TG + 1) / 2;
+    // One k-step, product-major: all W_l fragments of the stage are requested first, then the W_l x_h pass runs with ONE W_h fragment
+    // read issued behind each of its MFMAs (they land long before the second pass needs them), then W_h x_l and W_h x_h.  The order
+    // is pinned with sched_group_barrier: left alone, hipcc issues every fragment read directly in front of the MFMA that consumes
+    // it -- eight exposed LDS latencies per k-step (K = 2688 of linear_out: 190 -> 155 us; the K = 256 projections are bound by their
+    // prologue / epilogue / output traffic and do not move).
     auto compute = [&](int par, const f16x8 (&x)[2]) {
         const lds_frag* wl = (const lds_frag*)((lds_char*)s_w + par * kStage) + lane;
-        f16x8 f[2][4];
-        auto fetch = [&](int p, f16x8 (&d)[4]) {
-            const lds_frag* q = wl + (2 * p) * 2 * 64;
-            d[0] = q[0]; d[1] = q[64];
-            if (2 * p + 1 < TG) { d[2] = q[128]; d[3] = q[192]; }
-        };
-        fetch(0, f[0]);
+        auto mm = [&](const f16x8& wf, const f16x8& xf, f32x16 c) { return VF ? mfma_f16(xf, wf, c) : mfma_f16(wf, xf, c); };
+        f16x8 fl[TG], fh[TG];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            if (p + 1 < NP) fetch(p + 1, f[(p + 1) & 1]);
-            const f16x8 (&w)[4] = f[p & 1];
-            auto mm = [&](const f16x8& wf, const f16x8& xf, f32x16 c) { return VF ? mfma_f16(xf, wf, c) : mfma_f16(wf, xf, c); };
-            if (2 * p + 1 < TG) {
-                f32x16 c = acc[2 * p], d = acc[2 * p + 1];
-                c = mm(w[1], x[0], c); d = mm(w[3], x[0], d);  // W_l x_h
-                c = mm(w[0], x[1], c); d = mm(w[2], x[1], d);  // W_h x_l
-                c = mm(w[0], x[0], c); d = mm(w[2], x[0], d);  // W_h x_h
-                acc[2 * p] = c; acc[2 * p + 1] = d;
-            } else {
-                f32x16 c = acc[2 * p];
-                c = mm(w[1], x[0], c);
-                c = mm(w[0], x[1], c);
-                c = mm(w[0], x[0], c);
-                acc[2 * p] = c;
-            }
+        for (int t = 0; t < TG; ++t) fl[t] = wl[t * 128 + 64];
+#pragma unroll
+        for (int t = 0; t < TG; ++t) fh[t] = wl[t * 128];
+#pragma unroll
+        for (int t = 0; t < TG; ++t) acc[t] = mm(fl[t], x[0], acc[t]);  // W_l x_h
+#pragma unroll
+        for (int t = 0; t < TG; ++t) acc[t] = mm(fh[t], x[1], acc[t]);  // W_h x_l
+#pragma unroll
+        for (int t = 0; t < TG; ++t) acc[t] = mm(fh[t], x[0], acc[t]);  // W_h x_h
+        __builtin_amdgcn_sched_group_barrier(0x100, TG, 0);             // the W_l reads
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA of the first pass,
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // one W_h read behind it
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TG, 0);
+        __builtin_amdgcn_sched_barrier(0);
     };
 
     const long long row = rt * 32 + (lane & 31);
