@@ -62,10 +62,18 @@ int s2s_edge_transition(const float* edge, const float* node_ab, const float* no
  * part of the ABI version).
  *   Optional fused epilogue (proj_attn_bias != NULL): the NEXT IPA block's linear_b / down_z (see s2s_pair_project);
  *   the stream then carries a 31st stage with the chain-packed 64x128 [linear_b; down_z; 0] matrix, proj_bias_cat64 [64];
- *   outputs proj_attn_bias [B,8,N,N] (head-major) and proj_pair_z [B,N,N,32]. */
+ *   outputs proj_attn_bias [B,8,N,N] (head-major) and proj_pair_z [B,N,N,32].
+ *   Pair-tensor layouts (io_layout; 0 = the reference's [B,N,N,128] on both sides).  Between the library's own pair kernels the tensor
+ *   may travel TILED: the flat pair sequence in blocks of 32 pairs (16 KiB), block b = pairs 32 b .. 32 b + 31, inside a block
+ *   [16 groups g][2 halves h][32 pairs n][4 floats] = channels 8 g + 4 h .. + 3 of pair 32 b + n at float offset 4096 b + 256 g + 128 h + 4 n
+ *   -- the order in which a wavefront's lanes hold a 32-pair tile, so that one load / store instruction covers 8 whole cache lines
+ *   instead of 32 B in each of 32 (ops.pair_tiled / ops.pair_untiled convert).  The buffer of a tiled tensor holds whole blocks
+ *   (B N N rounded up to 32 pairs; the padding is never read as data).
+ *     io_layout bit 0: edge is tiled;  bit 1: out is written tiled;  bit 2: out is not written at all (out may be NULL; needs the
+ *     fused projection -- the last EdgeTransition of the trunk, whose pair vectors only feed the next block's projections). */
 int s2s_edge_transition_f16x3(const float* edge, const float* node_ab, const float* node_p, const void* weight_stream,
                               const float* b2, const float* bf, const float* ln_gamma, const float* ln_beta,
-                              const float* mask, float* out, int n_samples, int n_res, float ln_eps,
+                              const float* mask, float* out, int n_samples, int n_res, float ln_eps, int io_layout,
                               const float* proj_bias_cat64, float* proj_attn_bias, float* proj_pair_z, void* stream);
 
 /* EmbeddingModule.forward, edge branch (src/models/net/denoising_ipa.py:137-158, calc_distogram
@@ -89,13 +97,14 @@ int s2s_edge_embed(const float* node_a, const float* node_b, const float* rel_ta
  *   node_b [B][32][N][4], rel_table [32][n_rel][4], bin_table [32][n_bins][4], element [c][row][q] = channel 4c + q of that row
  *   (ops.column_blocked) -- so that the gathers of neighbouring pairs share cache lines; node_a stays [B,N,128];
  *   bin_lower must ascend (torch.linspace), n_bins <= 32.  Pair indices are 32-bit inside a launch: the entry point splits the
- *   samples over several launches when B*N*N >= 2^31 (N*N itself and n_rel*512 must stay below 2^31 / 2^32). */
+ *   samples over several launches when B*N*N >= 2^31 (N*N itself and n_rel*512 must stay below 2^31 / 2^32).
+ *   out_tiled = 1: out is written in the tiled pair layout (s2s_edge_transition_f16x3), its buffer holds whole 32-pair blocks. */
 int s2s_edge_embed_f16x3(const float* node_a, const float* node_b, const float* rel_table, const float* bin_table,
                          const float* bin_lower, const long long* residue_idx, const float* ca_xyz,
                          const void* weight_stream, const float* b2, const float* b3, const float* ln_gamma,
                          const float* ln_beta, const float* mask, float* out, int n_samples, int n_res, int rel_offset,
-                         int n_rel, int n_bins, float ln_eps, const float* proj_bias_cat64, float* proj_attn_bias,
-                         float* proj_pair_z, void* stream);
+                         int n_rel, int n_bins, float ln_eps, int out_tiled, const float* proj_bias_cat64,
+                         float* proj_attn_bias, float* proj_pair_z, void* stream);
 
 /* linear_b and down_z of InvariantPointAttention (src/models/net/ipa.py:177, :253) in one pass over z.
  *   w_packed: [linear_b.weight (8 rows); down_z.weight (32 rows); 24 zero rows] (64x128) packed

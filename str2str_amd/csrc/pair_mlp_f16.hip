@@ -118,6 +118,16 @@ constexpr SlotDesc slot_desc(int s) {
 }
 
 #define S2S_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+__device__ float s2s_one[1] = {1.0f};   // stands in for an absent node mask (read with stride 0)
+
+#ifdef S2S_ET_PROBE
+// Phase probe (tools/et_phase_probe.py): s_memtime stamps at 16 points of a tile, wave 0 of every workgroup, differences summed
+// per workgroup.  The stamps are SMEM results consumed only after the tile's last lgkmcnt(0) wait.
+__device__ unsigned long long g_et_probe[512 * 17];
+#define ET_STAMP(k) asm volatile("s_memtime %0" : "=s"(st##k))
+#else
+#define ET_STAMP(k)
+#endif
 
 // PROJ: also emit the NEXT IPA block's linear_b / down_z (ipa.py:177,253) of the pair vector just produced -- one more
 // weight stage (64 x 128 Wcat, chain-packed), 8 more slots on the LayerNorm output while it is still in registers,
@@ -127,7 +137,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     const float* __restrict__ edge, const float* __restrict__ node_ab, const float* __restrict__ node_p,
     const char* __restrict__ wblob, const float* __restrict__ b2, const float* __restrict__ bf,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask,
-    float* __restrict__ out, long long M, int N, float ln_eps, const float* __restrict__ proj_b,
+    float* __restrict__ out, long long M, int N, float ln_eps, int io_layout, unsigned mask_stride, const float* __restrict__ proj_b,
     float* __restrict__ proj_bias_out, float* __restrict__ proj_pz_out, int* __restrict__ range_flag) {
     constexpr int kStages = kStagesBase + (PROJ ? 1 : 0);
     constexpr int kSlots = 8 * kStages;
@@ -174,8 +184,8 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     // 512-register limit, and one more long-lived VGPR costs hundreds of spills.
     struct PairCtx {
         unsigned p, bi, bj, boff;  // flat pair index; flat node rows of i and j; offset of head 0 of this pair in a head-major [B,8,N,N] tensor
-        float em;
-        bool valid;
+        float em_i, em_j;          // the two node masks, multiplied where the edge mask is used: a product formed here would wait
+        bool valid;                // for the loads (vmcnt(0): the whole weight pipe) in the middle of the final layer
     };
     const unsigned NNu = (unsigned)N * (unsigned)N;
     const long long NN = (long long)N * N;
@@ -202,12 +212,37 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         c.bi = bi;
         c.bj = bb * (unsigned)N + j;
         c.boff = p + 7u * bb * NNu;
-        c.em = mask ? mask[bi] * mask[c.bj] : 1.0f;
+        // (no branch on the mask's presence: a value merged from two paths is materialised -- and waited for -- at the join;
+        //  the launcher passes a one-element "1.0" and stride 0 for an absent mask)
+        c.em_i = mask[bi * mask_stride];
+        c.em_j = mask[c.bj * mask_stride];
         return c;
     };
-    auto erow_of = [&](const PairCtx& c) -> const float* { return edge + (unsigned long long)c.p * 128u; };
+    // The 32 pair rows of a wave are one 16 KiB block of z in either layout (header, "Pair-tensor layouts"): row-major, a lane's
+    // 16 B group g sits at  n 512 + g 32 + h 16  of the block; tiled, at  g 1024 + lane 16  -- a load / store instruction of the wave
+    // then covers 8 whole cache lines instead of 32 B of 32 lines.  (p & 31, not lane & 31: a clamped lane re-reads the last pair.)
+    const bool in_tiled = io_layout & 1, out_tiled = io_layout & 2, no_out = io_layout & 4;
+    const int in_step = in_tiled ? 256 : 8, out_step = out_tiled ? 256 : 8;   // floats between a lane's consecutive 16 B groups
+    auto row_of = [&](const float* base, unsigned p, bool tiled) -> const float* {
+        const unsigned blk = tiled ? p >> 5 : p, mul = tiled ? 4096u : 128u;
+        const unsigned in_blk = tiled ? ((lane & 32) + (p & 31)) * 4 : 4 * h;
+        return base + ((unsigned long long)blk * mul + in_blk);
+    };
+    auto erow_of = [&](const PairCtx& c) -> const float* { return row_of(edge, c.p, in_tiled); };
+    auto ldrow = [&](const float* r, int g) -> float4 { return *reinterpret_cast<const float4*>(r + g * in_step); };
     const long long n_wt = (M + 127) / 128;
     long long wt = blockIdx.x;
+#ifndef S2S_ET_PHASES
+#define S2S_ET_PHASES 16
+#endif
+    // Phase stagger.  Every workgroup runs the same schedule on equal tiles: left alone they stay in lockstep, and all 256 of them
+    // ask HBM for their next 64 KiB tile in the same microsecond (16 MiB: ~3.5 us at the achievable rate, which every workgroup
+    // then waits for -- the tile's edge row is needed 4 slots after it is requested).  Workgroups of one XCD start S2S_ET_PHASES
+    // different fractions of a tile apart (a tile is ~100 k cycles), so the requests arrive spread over the tile time.
+    if constexpr (S2S_ET_PHASES > 1) {
+        const int phase = (blockIdx.x >> 3) % S2S_ET_PHASES;
+        for (int i = 0; i < phase * (16 / (S2S_ET_PHASES > 16 ? 16 : S2S_ET_PHASES)); ++i) __builtin_amdgcn_s_sleep(98);   // 98 x 64 cycles = 1/16 tile
+    }
     PairCtx cur = setup(wt);
 
     // ---- the pair's 128 edge channels, split once: xpl[ks][plane] = B operand of layer-1 k-step ks.  Element j of k-step
@@ -222,7 +257,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     {
         float4 xv[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) xv[i] = ldg4(erow_of(cur), i, h);  // accumulator ("chain") channel order, see xpl
+        for (int i = 0; i < 16; ++i) xv[i] = ldrow(erow_of(cur), i);  // accumulator ("chain") channel order, see xpl
         for (int i = threadIdx.x; i < 768; i += 256)
             s_vec[i] = i < 384 ? b2[i] : (i < 512 ? bf[i - 384] : (i < 640 ? gamma[i - 512] : beta[i - 640]));
         if (PROJ && threadIdx.x < 64) s_vec[768 + threadIdx.x] = proj_b[threadIdx.x];
@@ -283,7 +318,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
 
     auto ln_epilogue = [&]() {
     // ---- + bf, LayerNorm(128) over the pair's channels (half here, half in lane^32), edge mask, store
-    const float em = cur.em;
+    const float em = cur.em_i * cur.em_j;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -308,7 +343,8 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             var += dd * dd;
         }
     const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / 128) + ln_eps * (kWS * kWS));
-    float* orow = out + (unsigned long long)cur.p * 128u;
+    float* orow = const_cast<float*>(row_of(out, cur.p, out_tiled));
+    const bool store = cur.valid && !no_out;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -320,11 +356,15 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             o.y = ((a3[t][4 * rq + 1] - mean) * rstd * ga.y + be.y) * em;
             o.z = ((a3[t][4 * rq + 2] - mean) * rstd * ga.z + be.z) * em;
             o.w = ((a3[t][4 * rq + 3] - mean) * rstd * ga.w + be.w) * em;
-            if (cur.valid) *reinterpret_cast<float4*>(orow + 8 * g + 4 * h) = o;
+            if (store) *reinterpret_cast<float4*>(orow + g * out_step) = o;
             a3[t][4 * rq + 0] = o.x; a3[t][4 * rq + 1] = o.y; a3[t][4 * rq + 2] = o.z; a3[t][4 * rq + 3] = o.w;  // projection input
         }
     };
 
+#ifdef S2S_ET_PROBE
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0, st7 = 0, st8 = 0, st9 = 0, st10 = 0, st11 = 0, st12 = 0,
+                       st13 = 0, st14 = 0, st15 = 0;
+#endif
     for (;;) {
     const long long wt_next = wt + gridDim.x;
     const bool has_next = wt_next < n_wt;
@@ -335,6 +375,39 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         constexpr int s = decltype(sc)::value;
         constexpr SlotDesc d = slot_desc(s);
         constexpr int stage = s / 8, ss = s % 8, par = stage & 1;
+#if defined(S2S_ET_PROBE) && S2S_ET_PROBE == 3   // fine view of one layer-2 block: slot tops 72 .. 87 (B_4 A_6), 88
+        if constexpr (s >= 72 && s <= 87) { if constexpr (s == 72) ET_STAMP(0); if constexpr (s == 73) ET_STAMP(1); if constexpr (s == 74) ET_STAMP(2);
+            if constexpr (s == 75) ET_STAMP(3); if constexpr (s == 76) ET_STAMP(4); if constexpr (s == 77) ET_STAMP(5); if constexpr (s == 78) ET_STAMP(6);
+            if constexpr (s == 79) ET_STAMP(7); if constexpr (s == 80) ET_STAMP(8); if constexpr (s == 81) ET_STAMP(9); if constexpr (s == 82) ET_STAMP(10);
+            if constexpr (s == 83) ET_STAMP(11); if constexpr (s == 84) ET_STAMP(12); if constexpr (s == 85) ET_STAMP(13); if constexpr (s == 86) ET_STAMP(14);
+            if constexpr (s == 87) ET_STAMP(15); }
+#elif defined(S2S_ET_PROBE) && S2S_ET_PROBE == 2   // fine view of the last final-layer block: slot tops 216 .. 239
+        if constexpr (s == 216) ET_STAMP(0);
+        if constexpr (s == 220) ET_STAMP(1);
+        if constexpr (s == 224) ET_STAMP(2);
+        if constexpr (s == 225) ET_STAMP(3);
+        if constexpr (s == 226) ET_STAMP(4);
+        if constexpr (s == 227) ET_STAMP(5);
+        if constexpr (s == 228) ET_STAMP(6);
+        if constexpr (s == 229) ET_STAMP(7);
+        if constexpr (s == 230) ET_STAMP(8);
+        if constexpr (s == 232) ET_STAMP(9);
+        if constexpr (s == 234) ET_STAMP(10);
+        if constexpr (s == 236) ET_STAMP(11);
+        if constexpr (s == 237) ET_STAMP(12);
+        if constexpr (s == 238) ET_STAMP(13);
+        if constexpr (s == 239) ET_STAMP(14);
+#else
+        if constexpr (s == 0) ET_STAMP(0);
+        if constexpr (s == 8) ET_STAMP(1);
+        if constexpr (s == 24) ET_STAMP(2);
+        if constexpr (s == 168) ET_STAMP(3);
+        if constexpr (s == 180) ET_STAMP(5);
+        if constexpr (s == 192) ET_STAMP(7);
+        if constexpr (s == 208) ET_STAMP(9);
+        if constexpr (s == 224) ET_STAMP(11);
+        if constexpr (s == 240) ET_STAMP(13);
+#endif
 
         // ---------------- top of the slot: next slot's fragments, weight copy, loads that land under later slots
         // weight pipe: group A of stage+2 is loaded at slot 4 and stored after slot 1 of the next stage (5 slots later);
@@ -342,21 +415,28 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         // predecessor used, which is free from that stage's barrier (top of its slot 7) on.
         if constexpr (ss < 7) {
             fetch(par, ss + 1, fr[(s + 1) & 1]);
-            if constexpr (ss == 0) cp_load_b((stage + 1) % kStages);   // the pipe wraps into the next tile's stages 0, 1
-            if constexpr (ss == 4) cp_load_a((stage + 2) % kStages);
         } else {
             S2S_LDS_BARRIER();
             fetch(par ^ 1, 0, fr[(s + 1) & 1]);
         }
         // next tile: context + edge row at the start of the last final-layer block, seeds of its tile 0 near the end
-        if constexpr (s == 224) {
-            nxt = setup(has_next ? wt_next : wt);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) xv[i] = ldg4(erow_of(nxt), i, h);
+        // (the edge row in pieces: a burst of 16 loads per wave holds the slot for ~2 k cycles -- the workgroup's 64 KiB through one
+        //  address unit -- and whatever waits next on the in-order counter waits for all of it.  Two loads per slot, in slots whose
+        //  next counter wait (the weight store 4+ slots later) is at least 6 slots away: HBM latency fits in between.)
+#ifndef S2S_ET_XV0
+#define S2S_ET_XV0 208
+#endif
+        if constexpr (s == S2S_ET_XV0) nxt = setup(has_next ? wt_next : wt);
+        if constexpr (s > S2S_ET_XV0 && s <= S2S_ET_XV0 + 16 && ((s & 3) == 1 || (s & 3) == 2)) {
+            constexpr int i = 4 * ((s - S2S_ET_XV0) / 4) + 2 * ((s & 3) - 1);   // 2 loads in each of the slots ss = 1, 2, 5, 6 of two stages
+            const float* er = erow_of(nxt);
+            xv[i] = ldrow(er, i);
+            xv[i + 1] = ldrow(er, i + 1);
         }
         if constexpr (s == 236) seeds_load(nxt, 0);
-        // seeds of a1 tile t+1 are fetched late in B_t (they are consumed under A_{t+2}, or right after B_10 for tile 11)
-        if constexpr (d.phase == 1 && d.a == 1 && d.b == 3 && d.t + 1 < 12) seeds_load(cur, d.t + 1);
+        // seeds of a1 tile t+1 are fetched early in B_t, in a slot without weight-pipe work (consumed under A_{t+2}, 10+ slots later; the
+        // slot-by-slot probe showed a fetch 3 slots ahead of its use costing ~300 cycles at the fetch and ~300 at the use)
+        if constexpr (d.phase == 1 && d.a == 1 && d.b == 0 && d.t + 1 < 12) seeds_load(cur, d.t + 1);
         __builtin_amdgcn_sched_barrier(0);
 
         // ---------------- the 12 MFMAs
@@ -403,11 +483,34 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             split4(x0, xpn[i][0], xpn[i][1], 0);
             split4(x1, xpn[i][0], xpn[i][1], 4);
         }
+        // weight pipe, one instruction behind each of the first four MFMAs (as a block in front of / behind the slot's MFMAs the four
+        // loads cost ~60 cycles and the four LDS stores ~120: the slot-by-slot probe, tools/et_phase_probe.py --block)
+        if constexpr (ss == 0) cp_load_b((stage + 1) % kStages);   // the pipe wraps into the next tile's stages 0, 1
+        if constexpr (ss == 4) cp_load_a((stage + 2) % kStages);
         if constexpr (ss == 1) cp_store_a(par ^ 1);
         if constexpr (ss == 5) cp_store_b(par ^ 1);
+        if constexpr (ss == 0 || ss == 4 || ss == 1 || ss == 5) {
+            constexpr int kind = (ss == 0 || ss == 4) ? 0x020 : 0x200;   // VMEM read | DS write
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(kind, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
 
         // ---------------- exposed steps
+#if defined(S2S_ET_PROBE) && S2S_ET_PROBE == 2
+        if constexpr (s == 239) ET_STAMP(15);
+#elif defined(S2S_ET_PROBE) && S2S_ET_PROBE == 3
+#else
+        if constexpr (s == 179) ET_STAMP(4);
+        if constexpr (s == 191) ET_STAMP(6);
+        if constexpr (s == 207) ET_STAMP(8);
+        if constexpr (s == 223) ET_STAMP(10);
+        if constexpr (s == 239) ET_STAMP(12);
+#endif
         if constexpr (s == 179) {  // B_10 done: tile 11 -> planes (nothing left to hide it under)
             s_quarter(a1t[1], IC<0>{}); s_quarter(a1t[1], IC<1>{}); s_quarter(a1t[1], IC<2>{}); s_quarter(a1t[1], IC<3>{});
         }
@@ -450,6 +553,9 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         }
     });
 
+#if defined(S2S_ET_PROBE) && S2S_ET_PROBE == 1
+    ET_STAMP(14);
+#endif
     if constexpr (!PROJ) ln_epilogue();
     if constexpr (PROJ) {
         // rows 0..7 (+ bias) -> attention bias, head-major; rows 8..39 -> pair_z channel row - 8 (same map as pair_mlp.hip)
@@ -470,6 +576,19 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             }
         }
     }
+#ifdef S2S_ET_PROBE
+#if S2S_ET_PROBE == 1
+    ET_STAMP(15);
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (wave == 0 && lane == 0 && blockIdx.x < 512) {
+        unsigned long long* pr = g_et_probe + blockIdx.x * 17;
+        const unsigned long long stv[16] = {st0, st1, st2, st3, st4, st5, st6, st7, st8, st9, st10, st11, st12, st13, st14, st15};
+#pragma unroll
+        for (int k = 0; k < 15; ++k) atomicAdd(pr + k, stv[k + 1] - stv[k]);
+        atomicAdd(pr + 16, 1ull);
+    }
+#endif
     if (!has_next) break;
     cur = nxt;
     wt = wt_next;
@@ -497,7 +616,7 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
     const float* __restrict__ bin_tab, const float* __restrict__ bin_lower, const long long* __restrict__ residue_idx,
     const float* __restrict__ ca, const char* __restrict__ wblob, const float* __restrict__ b2, const float* __restrict__ b3,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask, float* __restrict__ out,
-    long long M, int N, int rel_off, int n_rel, int n_bins, float ln_eps, const float* __restrict__ proj_b,
+    long long M, int N, int rel_off, int n_rel, int n_bins, float ln_eps, int out_tiled, const float* __restrict__ proj_b,
     float* __restrict__ proj_bias_out, float* __restrict__ proj_pz_out, int* __restrict__ range_flag) {
     constexpr int kStages = PROJ ? 5 : 4;
     constexpr int kSlots = 8 * kStages;
@@ -711,14 +830,17 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
         pin_frag(xp[k]);
     };
     float ln_mean = 0.f, ln_rstd = 0.f;
+    // output block of the wave (16 KiB): row-major  n 512 + g 32 + h 16,  tiled  g 1024 + lane 16  (edge transition, "Pair-tensor layouts")
+    const unsigned out_lane = out_tiled ? lane * 16u : (unsigned)((lane & 31) * 512 + h * 16), out_step = out_tiled ? 1024u : 32u;
     f16x8 xq[2][2];  // LayerNorm output planes of the projection's current / next k-step
     // LayerNorm output of k-step k (16 channels): scale, shift, edge mask, store (+ planes for the projection)
     __amdgpu_buffer_rsrc_t rs_out;  // this tile's 32 output rows; rows past M are outside num_records: their stores are dropped
     auto out_rsrc = [&](long long wg_tile) {
         const long long p0 = (wg_tile * 4 + __builtin_amdgcn_readfirstlane(wave)) * 32;
         const long long left = M - p0;
+        // (tiled layout: the pairs of a partial last tile are interleaved with its padding, which the buffer holds: whole block)
         rs_out = __builtin_amdgcn_make_buffer_rsrc((void*)(out + (p0 < M ? p0 : 0) * 128), 0,
-                                                   (unsigned)(left <= 0 ? 0 : (left < 32 ? left : 32)) * 512u, 0x00020000);
+                                                   (unsigned)(left <= 0 ? 0 : (left < 32 && !out_tiled ? left : 32)) * 512u, 0x00020000);
     };
     float4 lga[2], lbe[2];  // gamma / beta of the next LayerNorm piece, read at the top of its slot
     auto ln_load = [&](auto kc) {
@@ -745,7 +867,7 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
             o.z = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 2] - ln_mean, ln_rstd), ga.z, be.z), c.em);
             o.w = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 3] - ln_mean, ln_rstd), ga.w, be.w), c.em);
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)},
-                                                   rs_out, (unsigned)((lane & 31) * 512 + h * 16) + g * 32, 0, 0);
+                                                   rs_out, out_lane + (unsigned)g * out_step, 0, 0);
             if constexpr (PROJ) {
                 const float xx[4] = {o.x, o.y, o.z, o.w};
                 split4(xx, xq[k & 1][0], xq[k & 1][1], 4 * u);
@@ -787,8 +909,6 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
         if constexpr (PROJ && s >= 31 && s < 39) ln_load(IC<s - 31>{});
         if constexpr (ss < 7) {
             fetch(par, ss + 1, fr[(s + 1) & 1]);
-            if constexpr (ss == 0) cp_load_b((stage + 1) % kStages);
-            if constexpr (ss == 4) cp_load_a((stage + 2) % kStages);
         } else {
             S2S_LDS_BARRIER();
             fetch(par ^ 1, 0, fr[(s + 1) & 1]);
@@ -835,11 +955,16 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
         if constexpr (s == 23) { g1_split(xl, 7); pin_frag(xl); }
         // LayerNorm output k-step k + 1 under projection slot 32 + k
         if constexpr (PROJ && s >= 32 && s < 39) ln_piece(IC<s - 31>{}, cur);
+        // weight pipe: one load / LDS store behind each of the first four MFMAs (edge transition, same slots)
+        if constexpr (ss == 0) cp_load_b((stage + 1) % kStages);
+        if constexpr (ss == 4) cp_load_a((stage + 2) % kStages);
         if constexpr (ss == 1) cp_store_a(par ^ 1);
         if constexpr (ss == 5) cp_store_b(par ^ 1);
+        constexpr int copy_kind = (ss == 0 || ss == 4) ? 0x020 : ((ss == 1 || ss == 5) ? 0x200 : 0);   // VMEM read | DS write | none
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA,
+            if (copy_kind != 0 && i < 4) __builtin_amdgcn_sched_group_barrier(copy_kind, 1, 0);   // one piece of the weight pipe,
             __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // up to eight VALU instructions behind it
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -900,21 +1025,35 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
 }
 
 
+// smallest number of samples whose pairs fill whole 32-pair blocks (launch boundaries of a tiled pair tensor)
+long long tile_aligned_samples(long long NN) {
+    long long q = 32;
+    while (q > 1 && (NN * (32 / q)) % 32 != 0) q /= 2;   // 32 / q samples suffice when NN (32 / q) is a multiple of 32
+    return 32 / q;
+}
+
 }  // namespace
 
 extern "C" int s2s_edge_transition_f16x3(const float* edge, const float* node_ab, const float* node_p,
                                          const void* weight_stream, const float* b2, const float* bf,
                                          const float* ln_gamma, const float* ln_beta, const float* mask, float* out,
-                                         int n_samples, int n_res, float ln_eps, const float* proj_bias_cat64,
+                                         int n_samples, int n_res, float ln_eps, int io_layout, const float* proj_bias_cat64,
                                          float* proj_attn_bias, float* proj_pair_z, void* stream) {
     if (n_samples <= 0 || n_res <= 0) return 0;
+    if ((io_layout & ~7) || ((io_layout & 4) && !proj_attn_bias) || (!(io_layout & 4) && !out)) return (int)hipErrorInvalidValue;
     const long long NN = (long long)n_res * n_res;
     // 32-bit pair / head-major indices inside a launch (8 M < 2^32): split the samples over several launches when needed
     const char* cap_env = getenv("S2S_ET_MAX_PAIRS");   // test hook: a smaller per-launch pair budget exercises the split
     long long cap = cap_env ? atoll(cap_env) : 0;
     if (cap <= 0 || cap > (1ll << 29) - 1) cap = (1ll << 29) - 1;
-    const long long chunk = cap / NN;
+    long long chunk = cap / NN;
+    if ((io_layout & 3) && chunk < n_samples) chunk -= chunk % tile_aligned_samples(NN);   // launches of a tiled tensor start on a 32-pair block
     if (chunk < 1) return (int)hipErrorInvalidValue;
+    static const float* one_of[64] = {};   // per device: the address of s2s_one
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess || dev_id < 0 || dev_id >= 64) return (int)hipErrorInvalidValue;
+    if (!one_of[dev_id] && hipGetSymbolAddress((void**)&one_of[dev_id], HIP_SYMBOL(s2s_one)) != hipSuccess) return (int)hipErrorInvalidValue;
+    const float* one = one_of[dev_id];
     static int n_cu = 0;  // persistent workgroups, one per CU
     if (n_cu == 0) {
         int dev = 0;
@@ -929,28 +1068,40 @@ extern "C" int s2s_edge_transition_f16x3(const float* edge, const float* node_ab
         const float* e = edge + b0 * NN * 128;
         const float* nab = node_ab + rows0 * 768;
         const float* np = node_p + rows0 * 128;
-        const float* mk = mask ? mask + rows0 : nullptr;
-        float* o = out + b0 * NN * 128;
+        const float* mk = mask ? mask + rows0 : one;
+        const unsigned mks = mask ? 1u : 0u;
+        float* o = out ? out + b0 * NN * 128 : nullptr;
         if (proj_attn_bias)
             hipLaunchKernelGGL(edge_transition_f16_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, e, nab, np,
-                               (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mk, o, M, n_res, ln_eps, proj_bias_cat64,
+                               (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mk, o, M, n_res, ln_eps, io_layout, mks, proj_bias_cat64,
                                proj_attn_bias + b0 * 8 * NN, proj_pair_z + b0 * NN * 32, s2s::g_range_flag);
         else
             hipLaunchKernelGGL(edge_transition_f16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, e, nab, np,
-                               (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mk, o, M, n_res, ln_eps, (const float*)nullptr,
-                               (float*)nullptr, (float*)nullptr, s2s::g_range_flag);
+                               (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mk, o, M, n_res, ln_eps, io_layout, mks,
+                               (const float*)nullptr, (float*)nullptr, (float*)nullptr, s2s::g_range_flag);
     }
     return (int)hipGetLastError();
 }
+
+#ifdef S2S_ET_PROBE
+extern "C" int s2s_et_probe_read(unsigned long long* host_out, int reset) {   // 512 x 17 counters
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_et_probe), sizeof(unsigned long long) * 512 * 17);
+    if (e == hipSuccess && reset) {
+        static unsigned long long z[512 * 17];
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_et_probe), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif
 
 extern "C" int s2s_edge_embed_f16x3(const float* node_a, const float* node_b, const float* rel_table, const float* bin_table,
                                      const float* bin_lower, const long long* residue_idx, const float* ca_xyz,
                                      const void* weight_stream, const float* b2, const float* b3, const float* ln_gamma,
                                      const float* ln_beta, const float* mask, float* out, int n_samples, int n_res,
-                                     int rel_offset, int n_rel, int n_bins, float ln_eps, const float* proj_bias_cat64,
+                                     int rel_offset, int n_rel, int n_bins, float ln_eps, int out_tiled, const float* proj_bias_cat64,
                                      float* proj_attn_bias, float* proj_pair_z, void* stream) {
     if (n_samples <= 0 || n_res <= 0) return 0;
-    if (n_bins > 32) return (int)hipErrorInvalidValue;  // the distogram edges are counted from a 32-entry LDS table
+    if (n_bins > 32 || (out_tiled & ~1)) return (int)hipErrorInvalidValue;  // the distogram edges are counted from a 32-entry LDS table
     // 32-bit pair indices and buffer offsets inside a launch: split the samples over several launches when needed
     const long long NN = (long long)n_res * n_res;
     if (NN >= (1ll << 31) || (long long)n_rel * 512 >= (1ll << 32)) return (int)hipErrorInvalidValue;
@@ -960,6 +1111,7 @@ extern "C" int s2s_edge_embed_f16x3(const float* node_a, const float* node_b, co
     long long chunk = cap / NN;
     const long long rows_cap = ((1ll << 32) - 1) / ((long long)n_res * 512);  // node_b descriptor
     if (rows_cap < chunk) chunk = rows_cap;
+    if (out_tiled && chunk < n_samples) chunk -= chunk % tile_aligned_samples(NN);
     if (chunk < 1) return (int)hipErrorInvalidValue;
     int n_cu = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
@@ -978,12 +1130,12 @@ extern "C" int s2s_edge_embed_f16x3(const float* node_a, const float* node_b, co
         if (proj_attn_bias)
             hipLaunchKernelGGL(edge_embed_f16_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, na, nbp,
                                rel_table, bin_table, bin_lower, ridx, cap, (const char*)weight_stream, b2, b3, ln_gamma, ln_beta,
-                               mk, o, M, n_res, rel_offset, n_rel, n_bins, ln_eps, proj_bias_cat64,
+                               mk, o, M, n_res, rel_offset, n_rel, n_bins, ln_eps, out_tiled, proj_bias_cat64,
                                proj_attn_bias + b0 * 8 * NN, proj_pair_z + b0 * NN * 32, s2s::g_range_flag);
         else
             hipLaunchKernelGGL(edge_embed_f16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, na, nbp,
                                rel_table, bin_table, bin_lower, ridx, cap, (const char*)weight_stream, b2, b3, ln_gamma, ln_beta,
-                               mk, o, M, n_res, rel_offset, n_rel, n_bins, ln_eps, (const float*)nullptr, (float*)nullptr,
+                               mk, o, M, n_res, rel_offset, n_rel, n_bins, ln_eps, out_tiled, (const float*)nullptr, (float*)nullptr,
                                (float*)nullptr, s2s::g_range_flag);
     }
     return (int)hipGetLastError();

@@ -129,8 +129,9 @@ class EmbeddingModule(nn.Module):
         return self._idx_val
 
     def forward(self, residue_idx, t, fixed_mask, self_conditioning_ca, node_mask: Optional[torch.Tensor] = None,
-                next_proj=None, t_emb: Optional[torch.Tensor] = None):
-        """-> node_embed [B,N,D_node], edge_embed [B,N,N,D_edge] (reference :107-159).  ``t`` may live on
+                next_proj=None, t_emb: Optional[torch.Tensor] = None, edge_layout: str = "rowmajor"):
+        """-> node_embed [B,N,D_node], edge_embed [B,N,N,D_edge] (reference :107-159; ``edge_layout`` "tiled": as an ``ops.PairTiled``
+        for the trunk's f16x3 pair kernels, arithmetic "f16x3" only).  ``t`` may live on
         the host (the sampler knows it there): its embedding is then computed on the host and uploaded.
         ``node_mask`` optionally fuses DenoisingNet's mask multiplies (reference :186-187); ``next_proj`` (packed
         pair-projection weights of the first IPA block) adds (attn_bias, pair_z) as a third return value."""
@@ -183,8 +184,11 @@ class EmbeddingModule(nn.Module):
                 stream = self._proj_cache.get([ws, next_proj["wp_f16x2"]], lambda: torch.cat([ws, next_proj["wp_f16x2"]]))
                 proj = (stream, next_proj["b64"])
             edge_embed = ops.edge_embed_f16x3(node_a, node_b, self._rel_cb, w["bin_tab_cb"], w["bin_lower"], idx_dev, ca, ws, e2.bias,
-                                              e4.bias, ln.weight, ln.bias, mask, span, ln.eps, proj=proj, column_blocked_tables=True)
+                                              e4.bias, ln.weight, ln.bias, mask, span, ln.eps, proj=proj, column_blocked_tables=True,
+                                              out_layout=edge_layout)
         else:
+            if edge_layout != "rowmajor":
+                raise ops.HipLibraryError("EmbeddingModule: the tiled pair layout belongs to the f16x3 kernels")
             edge_embed = ops.edge_embed(node_a, node_b, rel_tab, w["bin_tab"], w["bin_lower"], idx_dev, ca, w["w2p"],
                                         w["w3p"], e2.bias, e4.bias, ln.weight, ln.bias, mask, span, ln.eps,
                                         proj=None if next_proj is None else (next_proj["wp"], next_proj["b64"]))
@@ -210,9 +214,12 @@ class DenoisingNet(nn.Module):
         node_mask = batch["residue_mask"].to(dev).type(torch.float)
         fixed_mask = batch["fixed_mask"].to(dev).type(torch.float)
         fuse = getattr(self.translator, "fuse_pair_projection", False)
+        # between the f16x3 pair kernels (embedding -> EdgeTransition 0 -> 1 -> ..) the pair tensor travels in their tiled layout
+        tiled = fuse and getattr(self.embedder, "arith", None) == "f16x3" and getattr(self.translator, "arith", None) == "f16x3"
         emb = self.embedder(residue_idx=batch["residue_idx"], t=batch["t"], fixed_mask=fixed_mask,
                             self_conditioning_ca=batch["sc_ca_t"], node_mask=node_mask, t_emb=batch.get("t_emb"),
-                            next_proj=self.translator.trunk["ipa_0"].pair_proj_weights() if fuse else None)
+                            next_proj=self.translator.trunk["ipa_0"].pair_proj_weights() if fuse else None,
+                            **({"edge_layout": "tiled"} if tiled else {}))
         node_embed, edge_embed = emb[0], emb[1]
         tb = dict(batch)
         tb["residue_mask"], tb["fixed_mask"] = node_mask, fixed_mask

@@ -256,6 +256,8 @@ class TranslationIPA(nn.Module):
             # ---- InvariantPointAttention (:100-268): projections -> points -> attention core -> linear_out (+mask, +residual, LN)
             if proj is None:
                 d = ipa._derived()
+                if isinstance(edge_embed, ops.PairTiled):
+                    edge_embed = ops.pair_untiled(edge_embed)
                 proj = ops.pair_project(edge_embed.contiguous(), d["wp"], d["b64"])
             feats_a = ipa.attention(s_a, B, N, curr7, node_mask, tuple(proj))
             proj = None
@@ -288,7 +290,11 @@ class TranslationIPA(nn.Module):
                 et = T[f"edge_transition_{b}"]
                 n_p, node_ab = et.node_parts(s_a, M)
                 nxt = T[f"ipa_{b + 1}"].pair_proj_weights() if self.fuse_pair_projection else None
-                res = et.pair_mlp(edge_embed, node_ab.view(B, N, -1), n_p.view(B, N, -1), node_mask, nxt)
+                # f16x3 with fused projections: the pair tensor stays in the kernels' tiled layout, and the last EdgeTransition's
+                # output (read by nothing but the projections it already carries) is not written
+                lay = "rowmajor" if not (f16 and nxt is not None) else ("none" if b == self.num_blocks - 2 else "tiled")
+                res = et.pair_mlp(edge_embed, node_ab.view(B, N, -1), n_p.view(B, N, -1), node_mask, nxt,
+                                  **({"out_layout": lay} if lay != "rowmajor" else {}))
                 if nxt is not None:
                     edge_embed, *proj = res
                 else:

@@ -158,9 +158,10 @@ class EdgeTransition(nn.Module):
         n_p, node_ab = self.node_parts(ops.to_act(node_embed.reshape(B * N, -1).float().contiguous(), self.arith), B * N)
         return self.pair_mlp(edge_embed, node_ab.view(B, N, -1), n_p.view(B, N, -1), edge_mask_1d, next_proj)
 
-    def pair_mlp(self, edge_embed, node_ab, n_p, edge_mask_1d=None, next_proj=None):
+    def pair_mlp(self, edge_embed, node_ab, n_p, edge_mask_1d=None, next_proj=None, out_layout: str = "rowmajor"):
         """The N x N part given the per-node vectors n' = initial_embed(node) [B,N,128] and
-        node_ab = [W1[:,128:256] n' + b1 | W1[:,256:] n'] [B,N,768] (``node_parts``)."""
+        node_ab = [W1[:,128:256] n' + b1 | W1[:,256:] n'] [B,N,768] (``node_parts``).  Arithmetic "f16x3" only: ``edge_embed`` may be
+        an ``ops.PairTiled`` and ``out_layout`` "tiled" / "none" (ops.edge_transition_f16x3) -- how the trunk chains its pair kernels."""
         if self._shape != (128, 128, 384, 128, 2):
             raise ops.HipLibraryError(f"EdgeTransition kernel is built for c_z=128, c_s=256 (got {self._shape})")
         mask = None if edge_mask_1d is None else edge_mask_1d.type(torch.float32).contiguous()
@@ -173,7 +174,9 @@ class EdgeTransition(nn.Module):
                 proj = (stream, next_proj["b64"])
             return ops.edge_transition_f16x3(edge_embed.contiguous(), node_ab, n_p, pk["wstream_f16"], self.trunk[2].bias,
                                              self.final_layer.bias, self.layer_norm.weight, self.layer_norm.bias, mask,
-                                             self.layer_norm.eps, proj=proj)
+                                             self.layer_norm.eps, proj=proj, out_layout=out_layout)
+        if out_layout != "rowmajor" or isinstance(edge_embed, ops.PairTiled):
+            raise ops.HipLibraryError("EdgeTransition: the tiled pair layout belongs to the f16x3 kernels")
         pk = self._packed_f32()
         return ops.edge_transition(edge_embed.contiguous(), node_ab, n_p, pk["w1p"], pk["w2p"], pk["wfp"],
                                    self.trunk[2].bias, self.final_layer.bias, self.layer_norm.weight,

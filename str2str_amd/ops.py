@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _lib = None
 _tables_loaded = False
@@ -27,9 +27,9 @@ _SIGNATURES = {
     "s2s_abi_version": [],
     "s2s_set_range_flag": [_vp],
     "s2s_edge_transition": [_vp] * 12 + [_i, _i, _f, _vp, _vp, _vp, _vp, _vp],
-    "s2s_edge_transition_f16x3": [_vp] * 10 + [_i, _i, _f, _vp, _vp, _vp, _vp],
+    "s2s_edge_transition_f16x3": [_vp] * 10 + [_i, _i, _f, _i, _vp, _vp, _vp, _vp],
     "s2s_edge_embed": [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
-    "s2s_edge_embed_f16x3": [_vp] * 14 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "s2s_edge_embed_f16x3": [_vp] * 14 + [_i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
     "s2s_pair_project": [_vp] * 5 + [_i, _i, _vp],
     "s2s_ipa_prep_points": [_vp] * 6 + [_ll, _i, _i, _i, _i, _vp],
     "s2s_ipa_attention": [_vp] * 12 + [_i, _i, _i, _i, _i, _i, _i, _f, _f, _vp],
@@ -256,14 +256,62 @@ def pack_f16x3_stream(w1_edge: torch.Tensor, w2: torch.Tensor, wf: torch.Tensor)
 
 
 # ------------------------------------------------------------------------------------------ ops
-def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps=1e-5, out=None, proj=None):
+class PairTiled:
+    """A [B,N,N,128] pair tensor in the TILED layout the f16x3 pair kernels exchange among themselves (include/str2str_hip.h,
+    "Pair-tensor layouts"): blocks of 32 consecutive pairs, inside a block [16 groups][2 halves][32 pairs][4 floats] -- the order in
+    which a wavefront holds a 32-pair tile, so its loads and stores are whole cache lines.  ``buf`` is the flat fp32 storage
+    (B N N rounded up to whole blocks); ``pair_tiled`` / ``pair_untiled`` convert from / to the reference's row-major tensor."""
+    __slots__ = ("buf", "B", "N")
+
+    def __init__(self, B: int, N: int, device=None, buf: Optional[torch.Tensor] = None):
+        self.B, self.N = int(B), int(N)
+        n = -(-(self.B * self.N * self.N) // 32) * 32 * 128
+        self.buf = torch.empty(n, device=device, dtype=torch.float32) if buf is None else buf
+        if self.buf.numel() != n or self.buf.dtype != torch.float32 or not self.buf.is_contiguous():
+            raise HipLibraryError("PairTiled: buffer must be a contiguous fp32 tensor of whole 32-pair blocks")
+
+    shape = property(lambda self: (self.B, self.N, self.N, 128))
+    device = property(lambda self: self.buf.device)
+    is_cuda = property(lambda self: self.buf.is_cuda)
+
+    def data_ptr(self):
+        return self.buf.data_ptr()
+
+    def contiguous(self):
+        return self
+
+
+def pair_tiled(z: torch.Tensor) -> PairTiled:
+    """Row-major [B,N,N,128] -> tiled (plain torch; conversion is for callers and tests, the kernels produce the layout themselves)."""
+    B, N = z.shape[0], z.shape[1]
+    M = B * N * N
+    t = PairTiled(B, N, z.device)
+    zp = torch.zeros(t.buf.numel() // 128, 128, device=z.device, dtype=torch.float32)
+    zp[:M] = z.reshape(M, 128)
+    t.buf.copy_(zp.view(-1, 32, 16, 2, 4).permute(0, 2, 3, 1, 4).reshape(-1))
+    return t
+
+
+def pair_untiled(t: PairTiled) -> torch.Tensor:
+    M = t.B * t.N * t.N
+    return t.buf.view(-1, 16, 2, 32, 4).permute(0, 3, 1, 2, 4).reshape(-1, 128)[:M].reshape(t.B, t.N, t.N, 128).contiguous()
+
+
+def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps=1e-5, out=None, proj=None,
+                          out_layout: str = "rowmajor"):
     """EdgeTransition on split-f16 MFMA (fp32-equivalent accuracy; csrc/pair_mlp_f16.hip); same contract as ``edge_transition``.
     ``proj`` = (31-stage stream = this layer's 30 stages (``pack_f16x3_stream``) + the next IPA block's projection stage
-    (``pack_f16x2_layer``), bias64) also returns that block's (attn_bias [B,8,N,N], pair_z [B,N,N,32])."""
+    (``pack_f16x2_layer``), bias64) also returns that block's (attn_bias [B,8,N,N], pair_z [B,N,N,32]).
+    ``edge`` may be a ``PairTiled``; ``out_layout``: "rowmajor" (the reference's tensor), "tiled" (-> ``PairTiled``) or "none" (the pair
+    vectors are not written: only with ``proj``, for the last EdgeTransition of a trunk; returns None in their place)."""
     lib = load_library()
     B, N = edge.shape[0], edge.shape[1]
-    _req(edge, name="edge")
-    if edge.shape != (B, N, N, 128) or node_ab.shape != (B, N, 768) or node_p.shape != (B, N, 128):
+    in_tiled = isinstance(edge, PairTiled)
+    if out_layout not in ("rowmajor", "tiled", "none") or (out_layout == "none" and proj is None):
+        raise HipLibraryError(f"edge_transition_f16x3: out_layout {out_layout!r}" + (" needs proj" if out_layout == "none" else ""))
+    if not in_tiled:
+        _req(edge, name="edge")
+    if tuple(edge.shape) != (B, N, N, 128) or node_ab.shape != (B, N, 768) or node_p.shape != (B, N, 128):
         raise HipLibraryError("edge_transition_f16x3: bad shapes")
     for n, t in (("node_ab", node_ab), ("node_p", node_p), ("b2", b2), ("bf", bf), ("gamma", gamma), ("beta", beta)):
         _req(t, name=n)
@@ -278,14 +326,20 @@ def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, m
         raise HipLibraryError("edge_transition_f16x3: weight stream has the wrong number of stages")
     if mask is not None:
         _req(mask, name="mask")
-    if out is None:
-        out = torch.empty_like(edge)
+    if out_layout == "none":
+        out = None
+    elif out is None:
+        out = PairTiled(B, N, edge.device) if out_layout == "tiled" else torch.empty(B, N, N, 128, device=edge.device, dtype=torch.float32)
     elif out.data_ptr() == edge.data_ptr():
         raise HipLibraryError("edge_transition: out may not alias edge")
+    elif isinstance(out, PairTiled) != (out_layout == "tiled"):
+        raise HipLibraryError("edge_transition_f16x3: out does not have the requested layout")
+    io = (1 if in_tiled else 0) | {"rowmajor": 0, "tiled": 2, "none": 4}[out_layout]
     range_flag()
     _check(_timed("s2s_edge_transition", lambda: lib.s2s_edge_transition_f16x3(
-        _p(edge), _p(node_ab), _p(node_p), _p(wstream), _p(b2), _p(bf), _p(gamma), _p(beta), _p(mask), _p(out), B, N,
-        ln_eps, _p(pb), _p(pbias), _p(ppz), _stream())), "s2s_edge_transition_f16x3")
+        _p(edge.buf if in_tiled else edge), _p(node_ab), _p(node_p), _p(wstream), _p(b2), _p(bf), _p(gamma), _p(beta), _p(mask),
+        _p(out.buf if isinstance(out, PairTiled) else out), B, N, ln_eps, io, _p(pb), _p(pbias), _p(ppz), _stream())),
+        "s2s_edge_transition_f16x3")
     return out if proj is None else (out, pbias, ppz)
 
 
@@ -360,9 +414,10 @@ def pack_f16x3_embed_stream(w2: torch.Tensor, w3: torch.Tensor) -> torch.Tensor:
 
 
 def edge_embed_f16x3(node_a, node_b, rel_table, bin_table, bin_lower, residue_idx, ca, wstream, b2, b3, gamma, beta, mask,
-                     rel_offset: int, ln_eps=1e-5, out=None, proj=None, column_blocked_tables=False):
+                     rel_offset: int, ln_eps=1e-5, out=None, proj=None, column_blocked_tables=False, out_layout: str = "rowmajor"):
     """Edge embedding on split-f16 MFMA (csrc/pair_mlp_f16.hip); ``proj`` = (5-stage stream, bias64) also returns (attn_bias, pair_z).
-    node_b / rel_table / bin_table: [.., rows, 128], or already ``column_blocked`` ([.., 32, rows, 4]) with the flag set."""
+    node_b / rel_table / bin_table: [.., rows, 128], or already ``column_blocked`` ([.., 32, rows, 4]) with the flag set.
+    ``out_layout`` "tiled" -> a ``PairTiled`` for ``edge_transition_f16x3``."""
     lib = load_library()
     B, N = node_a.shape[0], node_a.shape[1]
     if not column_blocked_tables:
@@ -384,13 +439,18 @@ def edge_embed_f16x3(node_a, node_b, rel_table, bin_table, bin_lower, residue_id
         raise HipLibraryError("s2s_edge_embed_f16x3: weight stream has the wrong number of stages")
     if mask is not None:
         _req(mask, name="mask")
+    if out_layout not in ("rowmajor", "tiled"):
+        raise HipLibraryError(f"edge_embed_f16x3: out_layout {out_layout!r}")
+    tiled = out_layout == "tiled"
     if out is None:
-        out = torch.empty(B, N, N, 128, device=node_a.device, dtype=torch.float32)
+        out = PairTiled(B, N, node_a.device) if tiled else torch.empty(B, N, N, 128, device=node_a.device, dtype=torch.float32)
+    elif isinstance(out, PairTiled) != tiled:
+        raise HipLibraryError("edge_embed_f16x3: out does not have the requested layout")
     range_flag()
     _check(_timed("s2s_edge_embed", lambda: lib.s2s_edge_embed_f16x3(
         _p(node_a), _p(node_b), _p(rel_table), _p(bin_table), _p(bin_lower), _p(residue_idx), _p(ca), _p(wstream), _p(b2), _p(b3),
-        _p(gamma), _p(beta), _p(mask), _p(out), B, N, int(rel_offset), rel_table.shape[1], bin_table.shape[1], ln_eps, _p(pb),
-        _p(pbias), _p(ppz), _stream())), "s2s_edge_embed_f16x3")
+        _p(gamma), _p(beta), _p(mask), _p(out.buf if tiled else out), B, N, int(rel_offset), rel_table.shape[1], bin_table.shape[1],
+        ln_eps, 1 if tiled else 0, _p(pb), _p(pbias), _p(ppz), _stream())), "s2s_edge_embed_f16x3")
     return out if proj is None else (out, pbias, ppz)
 
 

@@ -262,6 +262,50 @@ def test_edge_embed_launch_split(net_rough, monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("B,N", [(2, 32), (3, 7), (1, 75), (5, 24), (20, 6)])
+def test_pair_kernels_tiled_layout_is_bit_identical(net_rough, B, N, monkeypatch):
+    """Between themselves the f16x3 pair kernels pass the pair tensor in their TILED layout (32-pair blocks in wavefront order: whole
+    cache lines per load / store instruction; include/str2str_hip.h "Pair-tensor layouts").  Same numbers, other addresses: embedding
+    -> tiled == row-major embedding; EdgeTransition tiled in / tiled out / no output == the row-major call, incl. the fused projections;
+    partial last blocks (B N N not a multiple of 32) and launch splits (5 x 24 x 24 pairs in launches of 2 samples; 20 x 6 x 6 with a
+    budget of 10 samples, which the launcher lowers to 8 = whole blocks)."""
+    from str2str_amd import ops
+
+    g = torch.Generator().manual_seed(11 + N)
+    idx = torch.arange(N)[None].repeat(B, 1)
+    t = torch.rand(B, generator=g)
+    fixed = (torch.rand(B, N, generator=g) > 0.7).float().to(DEV)
+    ca = (torch.randn(B, N, 3, generator=g) * 8).to(DEV)
+    mask = (torch.rand(B, N, generator=g) > 0.1).float().to(DEV)
+    tr = net_rough.translator.trunk
+    if B >= 5:
+        monkeypatch.setenv("S2S_EE_MAX_PAIRS", str(B // 2 * N * N + 7))
+        monkeypatch.setenv("S2S_ET_MAX_PAIRS", str(B // 2 * N * N + 7))
+    with use_arith(net_rough, "f16x3"):
+        kw = dict(residue_idx=idx, t=t, fixed_mask=fixed, self_conditioning_ca=ca, node_mask=mask, next_proj=tr["ipa_0"].pair_proj_weights())
+        node, z_row, (b_row, pz_row) = net_rough.embedder(**kw)
+        _, z_til, (b_til, pz_til) = net_rough.embedder(**kw, edge_layout="tiled")
+        assert isinstance(z_til, ops.PairTiled) and torch.equal(ops.pair_untiled(z_til), z_row)
+        assert torch.equal(b_row, b_til) and torch.equal(pz_row, pz_til)
+        assert torch.equal(ops.pair_untiled(ops.pair_tiled(z_row)), z_row)
+        et = tr["edge_transition_0"]
+        n_p, node_ab = et.node_parts(ops.to_act(node.reshape(B * N, -1).contiguous(), "f16x3"), B * N)
+        args = (node_ab.view(B, N, -1), n_p.view(B, N, -1), mask, tr["ipa_1"].pair_proj_weights())
+        o_row, ob_row, opz_row = et.pair_mlp(z_row, *args)
+        o_til, ob_til, opz_til = et.pair_mlp(z_til, *args, out_layout="tiled")
+        assert torch.equal(ops.pair_untiled(o_til), o_row) and torch.equal(ob_til, ob_row) and torch.equal(opz_til, opz_row)
+        o_mix, _, _ = et.pair_mlp(z_til, *args)                          # tiled in, row-major out
+        assert torch.equal(o_mix, o_row)
+        o_none, ob_none, opz_none = et.pair_mlp(z_row, *args, out_layout="none")
+        assert o_none is None and torch.equal(ob_none, ob_row) and torch.equal(opz_none, opz_row)
+        plain = et.pair_mlp(ops.pair_tiled(z_row), args[0], args[1], mask, None, out_layout="tiled")   # without the fused projection
+        assert torch.equal(ops.pair_untiled(plain), et.pair_mlp(z_row, args[0], args[1], mask, None))
+        with pytest.raises(ops.HipLibraryError):
+            et.pair_mlp(z_row, args[0], args[1], mask, None, out_layout="none")
+    with use_arith(net_rough, "f32"), pytest.raises(ops.HipLibraryError):
+        et.pair_mlp(z_til, *args)
+
+
 def test_pair_project_vs_linear(net_rough):
     from str2str_amd import ops
 

@@ -226,3 +226,26 @@ def test_mixed_length_plan_covers_every_replica_once_and_balances():
         assert len(seen) == len(lens) * replicas
         if replicas >= world:
             assert max(loads) <= 1.12 * sum(loads) / world, (replicas, world, loads)
+
+
+def test_pair_tiled_layout_matches_the_header():
+    """ops.pair_tiled / pair_untiled against the formula of include/str2str_hip.h ("Pair-tensor layouts"): channel 8 g + 4 h + q of pair
+    32 b + n at float offset 4096 b + 256 g + 128 h + 4 n + q; whole blocks, zero padding; round trip."""
+    import torch
+
+    from str2str_amd import ops
+
+    for B, N in ((1, 8), (2, 5), (1, 3)):
+        M = B * N * N
+        z = torch.arange(M * 128, dtype=torch.float32).reshape(B, N, N, 128)
+        t = ops.pair_tiled(z)
+        assert t.buf.numel() == -(-M // 32) * 32 * 128 and t.shape == (B, N, N, 128)
+        flat = z.reshape(M, 128)
+        for p in {0, 1, 31, 32, M // 2, M - 1} & set(range(M)):
+            for c in (0, 3, 4, 7, 8, 77, 127):
+                b, n, g, h, q = p // 32, p % 32, c // 8, (c % 8) // 4, c % 4
+                assert t.buf[4096 * b + 256 * g + 128 * h + 4 * n + q] == flat[p, c]
+        assert torch.equal(ops.pair_untiled(t), z)
+        if M % 32:
+            pad = t.buf.view(-1, 16, 2, 32, 4)[-1, :, :, M % 32:, :]
+            assert float(pad.abs().max()) == 0.0

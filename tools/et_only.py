@@ -14,6 +14,7 @@ ap.add_argument("--N", type=int, default=256)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--mode", default="f16x3", choices=["f16x3", "f32"])
 ap.add_argument("--proj", action="store_true")
+ap.add_argument("--layout", default="rowmajor", choices=["rowmajor", "tiled", "none"], help="f16x3: pair-tensor layout (in and out)")
 a = ap.parse_args()
 os.environ["S2S_ARITH"] = a.mode
 from str2str_amd.factory import build_synthetic_net  # noqa: E402
@@ -25,6 +26,14 @@ g = torch.Generator(device="cuda").manual_seed(0)
 node = torch.randn(a.B, a.N, 256, device="cuda", generator=g)
 edge = torch.randn(a.B, a.N, a.N, 128, device="cuda", generator=g)
 mask = torch.ones(a.B, a.N, device="cuda")
+if a.layout != "rowmajor":   # the trunk's chaining: tiled in, tiled (or no) out; per-node parts outside the timed call
+    from str2str_amd import ops
+    n_p, node_ab = et.node_parts(ops.to_act(node.reshape(a.B * a.N, -1).contiguous(), "f16x3"), a.B * a.N)
+    zt = ops.pair_tiled(edge)
+    del edge
+    et = lambda *_, **__: net.translator.trunk["edge_transition_0"].pair_mlp(zt, node_ab.view(a.B, a.N, -1), n_p.view(a.B, a.N, -1), mask,
+                                                                          kw.get("next_proj"), out_layout=a.layout)
+    edge = None
 with torch.no_grad():
     for _ in range(2):
         et(node, edge, edge_mask_1d=mask, **kw)
@@ -37,4 +46,4 @@ with torch.no_grad():
     torch.cuda.synchronize()
 ms = s.elapsed_time(e) / a.iters
 pairs = a.B * a.N * a.N
-print(f"mode={a.mode} proj={a.proj} B={a.B} N={a.N}: {ms:.3f} ms/launch  fp32-equivalent {pairs * 491520 / ms / 1e9:.1f} TFLOP/s")
+print(f"mode={a.mode} proj={a.proj} layout={a.layout} B={a.B} N={a.N}: {ms:.3f} ms/launch  fp32-equivalent {pairs * 491520 / ms / 1e9:.1f} TFLOP/s")
