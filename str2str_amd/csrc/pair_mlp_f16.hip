@@ -70,6 +70,22 @@ __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 3
 // the same materialised fp32 value (node_gemm.hip split8_f16), the block stays where it is written (the schedule pins VALU pieces
 // under specific MFMAs), and the maximum does not enter the compiler's reasoning (as an fmaxf chain it cost 300 spilled registers).
 typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
+// two values -> elements at, at + 1 (at even) of the plane fragments: the unit the edge transition places behind single MFMAs
+__device__ __forceinline__ void split2_f16(float x0, float x1, f16x8& ph, f16x8& pl, int at, float& amax) {
+    unsigned hh, ll;
+    asm volatile(
+        "v_max3_f32 %2, %2, |%3|, |%4|\n\t"
+        "v_cvt_pk_f16_f32 %0, %3, %4\n\t"
+        "v_fma_mixlo_f16 %1, -%0, 1.0, %3 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, -%0, 1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(hh), "=&v"(ll), "+v"(amax)
+        : "v"(x0), "v"(x1));
+    u32x4p hv = __builtin_bit_cast(u32x4p, ph), lv = __builtin_bit_cast(u32x4p, pl);
+    hv[at / 2] = hh;
+    lv[at / 2] = ll;
+    ph = __builtin_bit_cast(f16x8, hv);
+    pl = __builtin_bit_cast(f16x8, lv);
+}
 __device__ __forceinline__ void split4_f16(const float (&x)[4], f16x8& ph, f16x8& pl, int at, float& amax) {
     unsigned h0, h1, l0, l1;
     asm volatile(
@@ -175,6 +191,25 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         lds_char* d = lds_image[par] + (wave * 8192 + 4096);
         *(lds_f4*)(d) = e0; *(lds_f4*)(d + 1024) = e1; *(lds_f4*)(d + 2048) = e2; *(lds_f4*)(d + 3072) = e3;
     };
+    // the same, one 1 KiB piece at a time (k = 0..3): inside the tile loop a piece rides behind a single MFMA
+    auto cp_load_piece = [&](auto grp, auto kc, int stage) {
+        constexpr int k = decltype(kc)::value;
+        const int so = stage * kStageBytes + (decltype(grp)::value ? 4096 : 0);
+        const f32x4 v = ldw(voff + 1024 * k, so);
+        if constexpr (decltype(grp)::value == 0) {
+            if constexpr (k == 0) c0 = v; else if constexpr (k == 1) c1 = v; else if constexpr (k == 2) c2 = v; else c3 = v;
+        } else {
+            if constexpr (k == 0) e0 = v; else if constexpr (k == 1) e1 = v; else if constexpr (k == 2) e2 = v; else e3 = v;
+        }
+    };
+    auto cp_store_piece = [&](auto grp, auto kc, int par) {
+        constexpr int k = decltype(kc)::value;
+        lds_char* d = lds_image[par] + (wave * 8192 + (decltype(grp)::value ? 4096 : 0) + 1024 * k);
+        if constexpr (decltype(grp)::value == 0)
+            *(lds_f4*)(d) = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
+        else
+            *(lds_f4*)(d) = k == 0 ? e0 : (k == 1 ? e1 : (k == 2 ? e2 : e3));
+    };
     cp_load_a(0);
     cp_load_b(0);
 
@@ -276,15 +311,19 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     f32x16 a3[4];
     f32x16 pq[2];      // fused projection accumulators (64 padded output rows)
     float sa[16], sb[16];  // per-node seeds A_i(+b1), B_j of the a1 tile that is split next
-    auto seeds_load = [&](const PairCtx& c, int t) {  // C layout of tile t: register 4rq + e = channel 32t + 8rq + 4h + e
+    // quarter rq of the seeds of tile t (C layout: register 4rq + e = channel 32t + 8rq + 4h + e): A_i + b1 (384 channels) and B_j of
+    // the per-node first-layer halves [B,N,768].  (The j-side rows differ from lane to lane -- 16 B in each of 32 rows per load
+    // instruction.  Reading them from a column-blocked copy [B][96][N][4], 8 cache lines per instruction as in the edge embedding,
+    // was measured: 2 % fewer cycles in the layer-2 blocks, no change in launch time; not worth a second copy of the node vectors.)
+    auto seeds_piece = [&](const PairCtx& c, int t, int rq) {
+        const float4 x = ldg4(node_ab + (unsigned long long)c.bi * 768u + 32 * t, rq, h);
+        const float4 y = ldg4(node_ab + (unsigned long long)c.bj * 768u + 384 + 32 * t, rq, h);
+        sa[4 * rq + 0] = x.x; sa[4 * rq + 1] = x.y; sa[4 * rq + 2] = x.z; sa[4 * rq + 3] = x.w;
+        sb[4 * rq + 0] = y.x; sb[4 * rq + 1] = y.y; sb[4 * rq + 2] = y.z; sb[4 * rq + 3] = y.w;
+    };
+    auto seeds_load = [&](const PairCtx& c, int t) {
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            // A_i + b1 (384 channels) and B_j of the per-node first-layer halves [B,N,768]
-            const float4 x = ldg4(node_ab + (unsigned long long)c.bi * 768u + 32 * t, rq, h);
-            const float4 y = ldg4(node_ab + (unsigned long long)c.bj * 768u + 384 + 32 * t, rq, h);
-            sa[4 * rq + 0] = x.x; sa[4 * rq + 1] = x.y; sa[4 * rq + 2] = x.z; sa[4 * rq + 3] = x.w;
-            sb[4 * rq + 0] = y.x; sb[4 * rq + 1] = y.y; sb[4 * rq + 2] = y.z; sb[4 * rq + 3] = y.w;
-        }
+        for (int rq = 0; rq < 4; ++rq) seeds_piece(c, t, rq);
     };
     seeds_load(cur, 0);
 
@@ -304,12 +343,20 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         for (int j = 0; j < 4; ++j) x[j] = fmaxf(__builtin_fmaf(tile_acc[4 * qd + j], kInvWS, sa[4 * qd + j] + sb[4 * qd + j]), 0.f);
         split4(x, xp[qd >> 1][0], xp[qd >> 1][1], 4 * (qd & 1));
     };
-    float rs[64];  // one 128-channel residual row in accumulator layout
-    auto row_load = [&](const float* r) {
+    // the same in two halves (values 2hh, 2hh+1 of the quarter): 10 VALU instructions, small enough to sit behind one MFMA
+    auto s_half = [&](const f32x16& tile_acc, auto qc, auto hc) {
+        constexpr int qd = decltype(qc)::value, j0 = 4 * qd + 2 * decltype(hc)::value;
+        const float x0 = fmaxf(__builtin_fmaf(tile_acc[j0], kInvWS, sa[j0] + sb[j0]), 0.f);
+        const float x1 = fmaxf(__builtin_fmaf(tile_acc[j0 + 1], kInvWS, sa[j0 + 1] + sb[j0 + 1]), 0.f);
+        split2_f16(x0, x1, xp[qd >> 1][0], xp[qd >> 1][1], 4 * (qd & 1) + 2 * decltype(hc)::value, amax);
+    };
+    // residual rows n'_i (block 1) and n'_j (block 2) of  x = [e | n'_i | n'_j]  in accumulator layout, two 16 B groups per call
+    float rs[64], rs2[64];
+    auto row_load2 = [&](const float* r, float (&dst)[64], int g0) {
 #pragma unroll
-        for (int g = 0; g < 16; ++g) {
+        for (int g = g0; g < g0 + 2; ++g) {
             const float4 v = ldg4(r, g, h);
-            rs[4 * g + 0] = v.x; rs[4 * g + 1] = v.y; rs[4 * g + 2] = v.z; rs[4 * g + 3] = v.w;
+            dst[4 * g + 0] = v.x; dst[4 * g + 1] = v.y; dst[4 * g + 2] = v.z; dst[4 * g + 3] = v.w;
         }
     };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -371,6 +418,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     PairCtx nxt = cur;  // next tile's context, edge row and planes: produced under the last 16 slots of this tile
     float4 xv[16];
     f16x8 xpn[8][2];
+    f16x8 xq[8][2];   // final-layer input planes of k-steps 8..15 (block 1 of the layer-2 epilogue)
     static_for<0, kSlots>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         constexpr SlotDesc d = slot_desc(s);
@@ -409,96 +457,94 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         if constexpr (s == 240) ET_STAMP(13);
 #endif
 
-        // ---------------- top of the slot: next slot's fragments, weight copy, loads that land under later slots
-        // weight pipe: group A of stage+2 is loaded at slot 4 and stored after slot 1 of the next stage (5 slots later);
-        // group B of stage+1 is loaded at slot 0 and stored after slot 5.  Both land in the buffer this stage's
-        // predecessor used, which is free from that stage's barrier (top of its slot 7) on.
+        // ---------------- top of the slot: next slot's fragments, loads that land under later slots
         if constexpr (ss < 7) {
             fetch(par, ss + 1, fr[(s + 1) & 1]);
         } else {
             S2S_LDS_BARRIER();
             fetch(par ^ 1, 0, fr[(s + 1) & 1]);
         }
-        // next tile: context + edge row at the start of the last final-layer block, seeds of its tile 0 near the end
+        // next tile: context + edge row under the middle final-layer block, seeds of its tile 0 near the end
         // (the edge row in pieces: a burst of 16 loads per wave holds the slot for ~2 k cycles -- the workgroup's 64 KiB through one
         //  address unit -- and whatever waits next on the in-order counter waits for all of it.  Two loads per slot, in slots whose
         //  next counter wait (the weight store 4+ slots later) is at least 6 slots away: HBM latency fits in between.)
-#ifndef S2S_ET_XV0
-#define S2S_ET_XV0 208
-#endif
-        if constexpr (s == S2S_ET_XV0) nxt = setup(has_next ? wt_next : wt);
-        if constexpr (s > S2S_ET_XV0 && s <= S2S_ET_XV0 + 16 && ((s & 3) == 1 || (s & 3) == 2)) {
-            constexpr int i = 4 * ((s - S2S_ET_XV0) / 4) + 2 * ((s & 3) - 1);   // 2 loads in each of the slots ss = 1, 2, 5, 6 of two stages
+        constexpr int kXv0 = 208;
+        if constexpr (s == kXv0) nxt = setup(has_next ? wt_next : wt);
+        if constexpr (s > kXv0 && s <= kXv0 + 16 && ((s & 3) == 1 || (s & 3) == 2)) {
+            constexpr int i = 4 * ((s - kXv0) / 4) + 2 * ((s & 3) - 1);   // 2 loads in each of the slots ss = 1, 2, 5, 6 of two stages
             const float* er = erow_of(nxt);
             xv[i] = ldrow(er, i);
             xv[i + 1] = ldrow(er, i + 1);
         }
         if constexpr (s == 236) seeds_load(nxt, 0);
-        // seeds of a1 tile t+1 are fetched early in B_t, in a slot without weight-pipe work (consumed under A_{t+2}, 10+ slots later; the
-        // slot-by-slot probe showed a fetch 3 slots ahead of its use costing ~300 cycles at the fetch and ~300 at the use)
-        if constexpr (d.phase == 1 && d.a == 1 && d.b == 0 && d.t + 1 < 12) seeds_load(cur, d.t + 1);
+        // seeds of a1 tile t+1 are fetched in the middle of B_t, in a slot without weight-pipe work (consumed under A_{t+2}, 6+ slots
+        // later; a fetch 3 slots ahead of its use cost ~300 cycles at the fetch and ~300 at the use: tools/et_phase_probe.py --block)
+        constexpr bool seeds_slot = d.phase == 1 && d.a == 1 && d.b == 0 && d.t + 1 < 12;   // a quarter behind each of its first 4 MFMAs
+        // residual rows of the layer-2 epilogue blocks 1 (n'_i, under B_11) and 2 (n'_j, under the first final-layer block)
+        if constexpr (s >= 184 && s < 192) row_load2(node_p + (unsigned long long)cur.bi * 128u, rs, 2 * (s - 184));
+        if constexpr (s >= 200 && s < 208) row_load2(node_p + (unsigned long long)cur.bj * 128u, rs2, 2 * (s - 200));
+        // bias of this slot's epilogue piece (below)
+        constexpr int ep_blk = (s >= 192 && s < 224) ? 1 + (s - 192) / 16 : 0, ep_q = (s - 192) % 16;
+        float4 ep_b = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (ep_blk != 0) ep_b = ldg4(s_vec + 128 * ep_blk, ep_q, h);
         __builtin_amdgcn_sched_barrier(0);
 
-        // ---------------- the 12 MFMAs
+        // ---------------- the 6 MFMAs, each followed by at most one piece of the weight pipe and one small VALU piece, pinned there
+        // (slot-by-slot probe: a slot of bare MFMAs runs at the matrix pipe's 192 cycles; weight-pipe instructions issued as a block
+        //  in front of / behind the MFMAs cost 60-120 cycles per slot, a 20-instruction VALU block behind the first MFMA ~100):
+        //   weight pipe  group B of stage+1 loaded in slot 0 and stored in slot 5, group A of stage+2 loaded in slot 4 and stored in
+        //                slot 1 of the next stage, one 1 KiB piece behind each of MFMAs 0..3; both land in the buffer this stage's
+        //                predecessor used, free from that stage's barrier (top of its slot 7) on;
+        //   A_t          relu + seeds + split of a1 tile t-1, half a quarter (2 values) behind MFMAs 2 and 4;
+        //   final layer  slots 192..223: the layer-2 epilogue  relu(a2 + b2) + x,  x = [e | n'_i | n'_j]  (layers.py:181) of blocks 1 and
+        //                2, one 4-value piece per slot in two halves -- block 1 into the planes xq while k-steps 0..7 read xpl, block 2 into
+        //                xpl while k-steps 8..15 read xq;  slots 228..235: split of the next tile's edge row, four halves per slot.
         const f16x8 (&f)[4] = fr[s & 1];
-        if constexpr (d.phase == 0) {
-            f32x16& acc = a1t[d.t & 1];
-            const f16x8 (&x0)[2] = xpl[2 * d.a], (&x1)[2] = xpl[2 * d.a + 1];
-            if constexpr (d.a == 0) acc = mfma_f16(f[1], x0[0], zero16); else acc = mfma_f16(f[1], x0[0], acc);  // W_l x_h
-            acc = mfma_f16(f[0], x0[1], acc);  // W_h x_l
-            acc = mfma_f16(f[0], x0[0], acc);  // W_h x_h
-            acc = mfma_f16(f[3], x1[0], acc);
-            acc = mfma_f16(f[2], x1[1], acc);
-            acc = mfma_f16(f[2], x1[0], acc);
-            // under A_t: relu + seeds + split of tile t-1, a quarter per slot
-            if constexpr (d.t >= 1) s_quarter(a1t[(d.t - 1) & 1], IC<d.a>{});
-        } else if constexpr (d.phase == 3) {
-            const f16x8 (&x)[2] = xpl[d.a];
-            f32x16 &t0 = pq[0], &t1 = pq[1];
-            if constexpr (d.a == 0) {
-                t0 = mfma_f16(f[1], x[0], zero16); t1 = mfma_f16(f[3], x[0], zero16);
+        auto mfma_i = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (d.phase == 0) {
+                f32x16& acc = a1t[d.t & 1];
+                const f16x8 (&x)[2] = xpl[2 * d.a + (i >= 3)];
+                constexpr int fa = (i == 0 ? 1 : (i < 3 ? 0 : (i == 3 ? 3 : 2))), xa = (i == 1 || i == 4) ? 1 : 0;   // W_l x_h, W_h x_l, W_h x_h
+                if constexpr (d.a == 0 && i == 0) acc = mfma_f16(f[fa], x[xa], zero16); else acc = mfma_f16(f[fa], x[xa], acc);
             } else {
-                t0 = mfma_f16(f[1], x[0], t0); t1 = mfma_f16(f[3], x[0], t1);
+                constexpr bool fin = d.phase == 2, prj = d.phase == 3;
+                constexpr bool first = i < 2 && (prj ? d.a == 0 : (fin ? d.a == 0 : (d.t == 0 && d.a == 0)));
+                f32x16& t = prj ? pq[i & 1] : (fin ? a3[2 * d.b + (i & 1)] : a2[2 * d.b + (i & 1)]);
+                const f16x8 (&x)[2] = prj ? xpl[d.a] : (fin ? ((d.a >> 3) == 1 ? xq[d.a & 7] : xpl[d.a & 7]) : xp[d.a]);
+                constexpr int fa = 2 * (i & 1) + (i < 2 ? 1 : 0), xa = (i == 2 || i == 3) ? 1 : 0;                   // W_l x_h, W_h x_l, W_h x_h
+                if constexpr (first) t = mfma_f16(f[fa], x[xa], zero16); else t = mfma_f16(f[fa], x[xa], t);
             }
-            t0 = mfma_f16(f[0], x[1], t0); t1 = mfma_f16(f[2], x[1], t1);
-            t0 = mfma_f16(f[0], x[0], t0); t1 = mfma_f16(f[2], x[0], t1);
-        } else {
-            constexpr bool fin = d.phase == 2;
-            constexpr bool first = fin ? d.a == 0 : (d.t == 0 && d.a == 0);
-            f32x16& t0 = fin ? a3[2 * d.b] : a2[2 * d.b];
-            f32x16& t1 = fin ? a3[2 * d.b + 1] : a2[2 * d.b + 1];
-            const f16x8 (&x)[2] = fin ? xpl[d.a & 7] : xp[d.a];
-            if constexpr (first) {
-                t0 = mfma_f16(f[1], x[0], zero16); t1 = mfma_f16(f[3], x[0], zero16);
-            } else {
-                t0 = mfma_f16(f[1], x[0], t0); t1 = mfma_f16(f[3], x[0], t1);  // W_l x_h
+        };
+        auto ep_half = [&](auto hc) {   // values 2hh, 2hh+1 of piece (block ep_blk, tile t, quarter rq)
+            constexpr int hh = decltype(hc)::value, t = ep_q / 4, rq = ep_q % 4, j0 = 4 * rq + 2 * hh;
+            const f32x16& a = a2[4 * ep_blk + t];
+            const float (&row)[64] = ep_blk == 1 ? rs : rs2;
+            const float x0 = fmaxf(__builtin_fmaf(a[j0], kInvWS, hh ? ep_b.z : ep_b.x), 0.f) + row[16 * t + j0];
+            const float x1 = fmaxf(__builtin_fmaf(a[j0 + 1], kInvWS, hh ? ep_b.w : ep_b.y), 0.f) + row[16 * t + j0 + 1];
+            f16x8 (&P)[2] = ep_blk == 1 ? xq[2 * t + (rq >> 1)] : xpl[2 * t + (rq >> 1)];
+            split2_f16(x0, x1, P[0], P[1], 4 * (rq & 1) + 2 * hh, amax);
+        };
+        static_for<0, 6>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            mfma_i(ic);
+            if constexpr (i < 4) {
+                if constexpr (ss == 0) cp_load_piece(IC<1>{}, ic, (stage + 1) % kStages);   // the pipe wraps into the next tile's stages 0, 1
+                if constexpr (ss == 4) cp_load_piece(IC<0>{}, ic, (stage + 2) % kStages);
+                if constexpr (ss == 1) cp_store_piece(IC<0>{}, ic, par ^ 1);
+                if constexpr (ss == 5) cp_store_piece(IC<1>{}, ic, par ^ 1);
             }
-            t0 = mfma_f16(f[0], x[1], t0); t1 = mfma_f16(f[2], x[1], t1);  // W_h x_l
-            t0 = mfma_f16(f[0], x[0], t0); t1 = mfma_f16(f[2], x[0], t1);  // W_h x_h
-        }
-        if constexpr (s >= 228 && s < 236) {  // split of the next tile's edge row, one k-step per slot
-            constexpr int i = s - 228;
-            const float x0[4] = {xv[2 * i].x, xv[2 * i].y, xv[2 * i].z, xv[2 * i].w};
-            const float x1[4] = {xv[2 * i + 1].x, xv[2 * i + 1].y, xv[2 * i + 1].z, xv[2 * i + 1].w};
-            split4(x0, xpn[i][0], xpn[i][1], 0);
-            split4(x1, xpn[i][0], xpn[i][1], 4);
-        }
-        // weight pipe, one instruction behind each of the first four MFMAs (as a block in front of / behind the slot's MFMAs the four
-        // loads cost ~60 cycles and the four LDS stores ~120: the slot-by-slot probe, tools/et_phase_probe.py --block)
-        if constexpr (ss == 0) cp_load_b((stage + 1) % kStages);   // the pipe wraps into the next tile's stages 0, 1
-        if constexpr (ss == 4) cp_load_a((stage + 2) % kStages);
-        if constexpr (ss == 1) cp_store_a(par ^ 1);
-        if constexpr (ss == 5) cp_store_b(par ^ 1);
-        if constexpr (ss == 0 || ss == 4 || ss == 1 || ss == 5) {
-            constexpr int kind = (ss == 0 || ss == 4) ? 0x020 : 0x200;   // VMEM read | DS write
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(kind, 1, 0);
+            if constexpr (seeds_slot && i < 4) seeds_piece(cur, d.t + 1, i);
+            if constexpr (d.phase == 0 && d.t >= 1 && (i == 2 || i == 4)) s_half(a1t[(d.t - 1) & 1], IC<d.a>{}, IC<(i - 2) / 2>{});
+            if constexpr (ep_blk != 0 && (i == 2 || i == 4)) ep_half(IC<(i - 2) / 2>{});
+            if constexpr (s >= 228 && s < 236 && i >= 1 && i <= 4) {   // next tile's edge row: k-step s - 228, elements 2(i-1), 2(i-1)+1
+                constexpr int k = s - 228, e = 2 * (i - 1);
+                const float4 v = xv[2 * k + (e >> 2)];
+                if constexpr ((e & 2) == 0) split2_f16(v.x, v.y, xpn[k][0], xpn[k][1], e, amax);
+                else split2_f16(v.z, v.w, xpn[k][0], xpn[k][1], e, amax);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
 
         // ---------------- exposed steps
 #if defined(S2S_ET_PROBE) && S2S_ET_PROBE == 2
@@ -514,9 +560,6 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         if constexpr (s == 179) {  // B_10 done: tile 11 -> planes (nothing left to hide it under)
             s_quarter(a1t[1], IC<0>{}); s_quarter(a1t[1], IC<1>{}); s_quarter(a1t[1], IC<2>{}); s_quarter(a1t[1], IC<3>{});
         }
-        // Layer-2 epilogue + split, one 128-channel block (= 8 final-layer k-steps) at a time, right before the final
-        // layer consumes it:  relu(a2 + b2) + x,  x = [e | n'_i | n'_j]  (layers.py:181), in accumulator layout, split
-        // while the values are in VGPRs into the plane registers the edge row used during layers 1-2.
         if constexpr (PROJ && s == 239) {
             // LayerNorm output (stored, and kept in a3) -> planes of the 8 projection k-steps (chain order)
             ln_epilogue();
@@ -528,28 +571,24 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
                     split4(x, xpl[2 * t + (rq >> 1)][0], xpl[2 * t + (rq >> 1)][1], 4 * (rq & 1));
                 }
         }
-        if constexpr (s == 191 || s == 207 || s == 223) {
-            constexpr int pb = (s - 191) / 16;
-            if constexpr (pb == 0) {  // residual block 0 = the edge row itself = x_h + x_l of its planes (to 2^-24 |x|)
-#pragma unroll
-                for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        rs[8 * ks + j] = (float)xpl[ks][0][j] + (float)xpl[ks][1][j];
-            }
+        // Layer-2 epilogue, block 0 (= final-layer k-steps 0..7), right before the final layer: relu(a2 + b2) + e, in accumulator layout,
+        // split in place into the plane registers the edge row used during layers 1-2 -- whose exact sum x_h + x_l (to 2^-24 |x|) is the
+        // residual row: no second read of e.  (Blocks 1 and 2 follow under the final layer's own MFMAs, above.)
+        if constexpr (s == 191) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
-                    const float4 bq = ldg4(s_vec + 128 * pb, 4 * t + rq, h);
-                    const f32x16& a = a2[4 * pb + t];
-                    const float x[4] = {fmaxf(__builtin_fmaf(a[4 * rq + 0], kInvWS, bq.x), 0.f) + rs[16 * t + 4 * rq + 0],
-                                        fmaxf(__builtin_fmaf(a[4 * rq + 1], kInvWS, bq.y), 0.f) + rs[16 * t + 4 * rq + 1],
-                                        fmaxf(__builtin_fmaf(a[4 * rq + 2], kInvWS, bq.z), 0.f) + rs[16 * t + 4 * rq + 2],
-                                        fmaxf(__builtin_fmaf(a[4 * rq + 3], kInvWS, bq.w), 0.f) + rs[16 * t + 4 * rq + 3]};
-                    split4(x, xpl[2 * t + (rq >> 1)][0], xpl[2 * t + (rq >> 1)][1], 4 * (rq & 1));
+                    const float4 bq = ldg4(s_vec, 4 * t + rq, h);
+                    const f32x16& a = a2[t];
+                    f16x8 (&P)[2] = xpl[2 * t + (rq >> 1)];
+                    const int e0 = 4 * (rq & 1);
+                    const float x[4] = {fmaxf(__builtin_fmaf(a[4 * rq + 0], kInvWS, bq.x), 0.f) + ((float)P[0][e0 + 0] + (float)P[1][e0 + 0]),
+                                        fmaxf(__builtin_fmaf(a[4 * rq + 1], kInvWS, bq.y), 0.f) + ((float)P[0][e0 + 1] + (float)P[1][e0 + 1]),
+                                        fmaxf(__builtin_fmaf(a[4 * rq + 2], kInvWS, bq.z), 0.f) + ((float)P[0][e0 + 2] + (float)P[1][e0 + 2]),
+                                        fmaxf(__builtin_fmaf(a[4 * rq + 3], kInvWS, bq.w), 0.f) + ((float)P[0][e0 + 3] + (float)P[1][e0 + 3])};
+                    split4(x, P[0], P[1], e0);
                 }
-            if constexpr (pb < 2) row_load(node_p + (unsigned long long)(pb == 0 ? cur.bi : cur.bj) * 128u);  // lands under the next 16 slots
         }
     });
 

@@ -337,7 +337,8 @@ def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, m
     io = (1 if in_tiled else 0) | {"rowmajor": 0, "tiled": 2, "none": 4}[out_layout]
     range_flag()
     _check(_timed("s2s_edge_transition", lambda: lib.s2s_edge_transition_f16x3(
-        _p(edge.buf if in_tiled else edge), _p(node_ab), _p(node_p), _p(wstream), _p(b2), _p(bf), _p(gamma), _p(beta), _p(mask),
+        _p(edge.buf if in_tiled else edge), _p(node_ab), _p(node_p), _p(wstream), _p(b2), _p(bf), _p(gamma), _p(beta),
+        _p(mask),
         _p(out.buf if isinstance(out, PairTiled) else out), B, N, ln_eps, io, _p(pb), _p(pbias), _p(ppz), _stream())),
         "s2s_edge_transition_f16x3")
     return out if proj is None else (out, pbias, ppz)
