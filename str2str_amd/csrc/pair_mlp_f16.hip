@@ -116,7 +116,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 // slot s of the schedule: phase 0 = A (layer 1), 1 = B (layer 2), 2 = F (final layer)
-struct SlotDesc { int phase, t, a, b; };  // A: tile t, a = k-step pair 0..3;  B: tile t, a = u (k-step 2t+u), b = tile pair 0..5;
+struct SlotDesc { int phase, t, a, b; };  // A: tile t, a = k-step pair 0..3;  B: tile t, a = u (k-step 2t+u), b = tile pair 0..5 (B_11: pair-major);
                                           // F: a = k-step 0..23, b = tile pair 0..1
 constexpr SlotDesc slot_desc(int s) {
     if (s < 8) return {0, s / 4, s % 4, 0};
@@ -125,10 +125,9 @@ constexpr SlotDesc slot_desc(int s) {
         if (o < 12) return {1, blk, o / 6, o % 6};
         return {0, blk + 2, o - 12, 0};
     }
-    if (s < 192) {
-        const int tau = s - 168;
-        return {1, 10 + tau / 12, (tau % 12) / 6, tau % 6};
-    }
+    if (s < 180) return {1, 10, (s - 168) / 6, (s - 168) % 6};
+    if (s < 192) return {1, 11, (s - 180) % 2, (s - 180) / 2};   // B_11 tile-pair major: output tiles 2b, 2b+1 are complete after slot 181 + 2b
+
     if (s < 240) return {2, 0, (s - 192) / 2, (s - 192) % 2};
     return {3, 0, s - 240, 0};  // P: fused projection k-step s - 240 (both output tiles)
 }
@@ -136,10 +135,12 @@ constexpr SlotDesc slot_desc(int s) {
 #define S2S_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 __device__ float s2s_one[1] = {1.0f};   // stands in for an absent node mask (read with stride 0)
 
-#ifdef S2S_ET_PROBE
+#if defined(S2S_ET_PROBE) || defined(S2S_EE_PROBE)
 // Phase probe (tools/et_phase_probe.py): s_memtime stamps at 16 points of a tile, wave 0 of every workgroup, differences summed
 // per workgroup.  The stamps are SMEM results consumed only after the tile's last lgkmcnt(0) wait.
 __device__ unsigned long long g_et_probe[512 * 17];
+#endif
+#ifdef S2S_ET_PROBE
 #define ET_STAMP(k) asm volatile("s_memtime %0" : "=s"(st##k))
 #else
 #define ET_STAMP(k)
@@ -483,10 +484,12 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         // residual rows of the layer-2 epilogue blocks 1 (n'_i, under B_11) and 2 (n'_j, under the first final-layer block)
         if constexpr (s >= 184 && s < 192) row_load2(node_p + (unsigned long long)cur.bi * 128u, rs, 2 * (s - 184));
         if constexpr (s >= 200 && s < 208) row_load2(node_p + (unsigned long long)cur.bj * 128u, rs2, 2 * (s - 200));
-        // bias of this slot's epilogue piece (below)
-        constexpr int ep_blk = (s >= 192 && s < 224) ? 1 + (s - 192) / 16 : 0, ep_q = (s - 192) % 16;
-        float4 ep_b = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (ep_blk != 0) ep_b = ldg4(s_vec + 128 * ep_blk, ep_q, h);
+        // bias of this slot's layer-2 epilogue pieces (below): block 0 two pieces per slot under the second half of B_11, blocks 1 and 2 one
+        constexpr int ep_blk = (s >= 184 && s < 192) ? 0 : ((s >= 192 && s < 224) ? 1 + (s - 192) / 16 : -1);
+        constexpr int ep_q = ep_blk == 0 ? 2 * (s - 184) : (s - 192) % 16;
+        float4 ep_b = {0.f, 0.f, 0.f, 0.f}, ep_b1 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (ep_blk >= 0) ep_b = ldg4(s_vec + 128 * ep_blk, ep_q, h);
+        if constexpr (ep_blk == 0) ep_b1 = ldg4(s_vec, ep_q + 1, h);
         __builtin_amdgcn_sched_barrier(0);
 
         // ---------------- the 6 MFMAs, each followed by at most one piece of the weight pipe and one small VALU piece, pinned there
@@ -496,9 +499,12 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         //                slot 1 of the next stage, one 1 KiB piece behind each of MFMAs 0..3; both land in the buffer this stage's
         //                predecessor used, free from that stage's barrier (top of its slot 7) on;
         //   A_t          relu + seeds + split of a1 tile t-1, half a quarter (2 values) behind MFMAs 2 and 4;
-        //   final layer  slots 192..223: the layer-2 epilogue  relu(a2 + b2) + x,  x = [e | n'_i | n'_j]  (layers.py:181) of blocks 1 and
-        //                2, one 4-value piece per slot in two halves -- block 1 into the planes xq while k-steps 0..7 read xpl, block 2 into
-        //                xpl while k-steps 8..15 read xq;  slots 228..235: split of the next tile's edge row, four halves per slot.
+        //   layer-2 epilogue  relu(a2 + b2) + x,  x = [e | n'_i | n'_j]  (layers.py:181), in accumulator layout, in 4-value pieces of two
+        //                halves: block 0 (its tiles are complete after slot 183: B_11 runs tile-pair major) two pieces per slot under
+        //                slots 184..191, in place into the planes the edge row used during layers 1-2 -- whose exact sum x_h + x_l is the
+        //                residual row e; block 1 one piece per slot under the final layer's k-steps 0..7 (slots 192..207) into the
+        //                planes xq, block 2 under k-steps 8..15 (which read xq) back into xpl;
+        //   slots 228..235  split of the next tile's edge row, four halves per slot.
         const f16x8 (&f)[4] = fr[s & 1];
         auto mfma_i = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -516,14 +522,24 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
                 if constexpr (first) t = mfma_f16(f[fa], x[xa], zero16); else t = mfma_f16(f[fa], x[xa], t);
             }
         };
-        auto ep_half = [&](auto hc) {   // values 2hh, 2hh+1 of piece (block ep_blk, tile t, quarter rq)
-            constexpr int hh = decltype(hc)::value, t = ep_q / 4, rq = ep_q % 4, j0 = 4 * rq + 2 * hh;
-            const f32x16& a = a2[4 * ep_blk + t];
-            const float (&row)[64] = ep_blk == 1 ? rs : rs2;
-            const float x0 = fmaxf(__builtin_fmaf(a[j0], kInvWS, hh ? ep_b.z : ep_b.x), 0.f) + row[16 * t + j0];
-            const float x1 = fmaxf(__builtin_fmaf(a[j0 + 1], kInvWS, hh ? ep_b.w : ep_b.y), 0.f) + row[16 * t + j0 + 1];
+        // (cutting a half once more -- arithmetic behind one MFMA, split behind the next -- measured 0.7 % slower: a VALU instruction costs
+        //  its ~5 cycles wherever it sits; what remains to gain is fewer of them)
+        auto ep_half = [&](auto qc, auto hc, const float4& bq) {   // values 2hh, 2hh+1 of piece q = (tile t, quarter rq) of block ep_blk
+            constexpr int q = decltype(qc)::value, hh = decltype(hc)::value, t = q / 4, rq = q % 4, j0 = 4 * rq + 2 * hh, e0 = 4 * (rq & 1) + 2 * hh;
+            const f32x16& a = a2[4 * (ep_blk < 0 ? 0 : ep_blk) + t];
             f16x8 (&P)[2] = ep_blk == 1 ? xq[2 * t + (rq >> 1)] : xpl[2 * t + (rq >> 1)];
-            split2_f16(x0, x1, P[0], P[1], 4 * (rq & 1) + 2 * hh, amax);
+            float r0, r1;
+            if constexpr (ep_blk == 0) {   // the residual of block 0 is the edge row = x_h + x_l of the planes this piece replaces (to 2^-24 |x|)
+                r0 = (float)P[0][e0] + (float)P[1][e0];
+                r1 = (float)P[0][e0 + 1] + (float)P[1][e0 + 1];
+            } else {
+                const float (&row)[64] = ep_blk == 1 ? rs : rs2;
+                r0 = row[16 * t + j0];
+                r1 = row[16 * t + j0 + 1];
+            }
+            const float x0 = fmaxf(__builtin_fmaf(a[j0], kInvWS, hh ? bq.z : bq.x), 0.f) + r0;
+            const float x1 = fmaxf(__builtin_fmaf(a[j0 + 1], kInvWS, hh ? bq.w : bq.y), 0.f) + r1;
+            split2_f16(x0, x1, P[0], P[1], e0, amax);
         };
         static_for<0, 6>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -536,7 +552,10 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             }
             if constexpr (seeds_slot && i < 4) seeds_piece(cur, d.t + 1, i);
             if constexpr (d.phase == 0 && d.t >= 1 && (i == 2 || i == 4)) s_half(a1t[(d.t - 1) & 1], IC<d.a>{}, IC<(i - 2) / 2>{});
-            if constexpr (ep_blk != 0 && (i == 2 || i == 4)) ep_half(IC<(i - 2) / 2>{});
+            if constexpr (ep_blk > 0 && (i == 2 || i == 4)) ep_half(IC<ep_q>{}, IC<(i - 2) / 2>{}, ep_b);
+            if constexpr (ep_blk == 0 && i >= 1 && i <= 4) {   // pieces ep_q (halves behind MFMAs 1, 2) and ep_q + 1 (3, 4)
+                if constexpr (i <= 2) ep_half(IC<ep_q>{}, IC<i - 1>{}, ep_b); else ep_half(IC<ep_q + 1>{}, IC<i - 3>{}, ep_b1);
+            }
             if constexpr (s >= 228 && s < 236 && i >= 1 && i <= 4) {   // next tile's edge row: k-step s - 228, elements 2(i-1), 2(i-1)+1
                 constexpr int k = s - 228, e = 2 * (i - 1);
                 const float4 v = xv[2 * k + (e >> 2)];
@@ -569,25 +588,6 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
                 for (int rq = 0; rq < 4; ++rq) {
                     const float x[4] = {a3[t][4 * rq + 0], a3[t][4 * rq + 1], a3[t][4 * rq + 2], a3[t][4 * rq + 3]};
                     split4(x, xpl[2 * t + (rq >> 1)][0], xpl[2 * t + (rq >> 1)][1], 4 * (rq & 1));
-                }
-        }
-        // Layer-2 epilogue, block 0 (= final-layer k-steps 0..7), right before the final layer: relu(a2 + b2) + e, in accumulator layout,
-        // split in place into the plane registers the edge row used during layers 1-2 -- whose exact sum x_h + x_l (to 2^-24 |x|) is the
-        // residual row: no second read of e.  (Blocks 1 and 2 follow under the final layer's own MFMAs, above.)
-        if constexpr (s == 191) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const float4 bq = ldg4(s_vec, 4 * t + rq, h);
-                    const f32x16& a = a2[t];
-                    f16x8 (&P)[2] = xpl[2 * t + (rq >> 1)];
-                    const int e0 = 4 * (rq & 1);
-                    const float x[4] = {fmaxf(__builtin_fmaf(a[4 * rq + 0], kInvWS, bq.x), 0.f) + ((float)P[0][e0 + 0] + (float)P[1][e0 + 0]),
-                                        fmaxf(__builtin_fmaf(a[4 * rq + 1], kInvWS, bq.y), 0.f) + ((float)P[0][e0 + 1] + (float)P[1][e0 + 1]),
-                                        fmaxf(__builtin_fmaf(a[4 * rq + 2], kInvWS, bq.z), 0.f) + ((float)P[0][e0 + 2] + (float)P[1][e0 + 2]),
-                                        fmaxf(__builtin_fmaf(a[4 * rq + 3], kInvWS, bq.w), 0.f) + ((float)P[0][e0 + 3] + (float)P[1][e0 + 3])};
-                    split4(x, P[0], P[1], e0);
                 }
         }
     });
@@ -933,9 +933,28 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
     Ctx nxt = cur;
     Raw nraw;
     f16x8 xl[2];  // the next tile's last k-step (xp[7] is read by the final layer's last slot)
+#ifdef S2S_EE_PROBE
+    unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0, st7 = 0, st8 = 0, st9 = 0, st10 = 0, st11 = 0, st12 = 0,
+                       st13 = 0, st14 = 0, st15 = 0;
+#define EE_STAMP(k) asm volatile("s_memtime %0" : "=s"(st##k))
+#else
+#define EE_STAMP(k)
+#endif
     static_for<0, kSlots>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         constexpr int stage = s / 8, ss = s % 8, par = stage & 1;
+        if constexpr (s == 0) EE_STAMP(0);
+        if constexpr (s == 4) EE_STAMP(1);
+        if constexpr (s == 8) EE_STAMP(2);
+        if constexpr (s == 12) EE_STAMP(3);
+        if constexpr (s == 16) EE_STAMP(4);
+        if constexpr (s == 20) EE_STAMP(5);
+        if constexpr (s == 24) EE_STAMP(6);
+        if constexpr (s == 28) EE_STAMP(7);
+        if constexpr (s == 31) EE_STAMP(8);
+        if constexpr (s == 32) EE_STAMP(10);
+        if constexpr (s == 36) EE_STAMP(11);
+        if constexpr (s == 39) EE_STAMP(12);
         constexpr int layer = s / 16;             // 0: layer 2, 1: layer 3, 2: projection
         constexpr int ks = layer < 2 ? (s % 16) / 2 : s - 32;
         constexpr int pr = layer < 2 ? s % 2 : 0;
@@ -1009,6 +1028,7 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
         __builtin_amdgcn_sched_barrier(0);
 
         // ---------------- exposed steps
+        if constexpr (s == 31) EE_STAMP(9);
         if constexpr (s == 31) {  // layer-3 output (bias included): LayerNorm statistics
             float sum = 0.f;
 #pragma unroll
@@ -1032,6 +1052,7 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
             }
         }
     });
+    EE_STAMP(13);
     if constexpr (PROJ) {
         if (cur.valid) {
             const float4 b0 = ldg4(s_vec + 512, 0, h);
@@ -1050,6 +1071,17 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
             }
         }
     }
+#ifdef S2S_EE_PROBE
+    EE_STAMP(14);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (PROJ && wave == 0 && lane == 0 && blockIdx.x < 512) {
+        unsigned long long* pr = g_et_probe + blockIdx.x * 17;
+        const unsigned long long stv[16] = {st0, st1, st2, st3, st4, st5, st6, st7, st8, st9, st10, st11, st12, st13, st14, st14};
+#pragma unroll
+        for (int k = 0; k < 14; ++k) atomicAdd(pr + k, stv[k + 1] - stv[k]);
+        atomicAdd(pr + 16, 1ull);
+    }
+#endif
     if (!has_next) break;
     cur = nxt;
     wt = wt_next;
@@ -1122,7 +1154,7 @@ extern "C" int s2s_edge_transition_f16x3(const float* edge, const float* node_ab
     return (int)hipGetLastError();
 }
 
-#ifdef S2S_ET_PROBE
+#if defined(S2S_ET_PROBE) || defined(S2S_EE_PROBE)
 extern "C" int s2s_et_probe_read(unsigned long long* host_out, int reset) {   // 512 x 17 counters
     hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_et_probe), sizeof(unsigned long long) * 512 * 17);
     if (e == hipSuccess && reset) {

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 _lib = None
 _tables_loaded = False
@@ -240,7 +240,8 @@ def pack_f16x3_stream(w1_edge: torch.Tensor, w2: torch.Tensor, wf: torch.Tensor)
     """The weight stream of s2s_edge_transition_f16x3 as int16: 240 slots of 4 fragments ((W_h, W_l) of two (k-step, tile) units;
     8 slots = one 32 KiB stage, 30 stages) in the kernel's consumption order (csrc/pair_mlp_f16.hip):
       A_t (4 slots): layer-1 output tile t, k-step pairs (2s, 2s+1), fragments [k-step][plane];
-      B_t (12 slots): layer-2 k-steps 2t + u (u = 0, 1) x output tile pairs 0..5, fragments [tile][plane];
+      B_t (12 slots): layer-2 k-steps 2t + u (u = 0, 1) x output tile pairs 0..5, fragments [tile][plane]; B_11 pair-major
+                      (pair b, then u): its first output tiles are complete early and their epilogue runs under the rest;
       F  (48 slots): final layer k-steps 0..23 x tile pairs 0..1;
     order  A_0 A_1 | B_0 A_2 | B_1 A_3 | ... | B_9 A_11 | B_10 B_11 | F."""
     l1, l2, lf = pack_f16x2_layer(w1_edge), pack_f16x2_layer(w2), pack_f16x2_layer(wf)
@@ -249,7 +250,8 @@ def pack_f16x3_stream(w1_edge: torch.Tensor, w2: torch.Tensor, wf: torch.Tensor)
     pieces = [A(0), A(1)]
     for t in range(10):
         pieces += [B(t), A(t + 2)]
-    pieces += [B(10), B(11), lf]
+    b11 = B(11)
+    pieces += [B(10), b11.reshape(2, 6, 2, *b11.shape[2:]).transpose(0, 1), lf]   # B_11 tile-pair major (slots: pair b, then k-step u)
     blob = torch.cat([x.contiguous().reshape(-1) for x in pieces]).view(torch.int16).contiguous()
     assert blob.numel() * 2 == 30 * 32 * 1024, blob.numel()
     return blob

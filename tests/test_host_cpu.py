@@ -129,7 +129,9 @@ def test_f16x3_weight_split_and_stream_layout():
     assert torch.equal(st[4 + 3], l1[6:8, 1].reshape(4, 64, 8))         # A_1 slot 3
     assert torch.equal(st[8 + 7], l2[1, 2:4].reshape(4, 64, 8))         # B_0 slot (u = 1, pair 1): k-step 1, tiles 2, 3
     assert torch.equal(st[8 + 12 + 1], l1[2:4, 2].reshape(4, 64, 8))    # A_2 slot 1 follows B_0
-    assert torch.equal(st[168 + 12 + 6], l2[23, 0:2].reshape(4, 64, 8))  # B_11 (u = 1, pair 0): k-step 2*11+1
+    assert torch.equal(st[168 + 7], l2[21, 2:4].reshape(4, 64, 8))       # B_10 (u = 1, pair 1): k-step major like every B_t but the last
+    assert torch.equal(st[180 + 1], l2[23, 0:2].reshape(4, 64, 8))       # B_11 is tile-pair major: slot 2 b + u = (pair b, k-step 22 + u)
+    assert torch.equal(st[180 + 6], l2[22, 6:8].reshape(4, 64, 8))
     assert torch.equal(st[192 + 2 * 5 + 1], lf[5, 2:4].reshape(4, 64, 8))  # final layer k-step 5, tiles 2, 3
     assert ops.pack_f16x3_embed_stream(torch.randn(128, 128, generator=g), torch.randn(128, 128, generator=g)).numel() * 2 == 4 * 32 * 1024
     assert ops.pack_node_weight(torch.randn(256, 320, generator=g), 8).numel() == 256 * 320 * 2

@@ -12,7 +12,8 @@ fixed = torch.zeros(B, N, device="cuda")
 mask = torch.ones(B, N, device="cuda")
 t_emb = net.embedder.time_embed(torch.full((1,), 0.5)).to("cuda")
 proj = net.translator.trunk["ipa_0"].pair_proj_weights()
-run = lambda: net.embedder(idx, None, fixed, ca, node_mask=mask, next_proj=proj, t_emb=t_emb)
+layout = os.environ.get("EE_LAYOUT", "rowmajor")   # rowmajor | tiled (what the network passes to its first EdgeTransition)
+run = lambda: net.embedder(idx, None, fixed, ca, node_mask=mask, next_proj=proj, t_emb=t_emb, edge_layout=layout)
 with torch.no_grad():
     for _ in range(3):
         run()
@@ -24,4 +25,4 @@ with torch.no_grad():
         run()
     e1.record()
     torch.cuda.synchronize()
-print(os.environ.get("STR2STR_HIP_LIB", "main").split("/")[-1], "embedder ms:", round(e0.elapsed_time(e1) / iters, 3))
+print(os.environ.get("STR2STR_HIP_LIB", "main").split("/")[-1], layout, "embedder ms:", round(e0.elapsed_time(e1) / iters, 3))
