@@ -13,7 +13,7 @@ python - <<PY
 import csv, glob, json, collections
 B, N = $B, $N
 pairs = B * N * N
-names = {"edge_transition_f16": ("edge_transition_f16x3", 1024 + 160), "edge_transition_kernel": ("edge_transition", 1024),
+names = {"edge_transition_f16": ("edge_transition_f16x3", (2 * (1024 + 160) + 512 + 160) / 3),   # the trunk's three launches (tools/kernel_bench.py) "edge_transition_kernel": ("edge_transition", 1024),
          "edge_embed_f16_kernel": ("edge_embed_f16x3", 512 + 160), "edge_embed_kernel": ("edge_embed", 512 + 160),
          "pair_project_kernel": ("pair_project", 672), "ipa_attention_f16w_kernel": ("ipa_attention", None),
          "ipa_opair_kernel": ("ipa_opair", None)}
