@@ -199,6 +199,9 @@ __device__ __forceinline__ void node_epilogue(f32x16 (&acc)[TG], const GemmArgs&
 // are then exactly the A fragment (k-step u) of a later  Z^T[col, i] += Y^T[col, row] P^T[row, i]  product over the rows, i.e. of
 // the attention's PV step with rows = keys (csrc/ipa_attention.hip).  The epilogue adds the bias, splits and stores them as
 //   out_vf[row tile][head][column tile in head][k-step u][plane 2][lane 64][8]   (f16 pairs; 1 KiB per (u, plane), lane-linear)
+#ifdef S2S_NODE_PROBE
+__device__ unsigned long long g_node_probe[8];
+#endif
 template <int TG, int WAVES, bool VF>
 __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
     // One weight stage = ONE k-step (TG tiles x 2 planes = 2 TG KiB), double buffered: 4 TG KiB of LDS and <= 256 registers, so
@@ -208,6 +211,10 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
     constexpr int kStage = 2 * TG * 1024;
     constexpr int kFrags = 2 * TG;                          // 1 KiB pieces per stage
     constexpr int kPieces = (kFrags + WAVES - 1) / WAVES;   // per wave
+#ifdef S2S_NODE_PROBE
+    unsigned long long probe_t0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(probe_t0)::"memory");
+#endif
     extern __shared__ __attribute__((aligned(16))) char s_w[];  // 2 stages
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar branches below
@@ -326,18 +333,38 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
         for (int p = 0; p < 2; ++p) { const f16x8 t = xa[p]; xa[p] = xc[p]; xb[p] = t; }
     }
 #else
+#ifdef S2S_NODE_PROBE
+    // phase probe (tools/node_gemm_probe.py): s_memtime at the kernel's start, before / after the k loop and, inside it, around compute,
+    // the weight copy and the barrier of the even k-steps; wave 0 of every workgroup, sums per launch in g_node_probe
+    unsigned long long p_loop, p_a = 0, p_b = 0, p_c = 0, p_d = 0, acc_cmp = 0, acc_cp = 0, acc_bar = 0;
+#define NP(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x)::"memory")
+    NP(p_loop);
+#else
+#define NP(x)
+#endif
     for (int ks = 0; ks < KS; ks += 2) {
         x_load(ks + 1, xb);
+        NP(p_a);
         compute(0, xa);
+        NP(p_b);
         w_store(1);                 // k-step ks + 1 (loaded one stage ago) -> buffer 1 (last read two barriers ago)
         w_load(ks + 2);
+        NP(p_c);
         __syncthreads();
+        NP(p_d);
+#ifdef S2S_NODE_PROBE
+        acc_cmp += p_b - p_a; acc_cp += p_c - p_b; acc_bar += p_d - p_c;
+#endif
         x_load(ks + 2, xa);
         compute(1, xb);
         w_store(0);
         w_load(ks + 3);
         __syncthreads();
     }
+#ifdef S2S_NODE_PROBE
+    unsigned long long p_end;
+    NP(p_end);
+#endif
 #endif
 
     float amax = 0.f;   // range guard: largest magnitude written as planes
@@ -366,6 +393,20 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
         return;
     }
     node_epilogue<TG>(acc, a, rt, n_rt, lane, cb, ps);
+#ifdef S2S_NODE_PROBE
+    unsigned long long p_fin;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(p_fin)::"memory");
+    if (threadIdx.x == 0) {
+        atomicAdd(&g_node_probe[0], p_loop - probe_t0);   // prologue
+        atomicAdd(&g_node_probe[1], acc_cmp);             // compute, even k-steps
+        atomicAdd(&g_node_probe[2], acc_cp);              // weight store + load issue
+        atomicAdd(&g_node_probe[3], acc_bar);             // barrier
+        atomicAdd(&g_node_probe[4], p_end - p_loop);      // whole k loop
+        atomicAdd(&g_node_probe[5], p_fin - p_end);       // epilogue incl. its stores
+        atomicAdd(&g_node_probe[6], 1ull);
+        atomicAdd(&g_node_probe[7], (unsigned long long)KS);
+    }
+#endif
 }
 
 // fp32 row-major [M, ld] (columns col0 .. col0 + 16 KS) -> packed planes at k-step offset ks0 of an XP buffer with xp_KS k-steps.
@@ -554,3 +595,14 @@ extern "C" int s2s_node_linear_vfrag(const void* xp, const void* w_packed, const
                map_src};
     return launch_gemm_w<TG, 4, true>(a, (hipStream_t)stream);
 }
+
+#ifdef S2S_NODE_PROBE
+extern "C" int s2s_node_probe_read(unsigned long long* host_out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_node_probe), sizeof(unsigned long long) * 8);
+    if (e == hipSuccess && reset) {
+        static unsigned long long z[8];
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_node_probe), z, sizeof(z));
+    }
+    return (int)e;
+}
+#endif

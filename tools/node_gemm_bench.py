@@ -11,6 +11,7 @@ from str2str_amd import ops  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--M", type=int, default=32768)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--tg", type=int, default=0, help="force tiles per column block where the shape allows it (0: ops.node_tiles)")
 a = ap.parse_args()
 M = a.M
 dev = "cuda"
@@ -35,6 +36,8 @@ for K, N, whole in [(256, 4096, False), (256, 2048, False), (256, 480 + 32, Fals
     w = torch.randn(N, K, device=dev) / K ** 0.5
     b = torch.randn(N, device=dev)
     tg = ops.node_tiles(N, whole_row=whole)
+    if a.tg and not whole and (N // 32) % a.tg == 0:
+        tg = a.tg
     wpk = ops.pack_node_weight(w, tg)
     xp = ops.pack_planes(x)
     out = torch.empty(M, N, device=dev)
