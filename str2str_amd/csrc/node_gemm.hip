@@ -50,25 +50,39 @@ __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 3
 
 constexpr float kInvWS = 1.0f / 32.0f;   // weights are packed as the split of 2^5 w: accumulators carry 32 x the output
 
-// planes of the node stream: (x_h, x_l), see the header
-__device__ __forceinline__ void split8_f16(const float* v, f16x8& ph, f16x8& pl) {
+// planes of the node stream: (x_h, x_l), see the header.  8 values -> the two 16 B plane fragments, 64 fragments apart, and into the
+// caller's range maximum.  The split as in csrc/pair_mlp_f16.hip (split4_f16): x_h = rn16(x) two per v_cvt_pk_f16_f32, x_l = rn16(x - x_h)
+// as ONE v_fma_mixlo / mixhi_f16 that reads x_h as f16 ((-x_h) * 1.0 + x is exact in fp32), the maximum as v_max3_f32 with |.| -- 2
+// instructions per value; hipcc's expansion of the C expressions is 6 (convert, convert back, subtract, convert, pack, max), and this
+// epilogue is what the K = 256 layers spend most of their time in.  One opaque block per 4 values: both planes come from the same
+// materialised fp32 value (with fp contraction the compiler otherwise derives x_h and x_l from DIFFERENT fused forms of the producing
+// expression, and near an f16 rounding tie the pair then misses x by a whole f16 ulp).
+__device__ __forceinline__ void split8_f16(const float* v, f16x8& ph, f16x8& pl, float& amax) {
+    typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+    u32x4s hv, lv;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        // materialise the value first: with fp contraction the compiler otherwise derives x_h and x_l from DIFFERENT fused forms of
-        // the producing expression (v_fma_mix straight to f16 vs a product rounded to fp32 first), and near an f16 rounding tie the
-        // pair then misses x by a whole f16 ulp (seen in the attention kernels' output planes: 6 of 393 k elements off by 1e-4)
-        float xv = v[j];
-        asm volatile("" : "+v"(xv));
-        const _Float16 a = (_Float16)xv;
-        ph[j] = a; pl[j] = (_Float16)(xv - (float)a);
+    for (int q = 0; q < 2; ++q) {
+        unsigned h0, h1, l0, l1;
+        asm volatile(
+            "v_max3_f32 %4, %4, |%5|, |%6|\n\t"
+            "v_cvt_pk_f16_f32 %0, %5, %6\n\t"
+            "v_max3_f32 %4, %4, |%7|, |%8|\n\t"
+            "v_cvt_pk_f16_f32 %1, %7, %8\n\t"
+            "v_fma_mixlo_f16 %2, -%0, 1.0, %5 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixlo_f16 %3, -%1, 1.0, %7 op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %2, -%0, 1.0, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+            "v_fma_mixhi_f16 %3, -%1, 1.0, %8 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+            : "=&v"(h0), "=&v"(h1), "=&v"(l0), "=&v"(l1), "+v"(amax)
+            : "v"(v[4 * q]), "v"(v[4 * q + 1]), "v"(v[4 * q + 2]), "v"(v[4 * q + 3]));
+        hv[2 * q] = h0; hv[2 * q + 1] = h1;
+        lv[2 * q] = l0; lv[2 * q + 1] = l1;
     }
+    ph = __builtin_bit_cast(f16x8, hv);
+    pl = __builtin_bit_cast(f16x8, lv);
 }
-// 8 values -> the two 16 B plane fragments (x_h, x_l), 64 fragments apart; the values feed the caller's range maximum
 __device__ __forceinline__ void store_planes(f16x8* q, const float* v, float& amax) {
     f16x8 ph, pl;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) amax = range_max(amax, v[j]);
-    split8_f16(v, ph, pl);
+    split8_f16(v, ph, pl, amax);
     q[0] = ph; q[64] = pl;
 }
 

@@ -44,8 +44,9 @@ for K, N, whole in [(256, 4096, False), (256, 2048, False), (256, 480 + 32, Fals
     oxp = ops.xp_alloc(M, N, dev)
     t_own = timeit(lambda: ops.node_linear(xp, wpk, b, M, K, N, tg, out_f32=out, out_xp=oxp), a.iters)
     t_f32only = timeit(lambda: ops.node_linear(xp, wpk, b, M, K, N, tg, out_f32=out), a.iters)
+    t_xponly = timeit(lambda: ops.node_linear(xp, wpk, b, M, K, N, tg, out_xp=oxp), a.iters)
     t_blas = timeit(lambda: torch.nn.functional.linear(x, w, b), a.iters)
     t_pack = timeit(lambda: ops.pack_planes(x, out=xp), a.iters)
     fl = 2.0 * M * K * N
-    print(f"K={K:5d} N={N:5d} TG={tg:2d}: own {t_own*1e3:7.1f} us ({fl/t_own/1e9:6.1f} TF-eq)  f32-out only {t_f32only*1e3:7.1f} us  "
+    print(f"K={K:5d} N={N:5d} TG={tg:2d}: own {t_own*1e3:7.1f} us ({fl/t_own/1e9:6.1f} TF-eq)  f32-out only {t_f32only*1e3:7.1f} us  planes only {t_xponly*1e3:7.1f} us  "
           f"rocBLAS {t_blas*1e3:7.1f} us ({fl/t_blas/1e9:6.1f} TF)  pack_planes(x) {t_pack*1e3:6.1f} us", flush=True)
