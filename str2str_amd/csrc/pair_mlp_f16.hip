@@ -943,6 +943,18 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
     static_for<0, kSlots>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         constexpr int stage = s / 8, ss = s % 8, par = stage & 1;
+#if defined(S2S_EE_PROBE) && S2S_EE_PROBE == 2   // slot by slot: tops of slots BASE .. BASE + 14
+#ifndef S2S_EE_PROBE_BASE
+#define S2S_EE_PROBE_BASE 0
+#endif
+        if constexpr (s >= S2S_EE_PROBE_BASE && s < S2S_EE_PROBE_BASE + 15) {
+            constexpr int k = s - S2S_EE_PROBE_BASE;
+            if constexpr (k == 0) EE_STAMP(0); if constexpr (k == 1) EE_STAMP(1); if constexpr (k == 2) EE_STAMP(2); if constexpr (k == 3) EE_STAMP(3);
+            if constexpr (k == 4) EE_STAMP(4); if constexpr (k == 5) EE_STAMP(5); if constexpr (k == 6) EE_STAMP(6); if constexpr (k == 7) EE_STAMP(7);
+            if constexpr (k == 8) EE_STAMP(8); if constexpr (k == 9) EE_STAMP(9); if constexpr (k == 10) EE_STAMP(10); if constexpr (k == 11) EE_STAMP(11);
+            if constexpr (k == 12) EE_STAMP(12); if constexpr (k == 13) EE_STAMP(13); if constexpr (k == 14) EE_STAMP(14);
+        }
+#else
         if constexpr (s == 0) EE_STAMP(0);
         if constexpr (s == 4) EE_STAMP(1);
         if constexpr (s == 8) EE_STAMP(2);
@@ -955,6 +967,7 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
         if constexpr (s == 32) EE_STAMP(10);
         if constexpr (s == 36) EE_STAMP(11);
         if constexpr (s == 39) EE_STAMP(12);
+#endif
         constexpr int layer = s / 16;             // 0: layer 2, 1: layer 3, 2: projection
         constexpr int ks = layer < 2 ? (s % 16) / 2 : s - 32;
         constexpr int pr = layer < 2 ? s % 2 : 0;
@@ -1028,7 +1041,9 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
         __builtin_amdgcn_sched_barrier(0);
 
         // ---------------- exposed steps
+#if !(defined(S2S_EE_PROBE) && S2S_EE_PROBE == 2)
         if constexpr (s == 31) EE_STAMP(9);
+#endif
         if constexpr (s == 31) {  // layer-3 output (bias included): LayerNorm statistics
             float sum = 0.f;
 #pragma unroll
@@ -1052,7 +1067,9 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
             }
         }
     });
+#if !(defined(S2S_EE_PROBE) && S2S_EE_PROBE == 2)
     EE_STAMP(13);
+#endif
     if constexpr (PROJ) {
         if (cur.valid) {
             const float4 b0 = ldg4(s_vec + 512, 0, h);
@@ -1072,7 +1089,9 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
         }
     }
 #ifdef S2S_EE_PROBE
+#if S2S_EE_PROBE != 2
     EE_STAMP(14);
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (PROJ && wave == 0 && lane == 0 && blockIdx.x < 512) {
         unsigned long long* pr = g_et_probe + blockIdx.x * 17;

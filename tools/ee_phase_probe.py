@@ -1,5 +1,5 @@
 """Where does a tile of the edge-embedding kernel spend its cycles?  Needs the probe build:
-    bash tools/build_variant.sh eeprobe -DS2S_EE_PROBE
+    bash tools/build_variant.sh eeprobe -DS2S_EE_PROBE=1
     STR2STR_HIP_LIB=str2str_amd/csrc/build/ab_eeprobe.so python tools/ee_phase_probe.py
 (s_memtime stamps at the tops of slots 0, 4, .. of a 40-slot tile, wave 0 of every workgroup; see tools/et_phase_probe.py)."""
 import ctypes
@@ -14,6 +14,7 @@ from str2str_amd import ops  # noqa: E402
 from str2str_amd.factory import build_synthetic_net  # noqa: E402
 
 B, N = 128, 256
+BASE = int(os.environ.get("EE_PROBE_BASE", "-1"))   # >= 0: library built with -DS2S_EE_PROBE=2 -DS2S_EE_PROBE_BASE=<base>: slots base .. base + 13
 lib = ops.load_library()
 lib.s2s_et_probe_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 net = build_synthetic_net(device="cuda")
@@ -43,6 +44,8 @@ names = [("layer 2, slots 0-3", 4), ("layer 2, slots 4-7", 4), ("layer 2, slots 
          ("layer 3, slots 20-23", 4), ("layer 3, slots 24-27", 4), ("layer 3, slots 28-30", 3), ("slot 31 up to its exposed step", 1),
          ("exposed: LayerNorm statistics + first piece", 0), ("projection, slots 32-35", 4), ("projection, slots 36-38", 3), ("slot 39", 1),
          ("projection stores", 0)]
+if BASE >= 0:
+    names = [(f"slot {BASE + k}", 1) for k in range(14)]
 tot = per.sum()
 print(f"{int(tiles)} probed tiles; {tot:.0f} counter ticks per tile (40 slots: {40 * 192} at the matrix pipe's rate)")
 for (n, slots), v in zip(names, per):
