@@ -1,12 +1,10 @@
 #!/bin/bash
-# instruction-fetch counters of one kernel:  tools/pmc_icache.sh <tag> <kernel-name-substring> -- <command...>
-TAG=$1; KN=$2; shift 3
+# tools/pmc_icache.sh <kernel-name-substring> -- <command...> : instruction-fetch counters of one kernel (is straight-line code fetch-bound?)
+KN=$1; shift 2
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/pmc_$TAG; mkdir -p $OUT
+OUT=gpurun_out/pmc_icache; rm -rf $OUT; mkdir -p $OUT
 i=0
-for grp in "SQ_IFETCH SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VALU" \
-           "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" \
-           "SQ_IFETCH_LEVEL SQ_WAIT_IFETCH SQ_INST_LEVEL_LDS SQ_WAVES"; do
+for grp in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_WAVE_CYCLES" "SQ_IFETCH SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVES" "SQC_ICACHE_MISSES_DUPLICATE SQ_INSTS_VALU SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_ANY"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/g$i -- "$@" > $OUT/g$i.log 2>&1 || tail -3 $OUT/g$i.log
 done
