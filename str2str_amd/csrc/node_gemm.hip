@@ -113,6 +113,8 @@ struct GemmArgs {
                              // attention kernel wants for ragged lengths (padded rows repeat the sample's last row: finite, masked there)
 };
 
+__device__ float s2s_zero[512];   // stands in for an absent bias / residual row (a column block is at most 320 wide)
+
 // Epilogue shared by the f16x3 and the fp32 kernel.  Lane (row m = lane & 31, half h): register r of tile t = column
 // 32 t + (r&3) + 8 (r>>2) + 4 h.   v = acc * ps + bias;  relu;  v *= pre_mask[row];  v += residual;  LayerNorm;  v *= post_mask[row]
 template <int TG>
@@ -124,28 +126,37 @@ __device__ __forceinline__ void node_epilogue(f32x16 (&acc)[TG], const GemmArgs&
     const long long rowc = valid ? row : a.M - 1;
     const float pm = a.pre_mask ? a.pre_mask[rowc] : 1.0f;
     const int col_base = cb * TG * 32;
-    #pragma unroll
-    for (int t = 0; t < TG; ++t)
+    // The per-column / per-row operands of a tile are requested ONE TILE AHEAD of their use.  Written the obvious way (`if (a.bias)
+    // load` inside the loop) every one of the 32 (tile, quarter) iterations was load, s_waitcnt vmcnt(0), use -- and at 256
+    // registers the compiler serialises even unconditional loads through one temporary: up to 64 exposed L2 round trips, more time
+    // than the whole k loop of the K = 256 layers (tools/node_gemm_probe.py).  Absent operands read a block of zeros.
+    const float* bias_p = a.bias ? a.bias + col_base + 4 * h : s2s_zero + 4 * h;
+    const float* res_p = a.residual ? a.residual + rowc * a.res_ld + col_base + 4 * h : s2s_zero + 4 * h;
+    float4 qb[2][4], qr[2][4];
+    auto fetch4 = [&](const float* p, int t, float4 (&q)[4]) {
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) q[rq] = *reinterpret_cast<const float4*>(p + 32 * t + 8 * rq);
+    };
+    fetch4(bias_p, 0, qb[0]);
+    fetch4(res_p, 0, qr[0]);
+    const bool relu = a.relu != 0;
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+        if (t + 1 < TG) {
+            fetch4(bias_p, t + 1, qb[(t + 1) & 1]);
+            fetch4(res_p, t + 1, qr[(t + 1) & 1]);
+        }
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-            const int c0 = col_base + 32 * t + 8 * rq + 4 * h;
-            float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.bias) b = *reinterpret_cast<const float4*>(a.bias + c0);
+            const float4 b = qb[t & 1][rq], rr = qr[t & 1][rq];
             float v[4] = {acc[t][4 * rq + 0] * ps + b.x, acc[t][4 * rq + 1] * ps + b.y, acc[t][4 * rq + 2] * ps + b.z,
                           acc[t][4 * rq + 3] * ps + b.w};
-            if (a.relu) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= pm;
-            if (a.residual) {
-                const float4 rr = *reinterpret_cast<const float4*>(a.residual + rowc * a.res_ld + c0);
-                v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t][4 * rq + e] = v[e];
+            for (int e = 0; e < 4; ++e) v[e] = relu ? fmaxf(v[e], 0.f) : v[e];
+            acc[t][4 * rq + 0] = v[0] * pm + rr.x; acc[t][4 * rq + 1] = v[1] * pm + rr.y;
+            acc[t][4 * rq + 2] = v[2] * pm + rr.z; acc[t][4 * rq + 3] = v[3] * pm + rr.w;
         }
+    }
     if (a.ln_gamma) {  // LayerNorm over the TG*32 columns of the row (half here, half in lane ^ 32)
         float sum = 0.f;
 #pragma unroll
@@ -162,17 +173,23 @@ __device__ __forceinline__ void node_epilogue(f32x16 (&acc)[TG], const GemmArgs&
                 var += d * d;
             }
         const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / (TG * 32)) + a.ln_eps);
+        fetch4(a.ln_gamma + col_base + 4 * h, 0, qb[0]);
+        fetch4(a.ln_beta + col_base + 4 * h, 0, qr[0]);
 #pragma unroll
-        for (int t = 0; t < TG; ++t)
+        for (int t = 0; t < TG; ++t) {
+            if (t + 1 < TG) {
+                fetch4(a.ln_gamma + col_base + 4 * h, t + 1, qb[(t + 1) & 1]);
+                fetch4(a.ln_beta + col_base + 4 * h, t + 1, qr[(t + 1) & 1]);
+            }
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                const int c0 = col_base + 32 * t + 8 * rq + 4 * h;
-                const float4 g = *reinterpret_cast<const float4*>(a.ln_gamma + c0), be = *reinterpret_cast<const float4*>(a.ln_beta + c0);
+                const float4 g = qb[t & 1][rq], be = qr[t & 1][rq];
                 acc[t][4 * rq + 0] = (acc[t][4 * rq + 0] - mean) * rstd * g.x + be.x;
                 acc[t][4 * rq + 1] = (acc[t][4 * rq + 1] - mean) * rstd * g.y + be.y;
                 acc[t][4 * rq + 2] = (acc[t][4 * rq + 2] - mean) * rstd * g.z + be.z;
                 acc[t][4 * rq + 3] = (acc[t][4 * rq + 3] - mean) * rstd * g.w + be.w;
             }
+        }
     }
     if (a.post_mask) {
         const float q = a.post_mask[rowc];
@@ -385,10 +402,16 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
     if constexpr (VF) {
         // lane (column c = lane & 31 of tile t, half h): register r = row (r&3) + 8 (r>>2) + 4 h of the wave's row tile
         if (rt < n_rt) {
+            // (the column biases of all tiles up front and unconditional, as in node_epilogue: not one exposed load per tile)
+            const float* bias_col = a.bias ? a.bias + (lane & 31) : s2s_zero;
+            const int bias_step = a.bias ? 32 : 0;
+            float bvs[TG];
+#pragma unroll
+            for (int t = 0; t < TG; ++t) bvs[t] = bias_col[bias_step * (cb * TG + t)];
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
                 const int T = cb * TG + t;
-                const float bv = a.bias ? a.bias[32 * T + (lane & 31)] : 0.f;
+                const float bv = bvs[t];
                 f16x8* o = a.out_vf + ((((rt * (a.n_col_blocks * TG / a.vf_tiles_per_head) + T / a.vf_tiles_per_head) * a.vf_tiles_per_head +
                                          T % a.vf_tiles_per_head) * 2) * 2) * 64 + lane;
 #pragma unroll
