@@ -20,22 +20,32 @@
 // Schedule.  One wave owns 32 pairs; the 4 waves of a workgroup share the weight stream (30 stages of 32 KiB, double buffered in
 // LDS).  A stage is 8 SLOTS of 6 MFMAs / 4 A fragments.  Per pair tile (240 slots):
 //   A_t  (4 slots)  layer-1 output tile t (32 of the 384 hidden channels) over the 8 k-steps of the 128 edge channels;
-//                   the edge row is split once into 8 x 2 f16 plane registers, so A_t is pure MFMA work.
+//                   the edge row is split once into 8 x 2 f16 plane registers.
 //   B_t  (12 slots) layer-2 k-steps 2t, 2t+1 (= the 32 channels of a1 tile t) into all 12 output tiles; the 192
-//                   layer-2 accumulators stay resident, a1 is never materialised beyond two tiles.
-//   order: A_0 A_1 | B_0 A_2 | B_1 A_3 | ... | B_9 A_11 | B_10 B_11 | final layer (48 slots, k-step major).
-//   The ReLU + per-node seeds + split of a1 tile t (VALU) runs under A_{t+1}; the final layer's input (ReLU + residual +
-//   split) is produced block-wise (8 k-steps) in three exposed steps -- hiding it under the final layer's own MFMAs measured
-//   slower.  Every activation is split exactly once (microbenchmark tools/ubench/mfma_fill.hip: at most 5 independent VALU issue
-//   slots hide under one 32-cycle MFMA, a dependent one or a v_accvgpr_read costs 8 cycles, one v_pk_add_f32 costs 18).
-//   C->B chaining as in pair_mlp.hip: element j of lane (pair, g) in k-step 2t'+u is accumulator register 8u+j of
-//   tile t' (row 32t' + (r&3) + 8(r>>2) + 4g); the host packs A fragments in that k order (ops.pack_f16x3_stream).
+//                   layer-2 accumulators stay resident, a1 is never materialised beyond two tiles.  B_11 runs tile-pair major
+//                   (its first output tiles are complete early), every other B_t k-step major.
+//   order: A_0 A_1 | B_0 A_2 | B_1 A_3 | ... | B_9 A_11 | B_10 B_11 | final layer (48 slots, k-step major) [| projection, 8 slots].
+//   A slot = six MFMAs, each followed by at most one 1 KiB piece of the weight pipe and one small VALU piece, pinned there by
+//   sched_barrier (the slot body in the kernel has the table).  Found with the in-kernel probe (-DS2S_ET_PROBE, tools/
+//   et_phase_probe.py): a slot of bare MFMAs runs at the matrix pipe's 192 cycles; the four loads / four LDS stores of the weight
+//   pipe issued as a block cost 60 / 120 cycles, a 20-instruction VALU block behind one MFMA ~100.  So:
+//     - the ReLU + per-node seeds + split of a1 tile t-1 runs in 2-value halves behind MFMAs 2 and 4 of the A_t slots;
+//     - the layer-2 epilogue (ReLU + residual + split = the final layer's input) runs in 4-value pieces: block 0 under the second
+//       half of B_11, block 1 under the final layer's k-steps 0..7 into a second plane buffer, block 2 under k-steps 8..15;
+//     - the next tile's edge row is requested two loads per slot over two stages (a 16-load burst held its slot for 2.4 k cycles) and
+//       split in halves under the last final-layer block; its per-node seeds a quarter behind each of four MFMAs;
+//     - what stays exposed: tile 11 of layer 1 -> planes (0.4 k cycles) and LayerNorm + store (5.2 k of a tile's 78 k).
+//   Every activation is split exactly once.  C->B chaining as in pair_mlp.hip: element j of lane (pair, g) in k-step 2t'+u is
+//   accumulator register 8u+j of tile t' (row 32t' + (r&3) + 8(r>>2) + 4g); the host packs A fragments in that k order and in the
+//   slot order above (ops.pack_f16x3_stream; part of the ABI version).
 //   Weight pipe: this wave's quarter of the next stage travels global -> VGPR -> LDS in two halves, each loaded (buffer
 //   loads: SGPR base + constant lane offset) five slots before it is stored; the workgroup barrier sits at the top
 //   of the last slot of a stage, after which the next stage's first fragments are fetched one slot ahead.
-//   Workgroups are persistent (one per CU); the next tile's edge row, seeds and weight stages are prefetched under the
-//   last final-layer block.  With the fused projection (PROJ) the stream has a 31st stage and the two LDS buffers swap
-//   roles after every tile (odd stage count).
+//   Workgroups are persistent (one per CU).  With the fused projection (PROJ) the stream has a 31st stage and the two LDS buffers
+//   swap roles after every tile (odd stage count).
+// Pair-tensor layouts: row-major [B,N,N,128] (the reference's) or TILED on either side (include/str2str_hip.h): a lane owns one pair,
+//   so on row-major rows every load / store instruction touches 32 B in each of 32 cache lines; tiled, 8 whole lines.  The last
+//   EdgeTransition of a trunk writes no pair tensor at all (io_layout bit 2).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
