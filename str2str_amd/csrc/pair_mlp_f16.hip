@@ -936,12 +936,14 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
     S2S_LDS_BARRIER();
     fetch(0, 0, fr[0]);
     f32x16 initA0 = bias16(s_vec, 0), initA1 = bias16(s_vec, 1), initB0, initB1;
+    // per-pair scalars (CA coordinates, residue indices, masks) of the tile after this one: requested a whole tile ahead -- used four
+    // slots after the request they cost the tile ~1.2 k cycles of waiting (tools/ee_phase_probe.py, slot 4)
+    Raw nraw = setup_a(wt + gridDim.x < n_wt ? wt + gridDim.x : wt);
 
     for (;;) {
     const long long wt_next = wt + gridDim.x;
     const bool has_next = wt_next < n_wt;
     Ctx nxt = cur;
-    Raw nraw;
     f16x8 xl[2];  // the next tile's last k-step (xp[7] is read by the final layer's last slot)
 #ifdef S2S_EE_PROBE
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0, st7 = 0, st8 = 0, st9 = 0, st10 = 0, st11 = 0, st12 = 0,
@@ -1022,8 +1024,8 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
         }
         t0 = mfma_f16(f[0], x[1], t0); t1 = mfma_f16(f[2], x[1], t1);      // W_h x_l
         t0 = mfma_f16(f[0], x[0], t0); t1 = mfma_f16(f[2], x[0], t1);      // W_h x_h
-        if constexpr (s == 0) nraw = setup_a(has_next ? wt_next : wt);
-        if constexpr (s == 4) nxt = setup_b(nraw);
+        if constexpr (s == 1) nxt = setup_b(nraw);                                                        // the next tile's context
+        if constexpr (s == 26) nraw = setup_a(wt_next + gridDim.x < n_wt ? wt_next + gridDim.x : wt_next);   // requests for the tile after it
         if constexpr (s == 12) row_add(1.0f);     // a + b   (same association as the fp32 kernel: ((a + b) + r) + kb k)
         if constexpr (s == 17) row_add(1.0f);     // + relative-position row
         if constexpr (s == 22) row_add(nxt.kb);   // + distogram row
