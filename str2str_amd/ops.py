@@ -311,8 +311,7 @@ def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, m
     in_tiled = isinstance(edge, PairTiled)
     if out_layout not in ("rowmajor", "tiled", "none") or (out_layout == "none" and proj is None):
         raise HipLibraryError(f"edge_transition_f16x3: out_layout {out_layout!r}" + (" needs proj" if out_layout == "none" else ""))
-    if not in_tiled:
-        _req(edge, name="edge")
+    _req(edge.buf if in_tiled else edge, name="edge")
     if tuple(edge.shape) != (B, N, N, 128) or node_ab.shape != (B, N, 768) or node_p.shape != (B, N, 128):
         raise HipLibraryError("edge_transition_f16x3: bad shapes")
     for n, t in (("node_ab", node_ab), ("node_p", node_p), ("b2", b2), ("bf", bf), ("gamma", gamma), ("beta", beta)):
