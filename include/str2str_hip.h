@@ -264,6 +264,11 @@ int s2s_node_linear_vfrag(const void* xp, const void* w_packed, const float* bia
 int s2s_encoder_attention(const float* qkv, const float* key_bias, float* out_f32, void* out_xp, int n_samples, int n_res,
                           int n_heads, int head_dim, void* stream);
 
+/* The same operator on split-f16 MFMA ("f16x3", the default arithmetic): q, k, v and the probabilities as f16 pairs, three products
+ * per block, fp32 softmax and accumulation; q, k, v feed the range guard.  Same arguments. */
+int s2s_encoder_attention_f16x3(const float* qkv, const float* key_bias, float* out_f32, void* out_xp, int n_samples, int n_res,
+                          int n_heads, int head_dim, void* stream);
+
 /* ---- Forward process / prior, once per trajectory ---- */
 
 /* FrameDiffuser.forward_marginal (src/models/score/frame.py:36-107; so3.py:244-272, :315-331, :13-19; r3.py:49-74) or, with

@@ -271,7 +271,8 @@ class TranslationIPA(nn.Module):
             xf, xx = x_f32, x_a
             for layer, lw in zip(T[f"transformer_{b}"].layers, w["layers"]):
                 qkv, _ = lin(xx, lw["in"])
-                sa_f32, sa_xp = ops.encoder_attention(qkv, key_bias, B, N, layer.self_attn.num_heads, want_f32=not f16, want_xp=f16)
+                sa_f32, sa_xp = ops.encoder_attention(qkv, key_bias, B, N, layer.self_attn.num_heads, want_f32=not f16, want_xp=f16,
+                                                      arith=self.arith)
                 x1, x1a = lin(sa_xp if f16 else sa_f32, lw["o"], residual=xf, ln=(layer.norm1.weight, layer.norm1.bias, layer.norm1.eps),
                               want_xp=True)
                 _, ha = lin(x1a, lw["l1"], relu=True, want_f32=False, want_xp=True)

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _lib = None
 _tables_loaded = False
@@ -47,6 +47,7 @@ _SIGNATURES = {
     "s2s_node_linear_f32": [_vp, _i, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _i, _vp],
     "s2s_encoder_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "s2s_encoder_attention_f16x3": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "s2s_ca_sample_stats": [_vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
     "s2s_ca_pwd_js": [_vp, _i, _vp, _i, _i, _i, _i, _d, _vp, _vp],
     "s2s_format_pdb_models": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _ll],
@@ -892,9 +893,10 @@ def node_linear_vfrag(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles_p
 
 
 def encoder_attention(qkv: torch.Tensor, key_bias: Optional[torch.Tensor], n_samples: int, n_res: int, n_heads: int = 4,
-                      want_f32: bool = False, want_xp: bool = True):
+                      want_f32: bool = False, want_xp: bool = True, arith: str = "f32"):
     """Self-attention core of one encoder layer on the in_proj output qkv [B*N, 3*D] -> (fp32 [B*N, D] or None, packed planes or
-    None).  ``key_bias`` [B,N] is added to the logits of key j (None = zeros)."""
+    None).  ``key_bias`` [B,N] is added to the logits of key j (None = zeros).  ``arith``: "f32" = exact fp32 MFMA, "f16x3" = split-f16
+    MFMA (str2str_amd/arith.py)."""
     lib = load_library()
     _req(qkv, name="qkv")
     M, D3 = qkv.shape
@@ -905,10 +907,13 @@ def encoder_attention(qkv: torch.Tensor, key_bias: Optional[torch.Tensor], n_sam
         _req(key_bias, name="key_bias")
     out = torch.empty(M, D, device=qkv.device, dtype=torch.float32) if want_f32 else None
     oxp = xp_alloc(M, D, qkv.device) if want_xp else None
-    if want_xp:
+    if arith not in ("f32", "f16x3"):
+        raise HipLibraryError(f"encoder_attention: arith {arith!r}")
+    if want_xp or arith == "f16x3":
         range_flag()
-    _check(_timed("s2s_encoder_attention", lambda: lib.s2s_encoder_attention(_p(qkv), _p(key_bias), _p(out), _p(oxp), n_samples, n_res,
-                                                                             n_heads, D // n_heads, _stream())), "s2s_encoder_attention")
+    fn = lib.s2s_encoder_attention_f16x3 if arith == "f16x3" else lib.s2s_encoder_attention
+    _check(_timed("s2s_encoder_attention", lambda: fn(_p(qkv), _p(key_bias), _p(out), _p(oxp), n_samples, n_res, n_heads, D // n_heads,
+                                                      _stream())), "s2s_encoder_attention")
     return out, oxp
 
 

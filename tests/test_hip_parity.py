@@ -667,8 +667,9 @@ def test_range_guard_flags_every_f16_producer():
     qp = torch.zeros(32, 192, device=DEV); kvp = torch.zeros(32, 480, device=DEV)
     assert flags(lambda: ops.ipa_prep_points_f16(r7, qp, kvp, d["hw"])) == 16
     qkv = torch.randn(64, 960, generator=g).to(DEV)
-    assert flags(lambda: ops.encoder_attention(qkv, None, 2, 32)) == 0
-    assert flags(lambda: ops.encoder_attention(qkv * 1.0e5, None, 2, 32)) == 32
+    for ar in MODES:   # the exact kernel reports what it writes as planes, the f16x3 kernel also the q / k / v it splits
+        assert flags(lambda: ops.encoder_attention(qkv, None, 2, 32, arith=ar)) == 0
+        assert flags(lambda: ops.encoder_attention(qkv * 1.0e5, None, 2, 32, arith=ar)) == 32
 
 
 @pytest.mark.parametrize("scale,why", [(8.0e3, "edge transition"), (3.0e4, "a weight does not fit")], ids=["activation", "weight"])
@@ -1390,9 +1391,10 @@ def test_node_linear_vfrag_equals_plain_output(M):
     check(f"node_linear_vfrag vs plain M{M}", rel(y[:M], y_plain.double()), 1e-6)
 
 
+@pytest.mark.parametrize("arith", MODES)
 @pytest.mark.parametrize("B,N", [(2, 37), (1, 256), (3, 130)])
-def test_encoder_attention_vs_torch(net_rough, B, N):
-    """s2s_encoder_attention against torch's own nn.TransformerEncoder (the module the reference calls, ipa.py:357) in float64
+def test_encoder_attention_vs_torch(net_rough, B, N, arith):
+    """s2s_encoder_attention (exact fp32 MFMA) and s2s_encoder_attention_f16x3 (split-f16 MFMA, the default) against torch's own nn.TransformerEncoder (the module the reference calls, ipa.py:357) in float64
     on the same parameters: full 2-layer encoder through the fused node kernels (in_proj -> attention -> out_proj + LN ->
     feed-forward + LN) with a partial FLOAT key-padding mask (added to the logits), and the exact-padding variant (-inf)."""
     import copy
@@ -1415,7 +1417,7 @@ def test_encoder_attention_vs_torch(net_rough, B, N):
         for layer, lw in zip(enc.layers, W):
             lin = lambda xp, w, **kw: ops.node_apply(xp, w, M, **kw)  # noqa: E731
             qkv, _ = lin(xx, lw["in"])
-            sa32, sa_xp = ops.encoder_attention(qkv, key_bias, B, N, 4, want_f32=True)
+            sa32, sa_xp = ops.encoder_attention(qkv, key_bias, B, N, 4, want_f32=True, arith=arith)
             assert bool(((ops.unpack_planes(sa_xp, M, 320) - sa32).abs() <= 2.0 ** -23 * sa32.abs() + 2.0 ** -24).all())
             x1, x1x = lin(sa_xp, lw["o"], residual=xf, ln=(layer.norm1.weight, layer.norm1.bias, layer.norm1.eps), want_xp=True)
             _, hx = lin(x1x, lw["l1"], relu=True, want_f32=False, want_xp=True)
@@ -1424,12 +1426,12 @@ def test_encoder_attention_vs_torch(net_rough, B, N):
 
     # float mask: added to the logits (what the reference's call does with src_key_padding_mask = 1 - mask)
     ref = ref_enc(x.double().transpose(0, 1), src_key_padding_mask=pad.double()).transpose(0, 1)
-    check(f"encoder (float mask) B{B} N{N}", rel(run(pad.contiguous()), ref), 2e-6)
+    check(f"encoder (float mask) B{B} N{N} {arith}", rel(run(pad.contiguous()), ref), 2e-6)
     # exact padding: padded keys removed (bool mask in torch)
     ref = ref_enc(x.double().transpose(0, 1), src_key_padding_mask=pad.bool()).transpose(0, 1)
     got = run(torch.where(pad > 0, float("-inf"), 0.0).contiguous())
     valid = mask.bool().numpy()
-    check(f"encoder (exact padding) B{B} N{N}", rel(got.cpu().numpy()[valid], ref.cpu().numpy()[valid]), 2e-6)
+    check(f"encoder (exact padding) B{B} N{N} {arith}", rel(got.cpu().numpy()[valid], ref.cpu().numpy()[valid]), 2e-6)
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
