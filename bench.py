@@ -79,7 +79,7 @@ def traffic_from_profiles(pairs, mode):
     """HBM bytes per launch of the dominant kernel.  NOT measured in this run: PMC counters need rocprofv3 around the
     process (separate --pmc passes, tools/pmc_hbm_traffic.sh), so the committed pass at B = 16, N = 256 is scaled by the
     pairs of this launch and labelled as such.  (None, None) if the file is absent."""
-    for name in ("r03g_pmc_hbm_traffic.json", "r03f_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02m_pmc_hbm_traffic.json", "r02l_pmc_hbm_traffic.json", "r02k_pmc_hbm_traffic.json", "r02i_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01i_pmc_hbm_traffic.json"):
+    for name in ("r03h_pmc_hbm_traffic.json", "r03g_pmc_hbm_traffic.json", "r03f_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02m_pmc_hbm_traffic.json", "r02l_pmc_hbm_traffic.json", "r02k_pmc_hbm_traffic.json", "r02i_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01i_pmc_hbm_traffic.json"):
         key = {"f16x3": "edge_transition_f16x3"}.get(mode, "edge_transition")
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
