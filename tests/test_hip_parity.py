@@ -495,6 +495,24 @@ def test_denoising_net_golden(net_rough):
         assert float(out["atom37"][..., 5:, :].abs().max()) == 0
 
 
+def test_network_is_independent_of_the_pair_layout(net_rough, monkeypatch):
+    """The network chains its f16x3 pair kernels in their tiled layout and lets the last EdgeTransition write no pair tensor; with the
+    embedding handed over row-major instead (its EdgeTransition then reads row-major and writes tiled) and with the tiled layout
+    switched off altogether (every pair tensor row-major, every EdgeTransition writing its output) the frames are bit-identical."""
+    g = golden("net_b2n16.npz")
+    batch = _batch(g, DEV)
+    ref = net_rough(batch)["rigids"].to_tensor_7().clone()
+    emb_fwd = type(net_rough.embedder).forward
+    monkeypatch.setattr(type(net_rough.embedder), "forward", lambda self, *a, edge_layout="rowmajor", **k: emb_fwd(self, *a, **k))
+    mixed = net_rough(batch)["rigids"].to_tensor_7().clone()          # embedding row-major, trunk tiled
+    assert torch.equal(mixed, ref)
+    et_cls = type(net_rough.translator.trunk["edge_transition_0"])
+    pair_mlp = et_cls.pair_mlp
+    monkeypatch.setattr(et_cls, "pair_mlp", lambda self, *a, out_layout="rowmajor", **k: pair_mlp(self, *a, **k))
+    plain = net_rough(batch)["rigids"].to_tensor_7()                  # nothing tiled, nothing skipped
+    assert torch.equal(plain, ref)
+
+
 def test_teacher_forced_trajectory(net_rough, diffuser):
     """All 20 steps of a reference trajectory, each re-done from the reference's own step inputs."""
     from str2str_amd.synth import synth_chain

@@ -1,5 +1,5 @@
 """Timeline of one workgroup of the f16 attention kernel (cycle stamps per key tile).
-    python tools/ipa_planes_probe.py build [block]   (CPU container)      python tools/ipa_planes_probe.py run   (GPU box)"""
+    python tools/ipa_f16w_probe.py build [block]   (CPU container)      python tools/ipa_f16w_probe.py run   (GPU box)"""
 import ctypes
 import os
 import subprocess
@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 D = os.path.join(ROOT, "str2str_amd", "csrc", "build")
-LIB = os.path.join(D, "lib_ipa8probe.so")
+LIB = os.path.join(D, "ab_ipa8probe.so")
 if sys.argv[1] == "build":
     block = sys.argv[2] if len(sys.argv) > 2 else "2000"
     env = dict(os.environ, UNIT="ipa_attention_f16w")
