@@ -141,6 +141,12 @@ constexpr SlotDesc slot_desc(int s) {
     if (s < 240) return {2, 0, (s - 192) / 2, (s - 192) % 2};
     return {3, 0, s - 240, 0};  // P: fused projection k-step s - 240 (both output tiles)
 }
+// ROTATED TILE LOOP (round 4).  LayerNorm + store and the fused projection of tile n run under / after the first two layer-1 tiles
+// of tile n + 1:  A_0 A_1 (+ LayerNorm of the previous tile in pieces behind their MFMAs) | P (projection of the previous tile) |
+// B_0 A_2 | ... | F.  The kernel's slot position ns (weight-pipe stage ns / 8) maps to the schedule slot s above; the weight
+// stream keeps the host's order (projection stage last): logical stage 1 of a PROJ stream is blob stage 30.
+constexpr int sched_slot(bool proj, int ns) { return !proj ? ns : (ns < 8 ? ns : (ns < 16 ? 240 + (ns - 8) : ns - 8)); }
+constexpr int blob_stage(bool proj, int st) { return !proj ? st : (st == 0 ? 0 : (st == 1 ? 30 : st - 1)); }
 
 #define S2S_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 __device__ float s2s_one[1] = {1.0f};   // stands in for an absent node mask (read with stride 0)
@@ -187,11 +193,11 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     f32x4 e0, e1, e2, e3;  // staging group B (second half)
     typedef __attribute__((address_space(3))) f32x4 lds_f4;
     auto cp_load_a = [&](int stage) {
-        const int so = stage * kStageBytes;  // compile-time at every call site
+        const int so = blob_stage(PROJ, stage) * kStageBytes;  // compile-time at every call site
         c0 = ldw(voff, so); c1 = ldw(voff + 1024, so); c2 = ldw(voff + 2048, so); c3 = ldw(voff + 3072, so);
     };
     auto cp_load_b = [&](int stage) {
-        const int so = stage * kStageBytes + 4096;
+        const int so = blob_stage(PROJ, stage) * kStageBytes + 4096;
         e0 = ldw(voff, so); e1 = ldw(voff + 1024, so); e2 = ldw(voff + 2048, so); e3 = ldw(voff + 3072, so);
     };
     auto cp_store_a = [&](int par) {
@@ -205,7 +211,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     // the same, one 1 KiB piece at a time (k = 0..3): inside the tile loop a piece rides behind a single MFMA
     auto cp_load_piece = [&](auto grp, auto kc, int stage) {
         constexpr int k = decltype(kc)::value;
-        const int so = stage * kStageBytes + (decltype(grp)::value ? 4096 : 0);
+        const int so = blob_stage(PROJ, stage) * kStageBytes + (decltype(grp)::value ? 4096 : 0);
         const f32x4 v = ldw(voff + 1024 * k, so);
         if constexpr (decltype(grp)::value == 0) {
             if constexpr (k == 0) c0 = v; else if constexpr (k == 1) c1 = v; else if constexpr (k == 2) c2 = v; else c3 = v;
@@ -305,7 +311,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) xv[i] = ldrow(erow_of(cur), i);  // accumulator ("chain") channel order, see xpl
         for (int i = threadIdx.x; i < 768; i += 256)
-            s_vec[i] = i < 384 ? b2[i] : (i < 512 ? bf[i - 384] : (i < 640 ? gamma[i - 512] : beta[i - 640]));
+            s_vec[i] = i < 384 ? b2[i] : (i < 512 ? kWS * bf[i - 384] : (i < 640 ? gamma[i - 512] : beta[i - 640]));   // 32 bf: start value of the final layer's accumulators
         if (PROJ && threadIdx.x < 64) s_vec[768 + threadIdx.x] = proj_b[threadIdx.x];
         cp_store_a(0);
         cp_load_a(1);
@@ -374,66 +380,83 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     S2S_LDS_BARRIER();  // stage 0 and s_vec are in LDS
     fetch(0, 0, fr[0]);
 
-    auto ln_epilogue = [&]() {
-    // ---- + bf, LayerNorm(128) over the pair's channels (half here, half in lane^32), edge mask, store
-    const float em = cur.em_i * cur.em_j;
+    // ---- LayerNorm(128) over the pair's channels (half here, half in lane ^ 32), + bf, edge mask, store -- of the PREVIOUS tile,
+    //      cut into pieces that ride behind the MFMAs of this tile's first eight slots (rotated tile loop: sched_slot above).  The
+    //      arithmetic and its order are those of a plain epilogue: bias, running sum and running sum of squared deviations over the
+    //      lane's 64 channels in accumulator order, ((a - mean) rstd) gamma + beta, mask.  (LayerNorm is scale invariant: the
+    //      statistics run on the 32 x scaled accumulator, with 1024 eps.)
+    PairCtx prv = cur;   // the tile whose final-layer accumulators a3 holds; none before the first tile (nothing is stored, and
+    prv.valid = false;   // a zero mask keeps the idle pass out of the range maximum)
+    prv.em_i = 0.f;
+    float ln_sum = 0.f, ln_var = 0.f, ln_mean = 0.f, ln_rstd = 0.f, ln_em = 0.f;
+    float* ln_orow = out;
+    f16x8 xln[8][2];     // PROJ: planes of the LayerNorm output = B operands of the projection k-steps (chain order)
+    auto ln_add = [&](auto qc) {   // piece q = (tile t, quarter rq): running sum (bf is the accumulators' start value, slots 192 / 193)
+        constexpr int q = decltype(qc)::value, t = q / 4, rq = q % 4;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+        for (int j = 0; j < 4; ++j) ln_sum += a3[t][4 * rq + j];
+    };
+    auto ln_dev = [&](auto qc) {
+        constexpr int q = decltype(qc)::value, t = q / 4, rq = q % 4;
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const float4 bq = ldg4(s_vec + 384, 4 * t + rq, h);
-            // (LayerNorm is scale invariant: the statistics run on the 32 x scaled accumulator, with 1024 eps)
-            a3[t][4 * rq + 0] = __builtin_fmaf(bq.x, kWS, a3[t][4 * rq + 0]); a3[t][4 * rq + 1] = __builtin_fmaf(bq.y, kWS, a3[t][4 * rq + 1]);
-            a3[t][4 * rq + 2] = __builtin_fmaf(bq.z, kWS, a3[t][4 * rq + 2]); a3[t][4 * rq + 3] = __builtin_fmaf(bq.w, kWS, a3[t][4 * rq + 3]);
-        }
-    float sum = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sum += a3[t][r];
-    const float mean = xhalf_sum(sum) * (1.0f / 128);
-    float var = 0.f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float dd = a3[t][r] - mean;
-            var += dd * dd;
-        }
-    const float rstd = 1.0f / sqrtf(xhalf_sum(var) * (1.0f / 128) + ln_eps * (kWS * kWS));
-    float* orow = const_cast<float*>(row_of(out, cur.p, out_tiled));
-    const bool store = cur.valid && !no_out;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const int g = 4 * t + rq;
-            const float4 ga = ldg4(s_vec + 512, g, h), be = ldg4(s_vec + 640, g, h);
-            float4 o;
-            o.x = ((a3[t][4 * rq + 0] - mean) * rstd * ga.x + be.x) * em;
-            o.y = ((a3[t][4 * rq + 1] - mean) * rstd * ga.y + be.y) * em;
-            o.z = ((a3[t][4 * rq + 2] - mean) * rstd * ga.z + be.z) * em;
-            o.w = ((a3[t][4 * rq + 3] - mean) * rstd * ga.w + be.w) * em;
-            if (store) *reinterpret_cast<float4*>(orow + g * out_step) = o;
-            a3[t][4 * rq + 0] = o.x; a3[t][4 * rq + 1] = o.y; a3[t][4 * rq + 2] = o.z; a3[t][4 * rq + 3] = o.w;  // projection input
+        for (int j = 0; j < 4; ++j) {
+            const float dd = a3[t][4 * rq + j] - ln_mean;
+            ln_var += dd * dd;
         }
     };
+    // normalise + mask + store [+ PROJ: planes of projection k-step q / 2]; a3 is only read (a value written back into an
+    // accumulator tuple drags the whole 16-register tuple into the VALU's half of the register file)
+    auto ln_out = [&](auto qc, const float4& ga, const float4& be) {
+        constexpr int q = decltype(qc)::value, t = q / 4, rq = q % 4;
+        float4 o;
+        o.x = ((a3[t][4 * rq + 0] - ln_mean) * ln_rstd * ga.x + be.x) * ln_em;
+        o.y = ((a3[t][4 * rq + 1] - ln_mean) * ln_rstd * ga.y + be.y) * ln_em;
+        o.z = ((a3[t][4 * rq + 2] - ln_mean) * ln_rstd * ga.z + be.z) * ln_em;
+        o.w = ((a3[t][4 * rq + 3] - ln_mean) * ln_rstd * ga.w + be.w) * ln_em;
+        if (prv.valid && !no_out) *reinterpret_cast<float4*>(ln_orow + q * out_step) = o;
+        if constexpr (PROJ) {
+            const float x[4] = {o.x, o.y, o.z, o.w};
+            split4(x, xln[2 * t + (rq >> 1)][0], xln[2 * t + (rq >> 1)][1], 4 * (rq & 1));
+        }
+    };
+    // PROJ: rows 0..7 (+ bias) -> attention bias, head-major; rows 8..39 -> pair_z channel row - 8 (same map as pair_mlp.hip); group g of 5
+    auto proj_store = [&](auto gc) {
+        constexpr int g = decltype(gc)::value;
+        if (prv.valid) {
+            const float4 bq = ldg4(s_vec + 768, g, h);
+            if constexpr (g == 0) {
+                float* o = proj_bias_out + ((unsigned long long)prv.boff + 4 * h * NN);
+                o[0] = __builtin_fmaf(pq[0][0], kInvWS, bq.x);
+                o[NN] = __builtin_fmaf(pq[0][1], kInvWS, bq.y);
+                o[2 * NN] = __builtin_fmaf(pq[0][2], kInvWS, bq.z);
+                o[3 * NN] = __builtin_fmaf(pq[0][3], kInvWS, bq.w);
+            } else {
+                constexpr int t = g >> 2, rq = g & 3;
+                *reinterpret_cast<float4*>(proj_pz_out + (unsigned long long)prv.p * 32u + 8 * (g - 1) + 4 * h) =
+                    make_float4(__builtin_fmaf(pq[t][4 * rq + 0], kInvWS, bq.x), __builtin_fmaf(pq[t][4 * rq + 1], kInvWS, bq.y),
+                                __builtin_fmaf(pq[t][4 * rq + 2], kInvWS, bq.z), __builtin_fmaf(pq[t][4 * rq + 3], kInvWS, bq.w));
+            }
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a3[t] = zero16;
 
 #ifdef S2S_ET_PROBE
     unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, st6 = 0, st7 = 0, st8 = 0, st9 = 0, st10 = 0, st11 = 0, st12 = 0,
                        st13 = 0, st14 = 0, st15 = 0;
 #endif
-    for (;;) {
-    const long long wt_next = wt + gridDim.x;
-    const bool has_next = wt_next < n_wt;
+    constexpr int kHead = PROJ ? 16 : 15;  // slots that still work for the previous tile: A_0 A_1 + its projection (PROJ) or the first seven slots of B_0
+    long long wt_next = wt;
+    bool has_next = false;
     PairCtx nxt = cur;  // next tile's context, edge row and planes: produced under the last 16 slots of this tile
     float4 xv[16];
     f16x8 xpn[8][2];
     f16x8 xq[8][2];   // final-layer input planes of k-steps 8..15 (block 1 of the layer-2 epilogue)
-    static_for<0, kSlots>([&](auto sc) {
-        constexpr int s = decltype(sc)::value;
+    auto slot = [&](auto sc) {
+        constexpr int ns = decltype(sc)::value;      // position in the tile loop: weight-pipe stage ns / 8
+        constexpr int s = sched_slot(PROJ, ns);      // slot of the schedule (slot_desc)
         constexpr SlotDesc d = slot_desc(s);
-        constexpr int stage = s / 8, ss = s % 8, par = stage & 1;
+        constexpr int stage = ns / 8, ss = ns % 8, par = stage & 1;
 #if defined(S2S_ET_PROBE) && S2S_ET_PROBE == 3   // fine view of one layer-2 block: slot tops 72 .. 87 (B_4 A_6), 88
         if constexpr (s >= 72 && s <= 87) { if constexpr (s == 72) ET_STAMP(0); if constexpr (s == 73) ET_STAMP(1); if constexpr (s == 74) ET_STAMP(2);
             if constexpr (s == 75) ET_STAMP(3); if constexpr (s == 76) ET_STAMP(4); if constexpr (s == 77) ET_STAMP(5); if constexpr (s == 78) ET_STAMP(6);
@@ -456,24 +479,25 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         if constexpr (s == 237) ET_STAMP(12);
         if constexpr (s == 238) ET_STAMP(13);
         if constexpr (s == 239) ET_STAMP(14);
-#else
-        if constexpr (s == 0) ET_STAMP(0);
-        if constexpr (s == 8) ET_STAMP(1);
-        if constexpr (s == 24) ET_STAMP(2);
-        if constexpr (s == 168) ET_STAMP(3);
-        if constexpr (s == 180) ET_STAMP(5);
-        if constexpr (s == 192) ET_STAMP(7);
-        if constexpr (s == 208) ET_STAMP(9);
-        if constexpr (s == 224) ET_STAMP(11);
-        if constexpr (s == 240) ET_STAMP(13);
+#else   // phases of one pass of the loop, in time order
+        if constexpr (ns == 0) ET_STAMP(0);
+        if constexpr (ns == 4) ET_STAMP(1);
+        if constexpr (ns == 8) ET_STAMP(2);
+        if constexpr (ns == kHead) ET_STAMP(3);
+        if constexpr (s == 24) ET_STAMP(4);
+        if constexpr (s == 168) ET_STAMP(5);
+        if constexpr (s == 180) ET_STAMP(7);
+        if constexpr (s == 192) ET_STAMP(9);
+        if constexpr (s == 208) ET_STAMP(11);
+        if constexpr (s == 224) ET_STAMP(13);
 #endif
 
         // ---------------- top of the slot: next slot's fragments, loads that land under later slots
         if constexpr (ss < 7) {
-            fetch(par, ss + 1, fr[(s + 1) & 1]);
+            fetch(par, ss + 1, fr[(ns + 1) & 1]);
         } else {
             S2S_LDS_BARRIER();
-            fetch(par ^ 1, 0, fr[(s + 1) & 1]);
+            fetch(par ^ 1, 0, fr[(ns + 1) & 1]);
         }
         // next tile: context + edge row under the middle final-layer block, seeds of its tile 0 near the end
         // (the edge row in pieces: a burst of 16 loads per wave holds the slot for ~2 k cycles -- the workgroup's 64 KiB through one
@@ -500,6 +524,24 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         float4 ep_b = {0.f, 0.f, 0.f, 0.f}, ep_b1 = {0.f, 0.f, 0.f, 0.f};
         if constexpr (ep_blk >= 0) ep_b = ldg4(s_vec + 128 * ep_blk, ep_q, h);
         if constexpr (ep_blk == 0) ep_b1 = ldg4(s_vec, ep_q + 1, h);
+        // previous tile's LayerNorm (table below): gamma / beta of the two pieces normalised in this slot
+        constexpr int ln_k = ns == 7 ? 0 : ((PROJ && d.phase == 3 && d.a < 7) ? d.a + 1 : ((!PROJ && ns >= 8 && ns < 15) ? ns - 7 : -1));   // their projection k-step
+        float4 lnv[4] = {};
+        if constexpr (ln_k >= 0) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { lnv[2 * k] = ldg4(s_vec + 512, 2 * ln_k + k, h); lnv[2 * k + 1] = ldg4(s_vec + 640, 2 * ln_k + k, h); }
+        }
+        // final layer: its accumulators start at 32 bf (tiles 0, 1 in slot 192, tiles 2, 3 in slot 193) -- the LayerNorm pieces only read them
+        if constexpr (s == 192 || s == 193) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const float4 v = ldg4(s_vec + 384, 4 * (2 * (s - 192) + u) + rq, h);
+                    a3[2 * (s - 192) + u][4 * rq + 0] = v.x; a3[2 * (s - 192) + u][4 * rq + 1] = v.y;
+                    a3[2 * (s - 192) + u][4 * rq + 2] = v.z; a3[2 * (s - 192) + u][4 * rq + 3] = v.w;
+                }
+        }
         __builtin_amdgcn_sched_barrier(0);
 
         // ---------------- the 6 MFMAs, each followed by at most one piece of the weight pipe and one small VALU piece, pinned there
@@ -514,8 +556,16 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         //                slots 184..191, in place into the planes the edge row used during layers 1-2 -- whose exact sum x_h + x_l is the
         //                residual row e; block 1 one piece per slot under the final layer's k-steps 0..7 (slots 192..207) into the
         //                planes xq, block 2 under k-steps 8..15 (which read xq) back into xpl;
-        //   slots 228..235  split of the next tile's edge row, four halves per slot.
-        const f16x8 (&f)[4] = fr[s & 1];
+        //   slots 228..235  split of the next tile's edge row, four halves per slot;
+        //   previous tile (positions ns 0..7 = A_0 A_1 of this one, 8..15 = its projection; MFMA i of the slot):
+        //                ns 0..3   running sum of piece 4 ns + i behind MFMAs 0..3
+        //                ns 4, 5   mean behind MFMA 0 of ns 4; squared deviations of pieces 6 (ns-4) + {0 1 | 2 3 | 4 5} behind MFMAs 1, 3, 5
+        //                ns 6      pieces 12 13 | 14 15 behind MFMAs 0, 1; rstd / mask / row pointer behind MFMA 3
+        //                normalise + mask + store + (PROJ) split of the two pieces of projection k-step k, behind MFMAs 1 and 3:
+        //                k = 0 in ns 7, k = a + 1 in projection slot a (whose MFMAs read k-step a): two k-steps of planes alive at a time
+        //                (!PROJ: k = ns - 7 in ns 8..14, the first slots of B_0);
+        //                PROJ: the projection's five store groups behind the MFMAs of the first slot after it (ns 16).
+        const f16x8 (&f)[4] = fr[ns & 1];
         auto mfma_i = [&](auto ic) {
             constexpr int i = decltype(ic)::value;
             if constexpr (d.phase == 0) {
@@ -525,9 +575,9 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
                 if constexpr (d.a == 0 && i == 0) acc = mfma_f16(f[fa], x[xa], zero16); else acc = mfma_f16(f[fa], x[xa], acc);
             } else {
                 constexpr bool fin = d.phase == 2, prj = d.phase == 3;
-                constexpr bool first = i < 2 && (prj ? d.a == 0 : (fin ? d.a == 0 : (d.t == 0 && d.a == 0)));
+                constexpr bool first = i < 2 && (prj ? d.a == 0 : (fin ? false : (d.t == 0 && d.a == 0)));   // (final layer: onto 32 bf)
                 f32x16& t = prj ? pq[i & 1] : (fin ? a3[2 * d.b + (i & 1)] : a2[2 * d.b + (i & 1)]);
-                const f16x8 (&x)[2] = prj ? xpl[d.a] : (fin ? ((d.a >> 3) == 1 ? xq[d.a & 7] : xpl[d.a & 7]) : xp[d.a]);
+                const f16x8 (&x)[2] = prj ? xln[d.a] : (fin ? ((d.a >> 3) == 1 ? xq[d.a & 7] : xpl[d.a & 7]) : xp[d.a]);
                 constexpr int fa = 2 * (i & 1) + (i < 2 ? 1 : 0), xa = (i == 2 || i == 3) ? 1 : 0;                   // W_l x_h, W_h x_l, W_h x_h
                 if constexpr (first) t = mfma_f16(f[fa], x[xa], zero16); else t = mfma_f16(f[fa], x[xa], t);
             }
@@ -572,6 +622,20 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
                 if constexpr ((e & 2) == 0) split2_f16(v.x, v.y, xpn[k][0], xpn[k][1], e, amax);
                 else split2_f16(v.z, v.w, xpn[k][0], xpn[k][1], e, amax);
             }
+            // ---- previous tile: LayerNorm pieces (table above)
+            if constexpr (ns < 4 && i < 4) ln_add(IC<4 * ns + i>{});
+            if constexpr (ns == 4 && i == 0) ln_mean = xhalf_sum(ln_sum) * (1.0f / 128);
+            if constexpr ((ns == 4 || ns == 5) && (i == 1 || i == 3 || i == 5)) { ln_dev(IC<6 * (ns - 4) + i - 1>{}); ln_dev(IC<6 * (ns - 4) + i>{}); }
+            if constexpr (ns == 6 && (i == 0 || i == 1)) { ln_dev(IC<12 + 2 * i>{}); ln_dev(IC<12 + 2 * i + 1>{}); }
+            if constexpr (ns == 6 && i == 3) {
+                ln_rstd = 1.0f / sqrtf(xhalf_sum(ln_var) * (1.0f / 128) + ln_eps * (kWS * kWS));
+                ln_em = prv.em_i * prv.em_j;
+                ln_orow = const_cast<float*>(row_of(out, prv.p, out_tiled));
+                ln_sum = 0.f;
+                ln_var = 0.f;
+            }
+            if constexpr (ln_k >= 0 && (i == 1 || i == 3)) ln_out(IC<2 * ln_k + (i - 1) / 2>{}, lnv[i - 1], lnv[i]);
+            if constexpr (PROJ && ns == kHead && i < 5) proj_store(ic);
             __builtin_amdgcn_sched_barrier(0);
         });
 
@@ -580,51 +644,21 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         if constexpr (s == 239) ET_STAMP(15);
 #elif defined(S2S_ET_PROBE) && S2S_ET_PROBE == 3
 #else
-        if constexpr (s == 179) ET_STAMP(4);
-        if constexpr (s == 191) ET_STAMP(6);
-        if constexpr (s == 207) ET_STAMP(8);
-        if constexpr (s == 223) ET_STAMP(10);
-        if constexpr (s == 239) ET_STAMP(12);
+        if constexpr (s == 179) ET_STAMP(6);
+        if constexpr (s == 191) ET_STAMP(8);
+        if constexpr (s == 207) ET_STAMP(10);
+        if constexpr (s == 223) ET_STAMP(12);
+        if constexpr (s == 239) ET_STAMP(14);
 #endif
         if constexpr (s == 179) {  // B_10 done: tile 11 -> planes (nothing left to hide it under)
             s_quarter(a1t[1], IC<0>{}); s_quarter(a1t[1], IC<1>{}); s_quarter(a1t[1], IC<2>{}); s_quarter(a1t[1], IC<3>{});
         }
-        if constexpr (PROJ && s == 239) {
-            // LayerNorm output (stored, and kept in a3) -> planes of the 8 projection k-steps (chain order)
-            ln_epilogue();
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const float x[4] = {a3[t][4 * rq + 0], a3[t][4 * rq + 1], a3[t][4 * rq + 2], a3[t][4 * rq + 3]};
-                    split4(x, xpl[2 * t + (rq >> 1)][0], xpl[2 * t + (rq >> 1)][1], 4 * (rq & 1));
-                }
-        }
-    });
+    };
+    for (;;) {
+    wt_next = wt + gridDim.x;
+    has_next = wt_next < n_wt;
+    static_for<0, kSlots>(slot);
 
-#if defined(S2S_ET_PROBE) && S2S_ET_PROBE == 1
-    ET_STAMP(14);
-#endif
-    if constexpr (!PROJ) ln_epilogue();
-    if constexpr (PROJ) {
-        // rows 0..7 (+ bias) -> attention bias, head-major; rows 8..39 -> pair_z channel row - 8 (same map as pair_mlp.hip)
-        if (cur.valid) {
-            const float4 b0 = ldg4(s_vec + 768, 0, h);
-            float* o = proj_bias_out + ((unsigned long long)cur.boff + 4 * h * NN);
-            o[0] = __builtin_fmaf(pq[0][0], kInvWS, b0.x);
-            o[NN] = __builtin_fmaf(pq[0][1], kInvWS, b0.y);
-            o[2 * NN] = __builtin_fmaf(pq[0][2], kInvWS, b0.z);
-            o[3 * NN] = __builtin_fmaf(pq[0][3], kInvWS, b0.w);
-#pragma unroll
-            for (int g = 1; g <= 4; ++g) {
-                const int t = g >> 2, rq = g & 3;
-                const float4 bq = ldg4(s_vec + 768, g, h);
-                *reinterpret_cast<float4*>(proj_pz_out + (unsigned long long)cur.p * 32u + 8 * (g - 1) + 4 * h) =
-                    make_float4(__builtin_fmaf(pq[t][4 * rq + 0], kInvWS, bq.x), __builtin_fmaf(pq[t][4 * rq + 1], kInvWS, bq.y),
-                                __builtin_fmaf(pq[t][4 * rq + 2], kInvWS, bq.z), __builtin_fmaf(pq[t][4 * rq + 3], kInvWS, bq.w));
-            }
-        }
-    }
 #ifdef S2S_ET_PROBE
 #if S2S_ET_PROBE == 1
     ET_STAMP(15);
@@ -638,9 +672,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         atomicAdd(pr + 16, 1ull);
     }
 #endif
-    if (!has_next) break;
-    cur = nxt;
-    wt = wt_next;
+    prv = cur;   // a3 holds this tile's final-layer accumulators: LayerNorm, store and projection in the next pass
 #pragma unroll
     for (int i = 0; i < 8; ++i) { xpl[i][0] = xpn[i][0]; xpl[i][1] = xpn[i][1]; }
     if constexpr (kStages % 2 == 1) {  // odd stage count: the next tile's stage 0 sits in the other buffer
@@ -648,7 +680,15 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         lds_image[0] = lds_image[1];
         lds_image[1] = sw;
     }
+    if (!has_next) break;
+    cur = nxt;
+    wt = wt_next;
     }  // persistent tile loop
+    // after the last tile: its LayerNorm, store and projection, i.e. the head of one more pass (a second copy of those slots: a branch
+    // out of the middle of the loop body costs ~250 spilled registers).  Its layer-1 MFMAs run on the last tile's planes once more
+    // (xpn is that tile's row again when there is no next tile) and their results are dropped.
+    static_for<0, kHead>(slot);
+    if constexpr (PROJ) { proj_store(IC<0>{}); proj_store(IC<1>{}); proj_store(IC<2>{}); proj_store(IC<3>{}); proj_store(IC<4>{}); }
     s2s::range_report(range_flag, amax, s2s::kRangeEdgeTransition);
 }
 

@@ -54,11 +54,11 @@ c = buf.reshape(512, 17).astype(np.float64)
 c = c[c[:, 16] > 0]
 tiles = c[:, 16].sum()
 per = c[:, :15].sum(0) / tiles
-names = [("A0 A1 (8 slots, layer 1 tiles 0-1)", 8), ("B0 A2 (16 slots)", 16), ("B1 A3 .. B9 A11 (144 slots)", 144),
-         ("B10 (11 slots + MFMAs of slot 179)", 12), ("exposed: tile 11 -> planes", 0), ("B11 (11 slots + MFMAs of 191)", 12),
-         ("exposed: epilogue block 0", 0), ("F k-steps 0-7 (15 slots + MFMAs of 207)", 16), ("exposed: epilogue block 1", 0),
-         ("F k-steps 8-15 (15 slots + MFMAs of 223)", 16), ("exposed: epilogue block 2", 0), ("F k-steps 16-23 (15 slots + MFMAs of 239)", 16),
-         ("exposed: LayerNorm + store + split (slot 239)", 0), ("P projection (8 slots)", 8), ("projection stores", 0)]
+names = [("A0 + previous tile's LayerNorm sums (4 slots)", 4), ("A1 + deviations, first normalised pieces (4 slots)", 4),
+         ("P of the previous tile + its normalise / store / split (8 slots)", 8), ("B0 A2 (16 slots; first: projection stores)", 16),
+         ("B1 A3 .. B9 A11 (144 slots)", 144), ("B10 (11 slots + MFMAs of slot 179)", 12), ("exposed: tile 11 -> planes", 0),
+         ("B11 (11 slots + MFMAs of 191)", 12), ("-", 0), ("F k-steps 0-7 (15 slots + MFMAs of 207)", 16), ("-", 0),
+         ("F k-steps 8-15 (15 slots + MFMAs of 223)", 16), ("-", 0), ("F k-steps 16-23 (15 slots + MFMAs of 239)", 16), ("end of the pass", 0)]
 if a.fine:
     names = [(f"slots {x} .. {y - 1}", y - x) for x, y in zip([216, 220, 224, 225, 226, 227, 228, 229, 230, 232, 234, 236, 237, 238], [220, 224, 225, 226, 227, 228, 229, 230, 232, 234, 236, 237, 238, 239])]
     names.append(("slot 239 up to its exposed step", 1))
