@@ -30,10 +30,13 @@ int s2s_abi_version(void);
  *           fp32-equivalent in precision, but an activation must stay below f16's 65504;
  *   "f32":  exact fp32 MFMA, no range limit (s2s_edge_transition, s2s_edge_embed, s2s_ipa_attention, s2s_node_linear_f32,
  *           s2s_encoder_attention): the reference arithmetic and the automatic fallback.
- * Range guard: every f16x3 kernel keeps a running maximum of the values it splits and ORs a bit into the device word registered
- * here when that maximum reaches 2^15 or is not finite (bits: 1 node GEMM, 2 pack_planes, 4 edge transition, 8 edge embedding,
- * 16 IPA points, 32 encoder attention).  The caller clears / reads the word (no kernel waits for it); NULL disables the reports. */
-int s2s_set_range_flag(int* device_word);
+ * Range guard: every f16x3 kernel keeps a running maximum of the values it splits and ORs a bit into word 0 of the 8-int device
+ * buffer registered here when that maximum reaches 2^15 or is not finite (bits: 1 node GEMM, 2 pack_planes, 4 edge transition,
+ * 8 edge embedding, 16 IPA points, 32 encoder attention, 64 IPA attention).  Words 1..7 (1 + log2(bit)) collect magnitude buckets
+ * of the same families: bit e set = a launch saw a maximum in [2^(8+e), 2^(9+e)) (e = 8: 2^16 or more); nothing is written below
+ * 2^8.  The caller clears / reads the buffer (no kernel waits for it); NULL disables the reports.  The caller decides what a raised
+ * bit means: str2str_amd/sampler.py re-runs the chunk with ONLY the flagged kernel families on their exact fp32 kernels. */
+int s2s_set_range_flag(int* device_words);
 
 /* ---- Pair-stream MLPs (fp32 MFMA).  Weight blobs are "packed" for the kernels' lane order:
  *      packed[((s4*T + t)*64 + lane)*4 + q] = W[32*t + (lane & 31)][8*s4 + 4*(lane >> 5) + q]

@@ -88,8 +88,11 @@ def pairwise_distance_ca(coords, k=1) -> np.ndarray:
 def tica_fit(x: np.ndarray, lagtime: int, dim: int = 2, epsilon: float = 1e-6):
     """Reversible TICA (time-lagged independent component analysis) of a trajectory x [T, D]: the ``dim`` slowest components.
     Same estimator as deeptime's TICA(dim, lagtime) up to each component's scale and sign: mean and covariances symmetrised over
-    the (x_t, x_{t+lag}) pairs, C00 whitened with a relative eigenvalue cut-off ``epsilon``, symmetric eigenproblem of the whitened
-    time-lagged covariance, components ordered by eigenvalue.  -> (mean [D], projection [D, dim]); transform = (x - mean) @ proj."""
+    the (x_t, x_{t+lag}) pairs, C00 whitened on the eigenvectors whose eigenvalue exceeds the ABSOLUTE cut-off ``epsilon`` (deeptime's
+    spd_eig: 1e-6, raised above the magnitude of the most negative eigenvalue when rounding produced one -- a relative cut-off keeps a
+    different subspace for rank-deficient pairwise-distance features, whose largest eigenvalue is 1e2 .. 1e4 A^2), symmetric
+    eigenproblem of the whitened time-lagged covariance, components ordered by eigenvalue.
+    -> (mean [D], projection [D, dim]); transform = (x - mean) @ proj.  Pinned by an analytic two-state process in tests/test_host_cpu.py."""
     x = np.asarray(x, dtype=np.float64)
     if x.shape[0] <= lagtime:
         raise ValueError(f"js_tica: {x.shape[0]} frames are not enough for lagtime {lagtime}")
@@ -100,7 +103,10 @@ def tica_fit(x: np.ndarray, lagtime: int, dim: int = 2, epsilon: float = 1e-6):
     c00 = (a.T @ a + b.T @ b) / (2.0 * n)
     c0t = (a.T @ b + b.T @ a) / (2.0 * n)
     w, v = np.linalg.eigh(c00)
-    keep = w > epsilon * w.max()
+    cut = max(epsilon, -w.min() + 1e-16) if w.min() < 0 else epsilon
+    keep = w > cut
+    if not keep.any():
+        raise ValueError("js_tica: the reference ensemble has no variance above the cut-off")
     white = v[:, keep] / np.sqrt(w[keep])              # [D, r]: white.T C00 white = I
     lam, u = np.linalg.eigh(white.T @ c0t @ white)
     order = np.argsort(-lam)[:dim]

@@ -168,12 +168,14 @@ class DiffusionLitModule(_Base):
             assert tg["aatype"].shape[0] == 1, "one chain per dataloader batch"
         lens = [int(tg["aatype"].shape[1]) for tg in targets]
         plan = plan_mixed_work(lens, n_replica, world)
+        seed_base = int(torch.initial_seed())   # the run seed (eval.py seeds every rank alike); see sampler.mixed_batch_seed
         saved = {k: [] for k in range(len(targets))}
         self.last_samples = {}
         for t_delta in delta_range:
             pieces = sample_mixed_lengths(self.net, self.diffuser, targets, n_replica, float(t_delta), num_timesteps=inf.num_timesteps,
                                           min_t=inf.min_t, noise_scale=inf.noise_scale, probability_flow=inf.probability_flow,
-                                          self_conditioning=self_cond, device=device, shard=(rank, world), rng=self.rng_mode, plan=plan)
+                                          self_conditioning=self_cond, device=device, shard=(rank, world), rng=self.rng_mode, plan=plan,
+                                          seed_base=seed_base)
             # this rank's pieces in plan order (chain, replica_lo, replica_hi) -> one flat buffer
             mine = [(k, lo, p) for k, ps in enumerate(pieces) for lo, p in ps]
             flat = torch.cat([p.reshape(-1) for _, _, p in mine]) if mine else torch.zeros(0, device=device)

@@ -67,7 +67,8 @@ class EmbeddingModule(nn.Module):
         self._wcache = ParamCache()
         self._w16cache = ParamCache()
         self._proj_cache = ParamCache()
-        self.arith = default_arith()   # "f16x3" (split-f16 MFMA, default) | "f32" (exact fp32 MFMA): see str2str_amd/arith.py
+        self.arith = default_arith()   # edge embedding kernels: "f16x3" (split-f16 MFMA, default) | "f32" (exact fp32 MFMA), str2str_amd/arith.py
+        self.node_arith = default_arith()   # the node MLP (node-stream family: follows the trunk)
         self._idx_key = None
         self._idx_val = None
         self._idx_src = None
@@ -165,7 +166,7 @@ class EmbeddingModule(nn.Module):
         M = B * L
         nw = w["node_mlp"]
         f16 = self.arith == "f16x3"
-        _, h2 = ops.node_apply(ops.to_act(h.reshape(M, -1).contiguous(), self.arith), nw[0], M, relu=True, want_f32=False, want_xp=True)
+        _, h2 = ops.node_apply(ops.to_act(h.reshape(M, -1).contiguous(), self.node_arith), nw[0], M, relu=True, want_f32=False, want_xp=True)
         node_embed, self.node_embed_act = ops.node_apply(h2, nw[1], M, ln=(ne[5].weight, ne[5].bias, ne[5].eps),
                                                          post_mask=None if mask is None else mask.reshape(M), want_xp=True)
         node_embed = node_embed.view(B, L, -1)
@@ -215,7 +216,9 @@ class DenoisingNet(nn.Module):
         fixed_mask = batch["fixed_mask"].to(dev).type(torch.float)
         fuse = getattr(self.translator, "fuse_pair_projection", False)
         # between the f16x3 pair kernels (embedding -> EdgeTransition 0 -> 1 -> ..) the pair tensor travels in their tiled layout
-        tiled = fuse and getattr(self.embedder, "arith", None) == "f16x3" and getattr(self.translator, "arith", None) == "f16x3"
+        # (producer and consumer both on their f16x3 kernels; the consumer of the embedding's pair tensor is EdgeTransition 0)
+        et0 = self.translator.trunk["edge_transition_0"] if "edge_transition_0" in getattr(self.translator, "trunk", {}) else None
+        tiled = fuse and getattr(self.embedder, "arith", None) == "f16x3" and getattr(et0, "arith", None) == "f16x3"
         emb = self.embedder(residue_idx=batch["residue_idx"], t=batch["t"], fixed_mask=fixed_mask,
                             self_conditioning_ca=batch["sc_ca_t"], node_mask=node_mask, t_emb=batch.get("t_emb"),
                             next_proj=self.translator.trunk["ipa_0"].pair_proj_weights() if fuse else None,

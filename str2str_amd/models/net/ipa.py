@@ -28,6 +28,20 @@ from ...common.rigid_utils import Rigid, Rotation
 from .layers import BackboneUpdate, EdgeTransition, Linear, NodeTransition, ParamCache, TorsionAngleHead
 
 
+class _LazyPack(dict):
+    """dict whose named entries are built when first read."""
+
+    def __init__(self, eager: dict, **lazy):
+        super().__init__(eager)
+        self._lazy = lazy
+
+    def __missing__(self, key):
+        if key not in self._lazy:
+            raise KeyError(key)
+        self[key] = self._lazy[key]()
+        return self[key]
+
+
 class InvariantPointAttention(nn.Module):
     def __init__(self, c_s: int, c_z: int, c_hidden: int, no_heads: int, no_qk_points: int, no_v_points: int,
                  inf: float = 1e5, eps: float = 1e-8):
@@ -59,8 +73,10 @@ class InvariantPointAttention(nn.Module):
             hw = F.softplus(self.head_weights.float()) * math.sqrt(1.0 / (3 * (self.no_qk_points * 9.0 / 2)))
             wcat64 = wcat.new_zeros(64, wcat.shape[1])
             wcat64[: wcat.shape[0]] = wcat
-            return {"wp": ops.pack_weight(wcat), "b64": b64.contiguous(), "hw": hw.contiguous(),
-                    "wp_f16x2": ops.pack_f16x2_layer(wcat64, "chain").reshape(-1).view(torch.int16).contiguous()}
+            # "wp_f16x2" (the projection as one f16x3 weight stage) is packed on first use: the packing refuses weights beyond f16's
+            # range (ops.WeightRangeError), and the exact kernels -- the fallback for exactly that case -- must not trip over it
+            return _LazyPack({"wp": ops.pack_weight(wcat), "b64": b64.contiguous(), "hw": hw.contiguous()},
+                             wp_f16x2=lambda: ops.pack_f16x2_layer(wcat64, "chain").reshape(-1).view(torch.int16).contiguous())
 
         return self._cache.get([self.linear_b.weight, self.linear_b.bias, self.down_z.weight, self.down_z.bias,
                                 self.head_weights], build)
@@ -106,17 +122,17 @@ class InvariantPointAttention(nn.Module):
         rmap, Mo = ((NP, N), B * NP) if NP != N else (None, M)
         _, q_xp = ops.node_apply(s_xp, w["q"], Mo, row_map=rmap, want_f32=False, want_xp=True)
         _, k_xp = ops.node_apply(s_xp, w["k"], Mo, row_map=rmap, want_f32=False, want_xp=True)
-        v_vf = ops.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], Mo, w["v"]["k"], w["v"]["n"], self.c_hidden // 32, row_map=rmap)
+        K = torch.ops.str2str_amd     # the kernels' operator surface (ops.register_torch_ops)
+        v_vf = K.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], Mo, w["v"]["k"], w["v"]["n"], self.c_hidden // 32, *(rmap or (0, 0)))
         qp, _ = ops.node_apply(s_xp, w["qp"], M)
         kvp, _ = ops.node_apply(s_xp, w["kvp"], M)
-        pts = ops.ipa_prep_points_f16(r7.view(B, N, 7), qp, kvp, d["hw"], H, self.no_qk_points, self.no_v_points, self.c_hidden)
+        pts = K.ipa_prep_points_f16(r7.view(B, N, 7), qp, kvp, d["hw"], H, self.no_qk_points, self.no_v_points, self.c_hidden)
         attn_bias, pair_z = pair_proj
-        feats, feats_xp = ops.ipa_attention_f16(q_xp, k_xp, v_vf, pts, attn_bias, pair_z, mask, r7, H, self.c_hidden,
-                                                self.no_qk_points, self.no_v_points, self.c_z // 4, self.inf, self.eps,
-                                                logits_inplace=True)
+        feats, feats_xp = K.ipa_attention_f16w(q_xp, k_xp, v_vf, *pts, attn_bias, pair_z, mask, r7, H, self.c_hidden,
+                                               self.no_qk_points, self.no_v_points, self.c_z // 4, self.inf, self.eps, True)
         c0 = H * self.c_hidden
         f2 = feats.view(M, -1)
-        ops.pack_planes(f2, col0=c0, n_cols=f2.shape[1] - c0, out=feats_xp, out_k=f2.shape[1], k0=c0)
+        K.pack_planes(f2, c0, f2.shape[1] - c0, feats_xp, f2.shape[1], c0)
         return feats_xp
 
     def attention_f32(self, s_act, B: int, N: int, r7, mask, pair_proj):
@@ -125,8 +141,8 @@ class InvariantPointAttention(nn.Module):
         w, d, M, H = self.node_packs(), self._derived(), B * N, self.no_heads
         lin = lambda x: ops.node_apply(s_act, x, M)[0]  # noqa: E731
         q, kv, qp, kvp = lin(w["q"]), lin(w["kv"]), lin(w["qp"]), lin(w["kvp"])
-        q_pts, k_pts, v_pts = ops.ipa_prep_points(r7.view(B, N, 7), qp.view(B, N, -1), kvp.view(B, N, -1), H, self.no_qk_points,
-                                                  self.no_v_points)
+        q_pts, k_pts, v_pts = torch.ops.str2str_amd.ipa_prep_points(r7.view(B, N, 7), qp.view(B, N, -1), kvp.view(B, N, -1), H,
+                                                                    self.no_qk_points, self.no_v_points)
         attn_bias, pair_z = pair_proj
         feats = ops.ipa_attention(q.view(B, N, H, -1), kv.view(B, N, H, -1), q_pts, k_pts, v_pts, attn_bias, pair_z, mask, r7,
                                   d["hw"], H, self.c_hidden, self.no_qk_points, self.no_v_points, self.c_z // 4, self.inf,
@@ -235,7 +251,7 @@ class TranslationIPA(nn.Module):
         diffuse_mask = ((1 - batch["fixed_mask"].type(torch.float)) * node_mask).contiguous()
         nm, dm = node_mask.reshape(M), diffuse_mask.reshape(M)
         init7 = batch["rigids_t"].type(torch.float).contiguous()
-        curr7 = ops.rigid_scale_trans(init7, self.coordinate_scaling, divide=False)
+        curr7 = torch.ops.str2str_amd.rigid_scale_trans(init7, self.coordinate_scaling, False)
         pad = 1.0 - node_mask
         # float key-padding mask of the encoder layers: ADDED to the logits (PyTorch semantics, a no-op for all-ones masks);
         # exact-padding mode removes padded keys instead
@@ -258,7 +274,7 @@ class TranslationIPA(nn.Module):
                 d = ipa._derived()
                 if isinstance(edge_embed, ops.PairTiled):
                     edge_embed = ops.pair_untiled(edge_embed)
-                proj = ops.pair_project(edge_embed.contiguous(), d["wp"], d["b64"])
+                proj = torch.ops.str2str_amd.pair_project(edge_embed.contiguous(), d["wp"], d["b64"])
             feats_a = ipa.attention(s_a, B, N, curr7, node_mask, tuple(proj))
             proj = None
             ln = T[f"ipa_ln_{b}"]
@@ -271,8 +287,7 @@ class TranslationIPA(nn.Module):
             xf, xx = x_f32, x_a
             for layer, lw in zip(T[f"transformer_{b}"].layers, w["layers"]):
                 qkv, _ = lin(xx, lw["in"])
-                sa_f32, sa_xp = ops.encoder_attention(qkv, key_bias, B, N, layer.self_attn.num_heads, want_f32=not f16, want_xp=f16,
-                                                      arith=self.arith)
+                sa_f32, sa_xp = torch.ops.str2str_amd.encoder_attention(qkv, key_bias, B, N, layer.self_attn.num_heads, not f16, f16, self.arith)
                 x1, x1a = lin(sa_xp if f16 else sa_f32, lw["o"], residual=xf, ln=(layer.norm1.weight, layer.norm1.bias, layer.norm1.eps),
                               want_xp=True)
                 _, ha = lin(x1a, lw["l1"], relu=True, want_f32=False, want_xp=True)
@@ -285,7 +300,7 @@ class TranslationIPA(nn.Module):
             s_f32, s_a = lin(h2, w["nt3"], residual=n_f32, ln=(nt.ln.weight, nt.ln.bias, nt.ln.eps), post_mask=nm, want_xp=True)
             # ---- backbone update (:361-365)
             upd, _ = lin(s_a, w["bb"], pre_scale=dm)
-            curr7 = ops.rigid_compose_update(curr7, upd[:, :6].contiguous().view(B, N, 6), diffuse_mask)
+            curr7 = torch.ops.str2str_amd.rigid_compose_update(curr7, upd[:, :6].contiguous().view(B, N, 6), diffuse_mask)
             # ---- EdgeTransition (:367-372): per-node parts here, the pair MLP in its own kernel
             if b < self.num_blocks - 1:
                 et = T[f"edge_transition_{b}"]
@@ -293,7 +308,13 @@ class TranslationIPA(nn.Module):
                 nxt = T[f"ipa_{b + 1}"].pair_proj_weights() if self.fuse_pair_projection else None
                 # f16x3 with fused projections: the pair tensor stays in the kernels' tiled layout, and the last EdgeTransition's
                 # output (read by nothing but the projections it already carries) is not written
-                lay = "rowmajor" if not (f16 and nxt is not None) else ("none" if b == self.num_blocks - 2 else "tiled")
+                # (each EdgeTransition in ITS arithmetic: the layouts change where an f16x3 kernel meets an exact one)
+                et16 = et.arith == "f16x3"
+                last = b == self.num_blocks - 2
+                nxt16 = (not last) and T[f"edge_transition_{b + 1}"].arith == "f16x3"
+                lay = "rowmajor" if not (et16 and nxt is not None) else ("none" if last else ("tiled" if nxt16 else "rowmajor"))
+                if not et16 and isinstance(edge_embed, ops.PairTiled):
+                    edge_embed = ops.pair_untiled(edge_embed)
                 res = et.pair_mlp(edge_embed, node_ab.view(B, N, -1), n_p.view(B, N, -1), node_mask, nxt,
                                   **({"out_layout": lay} if lay != "rowmajor" else {}))
                 if nxt is not None:
@@ -305,7 +326,7 @@ class TranslationIPA(nn.Module):
         _, t2 = lin(t1, wt["l2"], residual=s_f32, want_f32=False, want_xp=True)
         u = lin(t2, wt["fin"])[0][:, :2].reshape(B, N, 2)
         psi = u / torch.sqrt(torch.clamp(torch.sum(u**2, dim=-1, keepdim=True), min=self.torsion_pred.eps))
-        out7 = ops.rigid_scale_trans(curr7, self.coordinate_scaling, divide=True)
+        out7 = torch.ops.str2str_amd.rigid_scale_trans(curr7, self.coordinate_scaling, True)
         return {
             "in_rigids": Rigid.from_tensor_7(init7),
             "out_rigids": Rigid(Rotation(quats=out7[..., :4], normalize_quats=False), out7[..., 4:]),

@@ -172,9 +172,15 @@ class EdgeTransition(nn.Module):
                 stream = self._proj_cache.get([pk["wstream_f16"], next_proj["wp_f16x2"]],
                                               lambda: torch.cat([pk["wstream_f16"], next_proj["wp_f16x2"]]))
                 proj = (stream, next_proj["b64"])
-            return ops.edge_transition_f16x3(edge_embed.contiguous(), node_ab, n_p, pk["wstream_f16"], self.trunk[2].bias,
-                                             self.final_layer.bias, self.layer_norm.weight, self.layer_norm.bias, mask,
-                                             self.layer_norm.eps, proj=proj, out_layout=out_layout)
+            tiled_in = isinstance(edge_embed, ops.PairTiled)
+            B, N = edge_embed.shape[0], edge_embed.shape[1]
+            z, bias, pz = torch.ops.str2str_amd.edge_transition_f16x3_chain(
+                edge_embed.buf if tiled_in else edge_embed.contiguous(), tiled_in, B, N, node_ab, n_p,
+                pk["wstream_f16"] if proj is None else proj[0], self.trunk[2].bias, self.final_layer.bias, self.layer_norm.weight,
+                self.layer_norm.bias, mask, self.layer_norm.eps, None if proj is None else proj[1], out_layout)
+            if out_layout == "tiled":
+                z = ops.PairTiled(B, N, buf=z)
+            return z if proj is None else (z, bias, pz)
         if out_layout != "rowmajor" or isinstance(edge_embed, ops.PairTiled):
             raise ops.HipLibraryError("EdgeTransition: the tiled pair layout belongs to the f16x3 kernels")
         pk = self._packed_f32()

@@ -90,9 +90,9 @@ class FrameDiffuser:
             p2 = torch.stack([torch.exp(-0.5 * mb), torch.sqrt(1 - torch.exp(-mb))], dim=-1).float().to(dev).contiguous()
             rigids0_4x4 = rigids0_4x4.float().contiguous()
         dm = None if diffuse_mask is None else diffuse_mask.to(dev).float().contiguous()
-        return ops.forward_marginal(rigids0_4x4, z_axis, u, z_trans, cdf, inv.to(torch.int32).to(dev).contiguous(),
-                                    sd.discrete_omega.float().to(dev).contiguous(), p2, dm,
-                                    self.trans_diffuser.coordinate_scaling)
+        return torch.ops.str2str_amd.forward_marginal(rigids0_4x4, z_axis, u, z_trans, cdf, inv.to(torch.int32).to(dev).contiguous(),
+                                                      sd.discrete_omega.float().to(dev).contiguous(), p2, dm,
+                                                      self.trans_diffuser.coordinate_scaling)
 
     # ------------------------------------------------------------------ per step (HIP)
     def step_params(self, t: torch.Tensor) -> torch.Tensor:

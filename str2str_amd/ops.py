@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _lib = None
 _tables_loaded = False
@@ -131,18 +131,22 @@ def load_library(path: Optional[str] = None):
 
 
 # ------------------------------------------------------------------------------------------ range guard of the f16x3 kernels
-_range_flag = None   # one int32 device word, owned here for the life of the process (captured HIP graphs hold its address)
-RANGE_BITS = {1: "node GEMM", 2: "pack_planes", 4: "edge transition", 8: "edge embedding", 16: "IPA points", 32: "encoder attention"}
+_range_flag = None   # eight int32 device words, owned here for the life of the process (captured HIP graphs hold the address)
+RANGE_BITS = {1: "node GEMM", 2: "pack_planes", 4: "edge transition", 8: "edge embedding", 16: "IPA points", 32: "encoder attention",
+              64: "IPA attention"}
+# kernel families as the sampler demotes them (str2str_amd/arith.py): flag bits -> family
+RANGE_FAMILIES = {"node": 1 | 2 | 32, "edge_transition": 4, "edge_embed": 8, "ipa": 16 | 64}
 
 
 def range_flag() -> torch.Tensor:
-    """The device word the split-f16 kernels OR a bit into when a value they split into f16 planes reaches 2^15 (half of f16's
-    largest finite number) or is not finite (csrc/range_flag.h).  Registered with the library on first use."""
+    """The device buffer of the range guard (csrc/range_flag.h): word 0 = one bit per kernel family whose split values reached 2^15
+    (half of f16's largest finite number) or were not finite; words 1..7 = magnitude buckets per family (``range_headroom``).
+    Registered with the library on first use."""
     global _range_flag
     if _range_flag is None:
         if not torch.cuda.is_available():
             raise HipLibraryError("the range flag lives on the HIP device")
-        _range_flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _range_flag = torch.zeros(8, dtype=torch.int32, device="cuda")
         _check(load_library().s2s_set_range_flag(_p(_range_flag)), "s2s_set_range_flag")
     return _range_flag
 
@@ -153,11 +157,31 @@ def range_flag_reset():
 
 def range_flag_read() -> int:
     """Synchronising read of the flag word (0 = every f16x3 launch since the last reset stayed in range)."""
-    return int(range_flag().item())
+    return int(range_flag()[0].item())
 
 
 def range_flag_names(bits: int) -> str:
     return ", ".join(n for b, n in RANGE_BITS.items() if bits & b) or "none"
+
+
+def range_families(bits: int):
+    """Kernel families (keys of RANGE_FAMILIES) named by a flag word."""
+    return [f for f, m in RANGE_FAMILIES.items() if bits & m]
+
+
+def range_headroom() -> dict:
+    """{family: upper bound of max |x| / 2^15} over every f16x3 launch since the last reset (synchronising read).  The kernels record
+    maxima in power-of-two buckets from 2^8 up (nothing below: ordinary activations cost no atomic), so the figure is the bucket's
+    upper edge: 2^-6 = "never reached 256", 1.0 = "in [2^14, 2^15)", 2.0 and 4.0 = the guard fired (4.0: 2^16 or more / not finite)."""
+    words = range_flag().tolist()
+    out = {}
+    for fam, mask in RANGE_FAMILIES.items():
+        top = -1
+        for k in range(7):
+            if mask >> k & 1 and words[1 + k]:
+                top = max(top, int(words[1 + k]).bit_length() - 1)
+        out[fam] = 2.0 ** (top + 9 - 15) if top >= 0 else 2.0 ** (8 - 15)
+    return out
 
 
 def _check(rc: int, what: str):
@@ -857,10 +881,20 @@ def node_apply(x, layer: dict, n_rows: int, *, out_f32=None, out_col0: int = 0, 
     [n_rows, K] -> s2s_node_linear_f32.  ``layer`` = pack_node_layer(...).  Same calling convention and return value
     (fp32 output or None, activation-format output or None) in both; in the fp32 arithmetic the two outputs are the same tensor
     (``out_xp``, an fp32 buffer there, is written at column ``out_xp_k0`` when no ``out_f32`` is given)."""
+    T = torch.ops.str2str_amd
+    ep = dict(epilogue)
+    ln = ep.pop("ln", None)
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    row_map = ep.pop("row_map", None)
+    flat = (ep.pop("pre_scale", None), bool(ep.pop("relu", False)), ep.pop("pre_mask", None), ep.pop("residual", None), g, b, float(eps),
+            ep.pop("post_mask", None))
+    if ep:
+        raise TypeError(f"node_apply: unexpected arguments {sorted(ep)}")
     if x.dtype == torch.int16:
-        return node_linear(x, layer["w"], layer["b"], n_rows, layer["k"], layer["n"], layer["tg"], out_f32=out_f32, out_col0=out_col0,
-                           want_f32=want_f32, out_xp=out_xp, out_xp_k=out_xp_k, out_xp_k0=out_xp_k0, want_xp=want_xp, **epilogue)
-    if epilogue.pop("row_map", None) is not None:
+        mp, ms = row_map if row_map is not None else (0, 0)
+        return T.node_linear(x, layer["w"], layer["b"], n_rows, layer["k"], layer["n"], layer["tg"], *flat, out_f32, out_col0, want_f32,
+                             out_xp, -1 if out_xp_k is None else out_xp_k, out_xp_k0, want_xp, mp, ms)
+    if row_map is not None:
         raise HipLibraryError("node_apply: the row map belongs to the f16 attention operands")
     if out_f32 is not None:
         out, col0 = out_f32, out_col0
@@ -868,7 +902,7 @@ def node_apply(x, layer: dict, n_rows: int, *, out_f32=None, out_col0: int = 0, 
             raise HipLibraryError("node_apply (fp32): one output buffer")
     else:
         out, col0 = out_xp, out_xp_k0
-    y = node_linear_f32(x, layer["w32"], layer["b"], n_rows, layer["k"], layer["n"], layer["tg"], out=out, out_col0=col0, **epilogue)
+    y = T.node_linear_f32(x, layer["w32"], layer["b"], n_rows, layer["k"], layer["n"], layer["tg"], *flat, out, col0)
     return y, y
 
 
@@ -1024,35 +1058,111 @@ def merge_pdb_files(paths, out_path: str) -> int:
 _registered = False
 
 
+def _ln3(g, b, eps):
+    return None if g is None else (g, b, eps)
+
+
+def _opt_int(v):
+    return None if v is None or v < 0 else v
+
+
+# (the dispatcher passes positional arguments up to the last one the caller gave: the implementations carry the schema's defaults)
+def _op_node_linear(xp, wpk, bias, n_rows, k_in, n_out, tiles, pre_scale=None, relu=False, pre_mask=None, residual=None, ln_gamma=None,
+                    ln_beta=None, ln_eps=0.0, post_mask=None, out_f32=None, out_col0=0, want_f32=True, out_xp=None, out_xp_k=-1,
+                    out_xp_k0=0, want_xp=False, map_pad=0, map_src=0):
+    return node_linear(xp, wpk, bias, n_rows, k_in, n_out, tiles, pre_scale=pre_scale, relu=relu, pre_mask=pre_mask, residual=residual,
+                       ln=_ln3(ln_gamma, ln_beta, ln_eps), post_mask=post_mask, out_f32=out_f32, out_col0=out_col0, want_f32=want_f32,
+                       out_xp=out_xp, out_xp_k=_opt_int(out_xp_k), out_xp_k0=out_xp_k0, want_xp=want_xp,
+                       row_map=(map_pad, map_src) if map_pad else None)
+
+
+def _op_node_linear_f32(x, wpk32, bias, n_rows, k_in, n_out, tiles, pre_scale=None, relu=False, pre_mask=None, residual=None, ln_gamma=None,
+                        ln_beta=None, ln_eps=0.0, post_mask=None, out=None, out_col0=0):
+    return node_linear_f32(x, wpk32, bias, n_rows, k_in, n_out, tiles, pre_scale=pre_scale, relu=relu, pre_mask=pre_mask,
+                           residual=residual, ln=_ln3(ln_gamma, ln_beta, ln_eps), post_mask=post_mask, out=out, out_col0=out_col0)
+
+
+def _op_edge_transition_f16x3_chain(edge, in_tiled, B, N, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps, proj_bias64,
+                                    out_layout):
+    """The trunk's form of the edge transition: pair tensor in either layout (``edge`` = the flat tiled buffer when ``in_tiled``), the
+    next IPA block's projections fused in when ``proj_bias64`` is given (``wstream`` is then the 31-stage stream).
+    -> (pair tensor (row-major [B,N,N,128] | flat tiled buffer | None), attn_bias | None, pair_z | None)"""
+    e = PairTiled(B, N, buf=edge) if in_tiled else edge
+    r = edge_transition_f16x3(e, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps,
+                              proj=None if proj_bias64 is None else (wstream, proj_bias64), out_layout=out_layout)
+    z, bias, pz = r if proj_bias64 is not None else (r, None, None)
+    return (z.buf if isinstance(z, PairTiled) else z), bias, pz
+
+
+_TORCH_OPS = {
+    # ---- pair stream
+    "edge_transition(Tensor edge, Tensor node_ab, Tensor node_p, Tensor w1p, Tensor w2p, Tensor wfp, Tensor b2, "
+    "Tensor bf, Tensor gamma, Tensor beta, Tensor? mask, float ln_eps) -> Tensor": lambda *a: edge_transition(*a),
+    "edge_transition_f16x3(Tensor edge, Tensor node_ab, Tensor node_p, Tensor wstream, Tensor b2, Tensor bf, "
+    "Tensor gamma, Tensor beta, Tensor? mask, float ln_eps) -> Tensor": lambda *a: edge_transition_f16x3(*a),
+    "edge_transition_f16x3_chain(Tensor edge, bool in_tiled, int B, int N, Tensor node_ab, Tensor node_p, Tensor wstream, Tensor b2, "
+    "Tensor bf, Tensor gamma, Tensor beta, Tensor? mask, float ln_eps, Tensor? proj_bias64, str out_layout) -> (Tensor?, Tensor?, Tensor?)":
+        _op_edge_transition_f16x3_chain,
+    "edge_embed(Tensor node_a, Tensor node_b, Tensor rel_table, Tensor bin_table, Tensor bin_lower, Tensor residue_idx, Tensor ca, "
+    "Tensor w2p, Tensor w3p, Tensor b2, Tensor b3, Tensor gamma, Tensor beta, Tensor? mask, int rel_offset, float ln_eps) -> Tensor":
+        lambda *a: edge_embed(*a),
+    "edge_embed_f16x3(Tensor node_a, Tensor node_b, Tensor rel_table, Tensor bin_table, Tensor bin_lower, "
+    "Tensor residue_idx, Tensor ca, Tensor wstream, Tensor b2, Tensor b3, Tensor gamma, Tensor beta, Tensor? mask, "
+    "int rel_offset, float ln_eps) -> Tensor": lambda *a: edge_embed_f16x3(*a),
+    "pair_project(Tensor edge, Tensor wp, Tensor bias64) -> (Tensor, Tensor)": lambda *a: pair_project(*a),
+    # ---- attention
+    "ipa_prep_points(Tensor rigids7, Tensor q_pts_lin, Tensor kv_pts_lin, int n_heads=8, int n_qk=8, int n_v=12) -> (Tensor, Tensor, Tensor)":
+        lambda *a: ipa_prep_points(*a),
+    "ipa_attention(Tensor q, Tensor kv, Tensor q_pts, Tensor k_pts, Tensor v_pts, Tensor attn_bias, Tensor pair_z, "
+    "Tensor mask, Tensor rigids7, Tensor head_w) -> Tensor": lambda *a: ipa_attention(*a),
+    "ipa_prep_points_f16(Tensor rigids7, Tensor q_pts_lin, Tensor kv_pts_lin, Tensor head_w, int n_heads=8, int n_qk=8, int n_v=12, "
+    "int c_hidden=256) -> (Tensor, Tensor, Tensor, Tensor, Tensor)": lambda *a: ipa_prep_points_f16(*a),
+    "ipa_attention_f16w(Tensor q_xp, Tensor k_xp, Tensor v_vf, Tensor qp_xp, Tensor kp_xp, Tensor vp_vf, Tensor q2, Tensor k2, "
+    "Tensor(a!) attn_bias, Tensor pair_z, Tensor mask, Tensor rigids7, int n_heads=8, int c_hidden=256, int n_qk=8, int n_v=12, int c_pz=32, "
+    "float inf=1e5, float eps=1e-8, bool logits_inplace=False) -> (Tensor, Tensor)":
+        lambda q, k, v, qp, kp, vp, q2, k2, ab, pz, m, r7, *rest: ipa_attention_f16(q, k, v, (qp, kp, vp, q2, k2), ab, pz, m, r7, *rest),
+    "encoder_attention(Tensor qkv, Tensor? key_bias, int n_samples, int n_res, int n_heads=4, bool want_f32=False, bool want_xp=True, "
+    "str arith='f32') -> (Tensor?, Tensor?)": lambda *a: encoder_attention(*a),
+    # ---- node stream
+    "node_linear(Tensor xp, Tensor wpk, Tensor? bias, int n_rows, int k_in, int n_out, int tiles, Tensor? pre_scale=None, bool relu=False, "
+    "Tensor? pre_mask=None, Tensor? residual=None, Tensor? ln_gamma=None, Tensor? ln_beta=None, float ln_eps=0.0, Tensor? post_mask=None, "
+    "Tensor(a!)? out_f32=None, int out_col0=0, bool want_f32=True, Tensor(b!)? out_xp=None, int out_xp_k=-1, int out_xp_k0=0, "
+    "bool want_xp=False, int map_pad=0, int map_src=0) -> (Tensor?, Tensor?)": _op_node_linear,
+    "node_linear_f32(Tensor x, Tensor wpk32, Tensor? bias, int n_rows, int k_in, int n_out, int tiles, Tensor? pre_scale=None, "
+    "bool relu=False, Tensor? pre_mask=None, Tensor? residual=None, Tensor? ln_gamma=None, Tensor? ln_beta=None, float ln_eps=0.0, "
+    "Tensor? post_mask=None, Tensor(a!)? out=None, int out_col0=0) -> Tensor": _op_node_linear_f32,
+    "node_linear_vfrag(Tensor xp, Tensor wpk, Tensor? bias, int n_rows, int k_in, int n_out, int tiles_per_head=8, int map_pad=0, "
+    "int map_src=0) -> Tensor":
+        lambda xp, w, b, m, k, n, tph=8, mp=0, ms=0: node_linear_vfrag(xp, w, b, m, k, n, tph, row_map=(mp, ms) if mp else None),
+    "pack_planes(Tensor x, int col0=0, int n_cols=-1, Tensor(a!)? out=None, int out_k=-1, int k0=0, Tensor? row_scale=None) -> Tensor":
+        lambda x, c0=0, nc=-1, out=None, ok=-1, k0=0, rs=None: pack_planes(x, c0, _opt_int(nc), out, _opt_int(ok), k0, rs),
+    # ---- frames / diffusion geometry
+    "se3_step(Tensor x0_7, Tensor xt_7, Tensor mask, Tensor diffuse_mask, Tensor params8, float dt) -> Tensor":
+        lambda x0, xt, m, dm, p8, dt: se3_step(x0, xt, m, dm, p8, dt)[0],
+    "forward_marginal(Tensor? rigids0_4x4, Tensor z_axis, Tensor u01, Tensor z_trans, Tensor cdf_rows, Tensor row_of_sample, "
+    "Tensor omega_grid, Tensor? params2, Tensor? diffuse_mask=None, float coordinate_scaling=0.1) -> Tensor":
+        lambda *a: forward_marginal(*a),
+    "rigid_compose_update(Tensor rigids7, Tensor update6, Tensor mask) -> Tensor": lambda *a: rigid_compose_update(*a),
+    "rigid_scale_trans(Tensor rigids7, float scale, bool divide=False) -> Tensor": lambda *a: rigid_scale_trans(*a),
+    "frames_to_backbone(Tensor rigids7, Tensor psi, Tensor? aatype) -> Tensor": lambda r, p, a: frames_to_backbone(r, p, a)[0],
+}
+
+
 def register_torch_ops():
-    """Expose the kernels as ``torch.ops.str2str_amd.<name>`` (CUDA/HIP dispatch key only)."""
+    """Expose every tensor entry point of the library as ``torch.ops.str2str_amd.<name>`` (CUDA/HIP dispatch key only).
+    The model's modules reach their kernels through these ops (``node_apply``, ``encoder_attention``, the attention and
+    edge-transition call sites below and in models/net): ``torch.ops.str2str_amd`` is the operator surface, this module its
+    implementation over the C ABI.  Called by ``load_library``."""
     global _registered
     if _registered:
         return
     lib = torch.library.Library("str2str_amd", "DEF")
     impl = torch.library.Library("str2str_amd", "IMPL", "CUDA")
-    defs = {
-        "edge_transition(Tensor edge, Tensor node_ab, Tensor node_p, Tensor w1p, Tensor w2p, Tensor wfp, Tensor b2, "
-        "Tensor bf, Tensor gamma, Tensor beta, Tensor? mask, float ln_eps) -> Tensor":
-            lambda *a: edge_transition(*a),
-        "edge_transition_f16x3(Tensor edge, Tensor node_ab, Tensor node_p, Tensor wstream, Tensor b2, Tensor bf, "
-        "Tensor gamma, Tensor beta, Tensor? mask, float ln_eps) -> Tensor":
-            lambda *a: edge_transition_f16x3(*a),
-        "edge_embed_f16x3(Tensor node_a, Tensor node_b, Tensor rel_table, Tensor bin_table, Tensor bin_lower, "
-        "Tensor residue_idx, Tensor ca, Tensor wstream, Tensor b2, Tensor b3, Tensor gamma, Tensor beta, Tensor? mask, "
-        "int rel_offset, float ln_eps) -> Tensor":
-            lambda *a: edge_embed_f16x3(*a),
-        "pair_project(Tensor edge, Tensor wp, Tensor bias64) -> (Tensor, Tensor)": lambda *a: pair_project(*a),
-        "se3_step(Tensor x0_7, Tensor xt_7, Tensor mask, Tensor diffuse_mask, Tensor params8, float dt) -> Tensor":
-            lambda x0, xt, m, dm, p8, dt: se3_step(x0, xt, m, dm, p8, dt)[0],
-        "ipa_attention(Tensor q, Tensor kv, Tensor q_pts, Tensor k_pts, Tensor v_pts, Tensor attn_bias, Tensor pair_z, "
-        "Tensor mask, Tensor rigids7, Tensor head_w) -> Tensor": lambda *a: ipa_attention(*a),
-        "rigid_compose_update(Tensor rigids7, Tensor update6, Tensor mask) -> Tensor": lambda *a: rigid_compose_update(*a),
-        "frames_to_backbone(Tensor rigids7, Tensor psi, Tensor? aatype) -> Tensor":
-            lambda r, p, a: frames_to_backbone(r, p, a)[0],
-    }
-    for schema, fn in defs.items():
+    for schema, fn in _TORCH_OPS.items():
         lib.define(schema)
         impl.impl(schema.split("(")[0], fn)
     register_torch_ops._libs = (lib, impl)  # keep alive
     _registered = True
+
+
+register_torch_ops()

@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .arith import net_arith, use_arith
+from .arith import FAMILIES, family_slots, net_arith, use_arith
 from .common.all_atom import compute_backbone
 from .common.rigid_utils import Rigid
 
@@ -112,7 +112,7 @@ def _graph_key(net, feats, b, N):
         h.update(k.encode()); h.update(str(tuple(v.shape)).encode()); h.update(v.detach().cpu().numpy().tobytes())
     tr = getattr(net, "translator", None)
     # which kernels were captured: the arithmetic / kernel selectors of the modules
-    modes = tuple(sorted({str(getattr(m, "arith")) for m in net.modules() if hasattr(m, "arith")}))
+    modes = tuple(str(getattr(m, a)) for m, a in family_slots(net))   # per switch, in module order: a mixed network has many forms
     return (id(net), sum(p._version for p in net.parameters()), b, N, bool(getattr(tr, "exact_padding", False)),
             bool(getattr(tr, "fuse_pair_projection", False)), modes, h.hexdigest())
 
@@ -183,53 +183,52 @@ def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: flo
 
     Range guard: in the split-f16 arithmetic the pass runs with the library's range flag cleared; if a kernel raised it (an
     activation reached 2^15 -- f16 tops out at 65504) or the result is not finite, the SAME chunk (same starting frames, same
-    noise) is run again on the exact fp32 kernels, a warning is logged once, and the network stays in fp32 for later chunks
-    (``net.range_fallback``).  One flag read per chunk, at the point where the loop synchronises anyway."""
+    noise) is run again with ONLY the kernel families that raised it (str2str_amd/arith.py: node stream, edge transition, edge
+    embedding, IPA) on their exact fp32 kernels; a warning is logged once per family and those families stay in fp32 for later
+    chunks (``net.range_fallback`` = the set of demoted families) -- one out-of-range activation in, say, the encoder attention no
+    longer costs the edge transitions (73 % of the step) their 3x.  One flag read per chunk, where the loop synchronises anyway."""
     kw = dict(min_t=min_t, noise_scale=noise_scale, probability_flow=probability_flow, self_conditioning=self_conditioning,
               center_mode=center_mode, trace=trace)
-    if net_arith(net) != "f16x3":
+    if net_arith(net) == "f32":
         out = _denoise_pass(net, diffuser, feats, rigids_t, ts, dt, host_noise=host_noise, **kw)
         _require_finite(out[1], "fp32")
         return out
-    if getattr(net, "range_fallback", False):
-        with use_arith(net, "f32"):
-            out = _denoise_pass(net, diffuser, feats, rigids_t, ts, dt, host_noise=host_noise, **kw)
-        _require_finite(out[1], "fp32 (range fallback)")
-        return out
+    demoted = set(getattr(net, "range_fallback", None) or ())
     device_draws = host_noise is None and not probability_flow
     rng_state = torch.cuda.get_rng_state(rigids_t.device) if device_draws else None
-    drawn = []
-
-    def recording_noise():
-        z = host_noise()
-        drawn.append(z)
-        return z
-
-    ops.range_flag_reset()
-    try:
-        out = _denoise_pass(net, diffuser, feats, rigids_t, ts, dt, host_noise=recording_noise if host_noise is not None else None, **kw)
-        finite = bool(torch.isfinite(out[1]).all())     # (the synchronisation point of the chunk)
-        bits = ops.range_flag_read()
-        if bits == 0 and finite:
-            return out
-        why = f"an activation left f16's safe range in the split-f16 kernels ({ops.range_flag_names(bits)}{'' if finite else '; non-finite frames'})"
-    except ops.WeightRangeError as e:   # |32 w| >= 65504: the weights themselves cannot be packed for the f16 kernels
-        why = f"a weight does not fit the split-f16 packing ({e})"
-        for _ in range(len(ts) - 1 - len(drawn)):   # keep the host generator where a completed pass leaves it
-            recording_noise() if host_noise is not None else None
-    _log.warning("range guard: %s; re-running this chunk on the exact fp32 kernels and keeping the network there "
-                 "(set S2S_ARITH=f32 to start in fp32)", why)
-    net.range_fallback = True
-    if trace is not None:
-        del trace[:]
-    if rng_state is not None:
-        torch.cuda.set_rng_state(rng_state, rigids_t.device)
-    replay = iter(drawn)
-    with use_arith(net, "f32"):
-        out = _denoise_pass(net, diffuser, feats, rigids_t, ts, dt, host_noise=(lambda: next(replay)) if host_noise is not None else None,
-                            **kw)
-    _require_finite(out[1], "fp32 (range fallback)")
-    return out
+    # Host noise (parity mode) comes from the global CPU generator (forward_backward.host_noise): a replay re-draws it from the
+    # generator state saved here -- nothing is recorded (the draws of a long SDE trajectory at b = 128, N = 512 are ~0.6 GB), and
+    # every pass leaves the generator where one completed pass leaves it.
+    host_state = torch.get_rng_state() if host_noise is not None else None
+    while True:
+        if host_state is not None:
+            torch.set_rng_state(host_state)
+        ops.range_flag_reset()
+        try:
+            with use_arith(net, "f32", families=tuple(demoted)):
+                out = _denoise_pass(net, diffuser, feats, rigids_t, ts, dt, host_noise=host_noise, **kw)
+            finite = bool(torch.isfinite(out[1]).all())     # (the synchronisation point of the chunk)
+            bits = ops.range_flag_read()
+            if bits == 0 and finite:
+                return out
+            new = set(ops.range_families(bits)) - demoted
+            why = f"an activation left f16's safe range in the split-f16 kernels ({ops.range_flag_names(bits)}{'' if finite else '; non-finite frames'})"
+        except ops.WeightRangeError as e:   # |32 w| >= 65504: the weights themselves cannot be packed for the f16 kernels
+            new = set(FAMILIES) - demoted
+            why = f"a weight does not fit the split-f16 packing ({e})"
+        if not new:
+            if len(demoted) == len(FAMILIES):
+                _require_finite(out[1], "fp32 (range fallback)")
+                return out
+            new = set(FAMILIES) - demoted   # non-finite frames without a flag: nothing names a family, everything goes exact
+        demoted |= new
+        _log.warning("range guard: %s; re-running this chunk with the %s kernels on exact fp32 and keeping them there (now in fp32: %s; "
+                     "S2S_ARITH=f32 starts everything in fp32)", why, " + ".join(sorted(new)), ", ".join(sorted(demoted)))
+        net.range_fallback = frozenset(demoted)
+        if trace is not None:
+            del trace[:]
+        if rng_state is not None:
+            torch.cuda.set_rng_state(rng_state, rigids_t.device)
 
 
 def _require_finite(rigids7, what):
@@ -423,10 +422,17 @@ def plan_mixed_work(lengths, replicas: int, world: int = 1, *, max_pairs: int = 
 
 
 @torch.no_grad()
+def mixed_batch_seed(base_seed: int, t_delta: float, chain: int, replica_lo: int) -> int:
+    """Seed of the host generators for the padded batch whose first item is (chain, replica_lo): a function of the run seed and the
+    work item only, so no two batches of a run -- on one rank or on different ranks -- share a noise stream."""
+    return (int(base_seed) * 1000003 + int(round(float(t_delta) * 1000)) * 998244353 + int(chain) * 7919 + int(replica_lo) * 104729
+            + 12345) % (2 ** 63 - 1)
+
+
 def sample_mixed_lengths(net, diffuser, targets, replicas: int, t_delta: float, *, num_timesteps: int,
                          min_t: float = 0.01, noise_scale: float = 1.0, probability_flow: bool = True,
                          self_conditioning: bool = True, device=None, rigids_t_init=None, shard: Tuple[int, int] = (0, 1),
-                         rng: str = "host", max_pairs: int = 24 << 20, plan=None):
+                         rng: str = "host", max_pairs: int = 24 << 20, plan=None, seed_base: Optional[int] = None):
     """BASELINE configs[4]: many chains of different length, ``replicas`` each, in padded batches.
 
     The reference cannot do this (`assert batch size == 1`, diffusion_module.py:249) and its padding semantics
@@ -448,9 +454,19 @@ def sample_mixed_lengths(net, diffuser, targets, replicas: int, t_delta: float, 
     tr = net.translator
     keep = tr.exact_padding
     tr.exact_padding = True
+    base_seed = int(torch.initial_seed()) if seed_base is None else int(seed_base)   # (callers that loop over t_delta pass the run's seed: the per-batch seeding below replaces the generator's)
     try:
         for batch in plan[rank]:
             n_pad = batch["n_pad"]
+            if rng == "host":
+                # The host generators are seeded per batch from (run seed, t_delta, first (chain, replica) item of the batch): every
+                # rank starts from the same run seed (eval.py), and without this each rank would draw the noise of ITS blocks from the
+                # same stream -- identical starting frames and step noise for replica blocks 0-24, 25-49, ... of a chain, i.e. duplicate
+                # conformations in the gathered ensemble.  (The device mode offsets its Philox seed by the rank instead.)
+                ti0, lo0, _ = batch["items"][0]
+                item_seed = mixed_batch_seed(base_seed, t_delta, ti0, lo0)
+                torch.random.default_generator.manual_seed(item_seed)   # the CPU generator only: the device stream is not touched
+                np.random.seed(item_seed % (2 ** 32))
             rows, r_t = {k: [] for k in _REPEAT_KEYS}, []
             for ti, lo, hi in batch["items"]:
                 tg, L, b = targets[ti], lengths[ti], hi - lo

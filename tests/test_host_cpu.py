@@ -230,6 +230,53 @@ def test_mixed_length_plan_covers_every_replica_once_and_balances():
             assert max(loads) <= 1.12 * sum(loads) / world, (replicas, world, loads)
 
 
+def test_mixed_length_batches_never_share_a_host_noise_stream():
+    """Every rank of a run starts from the same seed (eval.py), so the host generators are re-seeded per padded batch from (run seed,
+    t_delta, first work item) -- sampler.mixed_batch_seed.  The advisor's case: lens [10, 20, 28, 35, 80] x 100 replicas over 4 ranks,
+    where every rank gets the same SHAPES of batches: no two batches of the run (on any ranks, at any t_delta) may get the same seed."""
+    from str2str_amd.sampler import mixed_batch_seed, plan_mixed_work
+
+    lens = [10, 20, 28, 35, 80]
+    for world in (1, 2, 4, 8):
+        plan = plan_mixed_work(lens, 100, world)
+        seeds = [mixed_batch_seed(3, t, *b["items"][0][:2]) for t in (0.1, 0.5, 1.0) for r in range(world) for b in plan[r]]
+        assert len(set(seeds)) == len(seeds) and all(0 <= s < 2 ** 63 for s in seeds)
+    assert mixed_batch_seed(3, 0.5, 1, 25) != mixed_batch_seed(4, 0.5, 1, 25)
+
+
+def test_tica_fit_recovers_the_slow_mode_of_a_two_state_process():
+    """metrics.tica_fit (the estimator behind js_tica when deeptime is not installed; reference src/metrics/metrics.py:169-200) on a
+    process with a known answer: a two-state jump process s_t = +-1 (switching probability p per frame, autocorrelation (1 - 2p)^lag)
+    seen through 6 features x_t = s_t a + fast noise + two constant-zero-variance directions (rank-deficient C00, as pairwise
+    distances are).  The slowest component must be the optimal linear read-out of s_t (correlation sqrt(snr / (1 + snr)) with it), its
+    autocorrelation at the lag must match the analytic value, the second component must carry no slow signal, and the absolute eigenvalue cut-off must drop the
+    degenerate directions instead of amplifying them."""
+    import numpy as np
+
+    from str2str_amd.metrics.metrics import tica_fit
+
+    rng = np.random.default_rng(0)
+    T, p, lag = 20000, 0.01, 20
+    flips = rng.random(T) < p
+    s = np.where(np.cumsum(flips) % 2 == 0, 1.0, -1.0)
+    a = np.array([2.0, -1.0, 0.5, 3.0])
+    x = s[:, None] * a[None, :] + rng.normal(size=(T, 4)) * np.array([1.0, 2.0, 0.5, 4.0])
+    x = np.concatenate([x, np.full((T, 1), 7.0), x[:, :1] * 1e-5], axis=1)    # a constant feature and a copy scaled below the cut-off
+    mean, proj = tica_fit(x, lag, dim=2)
+    assert proj.shape == (6, 2) and np.isfinite(proj).all()
+    y = (x - mean) @ proj
+    snr = np.sum((a / np.array([1.0, 2.0, 0.5, 4.0])) ** 2)             # signal variance in the noise-whitened direction
+    c1 = np.corrcoef(y[:, 0], s)[0, 1]
+    assert abs(abs(c1) - np.sqrt(snr / (1 + snr))) < 0.01, c1
+    assert abs(np.corrcoef(y[:, 1], s)[0, 1]) < 0.05
+    # whitened components have unit variance; the autocorrelation of the first at the lag = signal fraction x (1 - 2p)^lag
+    y0 = y[:, 0]
+    auto = np.mean(y0[:-lag] * y0[lag:]) / np.mean(y0 * y0)
+    want = (snr / (1 + snr)) * (1 - 2 * p) ** lag
+    assert abs(auto - want) < 0.03, (auto, want)
+    assert np.abs(proj[4:]).max() < 1e3          # neither the constant nor the sub-cut-off copy is blown up by the whitening
+
+
 def test_pair_tiled_layout_matches_the_header():
     """ops.pair_tiled / pair_untiled against the formula of include/str2str_hip.h ("Pair-tensor layouts"): channel 8 g + 4 h + q of pair
     32 b + n at float offset 4096 b + 256 g + 128 h + 4 n + q; whole blocks, zero padding; round trip."""
