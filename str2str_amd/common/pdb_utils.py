@@ -115,7 +115,14 @@ def extract_backbone_coords(input_path: str, max_n_model: Optional[int] = None) 
         models, cur, seen = [], [], set()
         with open(input_path) as fh:
             for ln in fh:
-                if ln.startswith("ATOM") and ln[12:16].strip() == "CA" and ln[17:20] in _AMINO_ACIDS:
+                if ln.startswith(("ATOM", "HETATM")) and ln[12:16] == " CA ":      # a C-alpha (a calcium ion is "CA  ")
+                    if ln[17:20] not in _AMINO_ACIDS:
+                        # biotite's filter_amino_acids accepts every peptide-linking component of the CCD (MSE, SEC, HYP, ...), a
+                        # table this reader does not carry: such a residue is an error here, not a silently shorter chain
+                        raise ValueError(f"{input_path}: C-alpha of non-standard residue {ln[17:20]!r} {ln[21]}{ln[22:27].strip()}: "
+                                         "only the 20 standard amino acids are read (convert the residue or extend _AMINO_ACIDS)")
+                    if not ln.startswith("ATOM"):
+                        continue
                     key = (ln[21], ln[22:27])          # chain id, resSeq + iCode
                     if key not in seen:                 # later altlocs of a residue already taken are skipped
                         seen.add(key)

@@ -56,6 +56,23 @@ class Linear(nn.Linear):
             else:
                 raise ValueError("Invalid init string.")
 
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """y = x W^T + b on the node kernel (s2s_node_linear / s2s_node_linear_f32 in the configured arithmetic) for callers outside
+        the sampler, which packs and fuses whole chains of these layers itself (TranslationIPA._node_weights).  No library GEMM and
+        no CPU path: every matrix product of the package runs on the package's own kernels."""
+        if not x.is_cuda:
+            raise ops.HipLibraryError("Linear.forward runs on the HIP device only (the package has no CPU / BLAS matrix path; "
+                                      "CPU restatements live under oracle/ for the tests)")
+        if not hasattr(self, "_pack"):
+            self._pack = ParamCache()
+        bias = self.bias if self.bias is not None else torch.zeros(self.out_features, device=x.device)
+        layer = self._pack.get([self.weight, bias], lambda: ops.pack_node_layer(self.weight, bias))
+        if self.in_features % 32:
+            raise ops.HipLibraryError(f"Linear.forward: the node kernel wants in_features in multiples of 32 (got {self.in_features})")
+        lead, M = x.shape[:-1], x.numel() // x.shape[-1]
+        y, _ = ops.node_apply(ops.to_act(x.reshape(M, x.shape[-1]).float().contiguous(), default_arith()), layer, M)
+        return y[:, : self.out_features].reshape(*lead, self.out_features)
+
 
 class ParamCache:
     """Derived device tensors (packed / concatenated weights) keyed on the source parameters'

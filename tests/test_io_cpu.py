@@ -178,7 +178,8 @@ def test_native_writer_byte_identical_to_reference_text(tmp_path, monkeypatch):
 
 def test_extract_backbone_coords_altloc_and_nonstandard(tmp_path):
     """Reference reader semantics (biotite, altloc='first' + filter_backbone, pdb_utils.py:255-317): the first alternate location of
-    a residue, amino-acid residues only, equal model lengths (a ragged file is an error, not a silent ragged array)."""
+    a residue, amino-acid residues only (a non-standard one is an error here), equal model lengths (a ragged file is an error, not a
+    silent ragged array)."""
     import pytest
 
     from str2str_amd.common.pdb_utils import extract_backbone_coords
@@ -187,13 +188,19 @@ def test_extract_backbone_coords_altloc_and_nonstandard(tmp_path):
         return f"ATOM  {serial:5d} {name:^4s}{alt}{res:>3s} {chain}{seq:4d}    {x:8.3f}{0.0:8.3f}{0.0:8.3f}  1.00  0.00           C  "
 
     model = [atom(1, "CA", "A", "ALA", "A", 1, 1.0), atom(2, "CA", "B", "ALA", "A", 1, 9.0),      # altloc B of residue 1: skipped
-             atom(3, "CA", " ", "GLY", "A", 2, 2.0), atom(4, "CA", " ", "MSE", "A", 3, 7.0),      # non-standard residue: skipped
+             atom(3, "CA", " ", "GLY", "A", 2, 2.0),
+             "HETATM    9 CA    CA A 900       5.000   0.000   0.000  1.00  0.00          CA  ",          # a calcium ion is not a C-alpha
              atom(5, "CA", " ", "SER", "A", 4, 3.0)]
     txt = "\n".join(["MODEL        1"] + model + ["ENDMDL", "MODEL        2"] + model + ["ENDMDL", "END"])
     p = tmp_path / "alt.pdb"
     p.write_text(txt)
     ca = extract_backbone_coords(str(p))
     assert ca.shape == (2, 3, 3) and ca[0, :, 0].tolist() == [1.0, 2.0, 3.0]
+    # a C-alpha of a residue outside the 20 standard names (biotite would keep MSE: its amino-acid table is the CCD's) is an error,
+    # not a silently shorter chain
+    (tmp_path / "mse.pdb").write_text("\n".join(model[:3] + [atom(4, "CA", " ", "MSE", "A", 3, 7.0).replace("ATOM  ", "HETATM")] + ["END"]))
+    with pytest.raises(ValueError, match="MSE"):
+        extract_backbone_coords(str(tmp_path / "mse.pdb"))
     (tmp_path / "ragged.pdb").write_text("\n".join(["MODEL        1"] + model + ["ENDMDL", "MODEL        2"] + model[:3]))
     with pytest.raises(ValueError):
         extract_backbone_coords(str(tmp_path / "ragged.pdb"))
