@@ -156,18 +156,20 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
     Ctx cur = setup(wt);
 
     // ---- edge rows of pair tile `wave` of a tile: 16 loads of 16 B per lane (chain channel order), split, 16 fragments into XB
-    float4 xv[16];
-    auto x_load = [&](const Ctx& c) {
-        const float* er = edge + pair_off(pick(c.p), in_tiled);
+    // in four quarters of two k-steps (16 registers in flight each): the kernel has no room for a whole row (64) beside a phase's operands
+    float4 xv[4];
+    auto x_load = [&](unsigned p_own, int qt) {   // p_own: this lane's pair in pair tile `wave`
+        const float* er = edge + pair_off(p_own, in_tiled);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) xv[i] = *reinterpret_cast<const float4*>(er + i * in_step);
+        for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4*>(er + (4 * qt + i) * in_step);
     };
-    auto x_store = [&]() {
+    auto x_store = [&](int qt) {
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int ks = 2 * qt + k2;
             u32x4 ph, pl;
-            const float a[4] = {xv[2 * ks].x, xv[2 * ks].y, xv[2 * ks].z, xv[2 * ks].w};
-            const float b[4] = {xv[2 * ks + 1].x, xv[2 * ks + 1].y, xv[2 * ks + 1].z, xv[2 * ks + 1].w};
+            const float a[4] = {xv[2 * k2].x, xv[2 * k2].y, xv[2 * k2].z, xv[2 * k2].w};
+            const float b[4] = {xv[2 * k2 + 1].x, xv[2 * k2 + 1].y, xv[2 * k2 + 1].z, xv[2 * k2 + 1].w};
             unsigned h0, h1, h2, h3, l0, l1, l2, l3;
             split4(a, h0, h1, l0, l1, amax);
             split4(b, h2, h3, l2, l3, amax);
@@ -178,8 +180,8 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
             frag_st(d, (ks * 2 + 1) * 4, pl);
         }
     };
-    x_load(cur);
-    x_store();
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) { x_load(pick(cur.p), qt); x_store(qt); }
 
     f32x16 a2[12];   // layer-2 accumulators: own hidden tile t (0..2) x pair tile q: a2[4 t + q]
     f32x16 s4[4];    // layer-1 tile of the round / final-layer output tile, per pair tile
@@ -212,12 +214,18 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // layer 2, one round: 8 k-steps x 36 MFMAs on a2; weight fragments [k-step][tile 3][plane 2] one k-step ahead
-    auto big_round = [&](int r, bool first, int next_wa) {   // next_wa: stream offset of the next small round's 16 fragments, requested at k-step 5
+    // layer 2, one round: 8 k-steps x 36 MFMAs on a2; weight fragments [k-step][tile 3][plane 2] one k-step ahead, the first k-step's
+    // requested by the caller before the round's barrier (fa0); `late` runs at k-step 5 (requests of the NEXT phase's operands)
+    u32x4 fa0[6];
+    auto fa0_load = [&](int r) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) fa0[i] = wld(kOffL2 + (r * 8 * 6 + i) * kFrag);
+    };
+    auto big_round = [&](int r, bool first, auto&& late) {
         u32x4 fa[2][6], fb[2][8];
         const int wbase = kOffL2 + r * 8 * 6 * kFrag;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) fa[0][i] = wld(wbase + i * kFrag);
+        for (int i = 0; i < 6; ++i) fa[0][i] = fa0[i];
 #pragma unroll
         for (int i = 0; i < 8; ++i) fb[0][i] = frag_ld(ring, i);
 #pragma unroll
@@ -228,7 +236,7 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
 #pragma unroll
                 for (int i = 0; i < 8; ++i) fb[(kk + 1) & 1][i] = frag_ld(ring, (kk + 1) * 8 + i);
             }
-            if (kk == 5) wa_load(next_wa);
+            if (kk == 5) late();
             __builtin_amdgcn_sched_barrier(0);
             const u32x4 (&a)[6] = fa[kk & 1];
             const u32x4 (&b)[8] = fb[kk & 1];
@@ -249,97 +257,132 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // 16 accumulator values of a unit -> planes of the next layer's k-steps u = 0, 1 -> RING[this wave][u][plane][pair tile q]
-    auto put_planes = [&](const float (&v)[16], int q) {
+    // 16 accumulator values of a unit -> planes of the next layer's k-steps u = 0, 1: staged in registers (pln[q][2 u + plane]) so that the
+    // arithmetic of a round's four units runs BEFORE the barrier that frees RING, and only the 16 stores after it
+    u32x4 pln[4][4];
+    auto make_planes = [&](const float (&v)[16], int q) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            u32x4 ph, pl;
             const float a[4] = {v[8 * u], v[8 * u + 1], v[8 * u + 2], v[8 * u + 3]};
             const float b[4] = {v[8 * u + 4], v[8 * u + 5], v[8 * u + 6], v[8 * u + 7]};
             unsigned h0, h1, h2, h3, l0, l1, l2, l3;
             split4(a, h0, h1, l0, l1, amax);
             split4(b, h2, h3, l2, l3, amax);
-            ph = u32x4{h0, h1, h2, h3};
-            pl = u32x4{l0, l1, l2, l3};
-            lds_char* d = ring + wave * (16 * kFrag);
-            frag_st(d, (u * 2 + 0) * 4 + q, ph);
-            frag_st(d, (u * 2 + 1) * 4 + q, pl);
+            pln[q][2 * u] = u32x4{h0, h1, h2, h3};
+            pln[q][2 * u + 1] = u32x4{l0, l1, l2, l3};
         }
     };
+    auto ring_put = [&]() {   // RING[this wave][u][plane][pair tile q]
+        lds_char* d = ring + wave * (16 * kFrag);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) frag_st(d, k * 4 + q, pln[q][k]);
+    };
     auto ld4 = [&](const float* p) -> float4 { return *reinterpret_cast<const float4*>(p); };
+    // per-node seeds A_i + b1, B_j of hidden tile T for pair tile q (accumulator layout), and the residual row of layer-2 tile T
+    float4 sa[3][4], sb[3][4];      // [pair tile mod 3][quarter]: three units in flight (a fourth set of 32 registers does not fit)
+    // (32-bit row offsets into a buffer resource: a 64-bit row pointer per pair tile and array, kept across the rounds by the
+    //  compiler, is what spilled in the first version -- and a scratch reload is a VMEM operation the weight prefetch then waits behind)
+    const __amdgpu_buffer_rsrc_t nab_rs = __builtin_amdgcn_make_buffer_rsrc((void*)node_ab, 0, (unsigned)((M / N) * 3072u), 0x00020000);
+    auto seeds = [&](const Ctx& c, int T, int q) {
+        const unsigned oa = c.bi[q] * 3072u + 16u * h, ob = c.bj[q] * 3072u + 1536u + 16u * h;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const u32x4 x = __builtin_amdgcn_raw_buffer_load_b128(nab_rs, oa, 128 * T + 32 * rq, 0);
+            const u32x4 y = __builtin_amdgcn_raw_buffer_load_b128(nab_rs, ob, 128 * T + 32 * rq, 0);
+            sa[q % 3][rq] = make_float4(__uint_as_float(x.x), __uint_as_float(x.y), __uint_as_float(x.z), __uint_as_float(x.w));
+            sb[q % 3][rq] = make_float4(__uint_as_float(y.x), __uint_as_float(y.y), __uint_as_float(y.z), __uint_as_float(y.w));
+        }
+    };
+    float4 rs[4][4];
+    // residual row x = [e | n'_i | n'_j] (layers.py:181) of layer-2 tile T, accumulator layout: ptr + rq * step.  T is wave-uniform;
+    // ONE unconditional form for the three sources (a conditional VMEM operation makes hipcc wait for everything older at every use)
+    auto resid = [&](int T, int q) {
+        const bool isE = T < 4, isI = T < 8;
+        const float* base = isE ? edge : node_p;
+        const unsigned p = cur.p[q];
+        const unsigned idx = isE ? (in_tiled ? p >> 5 : p) : (isI ? cur.bi[q] : cur.bj[q]);
+        const unsigned mul = (isE && in_tiled) ? 4096u : 128u;
+        const unsigned add = isE ? (in_tiled ? (unsigned)(h * 128) + (p & 31) * 4 + 1024u * T : 4u * h + 32u * T) : 4u * h + 32u * (T - (isI ? 4 : 8));
+        const float* ptr = base + ((unsigned long long)idx * mul + add);
+        const int step = isE ? in_step : 8;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) rs[q][rq] = *reinterpret_cast<const float4*>(ptr + rq * step);
+    };
 
-    WS_BARRIER();   // XB of the first tile, s_vec
+    const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    wa_load(kOffL1);
+    seeds(cur, 3 * wave, 0);
+    seeds(cur, 3 * wave, 1);
+    WS_LDS_BARRIER();   // XB of the first tile, s_vec
     for (;;) {
         const long long wt_next = wt + gridDim.x;
         const bool has_next = wt_next < n_wt;
         Ctx nxt = cur;
+        unsigned p_nx;   // this lane's pair in pair tile `wave` of the next tile (this tile again when there is none: nothing reads the rows then)
+        {
+            long long pl = (has_next ? wt_next : wt) * 128 + wave * 32 + col;
+            p_nx = (unsigned)(pl < M ? pl : M - 1);
+        }
         // =================================================== layers 1 and 2, three rounds
-        wa_load(kOffL1);
+        // entering a round: its 16 layer-1 weight fragments (wa) and the seeds of pair tiles 0, 1 are on their way
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int T = 3 * wave + r;   // hidden tile this wave produces in this round (wave-uniform)
-            // per-node seeds of the round's units, pair tile 0 (the others one unit ahead inside the epilogue)
-            float4 sa[2][4], sb[2][4];
-            auto seeds = [&](int q, float4 (&xa)[4], float4 (&xb_)[4]) {
-                const float* pa = node_ab + (unsigned long long)cur.bi[q] * 768u + 32 * T + 4 * h;
-                const float* pb = node_ab + (unsigned long long)cur.bj[q] * 768u + 384 + 32 * T + 4 * h;
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) { xa[rq] = ld4(pa + 8 * rq); xb_[rq] = ld4(pb + 8 * rq); }
-            };
-            seeds(0, sa[0], sb[0]);
-            const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 4; ++q) s4[q] = z16;
             small_round(xb, s4);
+            seeds(cur, T, 2);
+            fa0_load(r);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (q + 1 < 4) seeds(q + 1, sa[(q + 1) & 1], sb[(q + 1) & 1]);
                 float v[16];
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
-                    const float4 x = sa[q & 1][rq], y = sb[q & 1][rq];
+                    const float4 x = sa[q % 3][rq], y = sb[q % 3][rq];
                     v[4 * rq + 0] = fmaxf(__builtin_fmaf(s4[q][4 * rq + 0], kInvWS, x.x + y.x), 0.f);
                     v[4 * rq + 1] = fmaxf(__builtin_fmaf(s4[q][4 * rq + 1], kInvWS, x.y + y.y), 0.f);
                     v[4 * rq + 2] = fmaxf(__builtin_fmaf(s4[q][4 * rq + 2], kInvWS, x.z + y.z), 0.f);
                     v[4 * rq + 3] = fmaxf(__builtin_fmaf(s4[q][4 * rq + 3], kInvWS, x.w + y.w), 0.f);
                 }
-                put_planes(v, q);
+                make_planes(v, q);
+                if (q == 0) seeds(cur, T, 3);   // into the registers pair tile 0 has just released
             }
+            WS_LDS_BARRIER();          // nobody reads RING any more (the previous round / the previous tile's projection)
+            ring_put();
             WS_LDS_BARRIER();          // the round's a1 planes are in RING
-            big_round(r, r == 0, r < 2 ? kOffL1 + (r + 1) * 16 * kFrag : kOffLF);
-            WS_LDS_BARRIER();          // RING may be overwritten
+            if (r < 2) {
+                big_round(r, r == 0, [&]() {   // the next round's layer-1 weights and first seeds
+                    wa_load(kOffL1 + (r + 1) * 16 * kFrag);
+                    seeds(cur, T + 1, 0);
+                    seeds(cur, T + 1, 1);
+                });
+            } else {
+                big_round(r, false, [&]() {    // the residual rows of the first final-layer round
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) resid(3 * wave, q);
+                });
+            }
         }
-        // =================================================== final layer, three rounds; the next tile's edge rows on the way
+        // =================================================== final layer, three rounds
+        wa_load(kOffLF);
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
-            const int T = 3 * wave + r;
-            // residual row x = [e | n'_i | n'_j] of the own layer-2 tile, in accumulator layout: base + rq * step
-            float4 rs[2][4];
-            auto resid = [&](int q, float4 (&x)[4]) {
-                const float* p;
-                int step = 8;
-                if (T < 4) { p = edge + pair_off(cur.p[q], in_tiled) + (in_tiled ? 1024 * T : 32 * T); step = in_step; }
-                else if (T < 8) p = node_p + (unsigned long long)cur.bi[q] * 128u + 32 * (T - 4) + 4 * h;
-                else p = node_p + (unsigned long long)cur.bj[q] * 128u + 32 * (T - 8) + 4 * h;
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) x[rq] = ld4(p + rq * step);
-            };
-            resid(0, rs[0]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (q + 1 < 4) resid(q + 1, rs[(q + 1) & 1]);
                 float v[16];
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
                     const float4 bq = *reinterpret_cast<const float4*>(&s_vec[96 * wave + 32 * r + 8 * rq + 4 * h]);
-                    const float4 x = rs[q & 1][rq];
+                    const float4 x = rs[q][rq];
                     const f32x16& a = a2[4 * r + q];
                     v[4 * rq + 0] = fmaxf(__builtin_fmaf(a[4 * rq + 0], kInvWS, bq.x), 0.f) + x.x;
                     v[4 * rq + 1] = fmaxf(__builtin_fmaf(a[4 * rq + 1], kInvWS, bq.y), 0.f) + x.y;
                     v[4 * rq + 2] = fmaxf(__builtin_fmaf(a[4 * rq + 2], kInvWS, bq.z), 0.f) + x.z;
                     v[4 * rq + 3] = fmaxf(__builtin_fmaf(a[4 * rq + 3], kInvWS, bq.w), 0.f) + x.w;
                 }
-                put_planes(v, q);
+                make_planes(v, q);
             }
             if (r == 0) {   // output tile w starts at 32 bf
 #pragma unroll
@@ -350,44 +393,50 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
                         s4[q][4 * rq + 0] = bq.x; s4[q][4 * rq + 1] = bq.y; s4[q][4 * rq + 2] = bq.z; s4[q][4 * rq + 3] = bq.w;
                     }
             }
+            WS_LDS_BARRIER();          // RING free
+            ring_put();
+            if (r < 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) resid(3 * wave + r + 1, q);   // the next round's residual rows land under this round's MFMAs
+            }
             WS_LDS_BARRIER();          // the round's final-layer input planes are in RING
+            x_load(p_nx, r);           // a quarter of the next tile's edge rows per round (XB has been free since layer 1 ended)
             small_round(ring, s4);
+            x_store(r);
             if (r < 2) wa_load(kOffLF + (r + 1) * 16 * kFrag);
-            WS_LDS_BARRIER();
         }
-        // the next tile's edge rows: requested here, split and written to XB (free since layer 1 ended) behind the LayerNorm
-        if (has_next) nxt = setup(wt_next);
-        x_load(nxt);     // (nxt = this tile again when there is no next one; nothing reads the result then)
+        x_load(p_nx, 3);
         // =================================================== LayerNorm over a pair's 128 channels (32 here), mask, store
-        // (scale invariant: statistics on the 32 x scaled accumulators with 1024 eps; partials of the four waves through s_st)
+        // Scale invariant: statistics on the 32 x scaled accumulators with 1024 eps.  The four waves' partial statistics are combined
+        // in ONE exchange (Chan et al.): per wave the sum S_w and the squared deviations M2_w from ITS mean over its 32 channels;
+        // mean = sum S_w / 128,  M2 = sum M2_w + 32 sum (S_w / 32 - mean)^2.
         float mean[4], rstd[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float s = 0.f;
+            float sm = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s += s4[q][i];
-            s = xhalf_sum(s);
-            if (h == 0) s_st[0][32 * q + col][wave] = s;
-        }
-        WS_LDS_BARRIER();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 t = *reinterpret_cast<const float4*>(&s_st[0][32 * q + col][0]);
-            mean[q] = ((t.x + t.y) + (t.z + t.w)) * (1.0f / 128);
+            for (int i = 0; i < 16; ++i) sm += s4[q][i];
+            sm = xhalf_sum(sm);
+            const float mw = sm * (1.0f / 32);
             float v = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float dd = s4[q][i] - mean[q];
+                const float dd = s4[q][i] - mw;
                 v += dd * dd;
             }
             v = xhalf_sum(v);
-            if (h == 0) s_st[1][32 * q + col][wave] = v;
+            if (h == 0) { s_st[0][32 * q + col][wave] = sm; s_st[1][32 * q + col][wave] = v; }
         }
-        WS_LDS_BARRIER();
+        WS_LDS_BARRIER();              // (also: every wave is through its last final-layer round -- RING is free)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 t = *reinterpret_cast<const float4*>(&s_st[1][32 * q + col][0]);
-            rstd[q] = 1.0f / sqrtf(((t.x + t.y) + (t.z + t.w)) * (1.0f / 128) + ln_eps * (kWS * kWS));
+            const float4 t = *reinterpret_cast<const float4*>(&s_st[0][32 * q + col][0]);
+            const float4 m2 = *reinterpret_cast<const float4*>(&s_st[1][32 * q + col][0]);
+            mean[q] = ((t.x + t.y) + (t.z + t.w)) * (1.0f / 128);
+            const float d0 = t.x * (1.0f / 32) - mean[q], d1 = t.y * (1.0f / 32) - mean[q], d2 = t.z * (1.0f / 32) - mean[q],
+                        d3 = t.w * (1.0f / 32) - mean[q];
+            const float M2 = ((m2.x + m2.y) + (m2.z + m2.w)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
+            rstd[q] = 1.0f / sqrtf(M2 * (1.0f / 128) + ln_eps * (kWS * kWS));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -406,18 +455,22 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
                 if (store) *reinterpret_cast<float4*>(orow + rq * out_step) = o;
                 v[4 * rq + 0] = o.x; v[4 * rq + 1] = o.y; v[4 * rq + 2] = o.z; v[4 * rq + 3] = o.w;
             }
-            if constexpr (PROJ) put_planes(v, q);    // RING: free since the last final-layer round's closing barrier
+            if constexpr (PROJ) make_planes(v, q);
         }
-        x_store();
+        x_store(3);
+        if constexpr (PROJ) ring_put();   // the LayerNorm planes (RING has been free since the LayerNorm barrier)
+        if (has_next) nxt = setup(wt_next);
+        wa_load(kOffL1);               // the next tile's first layer-1 round: weights and first seeds
+        seeds(nxt, 3 * wave, 0);
+        seeds(nxt, 3 * wave, 1);
         if constexpr (PROJ) {
             // =============================================== fused projection of pair tile `wave`: 64 x 128 [linear_b; down_z; 0] on the LayerNorm
             // output; k-step 2 v + u = channels of wave v (chain order), weight stage [k-step 8][tile 2][plane 2] shared by the waves
             u32x4 pw[2][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) pw[0][i] = __builtin_amdgcn_raw_buffer_load_b128(prs, voff, i * kFrag, 0);
-            WS_LDS_BARRIER();          // every wave's LayerNorm planes are in RING
+            WS_LDS_BARRIER();          // every wave's LayerNorm planes are in RING, and the next tile's rows in XB
             f32x16 pq[2];
-            const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             pq[0] = z16; pq[1] = z16;
             lds_char* src = ring + wave * kFrag;
 #pragma unroll
@@ -455,11 +508,12 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
                                     __builtin_fmaf(pq[t][4 * rq + 2], kInvWS, bq.z), __builtin_fmaf(pq[t][4 * rq + 3], kInvWS, bq.w));
                 }
             }
+        } else {
+            WS_LDS_BARRIER();          // the next tile's rows are in XB
         }
         if (!has_next) break;
         cur = nxt;
         wt = wt_next;
-        WS_LDS_BARRIER();   // XB of the next tile is complete; nobody still reads RING
     }
     s2s::range_report(range_flag, amax, s2s::kRangeEdgeTransition);
 }
