@@ -79,15 +79,6 @@ int s2s_edge_transition_f16x3(const float* edge, const float* node_ab, const flo
                               const float* mask, float* out, int n_samples, int n_res, float ln_eps, int io_layout,
                               const float* proj_bias_cat64, float* proj_attn_bias, float* proj_pair_z, void* stream);
 
-/* The same operator and contract, WIDTH-SPLIT inside the workgroup (csrc/edge_transition_ws.hip): a workgroup owns 128 pairs, each
- * of its four waves 96 of the 384 hidden channels for all of them; weight fragments go from L2 straight into the one wave that uses
- * them, activations travel between the waves through LDS.  weight_stream: the same 30 (+1) stages, the first 30 ordered per wave
- * (ops.pack_f16x3_stream_ws); results agree with s2s_edge_transition_f16x3 to fp32 rounding (different summation order). */
-int s2s_edge_transition_f16x3_ws(const float* edge, const float* node_ab, const float* node_p, const void* weight_stream,
-                                 const float* b2, const float* bf, const float* ln_gamma, const float* ln_beta,
-                                 const float* mask, float* out, int n_samples, int n_res, float ln_eps, int io_layout,
-                                 const float* proj_bias_cat64, float* proj_attn_bias, float* proj_pair_z, void* stream);
-
 /* EmbeddingModule.forward, edge branch (src/models/net/denoising_ipa.py:137-158, calc_distogram
  * src/common/geo_utils.py:44-56) + edge-mask multiply (denoising_ipa.py:187).
  *   node_a/node_b [B,N,128]: row / column parts of the first Linear (incl. bias in node_a)

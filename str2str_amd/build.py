@@ -33,7 +33,6 @@ UNITS = {
     # the MFMA chains are fully unrolled on purpose (accumulator tiles must be statically indexed)
     "pair_mlp.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
     "pair_mlp_f16.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
-    "edge_transition_ws.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
     "ipa_attention.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
     "ipa_attention_f16w.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
     "node_gemm.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],

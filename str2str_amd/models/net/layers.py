@@ -136,7 +136,7 @@ class EdgeTransition(nn.Module):
         w1, w2, wf = self.trunk[0], self.trunk[2], self.final_layer
         ce = self._shape[0]
         return self._cache.get([w1.weight, w2.weight, wf.weight], lambda: {
-            "wstream_f16": ops.pack_et_stream(w1.weight[:, :ce].float(), w2.weight.float(), wf.weight.float())})
+            "wstream_f16": ops.pack_f16x3_stream(w1.weight[:, :ce].float(), w2.weight.float(), wf.weight.float())})
 
     def _packed_f32(self):
         w1, w2, wf = self.trunk[0], self.trunk[2], self.final_layer

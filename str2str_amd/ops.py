@@ -28,7 +28,6 @@ _SIGNATURES = {
     "s2s_set_range_flag": [_vp],
     "s2s_edge_transition": [_vp] * 12 + [_i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "s2s_edge_transition_f16x3": [_vp] * 10 + [_i, _i, _f, _i, _vp, _vp, _vp, _vp],
-    "s2s_edge_transition_f16x3_ws": [_vp] * 10 + [_i, _i, _f, _i, _vp, _vp, _vp, _vp],
     "s2s_edge_embed": [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "s2s_edge_embed_f16x3": [_vp] * 14 + [_i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
     "s2s_pair_project": [_vp] * 5 + [_i, _i, _vp],
@@ -283,34 +282,6 @@ def pack_f16x3_stream(w1_edge: torch.Tensor, w2: torch.Tensor, wf: torch.Tensor)
     return blob
 
 
-def pack_f16x3_stream_ws(w1_edge: torch.Tensor, w2: torch.Tensor, wf: torch.Tensor) -> torch.Tensor:
-    """The weight stream of the WIDTH-SPLIT edge transition (csrc/edge_transition_ws.hip) as int16: the same 960 fragments of 1 KiB as
-    ``pack_f16x3_stream``, ordered per WAVE w (hidden tiles 3 w .. 3 w + 2, output tile w): 4 x 240 KiB,
-      L1 [round r 3][k-step 8][plane 2]                  layer-1 output tile 3 w + r over the 8 k-steps of the edge row
-      L2 [round r 3][k-step in round 8][tile 3][plane 2] layer-2 k-step 2 (3 v + r) + u (the round's producer wave v, half u: kk = 2 v + u)
-                                                         into the wave's three output tiles
-      LF [round r 3][k-step in round 8][plane 2]         final layer, same k-steps, output tile w."""
-    l1, l2, lf = pack_f16x2_layer(w1_edge), pack_f16x2_layer(w2), pack_f16x2_layer(wf)   # [k-step][tile][plane][64][8]
-    rounds = [[2 * (3 * v + r) + u for v in range(4) for u in range(2)] for r in range(3)]   # k-steps of a round, in kk order
-    per_wave = []
-    for w in range(4):
-        p1 = torch.stack([l1[:, 3 * w + r] for r in range(3)])                                    # [r, ks, plane, 64, 8]
-        p2 = torch.stack([l2[rounds[r]][:, 3 * w:3 * w + 3] for r in range(3)])                   # [r, kk, t, plane, 64, 8]
-        pf = torch.stack([lf[rounds[r]][:, w] for r in range(3)])                                 # [r, kk, plane, 64, 8]
-        per_wave.append(torch.cat([p1.reshape(-1), p2.reshape(-1), pf.reshape(-1)]))
-        assert per_wave[-1].numel() * 2 == 240 * 1024
-    return torch.cat(per_wave).contiguous().view(torch.int16)
-
-
-# which edge-transition kernel serves the f16x3 arithmetic: "ws" = width-split (csrc/edge_transition_ws.hip), "lane" = pair-per-lane
-# (csrc/pair_mlp_f16.hip).  The weight stream's order belongs to the kernel; EdgeTransition._packed asks here.
-ET_KERNEL = os.environ.get("S2S_ET_KERNEL", "lane")
-
-
-def pack_et_stream(w1_edge, w2, wf):
-    return (pack_f16x3_stream_ws if ET_KERNEL == "ws" else pack_f16x3_stream)(w1_edge, w2, wf)
-
-
 # ------------------------------------------------------------------------------------------ ops
 class PairTiled:
     """A [B,N,N,128] pair tensor in the TILED layout the f16x3 pair kernels exchange among themselves (include/str2str_hip.h,
@@ -391,8 +362,7 @@ def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, m
         raise HipLibraryError("edge_transition_f16x3: out does not have the requested layout")
     io = (1 if in_tiled else 0) | {"rowmajor": 0, "tiled": 2, "none": 4}[out_layout]
     range_flag()
-    entry = lib.s2s_edge_transition_f16x3_ws if ET_KERNEL == "ws" else lib.s2s_edge_transition_f16x3
-    _check(_timed("s2s_edge_transition", lambda: entry(
+    _check(_timed("s2s_edge_transition", lambda: lib.s2s_edge_transition_f16x3(
         _p(edge.buf if in_tiled else edge), _p(node_ab), _p(node_p), _p(wstream), _p(b2), _p(bf), _p(gamma), _p(beta),
         _p(mask),
         _p(out.buf if isinstance(out, PairTiled) else out), B, N, ln_eps, io, _p(pb), _p(pbias), _p(ppz), _stream())),

@@ -73,6 +73,14 @@ __device__ __forceinline__ void split4(const float (&x)[4], unsigned& h0, unsign
 
 __device__ float s2s_ws_one[1] = {1.0f};   // stands in for an absent node mask (read with stride 0)
 
+#ifdef S2S_WS_PROBE
+// phase probe (tools/ws_phase_probe.py): s_memtime at the phase boundaries of a tile, thread 0 of workgroup 0, eight tiles kept
+__device__ unsigned long long g_ws_probe[8 * 64];
+#define WS_STAMP(k) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                         if (probe_on) g_ws_probe[(probe_it & 7) * 64 + (k)] = t_; } while (0)
+#else
+#define WS_STAMP(k)
+#endif
 #define WS_BARRIER() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define WS_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -121,8 +129,8 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
     };
     struct Ctx {
         unsigned p[4], bi[4], bj[4];   // flat pair index, flat node rows of i and j
-        float em[4];                   // edge mask = node mask i x node mask j
-        bool valid[4];
+        float em_i[4], em_j[4];        // node masks of i and j: multiplied where the edge mask is used (a product formed in setup would
+        bool valid[4];                 // wait for the loads right there)
     };
     auto setup = [&](long long wg_tile) -> Ctx {
         Ctx c;
@@ -138,7 +146,8 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
             c.p[q] = p;
             c.bi[q] = bi;
             c.bj[q] = bb * (unsigned)N + j;
-            c.em[q] = mask[bi * mask_stride] * mask[c.bj[q] * mask_stride];
+            c.em_i[q] = mask[bi * mask_stride];
+            c.em_j[q] = mask[c.bj[q] * mask_stride];
         }
         return c;
     };
@@ -157,19 +166,19 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
 
     // ---- edge rows of pair tile `wave` of a tile: 16 loads of 16 B per lane (chain channel order), split, 16 fragments into XB
     // in four quarters of two k-steps (16 registers in flight each): the kernel has no room for a whole row (64) beside a phase's operands
-    float4 xv[4];
-    auto x_load = [&](unsigned p_own, int qt) {   // p_own: this lane's pair in pair tile `wave`
+    float4 xv[2][4];
+    auto x_load = [&](unsigned p_own, int qt, int slot = 0) {   // p_own: this lane's pair in pair tile `wave`
         const float* er = edge + pair_off(p_own, in_tiled);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const float4*>(er + (4 * qt + i) * in_step);
+        for (int i = 0; i < 4; ++i) xv[slot][i] = *reinterpret_cast<const float4*>(er + (4 * qt + i) * in_step);
     };
-    auto x_store = [&](int qt) {
+    auto x_store = [&](int qt, int slot = 0) {
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             const int ks = 2 * qt + k2;
             u32x4 ph, pl;
-            const float a[4] = {xv[2 * k2].x, xv[2 * k2].y, xv[2 * k2].z, xv[2 * k2].w};
-            const float b[4] = {xv[2 * k2 + 1].x, xv[2 * k2 + 1].y, xv[2 * k2 + 1].z, xv[2 * k2 + 1].w};
+            const float a[4] = {xv[slot][2 * k2].x, xv[slot][2 * k2].y, xv[slot][2 * k2].z, xv[slot][2 * k2].w};
+            const float b[4] = {xv[slot][2 * k2 + 1].x, xv[slot][2 * k2 + 1].y, xv[slot][2 * k2 + 1].z, xv[slot][2 * k2 + 1].w};
             unsigned h0, h1, h2, h3, l0, l1, l2, l3;
             split4(a, h0, h1, l0, l1, amax);
             split4(b, h2, h3, l2, l3, amax);
@@ -192,27 +201,33 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
     };
     // 8 k-steps x 12 MFMAs: acc[q] += W[tile] . B[k-step][q];  B fragments from `src` (XB or RING: index (k-step 2 + plane) 4 + q)
     auto small_round = [&](lds_char* src, f32x16 (&acc)[4]) {
-        u32x4 fb[2][8];
+        // B fragments (k-step, plane, pair tile) come two pair tiles at a time, one half k-step ahead: 2 x 4 fragments in flight
+        u32x4 fb[2][4];   // [buffer][plane 2 x pair tile 2]
+        auto ldb = [&](int kk, int half, u32x4 (&f)[4]) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) fb[0][i] = frag_ld(src, i);
+            for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            if (kk + 1 < 8) {
+                for (int j = 0; j < 2; ++j) f[2 * pl + j] = frag_ld(src, (kk * 2 + pl) * 4 + 2 * half + j);
+        };
+        ldb(0, 0, fb[0]);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) fb[(kk + 1) & 1][i] = frag_ld(src, (kk + 1) * 8 + i);
+        for (int kk = 0; kk < 8; ++kk)
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int step = 2 * kk + half;
+                if (step + 1 < 16) ldb((step + 1) >> 1, (step + 1) & 1, fb[(step + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4& wh = wa[2 * kk];
+                const u32x4& wl = wa[2 * kk + 1];
+                const u32x4 (&b)[4] = fb[step & 1];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[2 * half + j] = mfma_f16(wl, b[j], acc[2 * half + j]);         // W_l x_h
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[2 * half + j] = mfma_f16(wh, b[2 + j], acc[2 * half + j]);     // W_h x_l
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[2 * half + j] = mfma_f16(wh, b[j], acc[2 * half + j]);         // W_h x_h
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            const u32x4& wh = wa[2 * kk];
-            const u32x4& wl = wa[2 * kk + 1];
-            const u32x4 (&b)[8] = fb[kk & 1];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = mfma_f16(wl, b[q], acc[q]);         // W_l x_h
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = mfma_f16(wh, b[4 + q], acc[q]);     // W_h x_l
-#pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] = mfma_f16(wh, b[q], acc[q]);         // W_h x_h
-            __builtin_amdgcn_sched_barrier(0);
-        }
     };
     // layer 2, one round: 8 k-steps x 36 MFMAs on a2; weight fragments [k-step][tile 3][plane 2] one k-step ahead, the first k-step's
     // requested by the caller before the round's barrier (fa0); `late` runs at k-step 5 (requests of the NEXT phase's operands)
@@ -222,39 +237,45 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
         for (int i = 0; i < 6; ++i) fa0[i] = wld(kOffL2 + (r * 8 * 6 + i) * kFrag);
     };
     auto big_round = [&](int r, bool first, auto&& late) {
-        u32x4 fa[2][6], fb[2][8];
+        // pair-tile major inside a k-step: the 6 weight fragments of the k-step against ONE pair tile's two planes (9 MFMAs on three
+        // accumulators), the next pair tile's planes requested meanwhile -- 2 x 2 activation fragments in flight instead of 2 x 8
+        u32x4 fa[2][6], fb[2][2];
         const int wbase = kOffL2 + r * 8 * 6 * kFrag;
 #pragma unroll
         for (int i = 0; i < 6; ++i) fa[0][i] = fa0[i];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) fb[0][i] = frag_ld(ring, i);
+        fb[0][0] = frag_ld(ring, 0);
+        fb[0][1] = frag_ld(ring, 4);
+        const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) {
-            if (kk + 1 < 8) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) fa[(kk + 1) & 1][i] = wld(wbase + ((kk + 1) * 6 + i) * kFrag);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) fb[(kk + 1) & 1][i] = frag_ld(ring, (kk + 1) * 8 + i);
-            }
             if (kk == 5) late();
-            __builtin_amdgcn_sched_barrier(0);
-            const u32x4 (&a)[6] = fa[kk & 1];
-            const u32x4 (&b)[8] = fb[kk & 1];
-            const bool zero = first && kk == 0;
-            const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+            for (int q = 0; q < 4; ++q) {
+                const int step = 4 * kk + q;
+                if (step + 1 < 32) {
+                    const int k2 = (step + 1) >> 2, q2 = (step + 1) & 3;
+                    fb[(step + 1) & 1][0] = frag_ld(ring, (k2 * 2 + 0) * 4 + q2);
+                    fb[(step + 1) & 1][1] = frag_ld(ring, (k2 * 2 + 1) * 4 + q2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4 (&a)[6] = fa[kk & 1];
+                const u32x4& xh = fb[step & 1][0];
+                const u32x4& xl = fb[step & 1][1];
+                const bool zero = first && kk == 0;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) a2[4 * t + q] = mfma_f16(a[2 * t + 1], b[q], zero ? z16 : a2[4 * t + q]);   // W_l x_h
+                for (int t = 0; t < 3; ++t) a2[4 * t + q] = mfma_f16(a[2 * t + 1], xh, zero ? z16 : a2[4 * t + q]);   // W_l x_h
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+                for (int t = 0; t < 3; ++t) a2[4 * t + q] = mfma_f16(a[2 * t], xl, a2[4 * t + q]);                   // W_h x_l
 #pragma unroll
-                for (int q = 0; q < 4; ++q) a2[4 * t + q] = mfma_f16(a[2 * t], b[4 + q], a2[4 * t + q]);               // W_h x_l
-#pragma unroll
-            for (int t = 0; t < 3; ++t)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a2[4 * t + q] = mfma_f16(a[2 * t], b[q], a2[4 * t + q]);                   // W_h x_h
-            __builtin_amdgcn_sched_barrier(0);
+                for (int t = 0; t < 3; ++t) a2[4 * t + q] = mfma_f16(a[2 * t], xh, a2[4 * t + q]);                   // W_h x_h
+                // the next k-step's six weight fragments, two behind each of the first three pair tiles' MFMAs (a block of six in
+                // front of the k-step costs the issue time of six VMEM instructions in one place)
+                if (kk + 1 < 8 && q < 3) {
+                    fa[(kk + 1) & 1][2 * q] = wld(wbase + ((kk + 1) * 6 + 2 * q) * kFrag);
+                    fa[(kk + 1) & 1][2 * q + 1] = wld(wbase + ((kk + 1) * 6 + 2 * q + 1) * kFrag);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
     // 16 accumulator values of a unit -> planes of the next layer's k-steps u = 0, 1: staged in registers (pln[q][2 u + plane]) so that the
@@ -316,7 +337,12 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
     seeds(cur, 3 * wave, 0);
     seeds(cur, 3 * wave, 1);
     WS_LDS_BARRIER();   // XB of the first tile, s_vec
+#ifdef S2S_WS_PROBE
+    const bool probe_on = blockIdx.x == 0 && threadIdx.x == 0;
+    int probe_it = 0;
+#endif
     for (;;) {
+        WS_STAMP(0);
         const long long wt_next = wt + gridDim.x;
         const bool has_next = wt_next < n_wt;
         Ctx nxt = cur;
@@ -333,6 +359,7 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
 #pragma unroll
             for (int q = 0; q < 4; ++q) s4[q] = z16;
             small_round(xb, s4);
+            WS_STAMP(1 + 5 * r);
             seeds(cur, T, 2);
             fa0_load(r);
 #pragma unroll
@@ -341,17 +368,20 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
 #pragma unroll
                 for (int rq = 0; rq < 4; ++rq) {
                     const float4 x = sa[q % 3][rq], y = sb[q % 3][rq];
-                    v[4 * rq + 0] = fmaxf(__builtin_fmaf(s4[q][4 * rq + 0], kInvWS, x.x + y.x), 0.f);
-                    v[4 * rq + 1] = fmaxf(__builtin_fmaf(s4[q][4 * rq + 1], kInvWS, x.y + y.y), 0.f);
-                    v[4 * rq + 2] = fmaxf(__builtin_fmaf(s4[q][4 * rq + 2], kInvWS, x.z + y.z), 0.f);
-                    v[4 * rq + 3] = fmaxf(__builtin_fmaf(s4[q][4 * rq + 3], kInvWS, x.w + y.w), 0.f);
+                    v[4 * rq + 0] = fmaxf(__builtin_fmaf(s4[q][4 * rq + 0], kInvWS, __fadd_rn(x.x, y.x)), 0.f);
+                    v[4 * rq + 1] = fmaxf(__builtin_fmaf(s4[q][4 * rq + 1], kInvWS, __fadd_rn(x.y, y.y)), 0.f);
+                    v[4 * rq + 2] = fmaxf(__builtin_fmaf(s4[q][4 * rq + 2], kInvWS, __fadd_rn(x.z, y.z)), 0.f);
+                    v[4 * rq + 3] = fmaxf(__builtin_fmaf(s4[q][4 * rq + 3], kInvWS, __fadd_rn(x.w, y.w)), 0.f);
                 }
                 make_planes(v, q);
                 if (q == 0) seeds(cur, T, 3);   // into the registers pair tile 0 has just released
             }
+            WS_STAMP(2 + 5 * r);
             WS_LDS_BARRIER();          // nobody reads RING any more (the previous round / the previous tile's projection)
+            WS_STAMP(3 + 5 * r);
             ring_put();
             WS_LDS_BARRIER();          // the round's a1 planes are in RING
+            WS_STAMP(4 + 5 * r);
             if (r < 2) {
                 big_round(r, r == 0, [&]() {   // the next round's layer-1 weights and first seeds
                     wa_load(kOffL1 + (r + 1) * 16 * kFrag);
@@ -364,7 +394,9 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
                     for (int q = 0; q < 4; ++q) resid(3 * wave, q);
                 });
             }
+            if (r < 2) WS_STAMP(5 + 5 * r);
         }
+        WS_STAMP(15);
         // =================================================== final layer, three rounds
         wa_load(kOffLF);
 #pragma unroll
@@ -377,10 +409,10 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
                     const float4 bq = *reinterpret_cast<const float4*>(&s_vec[96 * wave + 32 * r + 8 * rq + 4 * h]);
                     const float4 x = rs[q][rq];
                     const f32x16& a = a2[4 * r + q];
-                    v[4 * rq + 0] = fmaxf(__builtin_fmaf(a[4 * rq + 0], kInvWS, bq.x), 0.f) + x.x;
-                    v[4 * rq + 1] = fmaxf(__builtin_fmaf(a[4 * rq + 1], kInvWS, bq.y), 0.f) + x.y;
-                    v[4 * rq + 2] = fmaxf(__builtin_fmaf(a[4 * rq + 2], kInvWS, bq.z), 0.f) + x.z;
-                    v[4 * rq + 3] = fmaxf(__builtin_fmaf(a[4 * rq + 3], kInvWS, bq.w), 0.f) + x.w;
+                    v[4 * rq + 0] = __fadd_rn(fmaxf(__builtin_fmaf(a[4 * rq + 0], kInvWS, bq.x), 0.f), x.x);
+                    v[4 * rq + 1] = __fadd_rn(fmaxf(__builtin_fmaf(a[4 * rq + 1], kInvWS, bq.y), 0.f), x.y);
+                    v[4 * rq + 2] = __fadd_rn(fmaxf(__builtin_fmaf(a[4 * rq + 2], kInvWS, bq.z), 0.f), x.z);
+                    v[4 * rq + 3] = __fadd_rn(fmaxf(__builtin_fmaf(a[4 * rq + 3], kInvWS, bq.w), 0.f), x.w);
                 }
                 make_planes(v, q);
             }
@@ -393,101 +425,147 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
                         s4[q][4 * rq + 0] = bq.x; s4[q][4 * rq + 1] = bq.y; s4[q][4 * rq + 2] = bq.z; s4[q][4 * rq + 3] = bq.w;
                     }
             }
+            WS_STAMP(16 + 4 * r);
             WS_LDS_BARRIER();          // RING free
+            WS_STAMP(17 + 4 * r);
             ring_put();
             if (r < 2) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) resid(3 * wave + r + 1, q);   // the next round's residual rows land under this round's MFMAs
             }
             WS_LDS_BARRIER();          // the round's final-layer input planes are in RING
-            x_load(p_nx, r);           // a quarter of the next tile's edge rows per round (XB has been free since layer 1 ended)
+            WS_STAMP(18 + 4 * r);
+            x_load(p_nx, r);           // the next tile's edge rows, a quarter per round, two in the last (XB has been free since layer 1 ended)
+            if (r == 2) x_load(p_nx, 3, 1);
             small_round(ring, s4);
+            WS_STAMP(19 + 4 * r);
             x_store(r);
+            if (r == 2) x_store(3, 1);
             if (r < 2) wa_load(kOffLF + (r + 1) * 16 * kFrag);
         }
-        x_load(p_nx, 3);
         // =================================================== LayerNorm over a pair's 128 channels (32 here), mask, store
         // Scale invariant: statistics on the 32 x scaled accumulators with 1024 eps.  The four waves' partial statistics are combined
         // in ONE exchange (Chan et al.): per wave the sum S_w and the squared deviations M2_w from ITS mean over its 32 channels;
         // mean = sum S_w / 128,  M2 = sum M2_w + 32 sum (S_w / 32 - mean)^2.
+        // VMEM order of the tail (the counter is in order, and a global store is acknowledged a few thousand cycles late): nothing that
+        // is waited for soon may be younger than a store.  With the projection, the LayerNorm output stays in registers, the
+        // projection runs (its weight loads have no store in front of them), the next tile's first operands are requested, and only
+        // then the pair vectors and the projection are stored; without it, the next tile's operands are requested before the stores.
+        if (has_next) nxt = setup(wt_next);   // (index arithmetic + mask loads; nothing waits for the masks before the next LayerNorm)
+        if constexpr (!PROJ) {
+            wa_load(kOffL1);
+            seeds(nxt, 3 * wave, 0);
+            seeds(nxt, 3 * wave, 1);
+        }
         float mean[4], rstd[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float sm = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) sm += s4[q][i];
+            for (int i = 0; i < 16; ++i) sm = __fadd_rn(sm, s4[q][i]);
             sm = xhalf_sum(sm);
-            const float mw = sm * (1.0f / 32);
+            const float mw = __fmul_rn(sm, 1.0f / 32);
             float v = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float dd = s4[q][i] - mw;
-                v += dd * dd;
+            for (int i = 0; i < 16; ++i) {   // (explicit operations throughout the LayerNorm: the four unrolled copies -- one per pair tile --
+                const float dd = __fsub_rn(s4[q][i], mw);   //  must round alike, or a pair's result depends on which tile slot it falls into)
+                v = __builtin_fmaf(dd, dd, v);
             }
             v = xhalf_sum(v);
             if (h == 0) { s_st[0][32 * q + col][wave] = sm; s_st[1][32 * q + col][wave] = v; }
         }
+        WS_STAMP(28);
         WS_LDS_BARRIER();              // (also: every wave is through its last final-layer round -- RING is free)
+        WS_STAMP(29);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float4 t = *reinterpret_cast<const float4*>(&s_st[0][32 * q + col][0]);
             const float4 m2 = *reinterpret_cast<const float4*>(&s_st[1][32 * q + col][0]);
-            mean[q] = ((t.x + t.y) + (t.z + t.w)) * (1.0f / 128);
-            const float d0 = t.x * (1.0f / 32) - mean[q], d1 = t.y * (1.0f / 32) - mean[q], d2 = t.z * (1.0f / 32) - mean[q],
-                        d3 = t.w * (1.0f / 32) - mean[q];
-            const float M2 = ((m2.x + m2.y) + (m2.z + m2.w)) + 32.0f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3));
-            rstd[q] = 1.0f / sqrtf(M2 * (1.0f / 128) + ln_eps * (kWS * kWS));
+            mean[q] = __fmul_rn(__fadd_rn(__fadd_rn(t.x, t.y), __fadd_rn(t.z, t.w)), 1.0f / 128);
+            const float d0 = __builtin_fmaf(t.x, 1.0f / 32, -mean[q]), d1 = __builtin_fmaf(t.y, 1.0f / 32, -mean[q]),
+                        d2 = __builtin_fmaf(t.z, 1.0f / 32, -mean[q]), d3 = __builtin_fmaf(t.w, 1.0f / 32, -mean[q]);
+            const float sq = __builtin_fmaf(d3, d3, __builtin_fmaf(d2, d2, __builtin_fmaf(d1, d1, __fmul_rn(d0, d0))));
+            const float M2 = __builtin_fmaf(32.0f, sq, __fadd_rn(__fadd_rn(m2.x, m2.y), __fadd_rn(m2.z, m2.w)));
+            rstd[q] = 1.0f / sqrtf(__builtin_fmaf(M2, 1.0f / 128, ln_eps * (kWS * kWS)));
         }
+        float ov[4][16];   // PROJ: the LayerNorm output of the own 32 channels, stored after the projection
+        auto out_store = [&](int q, const float (&v)[16]) {
+            float* orow = out + pair_off(cur.p[q], out_tiled) + (out_tiled ? 1024 * wave : 32 * wave);
+            if (cur.valid[q] && !no_out) {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq)
+                    *reinterpret_cast<float4*>(orow + rq * out_step) = make_float4(v[4 * rq], v[4 * rq + 1], v[4 * rq + 2], v[4 * rq + 3]);
+            }
+        };
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float* orow = out + pair_off(cur.p[q], out_tiled) + (out_tiled ? 1024 * wave : 32 * wave);
-            const bool store = cur.valid[q] && !no_out;
             float v[16];
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 const float4 ga = *reinterpret_cast<const float4*>(&s_vec[512 + 32 * wave + 8 * rq + 4 * h]);
                 const float4 be = *reinterpret_cast<const float4*>(&s_vec[640 + 32 * wave + 8 * rq + 4 * h]);
                 float4 o;
-                o.x = ((s4[q][4 * rq + 0] - mean[q]) * rstd[q] * ga.x + be.x) * cur.em[q];
-                o.y = ((s4[q][4 * rq + 1] - mean[q]) * rstd[q] * ga.y + be.y) * cur.em[q];
-                o.z = ((s4[q][4 * rq + 2] - mean[q]) * rstd[q] * ga.z + be.z) * cur.em[q];
-                o.w = ((s4[q][4 * rq + 3] - mean[q]) * rstd[q] * ga.w + be.w) * cur.em[q];
-                if (store) *reinterpret_cast<float4*>(orow + rq * out_step) = o;
+                const float em = __fmul_rn(cur.em_i[q], cur.em_j[q]);
+                auto nrm = [&](float a, float g_, float b_) {
+                    return __fmul_rn(__builtin_fmaf(__fmul_rn(__fsub_rn(a, mean[q]), rstd[q]), g_, b_), em);
+                };
+                o.x = nrm(s4[q][4 * rq + 0], ga.x, be.x);
+                o.y = nrm(s4[q][4 * rq + 1], ga.y, be.y);
+                o.z = nrm(s4[q][4 * rq + 2], ga.z, be.z);
+                o.w = nrm(s4[q][4 * rq + 3], ga.w, be.w);
                 v[4 * rq + 0] = o.x; v[4 * rq + 1] = o.y; v[4 * rq + 2] = o.z; v[4 * rq + 3] = o.w;
             }
-            if constexpr (PROJ) make_planes(v, q);
+            if constexpr (PROJ) {
+                make_planes(v, q);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) ov[q][i] = v[i];
+            } else {
+                out_store(q, v);
+            }
         }
-        x_store(3);
+        WS_STAMP(30);
         if constexpr (PROJ) ring_put();   // the LayerNorm planes (RING has been free since the LayerNorm barrier)
-        if (has_next) nxt = setup(wt_next);
-        wa_load(kOffL1);               // the next tile's first layer-1 round: weights and first seeds
-        seeds(nxt, 3 * wave, 0);
-        seeds(nxt, 3 * wave, 1);
         if constexpr (PROJ) {
             // =============================================== fused projection of pair tile `wave`: 64 x 128 [linear_b; down_z; 0] on the LayerNorm
             // output; k-step 2 v + u = channels of wave v (chain order), weight stage [k-step 8][tile 2][plane 2] shared by the waves
-            u32x4 pw[2][4];
+            u32x4 pw[4][4];            // four k-steps of weight fragments in flight (a k-step is only 6 MFMAs = 192 cycles, L2 is ~800 away)
+            auto pwl = [&](int ks) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pw[0][i] = __builtin_amdgcn_raw_buffer_load_b128(prs, voff, i * kFrag, 0);
+                for (int i = 0; i < 4; ++i) pw[ks % 4][i] = __builtin_amdgcn_raw_buffer_load_b128(prs, voff, (ks * 4 + i) * kFrag, 0);
+            };
+            pwl(0); pwl(1); pwl(2); pwl(3);
+            WS_STAMP(31);
             WS_LDS_BARRIER();          // every wave's LayerNorm planes are in RING, and the next tile's rows in XB
+            WS_STAMP(32);
             f32x16 pq[2];
             pq[0] = z16; pq[1] = z16;
             lds_char* src = ring + wave * kFrag;
+            u32x4 px[2][2];
+            px[0][0] = frag_ld(src, 0); px[0][1] = frag_ld(src, 4);
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                if (ks + 1 < 8) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) pw[(ks + 1) & 1][i] = __builtin_amdgcn_raw_buffer_load_b128(prs, voff, ((ks + 1) * 4 + i) * kFrag, 0);
-                }
-                const u32x4 xh = frag_ld(src, (ks * 2 + 0) * 4), xl = frag_ld(src, (ks * 2 + 1) * 4);
-                const u32x4 (&w)[4] = pw[ks & 1];
+                if (ks + 1 < 8) { px[(ks + 1) & 1][0] = frag_ld(src, ((ks + 1) * 2 + 0) * 4); px[(ks + 1) & 1][1] = frag_ld(src, ((ks + 1) * 2 + 1) * 4); }
+                const u32x4& xh = px[ks & 1][0];
+                const u32x4& xl = px[ks & 1][1];
+                const u32x4 (&w)[4] = pw[ks % 4];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) pq[t] = mfma_f16(w[2 * t + 1], xh, pq[t]);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) pq[t] = mfma_f16(w[2 * t], xl, pq[t]);
 #pragma unroll
                 for (int t = 0; t < 2; ++t) pq[t] = mfma_f16(w[2 * t], xh, pq[t]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 4 < 8) pwl(ks + 4);   // into the registers this k-step has just released
+                __builtin_amdgcn_sched_barrier(0);
             }
+            WS_STAMP(34);
+            wa_load(kOffL1);           // the next tile's first layer-1 round: weights and first seeds
+            seeds(nxt, 3 * wave, 0);
+            seeds(nxt, 3 * wave, 1);
+            WS_STAMP(35);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) out_store(q, ov[q]);
+            WS_STAMP(36);
             // rows 0..7 (+ bias) -> attention bias, head-major; rows 8..39 -> pair_z channel row - 8 (same map as pair_mlp.hip)
             const bool ok = wave == 0 ? cur.valid[0] : (wave == 1 ? cur.valid[1] : (wave == 2 ? cur.valid[2] : cur.valid[3]));
             if (ok) {
@@ -511,6 +589,10 @@ __global__ void __launch_bounds__(256) edge_transition_ws_kernel(
         } else {
             WS_LDS_BARRIER();          // the next tile's rows are in XB
         }
+        WS_STAMP(33);
+#ifdef S2S_WS_PROBE
+        ++probe_it;
+#endif
         if (!has_next) break;
         cur = nxt;
         wt = wt_next;
@@ -572,3 +654,9 @@ extern "C" int s2s_edge_transition_f16x3_ws(const float* edge, const float* node
     }
     return (int)hipGetLastError();
 }
+
+#ifdef S2S_WS_PROBE
+extern "C" int s2s_ws_probe_read(unsigned long long* host_out) {   // 8 x 64 stamps
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ws_probe), sizeof(unsigned long long) * 8 * 64);
+}
+#endif
