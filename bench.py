@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5", "ref_default"])
     ap.add_argument("--n-res", type=int, default=None)
     ap.add_argument("--replicas", type=int, default=None, help="replicas per GPU per step")
     ap.add_argument("--denoise-steps", type=int, default=None)
@@ -159,7 +159,8 @@ def main():
         seen = [None] * world
         dist.all_gather_object(seen, (rank, uuid))
 
-    defaults = {"cfg2": (256, 128, 100), "cfg3": (None, 1000, 100), "cfg4": (512, 128, 200), "cfg5": (None, 256, 100)}[a.config]
+    defaults = {"cfg2": (256, 128, 100), "cfg3": (None, 1000, 100), "cfg4": (512, 128, 200), "cfg5": (None, 256, 100),
+                "ref_default": (None, 100, 1000)}[a.config]
     N = a.n_res if a.n_res is not None else defaults[0]
     B = a.replicas if a.replicas is not None else defaults[1]
     S = a.denoise_steps if a.denoise_steps is not None else defaults[2]
@@ -232,6 +233,36 @@ def main():
                                          residue_index=tg["residue_index"].numpy(), chain_index=tg["chain_index"].numpy())
                     extra["pdb_write_s"] += time.perf_counter() - t0
             return res
+    elif a.config == "ref_default":
+        # The reference's DEFAULT inference block (configs/model/diffusion.yaml:88-100): n_replica 100 in chunks of replica_per_batch 64
+        # (64 + 36), t_delta 0.25 .. 0.70 in steps of 0.05 (10 values), num_timesteps 1000 (=> 250 .. 700 steps per t_delta), on two
+        # synthetic targets of the Science2011 size range (N = 35 and 80): the regime users run, between the HIP-graph regime of tiny
+        # chunks and the GPU-bound one.  B = replicas per target, S = num_timesteps.
+        lens = [35, 80]
+        targets = [synth_chain(n, frame_seed=3 + n, aatype_seed=4 + n) for n in lens]
+        deltas = [round(0.25 + 0.05 * k, 2) for k in range(10)]
+        chunks = [64] * (B // 64) + ([B % 64] if B % 64 else [])
+        per_rank = B * len(targets) * len(deltas)
+        n_eval = sum(int(S * d) + 1 for d in deltas)
+        workload = (f"reference default inference block: {len(targets)} synthetic targets N = {lens}, {B} replicas each in chunks of {chunks}, "
+                    f"t_delta {deltas[0]} .. {deltas[-1]} ({len(deltas)} values), num_timesteps {S}: {n_eval} network evaluations per chunk")
+        pairs_main = 64 * max(lens) ** 2
+        eval_pairs = eval_ipa_bytes = 0
+        extra["evaluations_per_step"] = n_eval * len(chunks) * len(targets)
+        extra["hip_graph"] = os.environ.get("S2S_HIP_GRAPH", "auto")
+
+        def one_step(seed):
+            torch.manual_seed(seed * 1000 + rank)
+            torch.cuda.manual_seed(seed * 1000 + rank)
+            res = None
+            for tg in targets:
+                for d in deltas:
+                    for c in chunks:
+                        rig0 = Rigid.from_tensor_4x4(tg["rigidgroups_gt_frames"][..., 0, :, :].repeat(c, 1, 1, 1))
+                        a37 = forward_backward(net, diff, tg, rig0, d, num_timesteps=S, min_t=0.01, probability_flow=True,
+                                               self_conditioning=True, device=dev, rng=a.rng)
+                        res = a37[..., :5, :]
+            return res.cpu() if rank == 0 else None
     else:  # cfg5
         lens = [int(x) for x in np.random.default_rng(5).integers(64, 385, size=32)]
         targets = [synth_chain(n, frame_seed=3 + n, aatype_seed=4 + n) for n in lens]
@@ -274,7 +305,7 @@ def main():
 
     for w in range(a.warmup):
         one_step(w)
-    extra = {k: 0.0 for k in extra}
+    extra = {k: (0.0 if k == "pdb_write_s" else v) for k, v in extra.items()}
     barrier()
     t0 = time.perf_counter()
     timed = ("s2s_edge_transition", "s2s_ipa_attention") if a.config in ("cfg2", "cfg4") else ()  # (timers disable HIP graphs)

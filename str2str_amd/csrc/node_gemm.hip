@@ -345,19 +345,43 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
 #define S2S_NODE_XDEPTH 1
 #endif
 #if S2S_NODE_XDEPTH == 2
-    // activation fragments fetched TWO k-steps ahead (they come from HBM / a remote L2, ~2 us away; a k-step is ~0.9 us)
+    // Both operand streams TWO k-steps ahead (-DS2S_NODE_XDEPTH=2; NOT the default): a second weight staging set (wst2: k-step
+    // ks + 2 is requested while ks + 1 still waits in the first) and a third activation fragment pair.  Measured in round 4 at
+    // M = 2240 / 5120 / 32768 rows (profiles/r04_node_gemm_small_m.txt): no change for the 8-tile layers at any M -- a [5120 x 256] x
+    // [256 x 256] layer takes 18.5 us either way, of which the k loop is the smaller part: the epilogue's 64 stores per wave go
+    // through a CU store path that moves ~1 KiB per 44-59 cycles (tools/ubench/store_rate.hip) -- and slower for the 10-tile layers
+    // (the 16 extra registers cost the second workgroup per CU).
     f16x8 xc[2];
+    f32x4 wst2[kPieces];
+    auto w_load2 = [&](int ks) {
+        ks = ks < KS ? ks : KS - 1;
+        const char* src = wsrc + (long long)ks * kStage;
+#pragma unroll
+        for (int k = 0; k < kPieces; ++k) {
+            if (WAVES * k + WAVES - 1 < kFrags || WAVES * k + wave < kFrags)
+                wst2[k] = *reinterpret_cast<const f32x4*>(src + (WAVES * k + wave) * 1024);
+        }
+    };
+    auto w_store2 = [&](int par) {
+        lds_char* dst = (lds_char*)s_w + par * kStage + lane * 16;
+#pragma unroll
+        for (int k = 0; k < kPieces; ++k) {
+            if (WAVES * k + WAVES - 1 < kFrags || WAVES * k + wave < kFrags) *(lds_f4*)(dst + (WAVES * k + wave) * 1024) = wst2[k];
+        }
+    };
+    // on entry: LDS 0 = k-step 0, wst = k-step 1 (prologue above); now wst2 = k-step 2
+    w_load2(2);
     x_load(1, xb);
     for (int ks = 0; ks < KS; ks += 2) {
         x_load(ks + 2, xc);
         compute(0, xa);
-        w_store(1);
-        w_load(ks + 2);
+        w_store(1);                 // k-step ks + 1, requested two k-steps ago
+        w_load(ks + 3);
         __syncthreads();
         x_load(ks + 3, xa);
         compute(1, xb);
-        w_store(0);
-        w_load(ks + 3);
+        w_store2(0);                // k-step ks + 2
+        w_load2(ks + 4);
         __syncthreads();
         // rotate: (xa, xb) <- (k-step ks + 2, ks + 3)
 #pragma unroll
