@@ -260,6 +260,21 @@ int s2s_node_linear_f32(const float* x, int x_ld, const float* w_packed, const f
 int s2s_node_linear_vfrag(const void* xp, const void* w_packed, const float* bias, long long n_rows, int k_in, int n_out,
                           int tiles_per_head, void* out_vf, int map_pad, int map_src, void* stream);
 
+/* Up to six INDEPENDENT node layers (bias / ReLU epilogues, no residual / LayerNorm / masks) in one launch -- the five projections of an
+ * IPA block (linear_q, the k and v halves of linear_kv, linear_q_points, linear_kv_points: ipa.py:131-171) read the same activations
+ * and nothing of each other.  Each problem is the argument list of s2s_node_linear (tiles_per_block 4, 5, 6, 8 or 10) or, with
+ * vfrag_tiles_per_head > 0, of s2s_node_linear_vfrag. */
+typedef struct s2s_node_problem {
+    const void* xp; const void* w_packed; const float* bias;
+    long long n_rows; int k_in, n_out, tiles_per_block;
+    int vfrag_tiles_per_head;
+    float* out_f32; int out_ld, out_col0;
+    void* out_xp; int out_xp_ksteps, out_xp_kstep0;
+    void* out_vf;
+    int map_pad, map_src, relu;
+} s2s_node_problem;
+int s2s_node_linear_multi(const s2s_node_problem* problems, int n_problems, void* stream);
+
 /* Self-attention core of the trunk's TransformerEncoderLayer (src/models/net/ipa.py:312-317,357; torch.nn.MultiheadAttention with
  * d_model = n_heads * head_dim, head_dim = 80): softmax(q k^T / sqrt(head_dim) + key_bias[j]) v per (sample, head), exact fp32 MFMA.
  *   qkv [B*N, 3*D] fp32 = in_proj output (q | k | v); key_bias [B,N] or NULL: added to the logits of key j (PyTorch's float

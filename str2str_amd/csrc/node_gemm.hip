@@ -233,8 +233,9 @@ __device__ __forceinline__ void node_epilogue(f32x16 (&acc)[TG], const GemmArgs&
 #ifdef S2S_NODE_PROBE
 __device__ unsigned long long g_node_probe[8];
 #endif
+// (the body of one workgroup, as a device function: one launch can carry several independent layers -- node_gemm_multi_kernel below)
 template <int TG, int WAVES, bool VF>
-__global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
+__device__ __forceinline__ void node_gemm_body(const GemmArgs& a, const int bx, const int by) {
     // One weight stage = ONE k-step (TG tiles x 2 planes = 2 TG KiB), double buffered: 4 TG KiB of LDS and <= 256 registers, so
     // two workgroups share a CU (two waves per SIMD): one's barrier / LDS latency hides under the other's MFMAs.
     // (Measured and dropped: LDS-DMA for the weight copy, 2-wave workgroups for single-column-block shapes, and persistent
@@ -249,7 +250,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) char s_w[];  // 2 stages
     const int lane = threadIdx.x & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // provably wave-uniform: scalar branches below
-    const long long rt = (long long)blockIdx.x * WAVES + wave;
+    const long long rt = (long long)bx * WAVES + wave;
     const long long n_rt = (a.M + 31) / 32;
     const long long rtc = rt < n_rt ? rt : n_rt - 1;  // waves past the end redo the last row tile and store nothing
     const int KS = a.KS;                               // even
@@ -261,7 +262,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
     // weight copy global -> VGPR -> LDS (an LDS-DMA copy costs ~100 issue cycles per 1 KiB piece on the wave that issues it,
     // measured slower here as in the edge kernel): piece k of this wave = KiB number WAVES k + wave of the stage
     f32x4 wst[kPieces];
-    const char* wsrc = a.wpk + (long long)blockIdx.y * KS * kStage + lane * 16;
+    const char* wsrc = a.wpk + (long long)by * KS * kStage + lane * 16;
     auto w_load = [&](int ks) {  // clamped to the last k-step (the extra loads are never stored)
         ks = ks < KS ? ks : KS - 1;
         const char* src = wsrc + (long long)ks * kStage;
@@ -335,7 +336,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
     const long long rowc = (rt < n_rt && row < a.M) ? row : a.M - 1;
     const float ps = (a.pre_scale ? a.pre_scale[rowc] : 1.0f) * kInvWS;   // (the accumulators carry 32 x the product)
 
-    const int cb = blockIdx.y;
+    const int cb = by;
 #pragma unroll
     for (int t = 0; t < TG; ++t)
 #pragma unroll
@@ -468,6 +469,43 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
         atomicAdd(&g_node_probe[7], (unsigned long long)KS);
     }
 #endif
+}
+
+template <int TG, int WAVES, bool VF>
+__global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
+    node_gemm_body<TG, WAVES, VF>(a, blockIdx.x, blockIdx.y);
+}
+
+// Several INDEPENDENT layers in one launch (s2s_node_linear_multi): the five projections of an IPA block read the same activations
+// and nothing of each other (reference ipa.py:131-171).  As five launches each of them is one workgroup's latency chain (prologue ->
+// K / 16 k-steps -> epilogue, 11-25 us on a few thousand rows whatever the size) on a chip that is mostly idle; as one launch the
+// chains run side by side and the grid fills the chip sooner.  A flat grid: workgroup b belongs to problem p with cum[p] <= b <
+// cum[p + 1], its (row block, column block) = ((b - cum[p]) % nx[p], (b - cum[p]) / nx[p]).
+constexpr int kMultiMax = 6;
+struct MultiArgs {
+    GemmArgs a[kMultiMax];
+    int kind[kMultiMax];    // 0: <8, false>  1: <8, true> (A-fragment output)  2: <6, false>  3: <5, false>  4: <10, false>  5: <4, false>
+    int nx[kMultiMax];
+    int cum[kMultiMax + 1];
+    int n;
+};
+__global__ void __launch_bounds__(256, 2) node_gemm_multi_kernel(MultiArgs ma) {
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < kMultiMax; ++q)
+        if (q < ma.n && (int)blockIdx.x >= ma.cum[q]) p = q;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const int local = (int)blockIdx.x - ma.cum[p];
+    const int bx = local % ma.nx[p], by = local / ma.nx[p];
+    const GemmArgs& a = ma.a[p];
+    switch (ma.kind[p]) {
+        case 0: node_gemm_body<8, 4, false>(a, bx, by); break;
+        case 1: node_gemm_body<8, 4, true>(a, bx, by); break;
+        case 2: node_gemm_body<6, 4, false>(a, bx, by); break;
+        case 3: node_gemm_body<5, 4, false>(a, bx, by); break;
+        case 4: node_gemm_body<10, 4, false>(a, bx, by); break;
+        default: node_gemm_body<4, 4, false>(a, bx, by); break;
+    }
 }
 
 // fp32 row-major [M, ld] (columns col0 .. col0 + 16 KS) -> packed planes at k-step offset ks0 of an XP buffer with xp_KS k-steps.
@@ -667,3 +705,52 @@ extern "C" int s2s_node_probe_read(unsigned long long* host_out, int reset) {
     return (int)e;
 }
 #endif
+
+// Up to six independent layers (bias / ReLU epilogues only) in ONE launch: see node_gemm_multi_kernel.
+extern "C" int s2s_node_linear_multi(const s2s_node_problem* pr, int n, void* stream) {
+    if (n <= 0) return 0;
+    if (!pr || n > kMultiMax) return (int)hipErrorInvalidValue;
+    MultiArgs ma{};
+    ma.n = n;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        const s2s_node_problem& q = pr[i];
+        const bool vf = q.vfrag_tiles_per_head > 0;
+        const int TG = vf ? 8 : q.tiles_per_block;
+        if (q.n_rows <= 0 || !q.xp || !q.w_packed || q.k_in <= 0 || q.k_in % 32 || q.n_out <= 0 || TG <= 0 || q.n_out % (32 * TG) ||
+            q.map_pad < 0 || (q.map_pad > 0 && (q.map_src <= 0 || q.map_src > q.map_pad || q.map_pad % 32 || q.n_rows % q.map_pad)))
+            return (int)hipErrorInvalidValue;
+        int kind;
+        if (vf) {
+            if (!q.out_vf || (q.n_out / 32) % q.vfrag_tiles_per_head) return (int)hipErrorInvalidValue;
+            kind = 1;
+        } else {
+            if ((!q.out_f32 && !q.out_xp) || check_epilogue(q.n_out, TG, nullptr, nullptr, q.out_f32, q.out_ld, q.out_col0, nullptr, 0) ||
+                (q.out_xp && (q.out_xp_kstep0 < 0 || q.out_xp_kstep0 % 2 || q.out_xp_kstep0 + q.n_out / 16 > q.out_xp_ksteps)))
+                return (int)hipErrorInvalidValue;
+            kind = TG == 8 ? 0 : (TG == 6 ? 2 : (TG == 5 ? 3 : (TG == 10 ? 4 : (TG == 4 ? 5 : -1))));
+            if (kind < 0) return (int)hipErrorInvalidValue;
+        }
+        const int ncb = q.n_out / (32 * TG);
+        ma.a[i] = GemmArgs{(const f16x8*)q.xp, (const char*)q.w_packed, q.bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           vf ? nullptr : q.out_f32, vf ? nullptr : (f16x8*)q.out_xp, vf ? (f16x8*)q.out_vf : nullptr,
+                           vf ? q.vfrag_tiles_per_head : 0, q.n_rows, q.k_in / 16, ncb, 0, q.out_ld, q.out_col0, q.out_xp_ksteps,
+                           q.out_xp_kstep0, q.relu, 0.f, 0, s2s::g_range_flag, q.map_pad, q.map_src};
+        ma.kind[i] = kind;
+        const long long n_rt = (q.n_rows + 31) / 32;
+        ma.nx[i] = (int)((n_rt + 3) / 4);
+        ma.cum[i] = (int)total;
+        total += (long long)ma.nx[i] * ncb;
+        if (total > (1ll << 30)) return (int)hipErrorInvalidValue;
+    }
+    for (int i = n; i <= kMultiMax; ++i) ma.cum[i] = (int)total;
+    constexpr int lds = 2 * 2 * 10 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&node_gemm_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(node_gemm_multi_kernel, dim3((unsigned)total), dim3(256), lds, (hipStream_t)stream, ma);
+    return (int)hipGetLastError();
+}

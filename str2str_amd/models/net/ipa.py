@@ -120,12 +120,11 @@ class InvariantPointAttention(nn.Module):
         NP = ops.padded_len(N)
         # a ragged length: the q / k / v operands are produced straight into the per-sample padded row layout of the kernel
         rmap, Mo = ((NP, N), B * NP) if NP != N else (None, M)
-        _, q_xp = ops.node_apply(s_xp, w["q"], Mo, row_map=rmap, want_f32=False, want_xp=True)
-        _, k_xp = ops.node_apply(s_xp, w["k"], Mo, row_map=rmap, want_f32=False, want_xp=True)
         K = torch.ops.str2str_amd     # the kernels' operator surface (ops.register_torch_ops)
-        v_vf = K.node_linear_vfrag(s_xp, w["v"]["w"], w["v"]["b"], Mo, w["v"]["k"], w["v"]["n"], self.c_hidden // 32, *(rmap or (0, 0)))
-        qp, _ = ops.node_apply(s_xp, w["qp"], M)
-        kvp, _ = ops.node_apply(s_xp, w["kvp"], M)
+        # the five projections read the same planes and nothing of each other: ONE launch (s2s_node_linear_multi)
+        names = ("q", "k", "v", "qp", "kvp")
+        dims = [x for n in names for x in (w[n]["k"], w[n]["n"], w[n]["tg"])]
+        q_xp, k_xp, v_vf, qp, kvp = K.ipa_projections(s_xp, *[[w[n]["w"], w[n]["b"]] for n in names], dims, M, Mo, *(rmap or (0, 0)))
         pts = K.ipa_prep_points_f16(r7.view(B, N, 7), qp, kvp, d["hw"], H, self.no_qk_points, self.no_v_points, self.c_hidden)
         attn_bias, pair_z = pair_proj
         feats, feats_xp = K.ipa_attention_f16w(q_xp, k_xp, v_vf, *pts, attn_bias, pair_z, mask, r7, H, self.c_hidden,

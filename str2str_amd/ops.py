@@ -45,6 +45,7 @@ _SIGNATURES = {
     "s2s_pack_planes": [_vp, _ll, _i, _i, _i, _vp, _i, _i, _vp, _vp],
     "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "s2s_node_linear_f32": [_vp, _i, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
+    "s2s_node_linear_multi": [_vp, _i, _vp],
     "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _i, _vp],
     "s2s_encoder_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "s2s_encoder_attention_f16x3": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -926,6 +927,46 @@ def node_linear_vfrag(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles_p
     return out
 
 
+class _NodeProblem(ctypes.Structure):   # s2s_node_problem (include/str2str_hip.h)
+    _fields_ = [("xp", ctypes.c_void_p), ("w_packed", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("n_rows", ctypes.c_longlong),
+                ("k_in", ctypes.c_int), ("n_out", ctypes.c_int), ("tiles_per_block", ctypes.c_int), ("vfrag_tiles_per_head", ctypes.c_int),
+                ("out_f32", ctypes.c_void_p), ("out_ld", ctypes.c_int), ("out_col0", ctypes.c_int), ("out_xp", ctypes.c_void_p),
+                ("out_xp_ksteps", ctypes.c_int), ("out_xp_kstep0", ctypes.c_int), ("out_vf", ctypes.c_void_p), ("map_pad", ctypes.c_int),
+                ("map_src", ctypes.c_int), ("relu", ctypes.c_int)]
+
+
+def ipa_projections(s_xp, q, k, v, qp, kvp, n_rows: int, n_rows_padded: int, row_map: Optional[tuple] = None, tiles_per_head: int = 8):
+    """The five projections of an IPA block (reference ipa.py:131-171) in ONE launch (s2s_node_linear_multi): ``q`` / ``k`` -> packed
+    planes over ``n_rows_padded`` rows (the attention kernel's per-sample padded layout when ``row_map`` = (n_pad, n_src)), ``v`` -> A
+    fragments over the same rows, ``qp`` / ``kvp`` (point projections) -> fp32 [n_rows, n].  Each argument is a ``pack_node_layer``
+    dict.  -> (q_xp, k_xp, v_vf, qp_f32, kvp_f32); bitwise what the five separate launches give."""
+    lib = load_library()
+    _req(s_xp, torch.int16, "xp")
+    dev = s_xp.device
+    mp, ms = row_map if row_map is not None else (0, 0)
+    q_xp, k_xp = xp_alloc(n_rows_padded, q["n"], dev), xp_alloc(n_rows_padded, k["n"], dev)
+    v_vf = torch.empty(((n_rows_padded + 31) // 32) * (v["n"] // 32) * 2 * 2 * 64 * 8, dtype=torch.int16, device=dev)
+    qp_o = torch.empty(n_rows, qp["n"], device=dev, dtype=torch.float32)
+    kvp_o = torch.empty(n_rows, kvp["n"], device=dev, dtype=torch.float32)
+    arr = (_NodeProblem * 5)()
+
+    def fill(i, layer, rows, **kw):
+        p = arr[i]
+        p.xp, p.w_packed, p.bias = s_xp.data_ptr(), layer["w"].data_ptr(), layer["b"].data_ptr()
+        p.n_rows, p.k_in, p.n_out, p.tiles_per_block = rows, layer["k"], layer["n"], layer["tg"]
+        for name, val in kw.items():
+            setattr(p, name, val)
+
+    fill(0, q, n_rows_padded, out_xp=q_xp.data_ptr(), out_xp_ksteps=q["n"] // 16, map_pad=mp, map_src=ms)
+    fill(1, k, n_rows_padded, out_xp=k_xp.data_ptr(), out_xp_ksteps=k["n"] // 16, map_pad=mp, map_src=ms)
+    fill(2, v, n_rows_padded, vfrag_tiles_per_head=tiles_per_head, out_vf=v_vf.data_ptr(), map_pad=mp, map_src=ms)
+    fill(3, qp, n_rows, out_f32=qp_o.data_ptr(), out_ld=qp["n"])
+    fill(4, kvp, n_rows, out_f32=kvp_o.data_ptr(), out_ld=kvp["n"])
+    range_flag()
+    _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_multi(ctypes.byref(arr), 5, _stream())), "s2s_node_linear_multi")
+    return q_xp, k_xp, v_vf, qp_o, kvp_o
+
+
 def encoder_attention(qkv: torch.Tensor, key_bias: Optional[torch.Tensor], n_samples: int, n_res: int, n_heads: int = 4,
                       want_f32: bool = False, want_xp: bool = True, arith: str = "f32"):
     """Self-attention core of one encoder layer on the in_proj output qkv [B*N, 3*D] -> (fp32 [B*N, D] or None, packed planes or
@@ -1134,6 +1175,11 @@ _TORCH_OPS = {
     "node_linear_vfrag(Tensor xp, Tensor wpk, Tensor? bias, int n_rows, int k_in, int n_out, int tiles_per_head=8, int map_pad=0, "
     "int map_src=0) -> Tensor":
         lambda xp, w, b, m, k, n, tph=8, mp=0, ms=0: node_linear_vfrag(xp, w, b, m, k, n, tph, row_map=(mp, ms) if mp else None),
+    "ipa_projections(Tensor s_xp, Tensor[] q, Tensor[] k, Tensor[] v, Tensor[] qp, Tensor[] kvp, int[] dims, int n_rows, int n_rows_padded, "
+    "int map_pad=0, int map_src=0) -> (Tensor, Tensor, Tensor, Tensor, Tensor)":
+        lambda s_xp, q, k, v, qp, kvp, dims, m, mo, mp=0, ms=0: ipa_projections(
+            s_xp, *[{"w": t[0], "b": t[1], "k": dims[3 * i], "n": dims[3 * i + 1], "tg": dims[3 * i + 2]} for i, t in enumerate((q, k, v, qp, kvp))],
+            m, mo, (mp, ms) if mp else None),
     "pack_planes(Tensor x, int col0=0, int n_cols=-1, Tensor(a!)? out=None, int out_k=-1, int k0=0, Tensor? row_scale=None) -> Tensor":
         lambda x, c0=0, nc=-1, out=None, ok=-1, k0=0, rs=None: pack_planes(x, c0, _opt_int(nc), out, _opt_int(ok), k0, rs),
     # ---- frames / diffusion geometry

@@ -650,7 +650,7 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
     names = {sch.split("(")[0] for sch in ops._TORCH_OPS}
     assert names >= {"edge_transition", "edge_transition_f16x3", "edge_transition_f16x3_chain", "edge_embed", "edge_embed_f16x3", "pair_project",
                      "ipa_prep_points", "ipa_attention", "ipa_prep_points_f16", "ipa_attention_f16w", "encoder_attention", "node_linear",
-                     "node_linear_f32", "node_linear_vfrag", "pack_planes", "se3_step", "forward_marginal", "rigid_compose_update",
+                     "node_linear_f32", "node_linear_vfrag", "ipa_projections", "pack_planes", "se3_step", "forward_marginal", "rigid_compose_update",
                      "rigid_scale_trans", "frames_to_backbone"}
     gen = torch.Generator().manual_seed(11)
     rn = lambda *sh: torch.randn(*sh, generator=gen).to(DEV)
@@ -674,6 +674,14 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
     a = K.node_linear_vfrag(xp, w["v"]["w"], w["v"]["b"], B * NP, w["v"]["k"], w["v"]["n"], 8, NP, N)
     v_vf = ops.node_linear_vfrag(xp, w["v"]["w"], w["v"]["b"], B * NP, w["v"]["k"], w["v"]["n"], 8, row_map=(NP, N))
     assert torch.equal(a, v_vf)
+    # the five projections of an IPA block in one launch == the five launches
+    names = ("q", "k", "v", "qp", "kvp")
+    dims = [x_ for n_ in names for x_ in (w[n_]["k"], w[n_]["n"], w[n_]["tg"])]
+    five = K.ipa_projections(xp, *[[w[n_]["w"], w[n_]["b"]] for n_ in names], dims, M, B * NP, NP, N)
+    assert torch.equal(five[0], ops.node_apply(xp, w["q"], B * NP, row_map=(NP, N), want_f32=False, want_xp=True)[1])
+    assert torch.equal(five[1], ops.node_apply(xp, w["k"], B * NP, row_map=(NP, N), want_f32=False, want_xp=True)[1])
+    assert torch.equal(five[2], v_vf)
+    assert torch.equal(five[3], ops.node_apply(xp, w["qp"], M)[0]) and torch.equal(five[4], ops.node_apply(xp, w["kvp"], M)[0])
     qkv = rn(M, 960)
     for ar in MODES:
         assert eq([t for t in K.encoder_attention(qkv, None, B, N, 4, True, True, ar)], [t for t in ops.encoder_attention(qkv, None, B, N, 4, True, True, ar)])
