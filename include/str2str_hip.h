@@ -262,7 +262,7 @@ int s2s_node_linear_vfrag(const void* xp, const void* w_packed, const float* bia
 
 /* Up to six INDEPENDENT node layers (bias / ReLU epilogues, no residual / LayerNorm / masks) in one launch -- the five projections of an
  * IPA block (linear_q, the k and v halves of linear_kv, linear_q_points, linear_kv_points: ipa.py:131-171) read the same activations
- * and nothing of each other.  Each problem is the argument list of s2s_node_linear (tiles_per_block 4, 5, 6, 8 or 10) or, with
+ * and nothing of each other.  Each problem is the argument list of s2s_node_linear (tiles_per_block 2, 4, 5, 6, 8 or 10) or, with
  * vfrag_tiles_per_head > 0, of s2s_node_linear_vfrag. */
 typedef struct s2s_node_problem {
     const void* xp; const void* w_packed; const float* bias;

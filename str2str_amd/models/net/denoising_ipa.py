@@ -94,7 +94,7 @@ class EmbeddingModule(nn.Module):
                 "wn_t": wn[:, :ie].contiguous(), "wn_f": wn[:, ie].contiguous(), "wn_pos": wn[:, t1:t1 + ie].contiguous(),
                 "bn0": n0.bias.float().contiguous(),
                 "w2p": ops.pack_weight(e2.weight.float()), "w3p": ops.pack_weight(e4.weight.float()),
-                "node_mlp": [ops.pack_node_layer(self.node_embed[2].weight, self.node_embed[2].bias, True),
+                "node_mlp": [ops.pack_node_layer(self.node_embed[2].weight, self.node_embed[2].bias),
                              ops.pack_node_layer(self.node_embed[4].weight, self.node_embed[4].bias, True)],
             }
             if self.self_conditioning:

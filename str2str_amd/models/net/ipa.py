@@ -123,8 +123,9 @@ class InvariantPointAttention(nn.Module):
         K = torch.ops.str2str_amd     # the kernels' operator surface (ops.register_torch_ops)
         # the five projections read the same planes and nothing of each other: ONE launch (s2s_node_linear_multi)
         names = ("q", "k", "v", "qp", "kvp")
-        dims = [x for n in names for x in (w[n]["k"], w[n]["n"], w[n]["tg"])]
-        q_xp, k_xp, v_vf, qp, kvp = K.ipa_projections(s_xp, *[[w[n]["w"], w[n]["b"]] for n in names], dims, M, Mo, *(rmap or (0, 0)))
+        var = {n: (("w", w[n]["tg"]) if n == "v" else ops.small_rows_variant(w[n], M)) for n in names}   # (v: A fragments, 8 tiles per head)
+        dims = [x for n in names for x in (w[n]["k"], w[n]["n"], var[n][1])]
+        q_xp, k_xp, v_vf, qp, kvp = K.ipa_projections(s_xp, *[[w[n][var[n][0]], w[n]["b"]] for n in names], dims, M, Mo, *(rmap or (0, 0)))
         pts = K.ipa_prep_points_f16(r7.view(B, N, 7), qp, kvp, d["hw"], H, self.no_qk_points, self.no_v_points, self.c_hidden)
         attn_bias, pair_z = pair_proj
         feats, feats_xp = K.ipa_attention_f16w(q_xp, k_xp, v_vf, *pts, attn_bias, pair_z, mask, r7, H, self.c_hidden,
@@ -221,17 +222,18 @@ class TranslationIPA(nn.Module):
             pk = lambda lin, whole=False: ops.pack_node_layer(lin.weight, lin.bias, whole)  # noqa: E731
             out = {}
             for b in range(self.num_blocks):
-                d = {"skip": pk(T[f"skip_embed_{b}"]), "lin": pk(T[f"linear_{b}"], True), "bb": pk(T[f"bb_update_{b}"].linear)}
+                d = {"skip": pk(T[f"skip_embed_{b}"]), "lin": pk(T[f"linear_{b}"]), "bb": pk(T[f"bb_update_{b}"].linear)}
                 nt = T[f"node_transition_{b}"]
-                d["nt1"], d["nt2"], d["nt3"] = pk(nt.linear_1, True), pk(nt.linear_2, True), pk(nt.linear_3, True)
+                # (whole = the layer's epilogue normalises over the row: only those are tied to one column block at small row counts)
+                d["nt1"], d["nt2"], d["nt3"] = pk(nt.linear_1), pk(nt.linear_2), pk(nt.linear_3, True)
                 d["layers"] = []
                 for layer in T[f"transformer_{b}"].layers:
                     att = layer.self_attn
                     d["layers"].append({"in": ops.pack_node_layer(att.in_proj_weight, att.in_proj_bias), "o": pk(att.out_proj, True),
-                                        "l1": pk(layer.linear1, True), "l2": pk(layer.linear2, True)})
+                                        "l1": pk(layer.linear1), "l2": pk(layer.linear2, True)})
                 out[b] = d
             tp = self.torsion_pred
-            out["tor"] = {"l1": pk(tp.linear_1, True), "l2": pk(tp.linear_2, True), "fin": pk(tp.linear_final)}
+            out["tor"] = {"l1": pk(tp.linear_1), "l2": pk(tp.linear_2), "fin": pk(tp.linear_final)}
             return out
 
         return self._wcache.get(list(self.parameters()), build)

@@ -761,7 +761,13 @@ def pack_node_layer(w: torch.Tensor, bias, whole_row: bool = False) -> dict:
     b = w.new_zeros(n_pad, dtype=torch.float32)
     if bias is not None:
         b[:n_out] = bias.detach().float()
-    return _NodeLayer({"b": b.contiguous(), "n": n_pad, "k": k, "tg": tg}, w.detach())
+    # "tg_s": the column block for SMALL row counts (a few thousand rows: the reference's default inference block).  There a launch is one
+    # workgroup's latency chain, and narrower blocks mean more workgroups with shorter k-steps and epilogues (profiles/
+    # r04_node_gemm_small_m.txt: 320 -> 960 columns 29.5 -> 19.8 us, 256 -> 512 20.4 -> 13.0 us at 5120 rows); with rows to spare the wide
+    # block wins (every weight stage serves more MFMAs).  A layer that needs the whole row in one block (LayerNorm) has no choice.
+    t = n_pad // 32
+    tg_s = tg if whole_row else (2 if t % 2 == 0 else tg)
+    return _NodeLayer({"b": b.contiguous(), "n": n_pad, "k": k, "tg": tg, "tg_s": tg_s}, w.detach())
 
 
 class _NodeLayer(dict):
@@ -772,6 +778,8 @@ class _NodeLayer(dict):
     def __missing__(self, key):
         if key == "w":
             self[key] = pack_node_weight(self._w.float(), self["tg"])
+        elif key == "w_s":
+            self[key] = self["w"] if self["tg_s"] == self["tg"] else pack_node_weight(self._w.float(), self["tg_s"])
         elif key == "w32":
             self[key] = pack_node_weight_f32(self._w.float(), self["tg"])
         else:
@@ -876,6 +884,16 @@ def node_linear_f32(x, wpk32, bias, n_rows: int, k_in: int, n_out: int, tiles: i
     return out
 
 
+SMALL_ROWS = 8192   # at or below: the narrow column blocks ("tg_s") of a layer
+
+
+def small_rows_variant(layer: dict, n_rows: int):
+    """-> (key of the packed weights, tiles per column block) a layer runs with at this row count."""
+    if n_rows <= SMALL_ROWS and layer.get("tg_s", layer["tg"]) != layer["tg"]:
+        return "w_s", layer["tg_s"]
+    return "w", layer["tg"]
+
+
 def node_apply(x, layer: dict, n_rows: int, *, out_f32=None, out_col0: int = 0, want_f32=True, out_xp=None, out_xp_k=None,
                out_xp_k0: int = 0, want_xp=False, **epilogue):
     """One layer of the node stream in the arithmetic of its INPUT: ``x`` packed f16 planes (int16) -> s2s_node_linear, ``x`` fp32
@@ -893,7 +911,8 @@ def node_apply(x, layer: dict, n_rows: int, *, out_f32=None, out_col0: int = 0, 
         raise TypeError(f"node_apply: unexpected arguments {sorted(ep)}")
     if x.dtype == torch.int16:
         mp, ms = row_map if row_map is not None else (0, 0)
-        return T.node_linear(x, layer["w"], layer["b"], n_rows, layer["k"], layer["n"], layer["tg"], *flat, out_f32, out_col0, want_f32,
+        wk, tg = small_rows_variant(layer, n_rows)
+        return T.node_linear(x, layer[wk], layer["b"], n_rows, layer["k"], layer["n"], tg, *flat, out_f32, out_col0, want_f32,
                              out_xp, -1 if out_xp_k is None else out_xp_k, out_xp_k0, want_xp, mp, ms)
     if row_map is not None:
         raise HipLibraryError("node_apply: the row map belongs to the f16 attention operands")
@@ -952,7 +971,7 @@ def ipa_projections(s_xp, q, k, v, qp, kvp, n_rows: int, n_rows_padded: int, row
 
     def fill(i, layer, rows, **kw):
         p = arr[i]
-        p.xp, p.w_packed, p.bias = s_xp.data_ptr(), layer["w"].data_ptr(), layer["b"].data_ptr()
+        p.xp, p.w_packed, p.bias = s_xp.data_ptr(), layer["w"].data_ptr(), layer["b"].data_ptr()   # (the caller picked the variant: "w" / "tg")
         p.n_rows, p.k_in, p.n_out, p.tiles_per_block = rows, layer["k"], layer["n"], layer["tg"]
         for name, val in kw.items():
             setattr(p, name, val)
