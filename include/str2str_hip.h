@@ -275,6 +275,14 @@ typedef struct s2s_node_problem {
 } s2s_node_problem;
 int s2s_node_linear_multi(const s2s_node_problem* problems, int n_problems, void* stream);
 
+/* The LayerNorm (+ post mask) half of a node layer on its own: fp32 rows x [n_rows, x_ld] (n_cols = 256 or 320) -> out_f32 and / or packed
+ * planes, with the epilogue code of s2s_node_linear -- a layer run as s2s_node_linear(ln = NULL, out_f32 = x) followed by this call
+ * equals the fused layer bit for bit.  For long contractions on few rows (linear_out, K = 2688, ipa.py:259-266): the GEMM can then run
+ * in narrow column blocks instead of one block per row tile. */
+int s2s_row_layernorm(const float* x, int x_ld, long long n_rows, int n_cols, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                      const float* post_mask, float* out_f32, int out_ld, int out_col0, void* out_xp, int out_xp_ksteps,
+                      int out_xp_kstep0, void* stream);
+
 /* Self-attention core of the trunk's TransformerEncoderLayer (src/models/net/ipa.py:312-317,357; torch.nn.MultiheadAttention with
  * d_model = n_heads * head_dim, head_dim = 80): softmax(q k^T / sqrt(head_dim) + key_bias[j]) v per (sample, head), exact fp32 MFMA.
  *   qkv [B*N, 3*D] fp32 = in_proj output (q | k | v); key_bias [B,N] or NULL: added to the logits of key j (PyTorch's float

@@ -509,6 +509,29 @@ __global__ void __launch_bounds__(256, 2) node_gemm_multi_kernel(MultiArgs ma) {
     }
 }
 
+// The LayerNorm half of a layer whose GEMM ran WITHOUT it (s2s_row_layernorm): a wave loads its 32 rows of the pre-LayerNorm fp32
+// values into accumulator layout and runs the SAME epilogue function as the fused kernel (scale 1, zero bias: x * 1 + 0 is exact),
+// so the split form equals the fused one bit for bit.  For layers with a long contraction on few rows (linear_out: K = 2688), where
+// one column block per row tile means 168 serial k-steps of 24 MFMAs: the GEMM then runs in narrow column blocks.
+template <int TG>
+__global__ void __launch_bounds__(256) node_ln_kernel(GemmArgs a, const float* __restrict__ x, int x_ld) {
+    const int lane = threadIdx.x & 63, h = lane >> 5, wave = threadIdx.x >> 6;
+    const long long rt = (long long)blockIdx.x * 4 + wave;
+    const long long n_rt = (a.M + 31) / 32;
+    const long long row = rt * 32 + (lane & 31);
+    const long long rowc = (rt < n_rt && row < a.M) ? row : a.M - 1;
+    f32x16 acc[TG];
+    const float* p = x + rowc * x_ld + 4 * h;
+#pragma unroll
+    for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const float4 v = *reinterpret_cast<const float4*>(p + 32 * t + 8 * rq);
+            acc[t][4 * rq + 0] = v.x; acc[t][4 * rq + 1] = v.y; acc[t][4 * rq + 2] = v.z; acc[t][4 * rq + 3] = v.w;
+        }
+    node_epilogue<TG>(acc, a, rt, n_rt, lane, 0, 1.0f);
+}
+
 // fp32 row-major [M, ld] (columns col0 .. col0 + 16 KS) -> packed planes at k-step offset ks0 of an XP buffer with xp_KS k-steps.
 // One wave per (row tile, k-step): lane (row m, half g) gathers its 8 chain-ordered channels (two float4), splits, stores 2 x 16 B.
 __global__ void __launch_bounds__(256) pack_planes_kernel(const float* __restrict__ x, long long M, int ld, int col0, int KS,
@@ -753,5 +776,25 @@ extern "C" int s2s_node_linear_multi(const s2s_node_problem* pr, int n, void* st
         attr_set = true;
     }
     hipLaunchKernelGGL(node_gemm_multi_kernel, dim3((unsigned)total), dim3(256), lds, (hipStream_t)stream, ma);
+    return (int)hipGetLastError();
+}
+
+// LayerNorm (+ post mask) of fp32 rows x [n_rows, x_ld] (n_cols = 256 or 320 leading columns) -> out_f32 / packed planes, with the
+// epilogue code of s2s_node_linear: a layer run as  s2s_node_linear(ln = NULL, out_f32 = x)  +  this  equals the fused layer bit for bit.
+extern "C" int s2s_row_layernorm(const float* x, int x_ld, long long n_rows, int n_cols, const float* ln_gamma, const float* ln_beta,
+                                 float ln_eps, const float* post_mask, float* out_f32, int out_ld, int out_col0, void* out_xp,
+                                 int out_xp_ksteps, int out_xp_kstep0, void* stream) {
+    if (n_rows <= 0) return 0;
+    const int TG = n_cols / 32;
+    if (!x || x_ld % 4 || !ln_gamma || !ln_beta || (n_cols != 256 && n_cols != 320) || (!out_f32 && !out_xp) ||
+        check_epilogue(n_cols, TG, ln_gamma, ln_beta, out_f32, out_ld, out_col0, nullptr, 0) ||
+        (out_xp && (out_xp_kstep0 < 0 || out_xp_kstep0 % 2 || out_xp_kstep0 + n_cols / 16 > out_xp_ksteps)))
+        return (int)hipErrorInvalidValue;
+    GemmArgs a{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ln_gamma, ln_beta, post_mask, out_f32, (f16x8*)out_xp, nullptr, 0, n_rows,
+               0, 1, 0, out_ld, out_col0, out_xp_ksteps, out_xp_kstep0, 0, ln_eps, 0, s2s::g_range_flag, 0, 0};
+    const long long n_rt = (n_rows + 31) / 32;
+    const dim3 grid((unsigned)((n_rt + 3) / 4));
+    if (TG == 8) hipLaunchKernelGGL(node_ln_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, a, x, x_ld);
+    else hipLaunchKernelGGL(node_ln_kernel<10>, grid, dim3(256), 0, (hipStream_t)stream, a, x, x_ld);
     return (int)hipGetLastError();
 }

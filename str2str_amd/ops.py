@@ -46,6 +46,7 @@ _SIGNATURES = {
     "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "s2s_node_linear_f32": [_vp, _i, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "s2s_node_linear_multi": [_vp, _i, _vp],
+    "s2s_row_layernorm": [_vp, _i, _ll, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
     "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _i, _vp],
     "s2s_encoder_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "s2s_encoder_attention_f16x3": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -894,6 +895,30 @@ def small_rows_variant(layer: dict, n_rows: int):
     return "w", layer["tg"]
 
 
+def row_layernorm(x, n_rows: int, n_cols: int, gamma, beta, eps: float, post_mask=None, out_f32=None, out_col0: int = 0, want_f32=True,
+                  out_xp=None, out_xp_k: Optional[int] = None, out_xp_k0: int = 0, want_xp=False):
+    """LayerNorm (+ post mask) of the leading ``n_cols`` columns of fp32 rows with the node GEMM's epilogue code (s2s_row_layernorm):
+    the second half of a layer whose GEMM ran without its LayerNorm.  Same output conventions as ``node_linear``."""
+    lib = load_library()
+    _req(x, name="x"); _req(gamma, name="ln.gamma"); _req(beta, name="ln.beta")
+    dev = x.device
+    if post_mask is not None:
+        _req(post_mask, name="post_mask")
+    if out_f32 is None and want_f32:
+        out_f32 = torch.empty(n_rows, n_cols, device=dev, dtype=torch.float32)
+    if out_xp is None and want_xp:
+        out_xp_k = n_cols if out_xp_k is None else out_xp_k
+        out_xp = xp_alloc(n_rows, out_xp_k, dev)
+    if out_xp is not None:
+        out_xp_k = n_cols if out_xp_k is None else out_xp_k
+    range_flag()
+    _check(_timed("s2s_node_linear", lambda: lib.s2s_row_layernorm(
+        _p(x), x.shape[-1], n_rows, n_cols, _p(gamma), _p(beta), float(eps), _p(post_mask), _p(out_f32),
+        out_f32.shape[-1] if out_f32 is not None else 0, out_col0, _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16, _stream())),
+        "s2s_row_layernorm")
+    return out_f32, out_xp
+
+
 def node_apply(x, layer: dict, n_rows: int, *, out_f32=None, out_col0: int = 0, want_f32=True, out_xp=None, out_xp_k=None,
                out_xp_k0: int = 0, want_xp=False, **epilogue):
     """One layer of the node stream in the arithmetic of its INPUT: ``x`` packed f16 planes (int16) -> s2s_node_linear, ``x`` fp32
@@ -909,6 +934,17 @@ def node_apply(x, layer: dict, n_rows: int, *, out_f32=None, out_col0: int = 0, 
             ep.pop("post_mask", None))
     if ep:
         raise TypeError(f"node_apply: unexpected arguments {sorted(ep)}")
+    if x.dtype == torch.int16 and g is not None and n_rows <= SMALL_ROWS and layer["k"] >= 1024 and layer["n"] in (256, 320) and row_map is None:
+        # a long contraction on few rows whose epilogue normalises over the row (linear_out, K = 2688): one column block per row tile
+        # is K / 16 serial k-steps of 24 MFMAs on 1 / 6 of the chip; GEMM in narrow blocks + the LayerNorm on its own is the same
+        # arithmetic (s2s_row_layernorm) in a third of the time
+        if "w_n" not in layer:
+            layer["w_n"] = pack_node_weight(layer._w.float(), 2)
+        pre = torch.empty(n_rows, layer["n"], device=x.device, dtype=torch.float32)
+        T.node_linear(x, layer["w_n"], layer["b"], n_rows, layer["k"], layer["n"], 2, flat[0], flat[1], flat[2], flat[3], None, None, 0.0, None,
+                      pre, 0, True, None, -1, 0, False, 0, 0)
+        return T.row_layernorm(pre, n_rows, layer["n"], g, b, float(eps), flat[7], out_f32, out_col0, want_f32, out_xp,
+                               -1 if out_xp_k is None else out_xp_k, out_xp_k0, want_xp)
     if x.dtype == torch.int16:
         mp, ms = row_map if row_map is not None else (0, 0)
         wk, tg = small_rows_variant(layer, n_rows)
@@ -1199,6 +1235,10 @@ _TORCH_OPS = {
         lambda s_xp, q, k, v, qp, kvp, dims, m, mo, mp=0, ms=0: ipa_projections(
             s_xp, *[{"w": t[0], "b": t[1], "k": dims[3 * i], "n": dims[3 * i + 1], "tg": dims[3 * i + 2]} for i, t in enumerate((q, k, v, qp, kvp))],
             m, mo, (mp, ms) if mp else None),
+    "row_layernorm(Tensor x, int n_rows, int n_cols, Tensor gamma, Tensor beta, float eps, Tensor? post_mask=None, Tensor(a!)? out_f32=None, "
+    "int out_col0=0, bool want_f32=True, Tensor(b!)? out_xp=None, int out_xp_k=-1, int out_xp_k0=0, bool want_xp=False) -> (Tensor?, Tensor?)":
+        lambda x, m, n, g, b, eps, pm=None, of=None, oc=0, wf=True, ox=None, ok=-1, ok0=0, wx=False: row_layernorm(
+            x, m, n, g, b, eps, pm, of, oc, wf, ox, _opt_int(ok), ok0, wx),
     "pack_planes(Tensor x, int col0=0, int n_cols=-1, Tensor(a!)? out=None, int out_k=-1, int k0=0, Tensor? row_scale=None) -> Tensor":
         lambda x, c0=0, nc=-1, out=None, ok=-1, k0=0, rs=None: pack_planes(x, c0, _opt_int(nc), out, _opt_int(ok), k0, rs),
     # ---- frames / diffusion geometry

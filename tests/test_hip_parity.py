@@ -650,7 +650,7 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
     names = {sch.split("(")[0] for sch in ops._TORCH_OPS}
     assert names >= {"edge_transition", "edge_transition_f16x3", "edge_transition_f16x3_chain", "edge_embed", "edge_embed_f16x3", "pair_project",
                      "ipa_prep_points", "ipa_attention", "ipa_prep_points_f16", "ipa_attention_f16w", "encoder_attention", "node_linear",
-                     "node_linear_f32", "node_linear_vfrag", "ipa_projections", "pack_planes", "se3_step", "forward_marginal", "rigid_compose_update",
+                     "node_linear_f32", "node_linear_vfrag", "ipa_projections", "row_layernorm", "pack_planes", "se3_step", "forward_marginal", "rigid_compose_update",
                      "rigid_scale_trans", "frames_to_backbone"}
     gen = torch.Generator().manual_seed(11)
     rn = lambda *sh: torch.randn(*sh, generator=gen).to(DEV)
@@ -682,6 +682,20 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
     assert torch.equal(five[1], ops.node_apply(xp, w["k"], B * NP, row_map=(NP, N), want_f32=False, want_xp=True)[1])
     assert torch.equal(five[2], v_vf)
     assert torch.equal(five[3], ops.node_apply(xp, w["qp"], M)[0]) and torch.equal(five[4], ops.node_apply(xp, w["kvp"], M)[0])
+    # linear_out (K = 2688) on few rows runs as a narrow-block GEMM + the LayerNorm on its own (s2s_row_layernorm): bitwise the fused layer
+    lo, lnm = w["out"], tr["ipa_ln_0"]
+    fx = ops.pack_planes(rn(M, 2688))
+    res, pmk = rn(M, 256), (torch.rand(M, generator=gen) > 0.2).float().to(DEV)
+    fused = ops.node_linear(fx, lo["w"], lo["b"], M, lo["k"], lo["n"], lo["tg"], pre_mask=pmk, residual=res,
+                            ln=(lnm.weight, lnm.bias, lnm.eps), post_mask=pmk, want_xp=True)
+    split = ops.node_apply(fx, lo, M, pre_mask=pmk, residual=res, ln=(lnm.weight, lnm.bias, lnm.eps), post_mask=pmk, want_xp=True)
+    assert "w_n" in lo and eq(fused, split)
+    pre = rn(M, 320)
+    l2n = tr["transformer_0"].layers[0].norm2
+    a = K.row_layernorm(pre, M, 320, l2n.weight, l2n.bias, l2n.eps, None, None, 0, True, None, -1, 0, True)
+    assert eq(a, ops.row_layernorm(pre, M, 320, l2n.weight, l2n.bias, l2n.eps, want_xp=True))
+    ref = torch.nn.functional.layer_norm(pre.double(), (320,), l2n.weight.double(), l2n.bias.double(), l2n.eps)
+    assert (a[0].double() - ref).abs().max() < 1e-5
     qkv = rn(M, 960)
     for ar in MODES:
         assert eq([t for t in K.encoder_attention(qkv, None, B, N, 4, True, True, ar)], [t for t in ops.encoder_attention(qkv, None, B, N, 4, True, True, ar)])
