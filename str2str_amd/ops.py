@@ -885,38 +885,17 @@ def node_linear_f32(x, wpk32, bias, n_rows: int, k_in: int, n_out: int, tiles: i
     return out
 
 
-SMALL_ROWS = 8192   # at or below: the narrow column blocks ("tg_s") of a layer
+SMALL_ROWS = 8192        # at or below: a long contraction with a row-normalising epilogue runs as narrow GEMM + LayerNorm (node_apply)
+NARROW_MAX_WORK = 24 << 20   # rows x output columns up to which the narrow column blocks ("tg_s") of a layer are the faster form
+#   (tools/node_gemm_bench.py --tg 2 against the default, profiles/r04_node_gemm_small_m.txt: 2048 columns win up to ~10 k rows and
+#    lose from ~24 k, 512 .. 960 columns still win at 24 k rows)
 
 
 def small_rows_variant(layer: dict, n_rows: int):
     """-> (key of the packed weights, tiles per column block) a layer runs with at this row count."""
-    if n_rows <= SMALL_ROWS and layer.get("tg_s", layer["tg"]) != layer["tg"]:
+    if n_rows * layer["n"] <= NARROW_MAX_WORK and layer.get("tg_s", layer["tg"]) != layer["tg"]:
         return "w_s", layer["tg_s"]
     return "w", layer["tg"]
-
-
-def row_layernorm(x, n_rows: int, n_cols: int, gamma, beta, eps: float, post_mask=None, out_f32=None, out_col0: int = 0, want_f32=True,
-                  out_xp=None, out_xp_k: Optional[int] = None, out_xp_k0: int = 0, want_xp=False):
-    """LayerNorm (+ post mask) of the leading ``n_cols`` columns of fp32 rows with the node GEMM's epilogue code (s2s_row_layernorm):
-    the second half of a layer whose GEMM ran without its LayerNorm.  Same output conventions as ``node_linear``."""
-    lib = load_library()
-    _req(x, name="x"); _req(gamma, name="ln.gamma"); _req(beta, name="ln.beta")
-    dev = x.device
-    if post_mask is not None:
-        _req(post_mask, name="post_mask")
-    if out_f32 is None and want_f32:
-        out_f32 = torch.empty(n_rows, n_cols, device=dev, dtype=torch.float32)
-    if out_xp is None and want_xp:
-        out_xp_k = n_cols if out_xp_k is None else out_xp_k
-        out_xp = xp_alloc(n_rows, out_xp_k, dev)
-    if out_xp is not None:
-        out_xp_k = n_cols if out_xp_k is None else out_xp_k
-    range_flag()
-    _check(_timed("s2s_node_linear", lambda: lib.s2s_row_layernorm(
-        _p(x), x.shape[-1], n_rows, n_cols, _p(gamma), _p(beta), float(eps), _p(post_mask), _p(out_f32),
-        out_f32.shape[-1] if out_f32 is not None else 0, out_col0, _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16, _stream())),
-        "s2s_row_layernorm")
-    return out_f32, out_xp
 
 
 def node_apply(x, layer: dict, n_rows: int, *, out_f32=None, out_col0: int = 0, want_f32=True, out_xp=None, out_xp_k=None,
