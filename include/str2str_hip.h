@@ -179,7 +179,15 @@ int s2s_ipa_opair(const float* logits, const float* stats, const float* pair_z, 
 /* Rigid.compose_q_update_vec (src/common/rigid_utils.py:1042-1066, :590-619, :268-277).
  *   rigids7 [M,7], update6 [M,6], mask [M], out7 [M,7] (may alias rigids7). */
 int s2s_rigid_compose_update(const float* rigids7, const float* update6, const float* mask, float* out7,
-                             long long n_frames, void* stream);
+                             long long n_frames, int update_ld, void* stream);   /* update_ld: floats between consecutive update rows (>= 6): the
+                                                                                    BackboneUpdate layer's padded [n, 32] output is read in place */
+
+/* TorsionAngleHead's normalisation (src/models/net/layers.py:199-213: u / sqrt(max(u0^2 + u1^2, eps)), normalize != 0) and / or
+ * DenoisingNet's blend with the input torsion under the fixed mask (denoising_ipa.py:193-195: gt * fixed + pred * (1 - fixed),
+ * gt_sin_cos != NULL: row r at gt_sin_cos + r * gt_row_stride, fixed_mask [n_rows]).  u: rows of u_ld >= 2 floats (the head's padded
+ * output is read in place); out2 [n_rows, 2]. */
+int s2s_torsion_head(const float* u, int u_ld, int normalize, const float* gt_sin_cos, long long gt_row_stride, const float* fixed_mask,
+                     float eps, float* out2, long long n_rows, void* stream);
 
 /* TranslationIPA scale_rigids / unscale_rigids (src/models/net/ipa.py:288-292): translation * scale,
  * or translation / scale (true division) when divide != 0. */

@@ -23,12 +23,12 @@ __device__ __forceinline__ void load7(const float* __restrict__ p, Quat<float>& 
 
 __global__ void __launch_bounds__(256) compose_update_kernel(const float* __restrict__ rig, const float* __restrict__ upd,
                                                              const float* __restrict__ mask, float* __restrict__ out,
-                                                             long long M) {
+                                                             long long M, int upd_ld) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= M) return;
     Quat<float> q; Vec3<float> t;
     load7(rig + r * 7, q, t);
-    const float* u = upd + r * 6;
+    const float* u = upd + r * upd_ld;
     const float m = mask[r];
     const Vec3<float> qv{u[0], u[1], u[2]};
     const Vec3<float> tv{u[3], u[4], u[5]};
@@ -181,13 +181,47 @@ inline int grid_for(long long n, int block) { return (int)((n + block - 1) / blo
 
 }  // namespace
 
+// TorsionAngleHead's normalisation (layers.py:199-213: u / sqrt(max(sum u^2, eps))) and DenoisingNet's blend with the input torsion
+// under the fixed mask (denoising_ipa.py:193-195: gt * fixed + pred * (1 - fixed)) -- each a chain of five tiny elementwise launches in
+// eager PyTorch, and a network evaluation of a small chunk is launch-latency bound.  Same operations in the same order (this file is
+// built with -ffp-contract=off).
+__global__ void __launch_bounds__(256) torsion_head_kernel(const float* __restrict__ u, int u_ld, int normalize, const float* __restrict__ gt,
+                                                           long long gt_stride, const float* __restrict__ fixed, float eps,
+                                                           float* __restrict__ out, long long M) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    float a = u[r * u_ld], b = u[r * u_ld + 1];
+    if (normalize) {
+        const float s = sqrtf(fmaxf(a * a + b * b, eps));
+        a = a / s;
+        b = b / s;
+    }
+    if (gt) {
+        const float f = fixed[r], c = 1.0f - f;
+        a = gt[r * gt_stride] * f + a * c;
+        b = gt[r * gt_stride + 1] * f + b * c;
+    }
+    out[2 * r] = a;
+    out[2 * r + 1] = b;
+}
+
 extern "C" {
 
+int s2s_torsion_head(const float* u, int u_ld, int normalize, const float* gt_sin_cos, long long gt_row_stride, const float* fixed_mask,
+                     float eps, float* out2, long long n_rows, void* stream) {
+    if (n_rows <= 0) return 0;
+    if (!u || u_ld < 2 || !out2 || ((gt_sin_cos != nullptr) != (fixed_mask != nullptr))) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(torsion_head_kernel, dim3(grid_for(n_rows, 256)), dim3(256), 0, (hipStream_t)stream, u, u_ld, normalize, gt_sin_cos,
+                       gt_row_stride, fixed_mask, eps, out2, n_rows);
+    return (int)hipGetLastError();
+}
+
 int s2s_rigid_compose_update(const float* rigids7, const float* update6, const float* mask, float* out7,
-                             long long n_frames, void* stream) {
+                             long long n_frames, int update_ld, void* stream) {
     if (n_frames <= 0) return 0;
+    if (update_ld < 6) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(compose_update_kernel, dim3(grid_for(n_frames, 256)), dim3(256), 0, (hipStream_t)stream, rigids7,
-                       update6, mask, out7, n_frames);
+                       update6, mask, out7, n_frames, update_ld);
     return (int)hipGetLastError();
 }
 

@@ -301,7 +301,7 @@ class TranslationIPA(nn.Module):
             s_f32, s_a = lin(h2, w["nt3"], residual=n_f32, ln=(nt.ln.weight, nt.ln.bias, nt.ln.eps), post_mask=nm, want_xp=True)
             # ---- backbone update (:361-365)
             upd, _ = lin(s_a, w["bb"], pre_scale=dm)
-            curr7 = torch.ops.str2str_amd.rigid_compose_update(curr7, upd[:, :6].contiguous().view(B, N, 6), diffuse_mask)
+            curr7 = torch.ops.str2str_amd.rigid_compose_update(curr7, upd, diffuse_mask)   # (the padded [M, 32] output in place: no copy)
             # ---- EdgeTransition (:367-372): per-node parts here, the pair MLP in its own kernel
             if b < self.num_blocks - 1:
                 et = T[f"edge_transition_{b}"]
@@ -325,8 +325,8 @@ class TranslationIPA(nn.Module):
         wt = W["tor"]
         _, t1 = lin(s_a, wt["l1"], relu=True, want_f32=False, want_xp=True)
         _, t2 = lin(t1, wt["l2"], residual=s_f32, want_f32=False, want_xp=True)
-        u = lin(t2, wt["fin"])[0][:, :2].reshape(B, N, 2)
-        psi = u / torch.sqrt(torch.clamp(torch.sum(u**2, dim=-1, keepdim=True), min=self.torsion_pred.eps))
+        # u / sqrt(max(sum u^2, eps)) (layers.py:199-213) straight from the head's padded output: one launch instead of six tiny ones
+        psi = torch.ops.str2str_amd.torsion_head(lin(t2, wt["fin"])[0], M, True, self.torsion_pred.eps).view(B, N, 2)
         out7 = torch.ops.str2str_amd.rigid_scale_trans(curr7, self.coordinate_scaling, True)
         return {
             "in_rigids": Rigid.from_tensor_7(init7),

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 20
+ABI_VERSION = 21
 
 _lib = None
 _tables_loaded = False
@@ -36,7 +36,8 @@ _SIGNATURES = {
     "s2s_ipa_opair": [_vp] * 4 + [_i, _i, _i, _i, _i, _i, _i, _vp],
     "s2s_ipa_prep_points_f16": [_vp] * 9 + [_i, _i, _i, _i, _i, _i, _vp],
     "s2s_ipa_attention_f16w": [_vp] * 15 + [_i] * 8 + [_f, _f, _vp],
-    "s2s_rigid_compose_update": [_vp] * 4 + [_ll, _vp],
+    "s2s_rigid_compose_update": [_vp] * 4 + [_ll, _i, _vp],
+    "s2s_torsion_head": [_vp, _i, _i, _vp, _ll, _vp, _f, _vp, _ll, _vp],
     "s2s_rigid_scale_trans": [_vp, _vp, _ll, _f, _i, _vp],
     "s2s_set_backbone_tables": [_vp] * 4,
     "s2s_frames_to_backbone": [_vp] * 5 + [_ll, _vp],
@@ -609,12 +610,42 @@ def ipa_attention_f16(q_xp, k_xp, v_vf, points, attn_bias, pair_z, mask, rigids7
 
 
 def rigid_compose_update(rigids7, update6, mask, out=None):
+    """``update6``: [..., 6] contiguous, or a 2-D [n_frames, ld >= 6] fp32 buffer whose leading six columns are the update (the
+    BackboneUpdate layer's padded output, read in place)."""
     lib = load_library()
     _req(rigids7, name="rigids7"); _req(update6, name="update6"); _req(mask, name="mask")
+    n = rigids7.numel() // 7
+    ld = update6.shape[-1] if (update6.ndim == 2 and update6.shape[0] == n) else 6
+    if ld < 6 or update6.numel() != n * ld:
+        raise HipLibraryError("rigid_compose_update: update6 must be [..., 6] or [n_frames, ld >= 6]")
     if out is None:
         out = torch.empty_like(rigids7)
-    _check(lib.s2s_rigid_compose_update(_p(rigids7), _p(update6), _p(mask), _p(out), rigids7.numel() // 7, _stream()),
+    _check(lib.s2s_rigid_compose_update(_p(rigids7), _p(update6), _p(mask), _p(out), n, ld, _stream()),
            "s2s_rigid_compose_update")
+    return out
+
+
+def torsion_head(u, n_rows: int, normalize: bool = True, eps: float = 1e-8, gt_sin_cos=None, fixed_mask=None):
+    """psi [n_rows, 2] from the torsion head's raw output ``u`` (2-D, leading two columns; normalised when ``normalize``) and, with
+    ``gt_sin_cos`` (a [.., 2] view whose rows are ``gt_sin_cos.stride(-2)`` floats apart) + ``fixed_mask`` [n_rows], blended with the
+    input torsion (s2s_torsion_head)."""
+    lib = load_library()
+    _req(u, name="u")
+    if u.ndim != 2 or u.shape[0] != n_rows or u.shape[1] < 2:
+        raise HipLibraryError("torsion_head: u must be [n_rows, ld >= 2]")
+    gs = 0
+    if gt_sin_cos is not None:
+        if gt_sin_cos.dtype != torch.float32 or not gt_sin_cos.is_cuda or gt_sin_cos.shape[-1] != 2 or gt_sin_cos.stride(-1) != 1:
+            raise HipLibraryError("torsion_head: gt_sin_cos must be a float32 device tensor [..., 2]")
+        g2 = gt_sin_cos.reshape(-1, 2) if gt_sin_cos.is_contiguous() else gt_sin_cos
+        gs = 2 if gt_sin_cos.is_contiguous() else gt_sin_cos.stride(-2)
+        if not gt_sin_cos.is_contiguous() and any(gt_sin_cos.stride(d) != gt_sin_cos.stride(d + 1) * gt_sin_cos.shape[d + 1]
+                                                  for d in range(gt_sin_cos.ndim - 2)):
+            raise HipLibraryError("torsion_head: gt_sin_cos rows must be evenly strided")
+        _req(fixed_mask, name="fixed_mask")
+    out = torch.empty(n_rows, 2, device=u.device, dtype=torch.float32)
+    _check(lib.s2s_torsion_head(_p(u), u.shape[1], int(bool(normalize)), _p(gt_sin_cos), gs, _p(fixed_mask), float(eps), _p(out), n_rows,
+                                _stream()), "s2s_torsion_head")
     return out
 
 
@@ -896,6 +927,30 @@ def small_rows_variant(layer: dict, n_rows: int):
     if n_rows * layer["n"] <= NARROW_MAX_WORK and layer.get("tg_s", layer["tg"]) != layer["tg"]:
         return "w_s", layer["tg_s"]
     return "w", layer["tg"]
+
+
+def row_layernorm(x, n_rows: int, n_cols: int, gamma, beta, eps: float, post_mask=None, out_f32=None, out_col0: int = 0, want_f32=True,
+                  out_xp=None, out_xp_k: Optional[int] = None, out_xp_k0: int = 0, want_xp=False):
+    """LayerNorm (+ post mask) of the leading ``n_cols`` columns of fp32 rows with the node GEMM's epilogue code (s2s_row_layernorm):
+    the second half of a layer whose GEMM ran without its LayerNorm.  Same output conventions as ``node_linear``."""
+    lib = load_library()
+    _req(x, name="x"); _req(gamma, name="ln.gamma"); _req(beta, name="ln.beta")
+    dev = x.device
+    if post_mask is not None:
+        _req(post_mask, name="post_mask")
+    if out_f32 is None and want_f32:
+        out_f32 = torch.empty(n_rows, n_cols, device=dev, dtype=torch.float32)
+    if out_xp is None and want_xp:
+        out_xp_k = n_cols if out_xp_k is None else out_xp_k
+        out_xp = xp_alloc(n_rows, out_xp_k, dev)
+    if out_xp is not None:
+        out_xp_k = n_cols if out_xp_k is None else out_xp_k
+    range_flag()
+    _check(_timed("s2s_node_linear", lambda: lib.s2s_row_layernorm(
+        _p(x), x.shape[-1], n_rows, n_cols, _p(gamma), _p(beta), float(eps), _p(post_mask), _p(out_f32),
+        out_f32.shape[-1] if out_f32 is not None else 0, out_col0, _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16, _stream())),
+        "s2s_row_layernorm")
+    return out_f32, out_xp
 
 
 def node_apply(x, layer: dict, n_rows: int, *, out_f32=None, out_col0: int = 0, want_f32=True, out_xp=None, out_xp_k=None,
@@ -1228,6 +1283,8 @@ _TORCH_OPS = {
         lambda *a: forward_marginal(*a),
     "rigid_compose_update(Tensor rigids7, Tensor update6, Tensor mask) -> Tensor": lambda *a: rigid_compose_update(*a),
     "rigid_scale_trans(Tensor rigids7, float scale, bool divide=False) -> Tensor": lambda *a: rigid_scale_trans(*a),
+    "torsion_head(Tensor u, int n_rows, bool normalize=True, float eps=1e-8, Tensor? gt_sin_cos=None, Tensor? fixed_mask=None) -> Tensor":
+        lambda *a: torsion_head(*a),
     "frames_to_backbone(Tensor rigids7, Tensor psi, Tensor? aatype) -> Tensor": lambda r, p, a: frames_to_backbone(r, p, a)[0],
 }
 

@@ -88,7 +88,7 @@ def _graph_read_tensors(net):
 
     keep = []
     for m in net.modules():
-        for name in ("_idx_val", "_rel_cb", "_idx_src", "node_embed_act"):
+        for name in ("_idx_val", "_rel_cb", "_idx_src", "_fx_val", "_fx_src", "node_embed_act"):
             if hasattr(m, name):
                 tensors(getattr(m, name), keep)
         for v in vars(m).values():

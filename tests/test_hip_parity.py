@@ -651,7 +651,7 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
     assert names >= {"edge_transition", "edge_transition_f16x3", "edge_transition_f16x3_chain", "edge_embed", "edge_embed_f16x3", "pair_project",
                      "ipa_prep_points", "ipa_attention", "ipa_prep_points_f16", "ipa_attention_f16w", "encoder_attention", "node_linear",
                      "node_linear_f32", "node_linear_vfrag", "ipa_projections", "row_layernorm", "pack_planes", "se3_step", "forward_marginal", "rigid_compose_update",
-                     "rigid_scale_trans", "frames_to_backbone"}
+                     "rigid_scale_trans", "torsion_head", "frames_to_backbone"}
     gen = torch.Generator().manual_seed(11)
     rn = lambda *sh: torch.randn(*sh, generator=gen).to(DEV)
     eq = lambda a, b: all(torch.equal(x, y) for x, y in zip(a, b)) if isinstance(a, (tuple, list)) else torch.equal(a, b)
@@ -745,6 +745,15 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
     #                                                                        flat form is held to ops.edge_embed by test_edge_embed_golden)
     # ---- frames
     assert torch.equal(K.rigid_scale_trans(r7, 0.1, False), ops.rigid_scale_trans(r7, 0.1))
+    u32 = rn(M, 32)
+    u32[3, :2] = 0.0                                                  # the clamp: 0 / sqrt(eps)
+    th = K.torsion_head(u32, M, True, 1e-8)
+    u2 = u32[:, :2]
+    assert torch.equal(th, ops.torsion_head(u32, M)) and torch.equal(th, u2 / torch.sqrt(torch.clamp(torch.sum(u2 ** 2, dim=-1, keepdim=True), min=1e-8)))
+    gt, fx = rn(B, N, 7, 2)[..., 2, :], (torch.rand(M, generator=gen) > 0.5).float().to(DEV)
+    assert torch.equal(K.torsion_head(u32, M, False, 1e-8, gt, fx), gt.reshape(M, 2) * fx[:, None] + u2 * (1 - fx[:, None]))
+    upd32 = rn(M, 32)
+    assert torch.equal(ops.rigid_compose_update(r7, upd32, mask), ops.rigid_compose_update(r7, upd32[:, :6].contiguous().view(B, N, 6), mask))
     psi = torch.nn.functional.normalize(rn(B, N, 2), dim=-1)
     aat = torch.randint(0, 21, (B, N), generator=gen).to(DEV)
     assert torch.equal(K.frames_to_backbone(r7, psi, aat), ops.frames_to_backbone(r7, psi, aat)[0])

@@ -298,3 +298,39 @@ def test_pair_tiled_layout_matches_the_header():
         if M % 32:
             pad = t.buf.view(-1, 16, 2, 32, 4)[-1, :, :, M % 32:, :]
             assert float(pad.abs().max()) == 0.0
+
+
+def test_every_global_name_the_package_uses_resolves():
+    """A function that went missing shows up only when its caller runs on a GPU box: check on the CPU that every global name the
+    package's functions and methods (and the torch-op implementations, lambdas included) load exists in its module or the builtins."""
+    import builtins
+    import dis
+    import importlib
+    import pkgutil
+    import types
+
+    import str2str_amd
+
+    def codes(c):
+        yield c
+        for k in c.co_consts:
+            if isinstance(k, types.CodeType):
+                yield from codes(k)
+
+    missing = set()
+    for info in pkgutil.walk_packages(str2str_amd.__path__, "str2str_amd."):
+        if info.name.rsplit(".", 1)[-1].startswith("lib"):         # the built shared library, not a Python module
+            continue
+        mod = importlib.import_module(info.name)
+        fns = [v for v in vars(mod).values() if isinstance(v, types.FunctionType) and v.__module__ == mod.__name__]
+        for cls in [v for v in vars(mod).values() if isinstance(v, type) and v.__module__ == mod.__name__]:
+            fns += [getattr(v, "__func__", v) for v in vars(cls).values()
+                    if isinstance(getattr(v, "__func__", v), types.FunctionType)]
+        if info.name == "str2str_amd.ops":
+            fns += [f for f in mod._TORCH_OPS.values() if isinstance(f, types.FunctionType)]
+        for f in fns:
+            for c in codes(f.__code__):
+                for ins in dis.get_instructions(c):
+                    if ins.opname == "LOAD_GLOBAL" and ins.argval not in f.__globals__ and not hasattr(builtins, ins.argval):
+                        missing.add((info.name, f.__name__, ins.argval))
+    assert not missing, sorted(missing)
