@@ -155,15 +155,27 @@ int s2s_ipa_attention(const float* q, const float* kv, const float* q_pts, const
  *   (map_pad = n_pad, map_src = n_res) when n_pad != n_res; points from s2s_ipa_prep_points_f16 (padded rows: zero points,
  *   k2 = -1e9, so a padded key never carries probability -- exactly the un-padded softmax).
  * attn_bias stays [B,H,n_res,n_res]; when n_pad != n_res logits_out must be a SEPARATE [B,H,n_pad,n_pad] buffer (s2s_ipa_opair:
- * logits_ld = n_pad); stats_out [B,H,n_res,2], out [B,n_res,feat] and out_xp (row tiles of the flat [B n_res] rows) are not padded. */
+ * logits_ld = n_pad); stats_out [B,H,n_res,2], out [B,n_res,feat] and out_xp (row tiles of the flat [B n_res] rows) are not padded.
+ *
+ * FOLDED PROJECTIONS (the default host path, str2str_amd/models/net/ipa.py fold_ipa_weights; ipa.py:131-143,183-190,229-252 of the
+ * reference with the weights regrouped).  With q = W_q s_i + b_q, k = W_k s_j + b_k per head, q.k = s_j . (W_k^T W_q s_i + W_k^T b_q)
+ * + terms that depend on i only and cancel in the softmax over j; and sum_j a_ij v_j = W_v (sum_j a_ij s_j) + b_v as the
+ * probabilities sum to one.  So with c_s = c_hidden = 256 the attention can read the block's input s as the K AND the V operand of
+ * every head: q' = (W_k^T W_q) s + W_k^T b_q is the only scalar projection left (linear_k / linear_v are never evaluated; W_v and
+ * b_v move into linear_out's weight and bias), and the kernel aggregates s instead of v.  n_kv_heads = 1 selects that operand
+ * layout: k_xp = packed planes of s [rows/32][16][2][64][8] (s itself when n_res % 32 == 0, else k_shared below), v_vf =
+ * [rows/32][8][2][2][64][8] (v_shared below); n_kv_heads = n_heads is the per-head layout above.
+ * s2s_ipa_prep_points_f16 with s_xp != NULL (n_heads = 8) writes those shared operands in the same launch: v_shared always,
+ * k_shared (rows gathered into the padded per-sample layout) when n_res % 32 != 0; NULL s_xp skips the step. */
 int s2s_ipa_prep_points_f16(const float* rigids7, const float* q_pts_lin, const float* kv_pts_lin, const float* head_w_scaled,
                             void* qp_xp, void* kp_xp, void* vp_vf, float* q2, float* k2, int n_samples, int n_res, int n_heads,
-                            int n_qk_points, int n_v_points, int c_hidden, void* stream);
+                            int n_qk_points, int n_v_points, int c_hidden, const void* s_xp, void* k_shared, void* v_shared,
+                            void* stream);
 int s2s_ipa_attention_f16w(const void* q_xp, const void* k_xp, const void* v_vf, const void* qp_xp, const void* kp_xp,
                              const void* vp_vf, const float* q2, const float* k2, const float* attn_bias, float* logits_out,
                              float* stats_out, const float* mask, const float* rigids7, float* out, void* out_xp,
                              int out_xp_ksteps, int n_samples, int n_res, int n_heads, int c_hidden, int n_qk_points,
-                             int n_v_points, int c_pair_z, float inf, float eps, void* stream);
+                             int n_v_points, int c_pair_z, float inf, float eps, int n_kv_heads, void* stream);
 
 /* The pair term of InvariantPointAttention.forward (src/models/net/ipa.py:253-257):
  *   o_pair[b,i,h,:] = sum_j softmax_j(logits[b,h,i,:])[j] * pair_z[b,i,j,:]

@@ -77,6 +77,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(8, len(UNITS))) as ex:
         objs = list(ex.map(compile_one, UNITS.items()))
+    for f in os.listdir(OBJ):                    # objects of units that are no longer part of the library (earlier variants)
+        if f.endswith(".o") and os.path.join(OBJ, f) not in objs:
+            os.remove(os.path.join(OBJ, f))
     if force or _stale(LIB, objs):
         cmd = [cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
         if verbose:

@@ -78,16 +78,42 @@ __global__ void __launch_bounds__(256) ipa_prep_f16_kernel(const float* __restri
                                                               const float* __restrict__ kvp_lin, const float* __restrict__ head_w,
                                                               float q_scale_c1, f16x8* __restrict__ qp_xp, f16x8* __restrict__ kp_xp,
                                                               f16x8* __restrict__ vp_vf, float* __restrict__ q2, float* __restrict__ k2,
-                                                              int H, int n_res, int n_pad, int* range_flag) {
+                                                              int H, int n_res, int n_pad, int* range_flag,
+                                                              const f16x8* __restrict__ s_xp, f16x8* __restrict__ k_sh, f16x8* __restrict__ v_sh) {
     // Row tiles are tiles of the PADDED residue range (n_pad = n_res rounded up to 32, per sample): tile rt = sample rt / (n_pad / 32);
     // residues >= n_res of the last tile are padding: zero points, q2 = 0, k2 = -1e9 (such a key can never carry probability).
     __shared__ float sq[32][33], sk[32][33], sv[32][65];
     __shared__ int s_pad[32];
+    __shared__ _Float16 s_t[2][32][34];
     const int tid = threadIdx.x;
     const int head = blockIdx.x % H;
     const long long rt = blockIdx.x / H;
     const float hw = head_w[head];
     const int tps = n_pad / 32;
+    // ---- folded projections (ops.fold_ipa_weights): the K and V operands of EVERY head are the block's input s itself (c_s = 256 = 16
+    // k-steps = 8 column tiles; H = 8): K image = the packed planes of s -- s_xp as it is when n_res % 32 == 0, else gathered here into
+    // the per-sample padded rows (k_sh; a padded row repeats the sample's last row: finite, and its k2 is -1e9) --, V image = the same
+    // values as A fragments [row tile][8 column tiles][2][2][64][8] (v_sh; node_gemm.hip's VF layout with one head): a 32 x 32
+    // transposition per (row tile, column tile), and workgroup (row tile, head) does column tile `head`.  Exact: f16 planes are moved.
+    if (s_xp) {
+        const int row = tid & 31, qd = tid >> 5, ksb = qd & 1, g = (qd >> 1) & 1, plane = qd >> 2;
+        const long long smp = rt / tps;
+        const int n = (int)(rt - smp * tps) * 32 + row;
+        const long long srow = smp * n_res + (n < n_res ? n : n_res - 1);
+        const f16x8 v = s_xp[(((srow >> 5) * 16 + 2 * head + ksb) * 2 + plane) * 64 + 32 * g + (int)(srow & 31)];
+        if (k_sh) k_sh[((rt * 16 + 2 * head + ksb) * 2 + plane) * 64 + 32 * g + row] = v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int rr = 8 * ksb + j;
+            s_t[plane][row][(rr & 3) + 8 * (rr >> 2) + 4 * g] = v[j];
+        }
+        __syncthreads();
+        const int u = tid >> 7, pl = (tid >> 6) & 1, lane = tid & 63;
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = s_t[pl][rowmap(8 * u + j, lane >> 5)][lane & 31];
+        v_sh[((((rt * 8) + head) * 2 + u) * 2 + pl) * 64 + lane] = o;
+    }
     {
         const int row = tid >> 3, p = tid & 7;
         const long long smp = rt / tps;
@@ -180,6 +206,7 @@ struct PlaneArgs {
     int NP;                  // N rounded up to the 32-residue tiles: the fragment arrays, q2 / k2 and the logits use NP rows per sample
     float inf, eps;
     int xcd_remap;
+    int HKV;                 // heads of the K / V fragment arrays: H, or 1 = one image serves every head (folded projections)
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -255,6 +282,7 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
     const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int N = a.N, H = a.H;
+    const int HKV = a.HKV;
     const int NP = RAGGED ? a.NP : N;             // logits stride / padded rows per sample
     const int NT = NP / 32;                       // key tiles = row tiles per sample
     const int n_qb = (NT + 3) / 4;
@@ -288,9 +316,9 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
     // sources as buffer resources over the whole arrays (the host checks that they are < 4 GiB): the per-piece offset is a scalar,
     // the per-lane part (lane * 16) one constant VGPR -- no vector address arithmetic in a copy slot
     const long long n_rt = (long long)a.B * NT;
-    const __amdgpu_buffer_rsrc_t r_k = __builtin_amdgcn_make_buffer_rsrc((void*)a.k_xp, 0, (int)(n_rt * 16 * H * 2048), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_k = __builtin_amdgcn_make_buffer_rsrc((void*)a.k_xp, 0, (int)(n_rt * 16 * HKV * 2048), 0x00020000);
     const __amdgpu_buffer_rsrc_t r_kp = __builtin_amdgcn_make_buffer_rsrc((void*)a.kp_xp, 0, (int)(n_rt * H * 4096), 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_v = __builtin_amdgcn_make_buffer_rsrc((void*)a.v_vf, 0, (int)(n_rt * H * 32768), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_v = __builtin_amdgcn_make_buffer_rsrc((void*)a.v_vf, 0, (int)(n_rt * HKV * 32768), 0x00020000);
     const __amdgpu_buffer_rsrc_t r_vp = __builtin_amdgcn_make_buffer_rsrc((void*)a.vp_vf, 0, (int)(n_rt * H * 8192), 0x00020000);
     const int lane16 = lane * 16;
     // piece p of this wave: p < 8: piece wave + 4 p of the first array (32 KiB), else piece wave + 4 (p - 8) of the second
@@ -303,7 +331,8 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
         const int pm = __builtin_amdgcn_readfirstlane(piece_ok(gg, p) ? p : 8);
         u32x4 r;
         if (p < 8) {
-            const unsigned off = (isk ? (rt * (16 * H) + 16 * hh) * 2 : (rt * H + hh) * 32) * 1024u + (wave + 4 * pm) * 1024u;
+            const int hk = HKV == 1 ? 0 : hh;
+            const unsigned off = (isk ? (rt * (16 * HKV) + 16 * hk) * 2 : (rt * HKV + hk) * 32) * 1024u + (wave + 4 * pm) * 1024u;
             r = __builtin_amdgcn_raw_buffer_load_b128(isk ? r_k : r_v, lane16, __builtin_amdgcn_readfirstlane((int)off), 0);
         } else {
             const unsigned off = (rt * H + hh) * (isk ? 4u : 8u) * 1024u + (wave + 4 * (pm - 8)) * 1024u;
@@ -316,8 +345,9 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
         const bool isk = g < NT;
         const long long rt = (long long)cur.b * NT + (isk ? g : g - NT);
         const int pm = piece_ok(g, p) ? p : 8;
+        const int hk = HKV == 1 ? 0 : cur.head;
         if (pm < 8)
-            return (isk ? a.k_xp + ((rt * (16 * H) + 16 * cur.head) * 2) * 64 : a.v_vf + ((rt * H + cur.head) * 32) * 64) + (wave + 4 * pm) * 64;
+            return (isk ? a.k_xp + ((rt * (16 * HKV) + 16 * hk) * 2) * 64 : a.v_vf + ((rt * HKV + hk) * 32) * 64) + (wave + 4 * pm) * 64;
         return (isk ? a.kp_xp + ((rt * H + cur.head) * 4) * 64 : a.vp_vf + ((rt * H + cur.head) * 8) * 64) + (wave + 4 * (pm - 8)) * 64;
     };
     auto piece_dst = [&](int g, int p) -> f16x8* {
@@ -779,15 +809,18 @@ extern "C" int s2s_debug_read_ipa8_probe(void* dst) {
 
 extern "C" int s2s_ipa_prep_points_f16(const float* rigids7, const float* q_pts_lin, const float* kv_pts_lin,
                                           const float* head_w_scaled, void* qp_xp, void* kp_xp, void* vp_vf, float* q2, float* k2,
-                                          int n_samples, int n_res, int n_heads, int n_qk_points, int n_v_points, int c_hidden, void* stream) {
+                                          int n_samples, int n_res, int n_heads, int n_qk_points, int n_v_points, int c_hidden,
+                                          const void* s_xp, void* k_shared, void* v_shared, void* stream) {
     if (n_samples <= 0 || n_res <= 0) return 0;
     if (n_qk_points != PQ || n_v_points != PV || c_hidden != 256 || n_heads < 1) return (int)hipErrorInvalidValue;
+    // shared K / V operands: 8 heads <-> 8 column tiles of a 256-wide s; padded lengths need the gathered K planes
+    if (s_xp && (n_heads != 8 || !v_shared || (n_res % 32 != 0 && !k_shared))) return (int)hipErrorInvalidValue;
     const int n_pad = (n_res + 31) / 32 * 32;
     const long long blocks = (long long)n_samples * (n_pad / 32) * n_heads;
     if (blocks >= (1ll << 31)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(ipa_prep_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, rigids7, q_pts_lin, kv_pts_lin,
                        head_w_scaled, sqrtf(1.0f / (3 * c_hidden)), (f16x8*)qp_xp, (f16x8*)kp_xp, (f16x8*)vp_vf, q2, k2, n_heads, n_res,
-                       n_pad, s2s::g_range_flag);
+                       n_pad, s2s::g_range_flag, (const f16x8*)s_xp, (f16x8*)(n_res % 32 != 0 ? k_shared : nullptr), (f16x8*)v_shared);
     return (int)hipGetLastError();
 }
 
@@ -795,10 +828,10 @@ extern "C" int s2s_ipa_attention_f16w(const void* q_xp, const void* k_xp, const 
                                         const void* vp_vf, const float* q2, const float* k2, const float* attn_bias,
                                         float* logits_out, float* stats_out, const float* mask, const float* rigids7, float* out,
                                         void* out_xp, int out_xp_ksteps, int n_samples, int n_res, int n_heads, int c_hidden,
-                                        int n_qk_points, int n_v_points, int c_pair_z, float inf, float eps, void* stream) {
+                                        int n_qk_points, int n_v_points, int c_pair_z, float inf, float eps, int n_kv_heads, void* stream) {
     if (n_samples <= 0 || n_res <= 0) return 0;
     if (c_hidden != 256 || n_qk_points != PQ || n_v_points != PV || c_pair_z != 32 || n_heads < 1 ||
-        out_xp_ksteps < 16 * n_heads || !out_xp)
+        out_xp_ksteps < 16 * n_heads || !out_xp || (n_kv_heads != n_heads && n_kv_heads != 1))
         return (int)hipErrorInvalidValue;
     const int n_pad = (n_res + 31) / 32 * 32;
     const bool ragged = n_pad != n_res;
@@ -821,7 +854,7 @@ extern "C" int s2s_ipa_attention_f16w(const void* q_xp, const void* k_xp, const 
     const long long blocks = items < n_cu ? items : n_cu;
     PlaneArgs a{(const f16x8*)q_xp, (const f16x8*)k_xp, (const f16x8*)v_vf, (const f16x8*)qp_xp, (const f16x8*)kp_xp,
                 (const f16x8*)vp_vf, q2, k2, attn_bias, logits_out, stats_out, mask, rigids7, out, (f16x8*)out_xp, out_xp_ksteps,
-                n_samples, n_res, n_heads, n_pad, inf, eps, (remap_env && items % 8 == 0 && blocks % 8 == 0 && n_qb > 1) ? 1 : 0};
+                n_samples, n_res, n_heads, n_pad, inf, eps, (remap_env && items % 8 == 0 && blocks % 8 == 0 && n_qb > 1) ? 1 : 0, n_kv_heads};
     if (ragged)
         hipLaunchKernelGGL(ipa_attention_f16w_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else

@@ -16,6 +16,7 @@ with fp32 row-major activations.  No BLAS / SDPA call is left in this module.
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -61,6 +62,8 @@ class InvariantPointAttention(nn.Module):
         self.softmax = nn.Softmax(dim=-1)
         self.softplus = nn.Softplus()
         self.arith = default_arith()   # "f16x3" (s2s_ipa_attention_f16w) | "f32" (s2s_ipa_attention), see str2str_amd/arith.py
+        self.fold = os.environ.get("S2S_IPA_FOLD", "1") != "0"   # f16 path: K = V = s, W_k / W_v folded into q' and linear_out (_folded_packs)
+        self._last_folded = False
         self._cache = ParamCache()
         self._packs = ParamCache()
 
@@ -95,10 +98,31 @@ class InvariantPointAttention(nn.Module):
                  "qp": pk(self.linear_q_points.weight, self.linear_q_points.bias),
                  "kvp": pk(self.linear_kv_points.weight, self.linear_kv_points.bias),
                  "out": pk(self.linear_out.weight, self.linear_out.bias, True)}
+            if self.c_s == C:
+                d.update(self._folded_packs(wkv, bkv))
             return d
 
         return self._packs.get([p for lin in (self.linear_q, self.linear_kv, self.linear_q_points, self.linear_kv_points,
                                               self.linear_out) for p in (lin.weight, lin.bias)], build)
+
+    def _folded_packs(self, wkv, bkv):
+        """FOLDED projections of the f16 attention path (include/str2str_hip.h, s2s_ipa_attention_f16w): per head
+            q_i . k_j = s_j . (W_k^T W_q s_i + W_k^T b_q) + (terms of i alone: they cancel in the softmax over j)
+            sum_j a_ij v_j = W_v (sum_j a_ij s_j) + b_v                                   (the probabilities sum to one)
+        so the attention reads the block's input s as K and V operand of every head (c_s = c_hidden), linear_k and linear_v are never
+        evaluated -- 2/3 of the projections' arithmetic and output bytes, and 16 of the 17 K / V images the attention streamed -- and
+        W_v / b_v move into linear_out.  "qf": s -> q' = (W_k^T W_q) s + W_k^T b_q [H c_s];  "outf": linear_out on [sum a s | o_pt ...].
+        The products are formed in float64 and rounded once to fp32 (reference weights: ipa.py:131-143,166-171,259-266)."""
+        H, C, cs = self.no_heads, self.c_hidden, self.c_s
+        wq, bq = self.linear_q.weight.double().view(H, C, cs), self.linear_q.bias.double().view(H, C)
+        wk, wv, bv = wkv[:, 0].double(), wkv[:, 1].double(), bkv[:, 1].double()
+        w_qf = torch.einsum("hca,hcb->hab", wk, wq).reshape(H * cs, cs).float()
+        b_qf = torch.einsum("hca,hc->ha", wk, bq).reshape(-1).float()
+        wo = self.linear_out.weight.double()
+        wo_o = wo[:, : H * C].view(-1, H, C)
+        w_of = torch.cat([torch.einsum("ohc,hca->oha", wo_o, wv).reshape(-1, H * cs), wo[:, H * C:]], dim=1).float()
+        b_of = (self.linear_out.bias.double() + torch.einsum("ohc,hc->o", wo_o, bv)).float()
+        return {"qf": ops.pack_node_layer(w_qf, b_qf), "outf": ops.pack_node_layer(w_of, b_of, True)}
 
     def use_f16(self, n_res: int, n_rows: int = 0) -> bool:
         """Does the pre-split f16 operand kernel serve this call?  It is built for the reference configuration (c_hidden 256,
@@ -113,8 +137,11 @@ class InvariantPointAttention(nn.Module):
 
     def attention_f16(self, s_xp, B: int, N: int, r7, mask, pair_proj):
         """Projections -> points -> attention core on pre-split f16 operands.  s_xp: packed planes of s [B*N, c_s].
-        -> packed planes of linear_out's input [B*N, H*(c_hidden + 4 Pv + c_z/4)]"""
+        -> packed planes of linear_out's input [B*N, H*(c_hidden + 4 Pv + c_z/4)] -- of the FOLDED linear_out (node_packs()["outf"])
+        when ``self.folded`` (the default: _folded_packs), of linear_out itself otherwise."""
         w, d, M, H = self.node_packs(), self._derived(), B * N, self.no_heads
+        if self.folded:
+            return self._attention_f16_folded(s_xp, B, N, r7, mask, pair_proj, w, d)
         if w["v"]["tg"] != 8:
             raise ops.HipLibraryError("s2s_node_linear_vfrag is instantiated for 8 tiles per column block")
         NP = ops.padded_len(N)
@@ -135,6 +162,37 @@ class InvariantPointAttention(nn.Module):
         K.pack_planes(f2, c0, f2.shape[1] - c0, feats_xp, f2.shape[1], c0)
         return feats_xp
 
+    def _attention_f16_folded(self, s_xp, B, N, r7, mask, pair_proj, w, d):
+        M, H = B * N, self.no_heads
+        NP = ops.padded_len(N)
+        rmap, Mo = ((NP, N), B * NP) if NP != N else (None, M)
+        K = torch.ops.str2str_amd
+        names = ("qf", "qp", "kvp")
+        var = {n: ops.small_rows_variant(w[n], M) for n in names}
+        dims = [x for n in ("qf", None, None, "qp", "kvp") for x in ((w[n]["k"], w[n]["n"], var[n][1]) if n else (0, 0, 0))]
+        q_xp, _, _, qp, kvp = K.ipa_projections(s_xp, [w["qf"][var["qf"][0]], w["qf"]["b"]], [], [], [w["qp"][var["qp"][0]], w["qp"]["b"]],
+                                                [w["kvp"][var["kvp"][0]], w["kvp"]["b"]], dims, M, Mo, *(rmap or (0, 0)))
+        *pts, k_sh, v_sh = K.ipa_prep_points_shared_kv(r7.view(B, N, 7), qp, kvp, d["hw"], s_xp, H, self.no_qk_points, self.no_v_points,
+                                                       self.c_hidden)
+        attn_bias, pair_z = pair_proj
+        feats, feats_xp = K.ipa_attention_f16w(q_xp, s_xp if k_sh is None else k_sh, v_sh, *pts, attn_bias, pair_z, mask, r7, H,
+                                               self.c_hidden, self.no_qk_points, self.no_v_points, self.c_z // 4, self.inf, self.eps, True)
+        c0 = H * self.c_hidden
+        f2 = feats.view(M, -1)
+        K.pack_planes(f2, c0, f2.shape[1] - c0, feats_xp, f2.shape[1], c0)
+        return feats_xp
+
+    @property
+    def folded(self) -> bool:
+        """Is the f16 attention path the folded one (K = V = s)?  Default on (S2S_IPA_FOLD=0 or ``fold = False`` restore the per-head
+        k / v projections: same kernels, the reference's grouping of the weights)."""
+        return self.fold and self.c_s == self.c_hidden and self.no_heads == 8
+
+    def out_pack(self, feats_a) -> dict:
+        """linear_out's packed layer for the features ``attention`` returned (folded for the folded f16 path)."""
+        w = self.node_packs()
+        return w["outf"] if (self.folded and self._last_folded) else w["out"]
+
     def attention_f32(self, s_act, B: int, N: int, r7, mask, pair_proj):
         """The same on the exact fp32-operand kernel (s2s_ipa_attention: any length, any magnitude, any input arithmetic)
         -> linear_out's input in the node stream's activation format (packed planes for a planes input, fp32 otherwise)."""
@@ -150,8 +208,11 @@ class InvariantPointAttention(nn.Module):
         return ops.pack_planes(feats.view(M, -1)) if s_act.dtype == torch.int16 else feats.view(M, -1)
 
     def attention(self, s_act, B: int, N: int, r7, mask, pair_proj):
-        """Attention core of the block on the kernel of the configured arithmetic (see the module docstring)."""
+        """Attention core of the block on the kernel of the configured arithmetic (see the module docstring).  The features go to
+        ``out_pack()`` -- the folded linear_out after the folded f16 path."""
+        self._last_folded = False
         if s_act.dtype == torch.int16 and self.use_f16(N, B * N):
+            self._last_folded = self.folded
             return self.attention_f16(s_act, B, N, r7, mask, pair_proj)
         return self.attention_f32(s_act, B, N, r7, mask, pair_proj)
 
@@ -175,7 +236,7 @@ class InvariantPointAttention(nn.Module):
         B, N = s.shape[:2]
         pp = _pair_proj if _pair_proj is not None else ops.pair_project(z.contiguous(), d["wp"], d["b64"])
         feats_a = self.attention(ops.to_act(s.reshape(B * N, -1).float().contiguous(), self.arith), B, N, r7, mask, pp)
-        out, _ = ops.node_apply(feats_a, self.node_packs()["out"], B * N)
+        out, _ = ops.node_apply(feats_a, self.out_pack(feats_a), B * N)
         return out.view(B, N, -1)
 
 
@@ -281,7 +342,7 @@ class TranslationIPA(nn.Module):
             ln = T[f"ipa_ln_{b}"]
             x_f32 = torch.empty(M, D, device=dev, dtype=torch.float32)     # [node_embed | skip_embed(init)] (:356)
             x_a = ops.xp_alloc(M, D, dev) if f16 else x_f32
-            lin(feats_a, ipa.node_packs()["out"], pre_mask=nm, residual=s_f32, ln=(ln.weight, ln.bias, ln.eps), out_f32=x_f32,
+            lin(feats_a, ipa.out_pack(feats_a), pre_mask=nm, residual=s_f32, ln=(ln.weight, ln.bias, ln.eps), out_f32=x_f32,
                 out_xp=x_a, out_xp_k=D)
             lin(init_a, w["skip"], out_f32=x_f32, out_col0=C, out_xp=x_a, out_xp_k=D, out_xp_k0=C)
             # ---- 2 x post-norm TransformerEncoderLayer (:312-317,357)

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 _lib = None
 _tables_loaded = False
@@ -34,8 +34,8 @@ _SIGNATURES = {
     "s2s_ipa_prep_points": [_vp] * 6 + [_ll, _i, _i, _i, _i, _vp],
     "s2s_ipa_attention": [_vp] * 12 + [_i, _i, _i, _i, _i, _i, _i, _f, _f, _vp],
     "s2s_ipa_opair": [_vp] * 4 + [_i, _i, _i, _i, _i, _i, _i, _vp],
-    "s2s_ipa_prep_points_f16": [_vp] * 9 + [_i, _i, _i, _i, _i, _i, _vp],
-    "s2s_ipa_attention_f16w": [_vp] * 15 + [_i] * 8 + [_f, _f, _vp],
+    "s2s_ipa_prep_points_f16": [_vp] * 9 + [_i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "s2s_ipa_attention_f16w": [_vp] * 15 + [_i] * 8 + [_f, _f, _i, _vp],
     "s2s_rigid_compose_update": [_vp] * 4 + [_ll, _i, _vp],
     "s2s_torsion_head": [_vp, _i, _i, _vp, _ll, _vp, _f, _vp, _ll, _vp],
     "s2s_rigid_scale_trans": [_vp, _vp, _ll, _f, _i, _vp],
@@ -546,10 +546,13 @@ def padded_len(n_res: int) -> int:
     return (n_res + 31) // 32 * 32
 
 
-def ipa_prep_points_f16(rigids7, q_pts_lin, kv_pts_lin, head_w_scaled, n_heads=8, n_qk=8, n_v=12, c_hidden=256):
+def ipa_prep_points_f16(rigids7, q_pts_lin, kv_pts_lin, head_w_scaled, n_heads=8, n_qk=8, n_v=12, c_hidden=256, s_xp=None):
     """Global-frame points of a block as MFMA fragments (two f16 planes per fragment group) + the squared-norm terms of the logits
     (s2s_ipa_prep_points_f16).  ANY n_res: the arrays hold padded_len(n_res) rows per sample (padded rows: zero points, k2 = -1e9).
-    rigids7 [B,N,7].  -> (qp_xp, kp_xp, vp_vf, q2, k2)"""
+    rigids7 [B,N,7].  -> (qp_xp, kp_xp, vp_vf, q2, k2)
+    With ``s_xp`` (packed planes of the block's input s [B*N, 256]; folded projections, ``fold_ipa_weights``) the same launch also
+    writes the K / V operands every head shares: -> (..., k_shared, v_shared), k_shared = the rows of s_xp gathered into the padded
+    per-sample layout (None when n_res % 32 == 0: s_xp itself is the K operand), v_shared = the same values as A fragments."""
     lib = load_library()
     _req(rigids7, name="rigids7"); _req(q_pts_lin, name="q_pts_lin"); _req(kv_pts_lin, name="kv_pts_lin")
     _req(head_w_scaled, name="head_w")
@@ -562,10 +565,18 @@ def ipa_prep_points_f16(rigids7, q_pts_lin, kv_pts_lin, head_w_scaled, n_heads=8
     vp = torch.empty(rt * n_heads * 4 * 2 * 64 * 8, dtype=torch.int16, device=dev)
     q2 = torch.empty(rt, n_heads, 32, dtype=torch.float32, device=dev)
     k2 = torch.empty_like(q2)
+    k_sh = v_sh = None
+    if s_xp is not None:
+        _req(s_xp, torch.int16, "s_xp")
+        if s_xp.numel() != ((B * N + 31) // 32) * 32 * 256 * 2:
+            raise HipLibraryError("ipa_prep_points_f16: s_xp must hold the packed planes of a [B*N, 256] activation")
+        v_sh = torch.empty(rt * 32 * 256 * 2, dtype=torch.int16, device=dev)
+        k_sh = None if N % 32 == 0 else torch.empty_like(v_sh)
     range_flag()
     _check(lib.s2s_ipa_prep_points_f16(_p(rigids7), _p(q_pts_lin), _p(kv_pts_lin), _p(head_w_scaled), _p(qp), _p(kp), _p(vp), _p(q2),
-                                       _p(k2), B, N, n_heads, n_qk, n_v, c_hidden, _stream()), "s2s_ipa_prep_points_f16")
-    return qp, kp, vp, q2, k2
+                                       _p(k2), B, N, n_heads, n_qk, n_v, c_hidden, _p(s_xp), _p(k_sh), _p(v_sh), _stream()),
+           "s2s_ipa_prep_points_f16")
+    return (qp, kp, vp, q2, k2) if s_xp is None else (qp, kp, vp, q2, k2, k_sh, v_sh)
 
 
 def ipa_attention_f16(q_xp, k_xp, v_vf, points, attn_bias, pair_z, mask, rigids7, n_heads=8, c_hidden=256, n_qk=8, n_v=12,
@@ -585,7 +596,10 @@ def ipa_attention_f16(q_xp, k_xp, v_vf, points, attn_bias, pair_z, mask, rigids7
     NP = padded_len(N)
     if attn_bias.shape != (B, n_heads, N, N) or pair_z.shape != (B, N, N, c_pz):
         raise HipLibraryError("ipa_attention_f16: attn_bias must be [B,H,N,N] and pair_z [B,N,N,c_pz]")
-    if q_xp.numel() != B * NP * n_heads * c_hidden * 2 or v_vf.numel() != q_xp.numel() or q2.numel() != B * NP * n_heads:
+    # K / V arrays of one head's size: one image serves every head (folded projections: both are the block's input s)
+    n_kv = 1 if (k_xp.numel() * n_heads == q_xp.numel() and n_heads > 1) else n_heads
+    if (q_xp.numel() != B * NP * n_heads * c_hidden * 2 or v_vf.numel() != k_xp.numel() or q2.numel() != B * NP * n_heads
+            or k_xp.numel() * (n_heads // n_kv) != q_xp.numel()):
         raise HipLibraryError("ipa_attention_f16: operand arrays do not hold padded_len(n_res) rows per sample")
     feat = n_heads * (c_hidden + 4 * n_v + c_pz)
     out = torch.empty(B, N, feat, device=mask.device, dtype=torch.float32)
@@ -599,7 +613,7 @@ def ipa_attention_f16(q_xp, k_xp, v_vf, points, attn_bias, pair_z, mask, rigids7
     def launch():
         rc = lib.s2s_ipa_attention_f16w(_p(q_xp), _p(k_xp), _p(v_vf), _p(qp), _p(kp), _p(vp), _p(q2), _p(k2), _p(attn_bias), _p(logits),
                                         _p(stats), _p(mask), _p(rigids7), _p(out), _p(out_xp), feat // 16, B, N, n_heads, c_hidden,
-                                        n_qk, n_v, c_pz, inf, eps, _stream())
+                                        n_qk, n_v, c_pz, inf, eps, n_kv, _stream())
         if rc:
             return rc
         return lib.s2s_ipa_opair(_p(logits), _p(stats), _p(pair_z), _p(out), B, N, n_heads, c_pz, feat,
@@ -1025,34 +1039,42 @@ class _NodeProblem(ctypes.Structure):   # s2s_node_problem (include/str2str_hip.
 
 
 def ipa_projections(s_xp, q, k, v, qp, kvp, n_rows: int, n_rows_padded: int, row_map: Optional[tuple] = None, tiles_per_head: int = 8):
-    """The five projections of an IPA block (reference ipa.py:131-171) in ONE launch (s2s_node_linear_multi): ``q`` / ``k`` -> packed
+    """The projections of an IPA block (reference ipa.py:131-171) in ONE launch (s2s_node_linear_multi): ``q`` / ``k`` -> packed
     planes over ``n_rows_padded`` rows (the attention kernel's per-sample padded layout when ``row_map`` = (n_pad, n_src)), ``v`` -> A
     fragments over the same rows, ``qp`` / ``kvp`` (point projections) -> fp32 [n_rows, n].  Each argument is a ``pack_node_layer``
-    dict.  -> (q_xp, k_xp, v_vf, qp_f32, kvp_f32); bitwise what the five separate launches give."""
+    dict; ``k`` / ``v`` may be None (folded projections, ``fold_ipa_weights``: the attention reads s itself).
+    -> (q_xp, k_xp, v_vf, qp_f32, kvp_f32), None for an absent layer; bitwise what the separate launches give."""
     lib = load_library()
     _req(s_xp, torch.int16, "xp")
     dev = s_xp.device
     mp, ms = row_map if row_map is not None else (0, 0)
-    q_xp, k_xp = xp_alloc(n_rows_padded, q["n"], dev), xp_alloc(n_rows_padded, k["n"], dev)
-    v_vf = torch.empty(((n_rows_padded + 31) // 32) * (v["n"] // 32) * 2 * 2 * 64 * 8, dtype=torch.int16, device=dev)
+    q_xp = xp_alloc(n_rows_padded, q["n"], dev)
+    k_xp = xp_alloc(n_rows_padded, k["n"], dev) if k is not None else None
+    v_vf = (torch.empty(((n_rows_padded + 31) // 32) * (v["n"] // 32) * 2 * 2 * 64 * 8, dtype=torch.int16, device=dev)
+            if v is not None else None)
     qp_o = torch.empty(n_rows, qp["n"], device=dev, dtype=torch.float32)
     kvp_o = torch.empty(n_rows, kvp["n"], device=dev, dtype=torch.float32)
     arr = (_NodeProblem * 5)()
+    n = 0
 
-    def fill(i, layer, rows, **kw):
-        p = arr[i]
+    def fill(layer, rows, **kw):
+        nonlocal n
+        p = arr[n]
+        n += 1
         p.xp, p.w_packed, p.bias = s_xp.data_ptr(), layer["w"].data_ptr(), layer["b"].data_ptr()   # (the caller picked the variant: "w" / "tg")
         p.n_rows, p.k_in, p.n_out, p.tiles_per_block = rows, layer["k"], layer["n"], layer["tg"]
         for name, val in kw.items():
             setattr(p, name, val)
 
-    fill(0, q, n_rows_padded, out_xp=q_xp.data_ptr(), out_xp_ksteps=q["n"] // 16, map_pad=mp, map_src=ms)
-    fill(1, k, n_rows_padded, out_xp=k_xp.data_ptr(), out_xp_ksteps=k["n"] // 16, map_pad=mp, map_src=ms)
-    fill(2, v, n_rows_padded, vfrag_tiles_per_head=tiles_per_head, out_vf=v_vf.data_ptr(), map_pad=mp, map_src=ms)
-    fill(3, qp, n_rows, out_f32=qp_o.data_ptr(), out_ld=qp["n"])
-    fill(4, kvp, n_rows, out_f32=kvp_o.data_ptr(), out_ld=kvp["n"])
+    fill(q, n_rows_padded, out_xp=q_xp.data_ptr(), out_xp_ksteps=q["n"] // 16, map_pad=mp, map_src=ms)
+    if k is not None:
+        fill(k, n_rows_padded, out_xp=k_xp.data_ptr(), out_xp_ksteps=k["n"] // 16, map_pad=mp, map_src=ms)
+    if v is not None:
+        fill(v, n_rows_padded, vfrag_tiles_per_head=tiles_per_head, out_vf=v_vf.data_ptr(), map_pad=mp, map_src=ms)
+    fill(qp, n_rows, out_f32=qp_o.data_ptr(), out_ld=qp["n"])
+    fill(kvp, n_rows, out_f32=kvp_o.data_ptr(), out_ld=kvp["n"])
     range_flag()
-    _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_multi(ctypes.byref(arr), 5, _stream())), "s2s_node_linear_multi")
+    _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_multi(ctypes.byref(arr), n, _stream())), "s2s_node_linear_multi")
     return q_xp, k_xp, v_vf, qp_o, kvp_o
 
 
@@ -1247,6 +1269,9 @@ _TORCH_OPS = {
     "Tensor mask, Tensor rigids7, Tensor head_w) -> Tensor": lambda *a: ipa_attention(*a),
     "ipa_prep_points_f16(Tensor rigids7, Tensor q_pts_lin, Tensor kv_pts_lin, Tensor head_w, int n_heads=8, int n_qk=8, int n_v=12, "
     "int c_hidden=256) -> (Tensor, Tensor, Tensor, Tensor, Tensor)": lambda *a: ipa_prep_points_f16(*a),
+    "ipa_prep_points_shared_kv(Tensor rigids7, Tensor q_pts_lin, Tensor kv_pts_lin, Tensor head_w, Tensor s_xp, int n_heads=8, int n_qk=8, "
+    "int n_v=12, int c_hidden=256) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor?, Tensor)":
+        lambda r7, qp, kvp, hw, s_xp, h=8, nq=8, nv=12, c=256: ipa_prep_points_f16(r7, qp, kvp, hw, h, nq, nv, c, s_xp),
     "ipa_attention_f16w(Tensor q_xp, Tensor k_xp, Tensor v_vf, Tensor qp_xp, Tensor kp_xp, Tensor vp_vf, Tensor q2, Tensor k2, "
     "Tensor(a!) attn_bias, Tensor pair_z, Tensor mask, Tensor rigids7, int n_heads=8, int c_hidden=256, int n_qk=8, int n_v=12, int c_pz=32, "
     "float inf=1e5, float eps=1e-8, bool logits_inplace=False) -> (Tensor, Tensor)":
@@ -1265,9 +1290,10 @@ _TORCH_OPS = {
     "int map_src=0) -> Tensor":
         lambda xp, w, b, m, k, n, tph=8, mp=0, ms=0: node_linear_vfrag(xp, w, b, m, k, n, tph, row_map=(mp, ms) if mp else None),
     "ipa_projections(Tensor s_xp, Tensor[] q, Tensor[] k, Tensor[] v, Tensor[] qp, Tensor[] kvp, int[] dims, int n_rows, int n_rows_padded, "
-    "int map_pad=0, int map_src=0) -> (Tensor, Tensor, Tensor, Tensor, Tensor)":
+    "int map_pad=0, int map_src=0) -> (Tensor, Tensor?, Tensor?, Tensor, Tensor)":      # (k / v: empty lists = absent, folded projections)
         lambda s_xp, q, k, v, qp, kvp, dims, m, mo, mp=0, ms=0: ipa_projections(
-            s_xp, *[{"w": t[0], "b": t[1], "k": dims[3 * i], "n": dims[3 * i + 1], "tg": dims[3 * i + 2]} for i, t in enumerate((q, k, v, qp, kvp))],
+            s_xp, *[({"w": t[0], "b": t[1], "k": dims[3 * i], "n": dims[3 * i + 1], "tg": dims[3 * i + 2]} if len(t) else None)
+                    for i, t in enumerate((q, k, v, qp, kvp))],
             m, mo, (mp, ms) if mp else None),
     "row_layernorm(Tensor x, int n_rows, int n_cols, Tensor gamma, Tensor beta, float eps, Tensor? post_mask=None, Tensor(a!)? out_f32=None, "
     "int out_col0=0, bool want_f32=True, Tensor(b!)? out_xp=None, int out_xp_k=-1, int out_xp_k0=0, bool want_xp=False) -> (Tensor?, Tensor?)":

@@ -649,7 +649,7 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
     K = torch.ops.str2str_amd
     names = {sch.split("(")[0] for sch in ops._TORCH_OPS}
     assert names >= {"edge_transition", "edge_transition_f16x3", "edge_transition_f16x3_chain", "edge_embed", "edge_embed_f16x3", "pair_project",
-                     "ipa_prep_points", "ipa_attention", "ipa_prep_points_f16", "ipa_attention_f16w", "encoder_attention", "node_linear",
+                     "ipa_prep_points", "ipa_attention", "ipa_prep_points_f16", "ipa_prep_points_shared_kv", "ipa_attention_f16w", "encoder_attention", "node_linear",
                      "node_linear_f32", "node_linear_vfrag", "ipa_projections", "row_layernorm", "pack_planes", "se3_step", "forward_marginal", "rigid_compose_update",
                      "rigid_scale_trans", "torsion_head", "frames_to_backbone"}
     gen = torch.Generator().manual_seed(11)
@@ -682,6 +682,16 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
     assert torch.equal(five[1], ops.node_apply(xp, w["k"], B * NP, row_map=(NP, N), want_f32=False, want_xp=True)[1])
     assert torch.equal(five[2], v_vf)
     assert torch.equal(five[3], ops.node_apply(xp, w["qp"], M)[0]) and torch.equal(five[4], ops.node_apply(xp, w["kvp"], M)[0])
+    # ... and with the folded projections (k / v absent): three problems in the launch
+    fdims = [x_ for n_ in ("qf", None, None, "qp", "kvp") for x_ in ((w[n_]["k"], w[n_]["n"], w[n_]["tg"]) if n_ else (0, 0, 0))]
+    three = K.ipa_projections(xp, [w["qf"]["w"], w["qf"]["b"]], [], [], [w["qp"]["w"], w["qp"]["b"]], [w["kvp"]["w"], w["kvp"]["b"]], fdims,
+                              M, B * NP, NP, N)
+    assert three[1] is None and three[2] is None and torch.equal(three[3], five[3]) and torch.equal(three[4], five[4])
+    assert torch.equal(three[0], ops.node_apply(xp, w["qf"], B * NP, row_map=(NP, N), want_f32=False, want_xp=True)[1])
+    r7s = torch.cat([torch.nn.functional.normalize(rn(B, N, 4), dim=-1), rn(B, N, 3)], -1).contiguous()
+    sh_op = K.ipa_prep_points_shared_kv(r7s, five[3], five[4], d["hw"], xp)
+    sh_fn = ops.ipa_prep_points_f16(r7s, five[3], five[4], d["hw"], s_xp=xp)
+    assert len(sh_op) == 7 and all((a_ is None and b_ is None) or torch.equal(a_, b_) for a_, b_ in zip(sh_op, sh_fn))
     # linear_out (K = 2688) on few rows runs as a narrow-block GEMM + the LayerNorm on its own (s2s_row_layernorm): bitwise the fused layer
     lo, lnm = w["out"], tr["ipa_ln_0"]
     fx = ops.pack_planes(rn(M, 2688))
@@ -1684,3 +1694,95 @@ def test_ensemble_metrics_match_reference(tag):
     assert M.js_pwd(d)["pred"] == float(g[f"{tag}_js_pwd"]) and M.js_pwd(d)["target"] == 0.0
     check(f"radius of gyration vs reference [{tag}]", float(np.abs(M.radius_of_gyration(d["pred"]) - g[f"{tag}_rg_pred"]).max()), 1.5e-6)
     check(f"js_rg vs reference [{tag}]", abs(M.js_rg(d)["pred"] - float(g[f"{tag}_js_rg"])), 2.1e-3)
+
+
+@pytest.mark.parametrize("B,N", [(2, 64), (3, 37), (1, 300)])
+def test_ipa_shared_kv_operands_are_the_planes_of_s(B, N):
+    """Folded projections (models/net/ipa.py _folded_packs): s2s_ipa_prep_points_f16 with s_xp emits the K / V operands every head
+    shares.  They are the f16 planes of s MOVED (exact): v_shared decodes -- through the decoder of the A-fragment layout used for
+    s2s_node_linear_vfrag -- to s in the padded per-sample rows (a padded row repeats the sample's last row), k_shared (ragged
+    lengths only) to the same rows as packed planes, bit for bit."""
+    from str2str_amd import ops
+
+    H, M, NP = 8, B * N, ops.padded_len(N)
+    g = torch.Generator().manual_seed(5 + N)
+    s = (torch.randn(M, 256, generator=g) * 3).to(DEV)
+    q4 = torch.randn(B, N, 4, generator=g)
+    r7 = torch.cat([q4 / q4.norm(dim=-1, keepdim=True), torch.randn(B, N, 3, generator=g)], -1).contiguous().to(DEV)
+    qp, kvp = torch.randn(M, 192, generator=g).to(DEV), torch.randn(M, 480, generator=g).to(DEV)
+    hw = torch.rand(H, generator=g).to(DEV)
+    s_xp = ops.pack_planes(s)
+    base = ops.ipa_prep_points_f16(r7, qp, kvp, hw)
+    *pts, k_sh, v_sh = torch.ops.str2str_amd.ipa_prep_points_shared_kv(r7, qp, kvp, hw, s_xp)
+    for a, b in zip(base, pts):
+        assert torch.equal(a, b)                                     # the point operands do not change
+    rows = (torch.arange(B)[:, None] * N + torch.arange(NP).clamp(max=N - 1)[None, :]).reshape(-1).to(DEV)
+    planes = s_xp.view(torch.float16).reshape(-1, 16, 2, 2, 32, 8)   # [RT, ks, plane, g, m, j]
+    ks = torch.arange(16)[:, None, None]; gg = torch.arange(2)[None, :, None]; j = torch.arange(8)[None, None, :]
+    r = 8 * (ks & 1) + j
+    chan = (32 * (ks >> 1) + (r & 3) + 8 * (r >> 2) + 4 * gg).reshape(-1).to(DEV)
+    want = []
+    for p in range(2):                                               # plane p of s as [rows, 256] f16, then the padded rows
+        x = torch.zeros(planes.shape[0], 32, 256, dtype=torch.float16, device=DEV)
+        x[:, :, chan] = planes[:, :, p].permute(0, 3, 1, 2, 4).reshape(planes.shape[0], 32, -1)
+        want.append(x.reshape(-1, 256)[rows])
+    RT = B * NP // 32
+    fr = v_sh.view(torch.float16).reshape(RT, 8, 2, 2, 2, 32, 8)      # [RT, ct, u, plane, h, c, j]
+    u = torch.arange(2)[:, None, None]; h = torch.arange(2)[None, :, None]
+    rr = 8 * u + j
+    row = ((rr & 3) + 8 * (rr >> 2) + 4 * h).reshape(-1).to(DEV)
+    for p in range(2):
+        y = torch.zeros(RT, 32, 256, dtype=torch.float16, device=DEV)
+        y[:, row] = fr[:, :, :, p].permute(0, 2, 3, 5, 1, 4).reshape(RT, 32, 256)   # [RT, (u h j), (ct c)]
+        assert torch.equal(y.reshape(-1, 256), want[p]), f"v_shared plane {p}"
+    if N % 32 == 0:
+        assert k_sh is None                                          # s_xp itself is the K operand
+    else:
+        kp = k_sh.view(torch.float16).reshape(RT, 16, 2, 2, 32, 8)
+        for p in range(2):
+            x = torch.zeros(RT, 32, 256, dtype=torch.float16, device=DEV)
+            x[:, :, chan] = kp[:, :, p].permute(0, 3, 1, 2, 4).reshape(RT, 32, -1)
+            assert torch.equal(x.reshape(-1, 256), want[p]), f"k_shared plane {p}"
+
+
+@pytest.mark.parametrize("B,N", [(2, 64), (3, 37), (1, 256)])
+def test_ipa_folded_projections_equal_the_per_head_path(B, N):
+    """The default f16 path reads s as the K and V operand of every head, with W_k folded into q' = (W_k^T W_q) s + W_k^T b_q and
+    W_v / b_v into linear_out (reference grouping: ipa.py:131-143,183-190,229-252,259-266).  The block's output equals the
+    per-head path's (same kernels, reference grouping) and the exact fp32 path's to fp32 rounding -- also with masked residues."""
+    from str2str_amd import ops
+    from str2str_amd.models.net.ipa import InvariantPointAttention
+
+    torch.manual_seed(3)
+    ipa = InvariantPointAttention(256, 128, 256, 8, 8, 12).to(DEV)
+    with torch.no_grad():
+        for p in ipa.parameters():
+            p.copy_(torch.randn_like(p) * 0.08)
+    H, M = 8, B * N
+    g = torch.Generator().manual_seed(17 + N)
+    s = torch.randn(M, 256, generator=g).to(DEV)
+    q4 = torch.randn(B, N, 4, generator=g)
+    r7 = torch.cat([q4 / q4.norm(dim=-1, keepdim=True), torch.randn(B, N, 3, generator=g)], -1).contiguous().to(DEV)
+    bias, pz = torch.randn(B, H, N, N, generator=g).to(DEV), torch.randn(B, N, N, 32, generator=g).to(DEV)
+    mask = torch.ones(B, N)
+    mask[-1, -3:] = 0
+    mask = mask.to(DEV)
+    s = s * mask.reshape(-1, 1)                                      # (the trunk hands masked activations to the block)
+    s_xp = ops.pack_planes(s)
+
+    def block(act):
+        feats = ipa.attention(act, B, N, r7, mask, (bias.clone(), pz))
+        return ops.node_apply(feats, ipa.out_pack(feats), M)[0].double()
+
+    with torch.no_grad():
+        ipa.arith = "f32"
+        ref = block(s)
+        ipa.arith = "f16x3"
+        assert ipa.folded
+        out_f = block(s_xp)
+        ipa.fold = False
+        out_h = block(s_xp)
+    valid = mask.reshape(-1).bool()
+    check(f"IPA block B{B} N{N}: folded projections vs exact fp32 path", rel(out_f[valid], ref[valid]), 5e-6)
+    check(f"IPA block B{B} N{N}: per-head projections vs exact fp32 path", rel(out_h[valid], ref[valid]), 5e-6)
+    check(f"IPA block B{B} N{N}: folded vs per-head projections", rel(out_f[valid], out_h[valid]), 5e-6)
