@@ -385,7 +385,12 @@ def main():
             line["ipa_kernel"] = {"bound": "hbm", "kernel": f"{ipa_name} + s2s_ipa_opair", "mean_launch_ms": ipa_ms,
                                   "launches_timed": ipa_n, "achieved": ipa_bytes / (ipa_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
                                   "unit": "GB/s", "frac": ipa_bytes / (ipa_ms * 1e-3) / HBM_PEAK,
-                                  "algorithmic_bytes_per_launch": ipa_bytes}
+                                  "algorithmic_bytes_per_launch": ipa_bytes,
+                                  # SURVEY 8(d) counts the operator as the reference states it (q, k, v per head).  The default f16 path
+                                  # folds W_k / W_v away and reads s as K and V of every head (models/net/ipa.py _folded_packs): what the
+                                  # launch pair must move then is 3584 floats per residue less
+                                  "operands": "K = V = s (folded projections)" if mode == "f16x3" and os.environ.get("S2S_IPA_FOLD", "1") != "0" else "per-head k / v",
+                                  "algorithmic_bytes_per_launch_folded_operands": B * 4 * (5928 * N + 40 * N * N)}
         if table is not None:
             line["kernel_times"] = table
             n_eval = S + 1

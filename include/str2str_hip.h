@@ -77,7 +77,14 @@ int s2s_edge_transition(const float* edge, const float* node_ab, const float* no
 int s2s_edge_transition_f16x3(const float* edge, const float* node_ab, const float* node_p, const void* weight_stream,
                               const float* b2, const float* bf, const float* ln_gamma, const float* ln_beta,
                               const float* mask, float* out, int n_samples, int n_res, float ln_eps, int io_layout,
-                              const float* proj_bias_cat64, float* proj_attn_bias, float* proj_pair_z, void* stream);
+                              const float* proj_bias_cat64, float* proj_attn_bias, float* proj_pair_z, int prescale_exp,
+                              void* stream);
+/*   prescale_exp = e in 0 .. 15 (0: none): BLOCK EXPONENT of the hidden activations.  The two hidden layers' outputs (relu(layer 1),
+ *   relu(layer 2) + x) are kept as f16 planes of 2^-e x their value: relu is positively homogeneous, so the factor rides in
+ *   constants the epilogues apply anyway and LayerNorm removes it -- exact for a power of two, no extra instruction, e = 0 is bit
+ *   for bit the unscaled kernel.  node_ab must then be handed in multiplied by 2^-e (the layer-1 seeds enter at the planes' scale).
+ *   It moves the kernel's usable range from 2^15 to 2^(15+e) at the price of f16's subnormal spacing on activations below
+ *   2^(e-3) (absolute error 2^(e-25): far below the large activations' own rounding); the range guard sees the SCALED values. */
 
 /* EmbeddingModule.forward, edge branch (src/models/net/denoising_ipa.py:137-158, calc_distogram
  * src/common/geo_utils.py:44-56) + edge-mask multiply (denoising_ipa.py:187).

@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     const char* __restrict__ wblob, const float* __restrict__ b2, const float* __restrict__ bf,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask,
     float* __restrict__ out, long long M, int N, float ln_eps, int io_layout, unsigned mask_stride, const float* __restrict__ proj_b,
-    float* __restrict__ proj_bias_out, float* __restrict__ proj_pz_out, int* __restrict__ range_flag) {
+    float* __restrict__ proj_bias_out, float* __restrict__ proj_pz_out, int* __restrict__ range_flag, float sk) {
     constexpr int kStages = kStagesBase + (PROJ ? 1 : 0);
     constexpr int kSlots = 8 * kStages;
     __shared__ __attribute__((aligned(16))) char s_w[2][kStageBytes];
@@ -302,6 +302,11 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     //      tile t), so the exact sum of the three planes later serves as the residual row of block 0 without a second read.
     f16x8 xpl[8][2];
     float amax = 0.f;   // range guard (range_flag.h): running maximum of every value that is split into f16 planes
+    // Block exponent of the hidden activations (sk = 2^-prescale_exp, 1 by default): the planes of h1 = relu(layer 1) and of
+    // relu(layer 2) + x hold sk x the value -- relu is positively homogeneous, so the factor rides in constants that exist anyway
+    // (layer 1: acc * (sk / 32) + sk * seeds, the caller hands node_ab in pre-scaled; layer 2: relu(acc / 32 + sk b2) + sk x; final layer:
+    // start value 32 sk bf) and LayerNorm removes it (eps scaled alike).  Exact for powers of two; sk = 1 gives today's bits.
+    const float inv1 = kInvWS * sk;
     // planes (x_h, x_l), see the header
     auto split4 = [&](const float (&x)[4], f16x8& ph, f16x8& pm, int at) {
         split4_f16(x, ph, pm, at, amax);
@@ -311,7 +316,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) xv[i] = ldrow(erow_of(cur), i);  // accumulator ("chain") channel order, see xpl
         for (int i = threadIdx.x; i < 768; i += 256)
-            s_vec[i] = i < 384 ? b2[i] : (i < 512 ? kWS * bf[i - 384] : (i < 640 ? gamma[i - 512] : beta[i - 640]));   // 32 bf: start value of the final layer's accumulators
+            s_vec[i] = i < 384 ? sk * b2[i] : (i < 512 ? (kWS * sk) * bf[i - 384] : (i < 640 ? gamma[i - 512] : beta[i - 640]));   // 32 bf: start value of the final layer's accumulators
         if (PROJ && threadIdx.x < 64) s_vec[768 + threadIdx.x] = proj_b[threadIdx.x];
         cp_store_a(0);
         cp_load_a(1);
@@ -357,14 +362,14 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         constexpr int qd = decltype(qc)::value;
         float x[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = fmaxf(__builtin_fmaf(tile_acc[4 * qd + j], kInvWS, sa[4 * qd + j] + sb[4 * qd + j]), 0.f);
+        for (int j = 0; j < 4; ++j) x[j] = fmaxf(__builtin_fmaf(tile_acc[4 * qd + j], inv1, sa[4 * qd + j] + sb[4 * qd + j]), 0.f);
         split4(x, xp[qd >> 1][0], xp[qd >> 1][1], 4 * (qd & 1));
     };
     // the same in two halves (values 2hh, 2hh+1 of the quarter): 10 VALU instructions, small enough to sit behind one MFMA
     auto s_half = [&](const f32x16& tile_acc, auto qc, auto hc) {
         constexpr int qd = decltype(qc)::value, j0 = 4 * qd + 2 * decltype(hc)::value;
-        const float x0 = fmaxf(__builtin_fmaf(tile_acc[j0], kInvWS, sa[j0] + sb[j0]), 0.f);
-        const float x1 = fmaxf(__builtin_fmaf(tile_acc[j0 + 1], kInvWS, sa[j0 + 1] + sb[j0 + 1]), 0.f);
+        const float x0 = fmaxf(__builtin_fmaf(tile_acc[j0], inv1, sa[j0] + sb[j0]), 0.f);
+        const float x1 = fmaxf(__builtin_fmaf(tile_acc[j0 + 1], inv1, sa[j0 + 1] + sb[j0 + 1]), 0.f);
         split2_f16(x0, x1, xp[qd >> 1][0], xp[qd >> 1][1], 4 * (qd & 1) + 2 * decltype(hc)::value, amax);
     };
     // residual rows n'_i (block 1) and n'_j (block 2) of  x = [e | n'_i | n'_j]  in accumulator layout, two 16 B groups per call
@@ -597,8 +602,8 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
                 r0 = row[16 * t + j0];
                 r1 = row[16 * t + j0 + 1];
             }
-            const float x0 = fmaxf(__builtin_fmaf(a[j0], kInvWS, hh ? bq.z : bq.x), 0.f) + r0;
-            const float x1 = fmaxf(__builtin_fmaf(a[j0 + 1], kInvWS, hh ? bq.w : bq.y), 0.f) + r1;
+            const float x0 = __builtin_fmaf(r0, sk, fmaxf(__builtin_fmaf(a[j0], kInvWS, hh ? bq.z : bq.x), 0.f));   // (sk = 1: r0 + relu(.), exactly)
+            const float x1 = __builtin_fmaf(r1, sk, fmaxf(__builtin_fmaf(a[j0 + 1], kInvWS, hh ? bq.w : bq.y), 0.f));
             split2_f16(x0, x1, P[0], P[1], e0, amax);
         };
         static_for<0, 6>([&](auto ic) {
@@ -628,7 +633,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             if constexpr ((ns == 4 || ns == 5) && (i == 1 || i == 3 || i == 5)) { ln_dev(IC<6 * (ns - 4) + i - 1>{}); ln_dev(IC<6 * (ns - 4) + i>{}); }
             if constexpr (ns == 6 && (i == 0 || i == 1)) { ln_dev(IC<12 + 2 * i>{}); ln_dev(IC<12 + 2 * i + 1>{}); }
             if constexpr (ns == 6 && i == 3) {
-                ln_rstd = 1.0f / sqrtf(xhalf_sum(ln_var) * (1.0f / 128) + ln_eps * (kWS * kWS));
+                ln_rstd = 1.0f / sqrtf(xhalf_sum(ln_var) * (1.0f / 128) + ln_eps * ((kWS * sk) * (kWS * sk)));
                 ln_em = prv.em_i * prv.em_j;
                 ln_orow = const_cast<float*>(row_of(out, prv.p, out_tiled));
                 ln_sum = 0.f;
@@ -1180,9 +1185,11 @@ extern "C" int s2s_edge_transition_f16x3(const float* edge, const float* node_ab
                                          const void* weight_stream, const float* b2, const float* bf,
                                          const float* ln_gamma, const float* ln_beta, const float* mask, float* out,
                                          int n_samples, int n_res, float ln_eps, int io_layout, const float* proj_bias_cat64,
-                                         float* proj_attn_bias, float* proj_pair_z, void* stream) {
+                                         float* proj_attn_bias, float* proj_pair_z, int prescale_exp, void* stream) {
     if (n_samples <= 0 || n_res <= 0) return 0;
     if ((io_layout & ~7) || ((io_layout & 4) && !proj_attn_bias) || (!(io_layout & 4) && !out)) return (int)hipErrorInvalidValue;
+    if (prescale_exp < 0 || prescale_exp > 15) return (int)hipErrorInvalidValue;
+    const float sk = ldexpf(1.0f, -prescale_exp);
     const long long NN = (long long)n_res * n_res;
     // 32-bit pair / head-major indices inside a launch (8 M < 2^32): split the samples over several launches when needed
     const char* cap_env = getenv("S2S_ET_MAX_PAIRS");   // test hook: a smaller per-launch pair budget exercises the split
@@ -1216,11 +1223,11 @@ extern "C" int s2s_edge_transition_f16x3(const float* edge, const float* node_ab
         if (proj_attn_bias)
             hipLaunchKernelGGL(edge_transition_f16_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, e, nab, np,
                                (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mk, o, M, n_res, ln_eps, io_layout, mks, proj_bias_cat64,
-                               proj_attn_bias + b0 * 8 * NN, proj_pair_z + b0 * NN * 32, s2s::g_range_flag);
+                               proj_attn_bias + b0 * 8 * NN, proj_pair_z + b0 * NN * 32, s2s::g_range_flag, sk);
         else
             hipLaunchKernelGGL(edge_transition_f16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, e, nab, np,
                                (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mk, o, M, n_res, ln_eps, io_layout, mks,
-                               (const float*)nullptr, (float*)nullptr, (float*)nullptr, s2s::g_range_flag);
+                               (const float*)nullptr, (float*)nullptr, (float*)nullptr, s2s::g_range_flag, sk);
     }
     return (int)hipGetLastError();
 }

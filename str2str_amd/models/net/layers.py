@@ -130,6 +130,8 @@ class EdgeTransition(nn.Module):
         self._proj_cache = ParamCache()   # (a captured HIP graph keeps pointing at its stream: sampler._GraphedNet pins it)
         self._node_cache = ParamCache()
         self.arith = default_arith()      # "f16x3" (csrc/pair_mlp_f16.hip) | "f32" (csrc/pair_mlp.hip): see str2str_amd/arith.py
+        self.prescale_exp = 0             # f16x3: block exponent of the hidden activations (planes hold 2^-e x the value; the sampler raises
+        #                                   it when the range guard reports activations of 2^15 and beyond: sampler.denoise_loop)
 
     def _packed(self):
         """Weight stream of the split-f16 kernel."""
@@ -194,7 +196,7 @@ class EdgeTransition(nn.Module):
             z, bias, pz = torch.ops.str2str_amd.edge_transition_f16x3_chain(
                 edge_embed.buf if tiled_in else edge_embed.contiguous(), tiled_in, B, N, node_ab, n_p,
                 pk["wstream_f16"] if proj is None else proj[0], self.trunk[2].bias, self.final_layer.bias, self.layer_norm.weight,
-                self.layer_norm.bias, mask, self.layer_norm.eps, None if proj is None else proj[1], out_layout)
+                self.layer_norm.bias, mask, self.layer_norm.eps, None if proj is None else proj[1], out_layout, int(self.prescale_exp))
             if out_layout == "tiled":
                 z = ops.PairTiled(B, N, buf=z)
             return z if proj is None else (z, bias, pz)

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 _lib = None
 _tables_loaded = False
@@ -27,7 +27,7 @@ _SIGNATURES = {
     "s2s_abi_version": [],
     "s2s_set_range_flag": [_vp],
     "s2s_edge_transition": [_vp] * 12 + [_i, _i, _f, _vp, _vp, _vp, _vp, _vp],
-    "s2s_edge_transition_f16x3": [_vp] * 10 + [_i, _i, _f, _i, _vp, _vp, _vp, _vp],
+    "s2s_edge_transition_f16x3": [_vp] * 10 + [_i, _i, _f, _i, _vp, _vp, _vp, _i, _vp],
     "s2s_edge_embed": [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "s2s_edge_embed_f16x3": [_vp] * 14 + [_i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
     "s2s_pair_project": [_vp] * 5 + [_i, _i, _vp],
@@ -328,15 +328,21 @@ def pair_untiled(t: PairTiled) -> torch.Tensor:
 
 
 def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps=1e-5, out=None, proj=None,
-                          out_layout: str = "rowmajor"):
+                          out_layout: str = "rowmajor", prescale_exp: int = 0):
     """EdgeTransition on split-f16 MFMA (fp32-equivalent accuracy; csrc/pair_mlp_f16.hip); same contract as ``edge_transition``.
     ``proj`` = (31-stage stream = this layer's 30 stages (``pack_f16x3_stream``) + the next IPA block's projection stage
     (``pack_f16x2_layer``), bias64) also returns that block's (attn_bias [B,8,N,N], pair_z [B,N,N,32]).
     ``edge`` may be a ``PairTiled``; ``out_layout``: "rowmajor" (the reference's tensor), "tiled" (-> ``PairTiled``) or "none" (the pair
-    vectors are not written: only with ``proj``, for the last EdgeTransition of a trunk; returns None in their place)."""
+    vectors are not written: only with ``proj``, for the last EdgeTransition of a trunk; returns None in their place).
+    ``prescale_exp`` = e (0 .. 15): the kernel keeps its hidden activations as f16 planes of 2^-e x the value (a block exponent: exact,
+    same speed) -- what the sampler sets when the range guard reports hidden activations of 2^15 and beyond."""
     lib = load_library()
     B, N = edge.shape[0], edge.shape[1]
     in_tiled = isinstance(edge, PairTiled)
+    if not 0 <= int(prescale_exp) <= 15:
+        raise HipLibraryError(f"edge_transition_f16x3: prescale_exp {prescale_exp} outside 0 .. 15")
+    if prescale_exp:
+        node_ab = node_ab * (2.0 ** -int(prescale_exp))     # the per-node seeds of layer 1 enter at the planes' scale (C ABI: the caller's job)
     if out_layout not in ("rowmajor", "tiled", "none") or (out_layout == "none" and proj is None):
         raise HipLibraryError(f"edge_transition_f16x3: out_layout {out_layout!r}" + (" needs proj" if out_layout == "none" else ""))
     _req(edge.buf if in_tiled else edge, name="edge")
@@ -368,7 +374,7 @@ def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, m
     _check(_timed("s2s_edge_transition", lambda: lib.s2s_edge_transition_f16x3(
         _p(edge.buf if in_tiled else edge), _p(node_ab), _p(node_p), _p(wstream), _p(b2), _p(bf), _p(gamma), _p(beta),
         _p(mask),
-        _p(out.buf if isinstance(out, PairTiled) else out), B, N, ln_eps, io, _p(pb), _p(pbias), _p(ppz), _stream())),
+        _p(out.buf if isinstance(out, PairTiled) else out), B, N, ln_eps, io, _p(pb), _p(pbias), _p(ppz), int(prescale_exp), _stream())),
         "s2s_edge_transition_f16x3")
     return out if proj is None else (out, pbias, ppz)
 
@@ -1235,13 +1241,13 @@ def _op_node_linear_f32(x, wpk32, bias, n_rows, k_in, n_out, tiles, pre_scale=No
 
 
 def _op_edge_transition_f16x3_chain(edge, in_tiled, B, N, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps, proj_bias64,
-                                    out_layout):
+                                    out_layout, prescale_exp=0):
     """The trunk's form of the edge transition: pair tensor in either layout (``edge`` = the flat tiled buffer when ``in_tiled``), the
     next IPA block's projections fused in when ``proj_bias64`` is given (``wstream`` is then the 31-stage stream).
     -> (pair tensor (row-major [B,N,N,128] | flat tiled buffer | None), attn_bias | None, pair_z | None)"""
     e = PairTiled(B, N, buf=edge) if in_tiled else edge
     r = edge_transition_f16x3(e, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps,
-                              proj=None if proj_bias64 is None else (wstream, proj_bias64), out_layout=out_layout)
+                              proj=None if proj_bias64 is None else (wstream, proj_bias64), out_layout=out_layout, prescale_exp=prescale_exp)
     z, bias, pz = r if proj_bias64 is not None else (r, None, None)
     return (z.buf if isinstance(z, PairTiled) else z), bias, pz
 
@@ -1251,9 +1257,11 @@ _TORCH_OPS = {
     "edge_transition(Tensor edge, Tensor node_ab, Tensor node_p, Tensor w1p, Tensor w2p, Tensor wfp, Tensor b2, "
     "Tensor bf, Tensor gamma, Tensor beta, Tensor? mask, float ln_eps) -> Tensor": lambda *a: edge_transition(*a),
     "edge_transition_f16x3(Tensor edge, Tensor node_ab, Tensor node_p, Tensor wstream, Tensor b2, Tensor bf, "
-    "Tensor gamma, Tensor beta, Tensor? mask, float ln_eps) -> Tensor": lambda *a: edge_transition_f16x3(*a),
+    "Tensor gamma, Tensor beta, Tensor? mask, float ln_eps, int prescale_exp=0) -> Tensor":
+        lambda e, nab, np_, ws, b2, bf, g, b, m, eps, pe=0: edge_transition_f16x3(e, nab, np_, ws, b2, bf, g, b, m, eps, prescale_exp=pe),
     "edge_transition_f16x3_chain(Tensor edge, bool in_tiled, int B, int N, Tensor node_ab, Tensor node_p, Tensor wstream, Tensor b2, "
-    "Tensor bf, Tensor gamma, Tensor beta, Tensor? mask, float ln_eps, Tensor? proj_bias64, str out_layout) -> (Tensor?, Tensor?, Tensor?)":
+    "Tensor bf, Tensor gamma, Tensor beta, Tensor? mask, float ln_eps, Tensor? proj_bias64, str out_layout, int prescale_exp=0) "
+    "-> (Tensor?, Tensor?, Tensor?)":
         _op_edge_transition_f16x3_chain,
     "edge_embed(Tensor node_a, Tensor node_b, Tensor rel_table, Tensor bin_table, Tensor bin_lower, Tensor residue_idx, Tensor ca, "
     "Tensor w2p, Tensor w3p, Tensor b2, Tensor b3, Tensor gamma, Tensor beta, Tensor? mask, int rel_offset, float ln_eps) -> Tensor":

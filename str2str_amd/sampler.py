@@ -113,6 +113,7 @@ def _graph_key(net, feats, b, N):
     tr = getattr(net, "translator", None)
     # which kernels were captured: the arithmetic / kernel selectors of the modules
     modes = tuple(str(getattr(m, a)) for m, a in family_slots(net))   # per switch, in module order: a mixed network has many forms
+    modes += tuple(int(m.prescale_exp) for m in net.modules() if hasattr(m, "prescale_exp"))   # block exponents are launch arguments
     return (id(net), sum(p._version for p in net.parameters()), b, N, bool(getattr(tr, "exact_padding", False)),
             bool(getattr(tr, "fuse_pair_projection", False)), modes, h.hexdigest())
 
@@ -186,7 +187,10 @@ def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: flo
     noise) is run again with ONLY the kernel families that raised it (str2str_amd/arith.py: node stream, edge transition, edge
     embedding, IPA) on their exact fp32 kernels; a warning is logged once per family and those families stay in fp32 for later
     chunks (``net.range_fallback`` = the set of demoted families) -- one out-of-range activation in, say, the encoder attention no
-    longer costs the edge transitions (73 % of the step) their 3x.  One flag read per chunk, where the loop synchronises anyway."""
+    longer costs the edge transitions (73 % of the step) their 3x.  One flag read per chunk, where the loop synchronises anyway.
+    The edge transitions -- the family whose demotion would cost 2x of the whole step -- are first given a BLOCK EXPONENT instead
+    (``EdgeTransition.prescale_exp`` 0 -> 5 -> 10 -> 15: the kernel keeps its hidden activations as planes of 2^-e x the value, exact
+    and at the same speed, include/str2str_hip.h) and only go to fp32 when 2^30 is not enough; ``net.range_prescale`` records it."""
     kw = dict(min_t=min_t, noise_scale=noise_scale, probability_flow=probability_flow, self_conditioning=self_conditioning,
               center_mode=center_mode, trace=trace)
     if net_arith(net) == "f32":
@@ -213,6 +217,20 @@ def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: flo
                 return out
             new = set(ops.range_families(bits)) - demoted
             why = f"an activation left f16's safe range in the split-f16 kernels ({ops.range_flag_names(bits)}{'' if finite else '; non-finite frames'})"
+            if "edge_transition" in new:
+                e_now = _raise_edge_prescale(net)
+                if e_now:
+                    new.discard("edge_transition")
+                    _log.warning("range guard: %s; the edge transitions keep the split-f16 kernel with a block exponent of %d on their "
+                                 "hidden activations (planes of 2^-%d x the value: exact, same speed; usable range 2^%d) -- re-running this chunk",
+                                 why, e_now, e_now, 15 + e_now)
+                    net.range_prescale = {"edge_transition": e_now}
+                    if not new:
+                        if trace is not None:
+                            del trace[:]
+                        if rng_state is not None:
+                            torch.cuda.set_rng_state(rng_state, rigids_t.device)
+                        continue
         except ops.WeightRangeError as e:   # |32 w| >= 65504: the weights themselves cannot be packed for the f16 kernels
             new = set(FAMILIES) - demoted
             why = f"a weight does not fit the split-f16 packing ({e})"
@@ -229,6 +247,17 @@ def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: flo
             del trace[:]
         if rng_state is not None:
             torch.cuda.set_rng_state(rng_state, rigids_t.device)
+
+
+def _raise_edge_prescale(net, step: int = 5, top: int = 15) -> int:
+    """Next block exponent of the network's EdgeTransition kernels (all of them: the guard's flag names the family); 0 = none left."""
+    mods = [m for m in net.modules() if hasattr(m, "prescale_exp") and getattr(m, "arith", None) == "f16x3"]
+    cur = max((int(m.prescale_exp) for m in mods), default=top)
+    if not mods or cur >= top:
+        return 0
+    for m in mods:
+        m.prescale_exp = min(cur + step, top)
+    return min(cur + step, top)
 
 
 def _require_finite(rigids7, what):

@@ -111,8 +111,9 @@ def cfg5():
     G.npz("cfg5_mixed_lengths.npz", lens=np.array(CFG5_LENS), R=R, num_timesteps=S, t_delta=td, **out)
 
 
-def trained():
-    """One evaluation (B = 2, N = 24, partial mask) with the trained-like weight recipe of str2str_amd/synth.py.  The yardstick for
+def trained(B=2, N=24, seed=77, name="net_b2n24_trained_like.npz"):
+    """One evaluation (B = 2, N = 24, partial mask; --trained256: B = 1, N = 256, the bench shape -> net_b1n256_trained_like.npz)
+    with the trained-like weight recipe of str2str_amd/synth.py.  The yardstick for
     the HIP path is the reference's OWN float32 uncertainty on this ill-conditioned input: the same evaluation repeated with 1 / 2 /
     4 CPU threads (only the GEMM summation order changes) and with every float input moved by one ulp (8 draws) -- ``ref_spread`` =
     the largest deviation of those runs from the stored one.  (A float64 evaluation is no anchor here: the distogram's strict bin
@@ -121,8 +122,8 @@ def trained():
 
     net, manifest = G.build_net(seed=0, sigma_final=0.02)
     net.load_state_dict(synth_state_dict(manifest, seed=0, sigma_final=0.02, style="trained_like"), strict=True)
-    g = torch.Generator().manual_seed(77)
-    batch = G.make_batch(g, 2, 24, True)
+    g = torch.Generator().manual_seed(seed)
+    batch = G.make_batch(g, B, N, True)
     amax = {}
 
     def hook(name):
@@ -156,7 +157,7 @@ def trained():
             spread_psi = max(spread_psi, float((o["psi"] - p0).abs().max()))
     print("reference float32 spread (threads, 1-ulp input jitter) on frames:", spread, " psi:", spread_psi)
     print("largest activations:", sorted(amax.items(), key=lambda kv: -kv[1])[:5])
-    G.npz("net_b2n24_trained_like.npz", **{f"in_{k}": v for k, v in batch.items()}, rigids7=r0, psi=p0,
+    G.npz(name, **{f"in_{k}": v for k, v in batch.items()}, rigids7=r0, psi=p0,
           atom37=out["atom37"][..., :5, :], ref_spread=spread, ref_psi_spread=spread_psi, hidden_amax=max(amax.values()))
 
 
@@ -169,3 +170,5 @@ if __name__ == "__main__":
         cfg5()
     if "--trained" in sys.argv:
         trained()
+    if "--trained256" in sys.argv:
+        trained(1, 256, 78, "net_b1n256_trained_like.npz")

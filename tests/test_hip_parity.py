@@ -201,6 +201,52 @@ def test_edge_transition_f16x3_is_fp32_equivalent(net_rough, N, amp):
     assert e16 < 1e-5 and e16 < 3 * e32 + 1e-6, (e32, e16)
 
 
+def test_edge_transition_block_exponent(net_rough):
+    """``prescale_exp`` (include/str2str_hip.h, s2s_edge_transition_f16x3): the hidden activations as f16 planes of 2^-e x their value.
+    On ordinary magnitudes e = 5 changes the result by rounding only (subnormal spacing of the low plane); with the first hidden
+    layer scaled by 8e3 (both hidden layers' activations ~1e5 > 2^15; the weights keep their ordinary size, so the fixed 2^5 weight
+    packing keeps its precision) the unscaled kernel raises the range flag, e = 5 keeps it quiet and stays as close to a float64
+    evaluation as the exact fp32 kernel."""
+    import copy
+
+    import torch.nn.functional as F
+
+    from str2str_amd import ops
+
+    et = copy.deepcopy(_edge_transition_module(net_rough))
+    g = torch.Generator().manual_seed(78)
+    Bn, N = 2, 48
+    node = torch.randn(Bn, N, 256, generator=g).to(DEV)
+    edge = (3.0 * torch.randn(Bn, N, N, 128, generator=g)).to(DEV)
+
+    def run(e, arith="f16x3"):
+        et.prescale_exp, et.arith = e, arith
+        ops.range_flag_reset()
+        out = et(node, edge)
+        return out, ops.range_flag_read()
+
+    with torch.no_grad():
+        o0, f0 = run(0)
+        o5, f5 = run(5)
+        assert f0 == 0 and f5 == 0
+        check("edge transition block exponent 5 vs 0, ordinary magnitudes: max |diff|", float((o0 - o5).abs().max()), 8e-6)
+        et.trunk[0].weight.mul_(8.0e3); et.trunk[0].bias.mul_(8.0e3)
+        o32, _ = run(0, "f32")
+        _, f0 = run(0)
+        o5, f5 = run(5)
+        assert f0 & 4 and f5 == 0, (f0, f5)
+        n = et.initial_embed(node).double()
+        x = torch.cat([edge.double(), n[:, :, None, :].expand(Bn, N, N, -1), n[:, None, :, :].expand(Bn, N, N, -1)], -1)
+        h1 = F.relu(F.linear(x, et.trunk[0].weight.double(), et.trunk[0].bias.double()))
+        h = F.relu(F.linear(h1, et.trunk[2].weight.double(), et.trunk[2].bias.double()))
+        y = F.linear(h + x, et.final_layer.weight.double(), et.final_layer.bias.double())
+        ref = F.layer_norm(y, (128,), et.layer_norm.weight.double(), et.layer_norm.bias.double(), et.layer_norm.eps)
+        assert float(h1.abs().max()) > 2.0 ** 15 and float(h.abs().max()) > 2.0 ** 15
+        e32, e5 = float((o32.double() - ref).abs().max()), float((o5.double() - ref).abs().max())
+        check(f"edge transition block exponent 5, hidden max {float(h1.abs().max()):.3g}: max |out - float64| (fp32 kernel: {e32:.2e})",
+              e5, 3 * e32 + 1e-6)
+
+
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("B,N", [(1, 5), (2, 37), (3, 64)])
 def test_edge_transition_vs_oracle(net_rough, B, N, mode):
@@ -859,7 +905,7 @@ def test_range_guard_flags_every_f16_producer():
         assert flags(lambda: ops.encoder_attention(qkv * 1.0e5, None, 2, 32, arith=ar)) == 32
 
 
-@pytest.mark.parametrize("where,scale,why,fams", [("et", 8.0e3, "edge transition", ("edge_transition",)),
+@pytest.mark.parametrize("where,scale,why,fams", [("et", 8.0e3, "edge transition", ()),
                                                   ("et", 3.0e4, "a weight does not fit", ("node", "edge_transition", "edge_embed", "ipa")),
                                                   ("nt", 1.0e3, "node GEMM", ("node",))], ids=["activation", "weight", "node-activation"])
 def test_range_guard_falls_back_per_kernel_family(diffuser, caplog, where, scale, why, fams):
@@ -870,6 +916,9 @@ def test_range_guard_falls_back_per_kernel_family(diffuser, caplog, where, scale
     (every family for an unpackable weight); the result IS that mixed arithmetic's (bit for bit, same noise) and within rounding of
     the all-fp32 network's, a warning names the cause and the family, the demotion persists (``net.range_fallback``), the other
     families stay on f16x3 -- an overflow in the node stream does not cost the edge transitions their 3x -- and nothing is non-finite.
+    The edge transitions themselves are NOT demoted for an activation (case "activation": 8e3 x the hidden layer, ~2^17): their
+    kernel gets a block exponent (``prescale_exp`` 5, ``net.range_prescale``) and every family ends on f16x3; the result is bit for
+    bit that of the network with the exponent set by hand, and within rounding of the all-fp32 network's.
     The un-scaled network, same seed, never leaves f16x3."""
     import logging
 
@@ -912,33 +961,50 @@ def test_range_guard_falls_back_per_kernel_family(diffuser, caplog, where, scale
     with use_arith(hot, "f32"):
         want_all = run(hot)                               # the exact arithmetic on the scaled network
     assert backbone_rmsd(want_all.cpu().numpy()[..., :5, :], ref_plain.cpu().numpy()[..., :5, :]) < 1e-3   # (the same function up to rounding)
+    ets = [m for m in hot.modules() if hasattr(m, "prescale_exp")]
+    presc = where == "et" and not fams                   # the edge transitions answer an activation with a block exponent
+    if presc:
+        for m in ets:
+            m.prescale_exp = 5
     with use_arith(hot, "f32", families=fams):
-        want = run(hot)                                   # only the offending family exact
+        want = run(hot)                                   # only the offending family exact / the exponent set by hand
+    for m in ets:
+        m.prescale_exp = 0
     assert backbone_rmsd(want.cpu().numpy()[..., :5, :], want_all.cpu().numpy()[..., :5, :]) < 1e-4
     with caplog.at_level(logging.WARNING, logger="str2str_amd.sampler"):
         got = run(hot)
     msgs = [r.getMessage() for r in caplog.records]
     assert any("range guard" in m and why in m for m in msgs), msgs
-    assert hot.range_fallback == frozenset(fams) and torch.isfinite(got).all()
-    assert set(FAMILIES) - set(hot.range_fallback) or len(fams) == len(FAMILIES)
+    assert (getattr(hot, "range_fallback", None) or frozenset()) == frozenset(fams) and torch.isfinite(got).all()
+    if presc:
+        assert hot.range_prescale == {"edge_transition": 5} and {int(m.prescale_exp) for m in ets} == {5}
+        assert any("block exponent" in m for m in msgs)
+    assert set(FAMILIES) - set(getattr(hot, "range_fallback", None) or ()) or len(fams) == len(FAMILIES)
     assert torch.equal(got, want)
     assert torch.equal(run(hot), want)                   # later chunks go straight to the demoted form
     assert {m.arith for m in hot.modules() if hasattr(m, "arith")} == {"f16x3"}     # (the switches themselves are untouched between chunks)
     # SDE branch: the re-run re-draws the noise of the first pass from the saved generator state, so it equals a plain run of the
     # mixed arithmetic under the same seed, and leaves the generator where one pass leaves it
     hot2 = build(scale)
+    ets2 = [m for m in hot2.modules() if hasattr(m, "prescale_exp")]
+    for m in ets2:
+        m.prescale_exp = 5 if presc else 0
     with use_arith(hot2, "f32", families=fams):
         want_sde = run(hot2, probability_flow=False)
         end_state = torch.get_rng_state()
-    assert torch.equal(run(hot2, probability_flow=False), want_sde) and hot2.range_fallback == frozenset(fams)
+    for m in ets2:
+        m.prescale_exp = 0
+    assert torch.equal(run(hot2, probability_flow=False), want_sde)
+    assert (getattr(hot2, "range_fallback", None) or frozenset()) == frozenset(fams)
     assert torch.equal(torch.get_rng_state(), end_state)
     # what the guard saw: the offending family's bucket is at or above 2^15, the others well below
     head = ops.range_headroom()
     assert set(head) == set(FAMILIES)
 
 
-def test_trained_like_magnitudes_golden():
-    """One evaluation with trained-like weight magnitudes (LayerNorm gains up to 10, dense weights 2x the fan-in scale: hidden
+@pytest.mark.parametrize("fixture", ["net_b2n24_trained_like.npz", "net_b1n256_trained_like.npz"])
+def test_trained_like_magnitudes_golden(fixture):
+    """One evaluation (B = 2, N = 24; B = 1, N = 256: the bench shape) with trained-like weight magnitudes (LayerNorm gains up to 10, dense weights 2x the fan-in scale: hidden
     activations of several tens, an ill-conditioned network) against the reference.  The yardstick is the reference's OWN float32
     uncertainty on this input (``ref_spread``: its output under 1 / 2 / 4 / 8 CPU threads and one-ulp jitter of its float inputs,
     tests/golden/make_golden_configs.py --trained): both arithmetics of this build must stay within 3x of it, without touching
@@ -947,7 +1013,8 @@ def test_trained_like_magnitudes_golden():
     from str2str_amd.factory import build_net
     from str2str_amd.synth import synth_state_dict
 
-    g = golden("net_b2n24_trained_like.npz")
+    g = golden(fixture)
+    tag = fixture.split("_")[1]
     net = build_net().to(DEV).eval()
     man = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
     net.load_state_dict(synth_state_dict(man, seed=0, sigma_final=0.02, style="trained_like"))
@@ -957,9 +1024,9 @@ def test_trained_like_magnitudes_golden():
             ops.range_flag_reset()
             out = net(_batch(g, DEV))
             assert ops.range_flag_read() == 0
-        check(f"trained-like net golden [{mode}]: max |frames - reference| (reference's own float32 spread {spread:.1e})",
+        check(f"trained-like net golden {tag} [{mode}]: max |frames - reference| (reference's own float32 spread {spread:.1e})",
               maxdiff(out["rigids"].to_tensor_7().cpu(), g["rigids7"]), 3 * spread)
-        check(f"trained-like net golden [{mode}]: max |psi - reference| (spread {spread_psi:.1e})", maxdiff(out["psi"].cpu(), g["psi"]),
+        check(f"trained-like net golden {tag} [{mode}]: max |psi - reference| (spread {spread_psi:.1e})", maxdiff(out["psi"].cpu(), g["psi"]),
               3 * spread_psi)
 
 
