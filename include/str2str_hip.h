@@ -241,6 +241,17 @@ int s2s_se3_step(const float* x0_7, const float* xt_7, const float* mask, const 
                  double coordinate_scaling, int probability_flow, int center_trans, double noise_scale,
                  void* stream);
 
+/* The embedder's per-evaluation assembly in one launch (EmbeddingModule.forward, src/models/net/denoising_ipa.py:107-136: the first
+ * Linear of the node MLP and of the edge MLP on [timestep embedding | fixed-mask column | positional block]).
+ *   t_img [512] = first-layer image of the chunk's timestep embedding + bias: [node MLP 256 | edge row part 128 | edge column part 128]
+ *   node_const [node_const_rows, 256] (rows = n_rows, or n_res when every sample shares it): fixed-mask + positional terms of the node MLP
+ *   fa [n_rows,128], fb (column-blocked [B,32,n_res,4] when b_col_blocked, else [n_rows,128]): fixed-mask terms of the edge MLP
+ *   -> h = relu(t_img[0:256] + node_const) as packed planes (h_xp) or fp32 [n_rows,256] (h_f32; exactly one of the two),
+ *      node_a = t_img[256:384] + fa, node_b = t_img[384:512] + fb: the operands of s2s_node_linear / s2s_edge_embed(_f16x3). */
+int s2s_embed_assemble(const float* t_img, const float* node_const, long long node_const_rows, const float* fa, const float* fb,
+                       long long n_rows, int n_res, void* h_xp, float* h_f32, float* node_a, float* node_b, int b_col_blocked,
+                       void* stream);
+
 /* ---- Per-node dense layers (split-f16 MFMA "f16x3", fp32-equivalent; see s2s_edge_transition_f16x3) ----
  * Activations travel between these layers as PACKED PLANES ("XP"): for X [M, K],
  *   XP[rt = row/32][ks = K/16][plane 2][lane 64][8] f16, lane = 32 g + (row & 31),

@@ -113,15 +113,27 @@ class EmbeddingModule(nn.Module):
         return self._wcache.get([e0.weight, e0.bias, e2.weight, e4.weight, ne[0].weight, ne[0].bias, ne[2].weight, ne[2].bias,
                                  ne[4].weight, ne[4].bias], build)
 
-    def _fixed_terms(self, fixed_mask: torch.Tensor, w: dict, dev):
-        """fixed-mask columns of the first layers, [B,L,1] x weight column: (node MLP term, edge row term, (edge column term in the
-        f16x3 kernel's gather layout [B,32,L,4], the same row-major)).  Cached on the mask tensor and the weights."""
-        key = (fixed_mask.data_ptr(), tuple(fixed_mask.shape), fixed_mask._version, str(fixed_mask.device), w["wn_f"].data_ptr(), w["wn_f"]._version)
+    def _fixed_terms(self, fixed_mask: torch.Tensor, w: dict, dev, node_pos: torch.Tensor):
+        """Per-target constants of the first layers that do not depend on t: (node MLP: fixed-mask column + positional image [B,L,256],
+        edge row term [B,L,128], (edge column term in the f16x3 kernel's gather layout [B,32,L,4], the same row-major)).  Cached on
+        the mask tensor, the positional image and the weights."""
+        key = (fixed_mask.data_ptr(), tuple(fixed_mask.shape), fixed_mask._version, str(fixed_mask.device), w["wn_f"].data_ptr(), w["wn_f"]._version,
+               node_pos.data_ptr(), node_pos._version)
         if key != getattr(self, "_fx_key", None) or getattr(self, "_fx_src", None) is not fixed_mask:
             fixed = fixed_mask.to(dev)[..., None].float()
-            self._fx_val = (fixed * w["wn_f"], fixed * w["w_row_f"], (fixed[:, None] * w["w_col_f"].view(1, 32, 1, 4), fixed * w["w_col_f"]))
+            B, L = fixed.shape[:2]
+            self._fx_val = ((fixed * w["wn_f"] + node_pos).contiguous(), (fixed * w["w_row_f"]).contiguous(),
+                            ((fixed[:, None] * w["w_col_f"].view(1, 32, 1, 4)).expand(B, 32, L, 4).contiguous(), (fixed * w["w_col_f"]).contiguous()))
             self._fx_key, self._fx_src = key, fixed_mask
         return self._fx_val
+
+    def time_images(self, t_emb: torch.Tensor) -> torch.Tensor:
+        """[n, 32] timestep embeddings -> [n, 512] first-layer images + biases [node MLP | edge row | edge column] (one row per
+        step of a schedule: the sampler evaluates this once per trajectory and hands ``forward`` a row as ``t_img``).  Elementwise
+        product + sum over the 32 embedding channels (no library GEMM), the same expression ``forward`` evaluates for a single t."""
+        w = self._weights()
+        t_emb = t_emb.to(w["b0"].device).reshape(-1, t_emb.shape[-1]).float()
+        return ((w["w_t_cat"][None] * t_emb[:, None, :]).sum(-1) + w["b_t_cat"]).contiguous()
 
     def _index_tables(self, residue_idx: torch.Tensor, w_rel: torch.Tensor, wn_pos: torch.Tensor):
         """Per-target constants: first-layer image of the node positional features and the relative-position
@@ -136,15 +148,15 @@ class EmbeddingModule(nn.Module):
             span = int(idx_cpu.max() - idx_cpu.min())
             d = torch.arange(-span, span + 1)
             dev = w_rel.device
-            rel = F.linear(self.position_embed(d).float().to(dev), w_rel).contiguous()
-            node_pos = F.linear(self.position_embed(idx_cpu).float().to(dev), wn_pos).contiguous()  # [B, L, node width]
+            rel = _table_linear(self.position_embed(d).float().to(dev), w_rel)
+            node_pos = _table_linear(self.position_embed(idx_cpu).float().to(dev), wn_pos)  # [B, L, node width]
             self._idx_val = (rel, span, node_pos, residue_idx.to(dev).contiguous())
             self._rel_cb = ops.column_blocked(rel)
             self._idx_key = key
         return self._idx_val
 
     def forward(self, residue_idx, t, fixed_mask, self_conditioning_ca, node_mask: Optional[torch.Tensor] = None,
-                next_proj=None, t_emb: Optional[torch.Tensor] = None, edge_layout: str = "rowmajor"):
+                next_proj=None, t_emb: Optional[torch.Tensor] = None, edge_layout: str = "rowmajor", t_img: Optional[torch.Tensor] = None):
         """-> node_embed [B,N,D_node], edge_embed [B,N,N,D_edge] (reference :107-159; ``edge_layout`` "tiled": as an ``ops.PairTiled``
         for the trunk's f16x3 pair kernels, arithmetic "f16x3" only).  ``t`` may live on
         the host (the sampler knows it there): its embedding is then computed on the host and uploaded.
@@ -158,10 +170,11 @@ class EmbeddingModule(nn.Module):
             raise ops.HipLibraryError("edge_embed kernel is built for edge_embed_size=128")
         B, L = residue_idx.shape
         rel_tab, span, node_pos, idx_dev = self._index_tables(residue_idx, w["w_rel"], w["wn_pos"])
-        fixed = fixed_mask.to(dev)[..., None].float()
         # [B, 32]; evaluated once per DISTINCT t (a sampler chunk shares one t, and the host sin/cos of arguments up to 1e4 rad
         # costs ~40 us per element): same values, row for row
-        if t_emb is not None:   # the sampler uploads the embeddings of the whole schedule once: no per-step H2D copy
+        if t_img is not None:   # the sampler's form: the timestep block's first-layer image of this step, computed with the schedule
+            t_emb = None
+        elif t_emb is not None:   # the sampler uploads the embeddings of the whole schedule once: no per-step H2D copy
             t_emb = t_emb.to(dev).reshape(-1, t_emb.shape[-1])                 # (a host->device copy here would make the
         else:                                                                  #  host wait for the GPU every evaluation)
             t_u, t_inv = torch.unique(t.detach().reshape(-1), return_inverse=True)
@@ -169,40 +182,38 @@ class EmbeddingModule(nn.Module):
         ne = self.node_embed
         mask = None if node_mask is None else node_mask.to(dev).float().contiguous()
         nn_, ne_ = w["wn_t"].shape[0], w["w_row_t"].shape[0]
-        single_t = t_emb.shape[0] == 1
+        single_t = t_img is not None or t_emb.shape[0] == 1
+        M = B * L
+        f16 = self.arith == "f16x3"
         if single_t:
             # one timestep for the whole chunk (every sampler call): the three [*, 32] first-layer images are one row each -- a 32-term dot
-            # product per output channel, evaluated elementwise for all three blocks at once; the fixed-mask terms do not depend on t
-            # and are cached on the mask tensor (a network evaluation of a small chunk is launch-latency bound: 22 -> 8 tiny launches here)
-            img = (w["w_t_cat"] * t_emb).sum(-1) + w["b_t_cat"]
-            tn, ta, tb = img[None, :nn_], img[None, nn_:nn_ + ne_], img[None, nn_ + ne_:]
-            Fn, Fa, Fb = self._fixed_terms(fixed_mask, w, dev)
-            h = F.relu(tn[:, None, :] + Fn + node_pos)
+            # product per output channel, evaluated elementwise for all three blocks at once (or handed in as t_img); the fixed-mask and
+            # positional terms do not depend on t and are cached.  What is left per evaluation -- relu(t + const) into the node
+            # stream's format and the two operand arrays of the edge embedding -- is ONE launch (s2s_embed_assemble; a network
+            # evaluation of a small chunk is launch-latency bound: 22 tiny launches here in round 3)
+            img = t_img.reshape(-1) if t_img is not None else (w["w_t_cat"] * t_emb).sum(-1) + w["b_t_cat"]
+            Fn, Fa, Fb = self._fixed_terms(fixed_mask, w, dev, node_pos)
+            h_act, node_a, node_b = torch.ops.str2str_amd.embed_assemble(img.contiguous(), Fn, Fa, Fb[0] if f16 else Fb[1], B, L,
+                                                                         self.node_arith == "f16x3", f16)
         else:
-            tl = lambda wt, b=None: F.linear(t_emb, wt, b)  # noqa: E731
+            fixed = fixed_mask.to(dev)[..., None].float()
+            tl = lambda wt, b=None: _table_linear(t_emb, wt, b)  # noqa: E731
             h = F.relu(tl(w["wn_t"], w["bn0"])[:, None, :] + fixed * w["wn_f"] + node_pos)
+            h_act = ops.to_act(h.reshape(M, -1).contiguous(), self.node_arith)
         # layers 2, 3 + LayerNorm (+ DenoisingNet's node mask) on the fused node kernels; the packed planes of the result are
         # what the trunk's first projections and every skip_embed read
-        M = B * L
         nw = w["node_mlp"]
-        f16 = self.arith == "f16x3"
-        _, h2 = ops.node_apply(ops.to_act(h.reshape(M, -1).contiguous(), self.node_arith), nw[0], M, relu=True, want_f32=False, want_xp=True)
+        _, h2 = ops.node_apply(h_act, nw[0], M, relu=True, want_f32=False, want_xp=True)
         node_embed, self.node_embed_act = ops.node_apply(h2, nw[1], M, ln=(ne[5].weight, ne[5].bias, ne[5].eps),
                                                          post_mask=None if mask is None else mask.reshape(M), want_xp=True)
         node_embed = node_embed.view(B, L, -1)
-        if single_t:
-            node_a = (ta[:, None, :] + Fa).expand(B, L, -1).contiguous()
-            if f16:  # column part straight in the kernel's gather layout [B, 32 chunks, L, 4]
-                node_b = (tb.view(-1, 32, 1, 4) + Fb[0]).expand(B, 32, L, 4).contiguous()
-            else:
-                node_b = (tb[:, None, :] + Fb[1]).expand(B, L, -1).contiguous()
-        else:
+        if not single_t:
             node_a = (tl(w["w_row_t"], w["b0"])[:, None, :] + fixed * w["w_row_f"]).expand(B, L, -1).contiguous()
             if f16:
                 node_b = (tl(w["w_col_t"]).view(-1, 32, 1, 4) + fixed[:, None] * w["w_col_f"].view(1, 32, 1, 4)).expand(B, 32, L, 4).contiguous()
             else:
                 node_b = (tl(w["w_col_t"])[:, None, :] + fixed * w["w_col_f"]).expand(B, L, -1).contiguous()
-        ca = self_conditioning_ca.to(dev).float().contiguous() if self.self_conditioning else t_emb.new_zeros(B, L, 3)
+        ca = self_conditioning_ca.to(dev).float().contiguous() if self.self_conditioning else node_a.new_zeros(B, L, 3)
         e2, e4, ln = self.edge_embed[2], self.edge_embed[4], self.edge_embed[5]
         if f16:
             e2w, e4w = e2.weight, e4.weight
@@ -226,6 +237,15 @@ class EmbeddingModule(nn.Module):
         return node_embed, edge_embed
 
 
+def _table_linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [..., 32] W^T (+ b) for the per-target / per-timestep tables of the embedder, on the exact fp32 node kernel
+    (s2s_node_linear_f32): the package has no library GEMM path."""
+    layer = ops.pack_node_layer(w, b if b is not None else torch.zeros(w.shape[0], device=w.device))
+    lead, n = x.shape[:-1], x.numel() // x.shape[-1]
+    y, _ = ops.node_apply(x.reshape(n, x.shape[-1]).float().contiguous(), layer, n)
+    return y[:, : w.shape[0]].reshape(*lead, w.shape[0]).contiguous()
+
+
 class DenoisingNet(nn.Module):
     def __init__(self, embedder: nn.Module, translator: nn.Module):
         super().__init__()
@@ -247,7 +267,7 @@ class DenoisingNet(nn.Module):
         et0 = self.translator.trunk["edge_transition_0"] if "edge_transition_0" in getattr(self.translator, "trunk", {}) else None
         tiled = fuse and getattr(self.embedder, "arith", None) == "f16x3" and getattr(et0, "arith", None) == "f16x3"
         emb = self.embedder(residue_idx=batch["residue_idx"], t=batch["t"], fixed_mask=fixed_mask,
-                            self_conditioning_ca=batch["sc_ca_t"], node_mask=node_mask, t_emb=batch.get("t_emb"),
+                            self_conditioning_ca=batch["sc_ca_t"], node_mask=node_mask, t_emb=batch.get("t_emb"), t_img=batch.get("t_img"),
                             next_proj=self.translator.trunk["ipa_0"].pair_proj_weights() if fuse else None,
                             **({"edge_layout": "tiled"} if tiled else {}))
         node_embed, edge_embed = emb[0], emb[1]
@@ -256,8 +276,11 @@ class DenoisingNet(nn.Module):
         tb["rigids_t"] = batch["rigids_t"].to(dev)
         tb["_node_embed_act"] = getattr(self.embedder, "node_embed_act", None)
         model_out = self.translator(node_embed, edge_embed, tb, **({"_first_proj": emb[2]} if fuse else {}))
-        gt_psi = batch["torsion_angles_sin_cos"].to(dev)[..., 2, :]
-        psi_pred = gt_psi * fixed_mask[..., None] + model_out["psi"] * (1 - fixed_mask[..., None])
+        if model_out.get("psi_blended"):     # the torsion head's kernel already blended with the input torsion under the fixed mask
+            psi_pred = model_out["psi"]
+        else:
+            gt_psi = batch["torsion_angles_sin_cos"].to(dev)[..., 2, :]
+            psi_pred = gt_psi * fixed_mask[..., None] + model_out["psi"] * (1 - fixed_mask[..., None])
         rigids_pred = model_out["out_rigids"]
         out = {"rigids": rigids_pred, "psi": psi_pred, "rigids7": model_out["out_rigids7"]}
         if self.backbone_in_forward:

@@ -114,14 +114,16 @@ class InvariantPointAttention(nn.Module):
         W_v / b_v move into linear_out.  "qf": s -> q' = (W_k^T W_q) s + W_k^T b_q [H c_s];  "outf": linear_out on [sum a s | o_pt ...].
         The products are formed in float64 and rounded once to fp32 (reference weights: ipa.py:131-143,166-171,259-266)."""
         H, C, cs = self.no_heads, self.c_hidden, self.c_s
-        wq, bq = self.linear_q.weight.double().view(H, C, cs), self.linear_q.bias.double().view(H, C)
-        wk, wv, bv = wkv[:, 0].double(), wkv[:, 1].double(), bkv[:, 1].double()
-        w_qf = torch.einsum("hca,hcb->hab", wk, wq).reshape(H * cs, cs).float()
-        b_qf = torch.einsum("hca,hc->ha", wk, bq).reshape(-1).float()
-        wo = self.linear_out.weight.double()
+        dev = self.linear_q.weight.device
+        c64 = lambda t: t.detach().double().cpu()  # noqa: E731  (weight preparation on the host, like every packer: once per load_state_dict)
+        wq, bq = c64(self.linear_q.weight).view(H, C, cs), c64(self.linear_q.bias).view(H, C)
+        wk, wv, bv = c64(wkv[:, 0]), c64(wkv[:, 1]), c64(bkv[:, 1])
+        w_qf = torch.einsum("hca,hcb->hab", wk, wq).reshape(H * cs, cs).float().to(dev)
+        b_qf = torch.einsum("hca,hc->ha", wk, bq).reshape(-1).float().to(dev)
+        wo = c64(self.linear_out.weight)
         wo_o = wo[:, : H * C].view(-1, H, C)
-        w_of = torch.cat([torch.einsum("ohc,hca->oha", wo_o, wv).reshape(-1, H * cs), wo[:, H * C:]], dim=1).float()
-        b_of = (self.linear_out.bias.double() + torch.einsum("ohc,hc->o", wo_o, bv)).float()
+        w_of = torch.cat([torch.einsum("ohc,hca->oha", wo_o, wv).reshape(-1, H * cs), wo[:, H * C:]], dim=1).float().to(dev)
+        b_of = (c64(self.linear_out.bias) + torch.einsum("ohc,hc->o", wo_o, bv)).float().to(dev)
         return {"qf": ops.pack_node_layer(w_qf, b_qf), "outf": ops.pack_node_layer(w_of, b_of, True)}
 
     def use_f16(self, n_res: int, n_rows: int = 0) -> bool:
@@ -299,6 +301,23 @@ class TranslationIPA(nn.Module):
 
         return self._wcache.get(list(self.parameters()), build)
 
+    def _mask_terms(self, residue_mask: torch.Tensor, fixed_mask: torch.Tensor):
+        """(node mask, diffuse mask = (1 - fixed) * node mask, the encoder layers' key bias, fixed mask flat), all float32: constants of a
+        chunk, cached on the two mask tensors (five tiny launches per evaluation otherwise)."""
+        key = (residue_mask.data_ptr(), residue_mask._version, tuple(residue_mask.shape), residue_mask.dtype, fixed_mask.data_ptr(),
+               fixed_mask._version, fixed_mask.dtype, bool(self.exact_padding))
+        if key != getattr(self, "_mk_key", None) or self._mk_src[0] is not residue_mask or self._mk_src[1] is not fixed_mask:
+            node_mask = residue_mask.type(torch.float).contiguous()
+            fixed = fixed_mask.type(torch.float).contiguous()
+            diffuse_mask = ((1 - fixed) * node_mask).contiguous()
+            pad = 1.0 - node_mask
+            # float key-padding mask of the encoder layers: ADDED to the logits (PyTorch semantics, a no-op for all-ones masks);
+            # exact-padding mode removes padded keys instead
+            key_bias = (torch.where(pad > 0, float("-inf"), 0.0) if self.exact_padding else pad).float().contiguous()
+            self._mk_val = (node_mask, diffuse_mask, key_bias, fixed.reshape(-1))
+            self._mk_key, self._mk_src = key, (residue_mask, fixed_mask)
+        return self._mk_val
+
     def forward(self, node_embed: torch.Tensor, edge_embed: torch.Tensor, batch: dict, _first_proj=None) -> dict:
         """reference :331-387.  Frames travel as one [B,N,7] tensor between the fused kernels; node activations as packed f16
         planes (arith "f16x3") or fp32 row-major (arith "f32") -- ``ops.node_apply`` runs a layer in the arithmetic of its input."""
@@ -309,15 +328,10 @@ class TranslationIPA(nn.Module):
         B, N, C = node_embed.shape
         M = B * N
         dev = node_embed.device
-        node_mask = batch["residue_mask"].type(torch.float).contiguous()
-        diffuse_mask = ((1 - batch["fixed_mask"].type(torch.float)) * node_mask).contiguous()
+        node_mask, diffuse_mask, key_bias, fixed_flat = self._mask_terms(batch["residue_mask"], batch["fixed_mask"])
         nm, dm = node_mask.reshape(M), diffuse_mask.reshape(M)
         init7 = batch["rigids_t"].type(torch.float).contiguous()
         curr7 = torch.ops.str2str_amd.rigid_scale_trans(init7, self.coordinate_scaling, False)
-        pad = 1.0 - node_mask
-        # float key-padding mask of the encoder layers: ADDED to the logits (PyTorch semantics, a no-op for all-ones masks);
-        # exact-padding mode removes padded keys instead
-        key_bias = (torch.where(pad > 0, float("-inf"), 0.0) if self.exact_padding else pad).float().contiguous()
         proj = _first_proj
 
         def lin(x, w, **kw):
@@ -387,9 +401,14 @@ class TranslationIPA(nn.Module):
         _, t1 = lin(s_a, wt["l1"], relu=True, want_f32=False, want_xp=True)
         _, t2 = lin(t1, wt["l2"], residual=s_f32, want_f32=False, want_xp=True)
         # u / sqrt(max(sum u^2, eps)) (layers.py:199-213) straight from the head's padded output: one launch instead of six tiny ones
-        psi = torch.ops.str2str_amd.torsion_head(lin(t2, wt["fin"])[0], M, True, self.torsion_pred.eps).view(B, N, 2)
+        # ... and DenoisingNet's blend with the input torsion under the fixed mask (denoising_ipa.py:192-193) in the same launch
+        gt = batch.get("torsion_angles_sin_cos")
+        blend = gt is not None and gt.is_cuda and gt.dtype == torch.float32 and gt.ndim == 4
+        psi = torch.ops.str2str_amd.torsion_head(lin(t2, wt["fin"])[0], M, True, self.torsion_pred.eps,
+                                                 gt[..., 2, :] if blend else None, fixed_flat if blend else None).view(B, N, 2)
         out7 = torch.ops.str2str_amd.rigid_scale_trans(curr7, self.coordinate_scaling, True)
         return {
+            "psi_blended": blend,
             "in_rigids": Rigid.from_tensor_7(init7),
             "out_rigids": Rigid(Rotation(quats=out7[..., :4], normalize_quats=False), out7[..., 4:]),
             "out_rigids7": out7,

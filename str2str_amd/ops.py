@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 _lib = None
 _tables_loaded = False
@@ -47,6 +47,7 @@ _SIGNATURES = {
     "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "s2s_node_linear_f32": [_vp, _i, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "s2s_node_linear_multi": [_vp, _i, _vp],
+    "s2s_embed_assemble": [_vp, _vp, _ll, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "s2s_row_layernorm": [_vp, _i, _ll, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
     "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _i, _vp],
     "s2s_encoder_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -949,6 +950,23 @@ def small_rows_variant(layer: dict, n_rows: int):
     return "w", layer["tg"]
 
 
+def embed_assemble(t_img, node_const, fa, fb, n_samples: int, n_res: int, planes: bool, b_col_blocked: bool):
+    """The embedder's per-evaluation assembly (s2s_embed_assemble): -> (h as packed planes [M,256] or fp32, node_a [B,L,128], node_b in
+    ``fb``'s layout) from the chunk's timestep image ``t_img`` [512] and the cached per-target terms."""
+    lib = load_library()
+    for n, t in (("t_img", t_img), ("node_const", node_const), ("fa", fa), ("fb", fb)):
+        _req(t, name=n)
+    M, dev = n_samples * n_res, t_img.device
+    if t_img.numel() != 512 or node_const.numel() not in (M * 256, n_res * 256) or fa.numel() != M * 128 or fb.numel() != M * 128:
+        raise HipLibraryError("embed_assemble: bad shapes")
+    h = xp_alloc(M, 256, dev) if planes else torch.empty(M, 256, device=dev, dtype=torch.float32)
+    node_a, node_b = torch.empty(n_samples, n_res, 128, device=dev, dtype=torch.float32), torch.empty_like(fb)
+    range_flag()
+    _check(lib.s2s_embed_assemble(_p(t_img), _p(node_const), node_const.numel() // 256, _p(fa), _p(fb), M, n_res, _p(h) if planes else None,
+                                  None if planes else _p(h), _p(node_a), _p(node_b), int(b_col_blocked), _stream()), "s2s_embed_assemble")
+    return h, node_a, node_b
+
+
 def row_layernorm(x, n_rows: int, n_cols: int, gamma, beta, eps: float, post_mask=None, out_f32=None, out_col0: int = 0, want_f32=True,
                   out_xp=None, out_xp_k: Optional[int] = None, out_xp_k0: int = 0, want_xp=False):
     """LayerNorm (+ post mask) of the leading ``n_cols`` columns of fp32 rows with the node GEMM's epilogue code (s2s_row_layernorm):
@@ -1303,6 +1321,8 @@ _TORCH_OPS = {
             s_xp, *[({"w": t[0], "b": t[1], "k": dims[3 * i], "n": dims[3 * i + 1], "tg": dims[3 * i + 2]} if len(t) else None)
                     for i, t in enumerate((q, k, v, qp, kvp))],
             m, mo, (mp, ms) if mp else None),
+    "embed_assemble(Tensor t_img, Tensor node_const, Tensor fa, Tensor fb, int n_samples, int n_res, bool planes, bool b_col_blocked) "
+    "-> (Tensor, Tensor, Tensor)": lambda *a: embed_assemble(*a),
     "row_layernorm(Tensor x, int n_rows, int n_cols, Tensor gamma, Tensor beta, float eps, Tensor? post_mask=None, Tensor(a!)? out_f32=None, "
     "int out_col0=0, bool want_f32=True, Tensor(b!)? out_xp=None, int out_xp_k=-1, int out_xp_k0=0, bool want_xp=False) -> (Tensor?, Tensor?)":
         lambda x, m, n, g, b, eps, pm=None, of=None, oc=0, wf=True, ox=None, ok=-1, ok0=0, wx=False: row_layernorm(

@@ -696,7 +696,7 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
     names = {sch.split("(")[0] for sch in ops._TORCH_OPS}
     assert names >= {"edge_transition", "edge_transition_f16x3", "edge_transition_f16x3_chain", "edge_embed", "edge_embed_f16x3", "pair_project",
                      "ipa_prep_points", "ipa_attention", "ipa_prep_points_f16", "ipa_prep_points_shared_kv", "ipa_attention_f16w", "encoder_attention", "node_linear",
-                     "node_linear_f32", "node_linear_vfrag", "ipa_projections", "row_layernorm", "pack_planes", "se3_step", "forward_marginal", "rigid_compose_update",
+                     "node_linear_f32", "node_linear_vfrag", "ipa_projections", "row_layernorm", "embed_assemble", "pack_planes", "se3_step", "forward_marginal", "rigid_compose_update",
                      "rigid_scale_trans", "torsion_head", "frames_to_backbone"}
     gen = torch.Generator().manual_seed(11)
     rn = lambda *sh: torch.randn(*sh, generator=gen).to(DEV)
@@ -738,6 +738,20 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
     sh_op = K.ipa_prep_points_shared_kv(r7s, five[3], five[4], d["hw"], xp)
     sh_fn = ops.ipa_prep_points_f16(r7s, five[3], five[4], d["hw"], s_xp=xp)
     assert len(sh_op) == 7 and all((a_ is None and b_ is None) or torch.equal(a_, b_) for a_, b_ in zip(sh_op, sh_fn))
+    # the embedder's per-evaluation assembly: one launch == the elementwise expressions it replaced, bit for bit (fp32 adds, relu, split)
+    Le = 40
+    timg, ncst, fa_ = rn(512), rn(B * Le, 256), rn(B, Le, 128)
+    fb_cb, fb_rm = rn(B, 32, Le, 4), rn(B, Le, 128)
+    h_want = torch.relu(timg[:256] + ncst)
+    for planes in (True, False):
+        for cb in (True, False):
+            got = K.embed_assemble(timg, ncst, fa_, fb_cb if cb else fb_rm, B, Le, planes, cb)
+            assert eq(got, ops.embed_assemble(timg, ncst, fa_, fb_cb if cb else fb_rm, B, Le, planes, cb))
+            assert torch.equal(got[0], ops.pack_planes(h_want) if planes else h_want)
+            assert torch.equal(got[1], timg[256:384] + fa_)
+            assert torch.equal(got[2], (timg[384:].view(32, 1, 4) + fb_cb) if cb else (timg[384:] + fb_rm))
+    got = K.embed_assemble(timg, ncst[:Le].contiguous(), fa_, fb_cb, B, Le, True, True)          # node constants shared by the samples
+    assert torch.equal(got[0], ops.pack_planes(torch.relu(timg[:256] + ncst[:Le]).repeat(B, 1)))
     # linear_out (K = 2688) on few rows runs as a narrow-block GEMM + the LayerNorm on its own (s2s_row_layernorm): bitwise the fused layer
     lo, lnm = w["out"], tr["ipa_ln_0"]
     fx = ops.pack_planes(rn(M, 2688))
