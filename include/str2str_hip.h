@@ -300,8 +300,10 @@ int s2s_node_linear_vfrag(const void* xp, const void* w_packed, const float* bia
 
 /* Up to six INDEPENDENT node layers (bias / ReLU epilogues, no residual / LayerNorm / masks) in one launch -- the five projections of an
  * IPA block (linear_q, the k and v halves of linear_kv, linear_q_points, linear_kv_points: ipa.py:131-171) read the same activations
- * and nothing of each other.  Each problem is the argument list of s2s_node_linear (tiles_per_block 2, 4, 5, 6, 8 or 10) or, with
- * vfrag_tiles_per_head > 0, of s2s_node_linear_vfrag. */
+ * and nothing of each other.  Each problem is the argument list of s2s_node_linear (bias / pre_scale / relu epilogue; tiles_per_block 1, 2,
+ * 4, 5, 6, 8 or 10) or, with vfrag_tiles_per_head > 0, of s2s_node_linear_vfrag.  Besides the IPA projections the trunk runs this way
+ * the four skip_embed layers (they all read the embedder's output) and, per block, BackboneUpdate + the EdgeTransition's per-node
+ * parts (+ the torsion head's first layer after the last block): layers of one input, one launch. */
 typedef struct s2s_node_problem {
     const void* xp; const void* w_packed; const float* bias;
     long long n_rows; int k_in, n_out, tiles_per_block;
@@ -310,6 +312,7 @@ typedef struct s2s_node_problem {
     void* out_xp; int out_xp_ksteps, out_xp_kstep0;
     void* out_vf;
     int map_pad, map_src, relu;
+    const float* pre_scale;   /* [n_rows] or NULL: row scale applied to the accumulator before the bias (s2s_node_linear) */
 } s2s_node_problem;
 int s2s_node_linear_multi(const s2s_node_problem* problems, int n_problems, void* stream);
 

@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) node_gemm_kernel(GemmArgs a) {
 constexpr int kMultiMax = 6;
 struct MultiArgs {
     GemmArgs a[kMultiMax];
-    int kind[kMultiMax];    // 0: <8, false>  1: <8, true> (A-fragment output)  2: <6, false>  3: <5, false>  4: <10, false>  5: <4, false>  6: <2, false>
+    int kind[kMultiMax];    // 0: <8, false>  1: <8, true> (A-fragment output)  2: <6, false>  3: <5, false>  4: <10, false>  5: <4, false>  6: <2, false>  7: <1, false>
     int nx[kMultiMax];
     int cum[kMultiMax + 1];
     int n;
@@ -505,7 +505,8 @@ __global__ void __launch_bounds__(256, 2) node_gemm_multi_kernel(MultiArgs ma) {
         case 3: node_gemm_body<5, 4, false>(a, bx, by); break;
         case 4: node_gemm_body<10, 4, false>(a, bx, by); break;
         case 5: node_gemm_body<4, 4, false>(a, bx, by); break;
-        default: node_gemm_body<2, 4, false>(a, bx, by); break;
+        case 6: node_gemm_body<2, 4, false>(a, bx, by); break;
+        default: node_gemm_body<1, 4, false>(a, bx, by); break;
     }
 }
 
@@ -828,11 +829,11 @@ extern "C" int s2s_node_linear_multi(const s2s_node_problem* pr, int n, void* st
             if ((!q.out_f32 && !q.out_xp) || check_epilogue(q.n_out, TG, nullptr, nullptr, q.out_f32, q.out_ld, q.out_col0, nullptr, 0) ||
                 (q.out_xp && (q.out_xp_kstep0 < 0 || q.out_xp_kstep0 % 2 || q.out_xp_kstep0 + q.n_out / 16 > q.out_xp_ksteps)))
                 return (int)hipErrorInvalidValue;
-            kind = TG == 8 ? 0 : (TG == 6 ? 2 : (TG == 5 ? 3 : (TG == 10 ? 4 : (TG == 4 ? 5 : (TG == 2 ? 6 : -1)))));
+            kind = TG == 8 ? 0 : (TG == 6 ? 2 : (TG == 5 ? 3 : (TG == 10 ? 4 : (TG == 4 ? 5 : (TG == 2 ? 6 : (TG == 1 ? 7 : -1))))));
             if (kind < 0) return (int)hipErrorInvalidValue;
         }
         const int ncb = q.n_out / (32 * TG);
-        ma.a[i] = GemmArgs{(const f16x8*)q.xp, (const char*)q.w_packed, q.bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+        ma.a[i] = GemmArgs{(const f16x8*)q.xp, (const char*)q.w_packed, q.bias, q.pre_scale, nullptr, nullptr, nullptr, nullptr, nullptr,
                            vf ? nullptr : q.out_f32, vf ? nullptr : (f16x8*)q.out_xp, vf ? (f16x8*)q.out_vf : nullptr,
                            vf ? q.vfrag_tiles_per_head : 0, q.n_rows, q.k_in / 16, ncb, 0, q.out_ld, q.out_col0, q.out_xp_ksteps,
                            q.out_xp_kstep0, q.relu, 0.f, 0, s2s::g_range_flag, q.map_pad, q.map_src};

@@ -343,6 +343,15 @@ class TranslationIPA(nn.Module):
             init_a = ops.to_act(s_f32, self.arith)
         s_a = init_a
         D = C + T["skip_embed_0"].out_features     # transformer width (320)
+        # every block's skip_embed reads the embedder's output: the four layers are ONE launch, each into its block's buffer
+        xbuf = []
+        for b in range(self.num_blocks):
+            xf = torch.empty(M, D, device=dev, dtype=torch.float32)
+            xbuf.append((xf, ops.xp_alloc(M, D, dev) if f16 else xf))
+        skip_done = None
+        if f16 and 2 <= self.num_blocks <= 6:
+            skip_done = ops.node_apply_multi(init_a, [(W[b]["skip"], dict(out_f32=xbuf[b][0], out_col0=C, out_xp=xbuf[b][1], out_xp_k=D, out_xp_k0=C))
+                                                      for b in range(self.num_blocks)], M)
         for b in range(self.num_blocks):
             w, ipa = W[b], T[f"ipa_{b}"]
             # ---- InvariantPointAttention (:100-268): projections -> points -> attention core -> linear_out (+mask, +residual, LN)
@@ -354,11 +363,11 @@ class TranslationIPA(nn.Module):
             feats_a = ipa.attention(s_a, B, N, curr7, node_mask, tuple(proj))
             proj = None
             ln = T[f"ipa_ln_{b}"]
-            x_f32 = torch.empty(M, D, device=dev, dtype=torch.float32)     # [node_embed | skip_embed(init)] (:356)
-            x_a = ops.xp_alloc(M, D, dev) if f16 else x_f32
+            x_f32, x_a = xbuf[b]                                           # [node_embed | skip_embed(init)] (:356)
             lin(feats_a, ipa.out_pack(feats_a), pre_mask=nm, residual=s_f32, ln=(ln.weight, ln.bias, ln.eps), out_f32=x_f32,
                 out_xp=x_a, out_xp_k=D)
-            lin(init_a, w["skip"], out_f32=x_f32, out_col0=C, out_xp=x_a, out_xp_k=D, out_xp_k0=C)
+            if skip_done is None:
+                lin(init_a, w["skip"], out_f32=x_f32, out_col0=C, out_xp=x_a, out_xp_k=D, out_xp_k0=C)
             # ---- 2 x post-norm TransformerEncoderLayer (:312-317,357)
             xf, xx = x_f32, x_a
             for layer, lw in zip(T[f"transformer_{b}"].layers, w["layers"]):
@@ -374,13 +383,21 @@ class TranslationIPA(nn.Module):
             _, h2 = lin(h1, w["nt2"], relu=True, want_f32=False, want_xp=True)
             nt = T[f"node_transition_{b}"]
             s_f32, s_a = lin(h2, w["nt3"], residual=n_f32, ln=(nt.ln.weight, nt.ln.bias, nt.ln.eps), post_mask=nm, want_xp=True)
-            # ---- backbone update (:361-365)
-            upd, _ = lin(s_a, w["bb"], pre_scale=dm)
+            # ---- backbone update (:361-365) and the layers that read the same s: the EdgeTransition's per-node parts (:367-372; their
+            #      pair MLP runs in its own kernel below), after the last block the torsion head's first layer -- ONE launch
+            has_et = b < self.num_blocks - 1
+            et = T[f"edge_transition_{b}"] if has_et else None
+            specs = [(w["bb"], dict(pre_scale=dm))]
+            if has_et:
+                nl = et.node_layers()
+                specs += [(nl["init"], {}), (nl["ab_s"], {})]
+            else:
+                specs += [(W["tor"]["l1"], dict(relu=True, want_f32=False, want_xp=True))]
+            outs = ops.node_apply_multi(s_a, specs, M)
+            upd = outs[0][0]
             curr7 = torch.ops.str2str_amd.rigid_compose_update(curr7, upd, diffuse_mask)   # (the padded [M, 32] output in place: no copy)
-            # ---- EdgeTransition (:367-372): per-node parts here, the pair MLP in its own kernel
-            if b < self.num_blocks - 1:
-                et = T[f"edge_transition_{b}"]
-                n_p, node_ab = et.node_parts(s_a, M)
+            if has_et:
+                n_p, node_ab = outs[1][0], outs[2][0]
                 nxt = T[f"ipa_{b + 1}"].pair_proj_weights() if self.fuse_pair_projection else None
                 # f16x3 with fused projections: the pair tensor stays in the kernels' tiled layout, and the last EdgeTransition's
                 # output (read by nothing but the projections it already carries) is not written
@@ -398,7 +415,7 @@ class TranslationIPA(nn.Module):
                 else:
                     edge_embed = res
         wt = W["tor"]
-        _, t1 = lin(s_a, wt["l1"], relu=True, want_f32=False, want_xp=True)
+        t1 = outs[1][1]
         _, t2 = lin(t1, wt["l2"], residual=s_f32, want_f32=False, want_xp=True)
         # u / sqrt(max(sum u^2, eps)) (layers.py:199-213) straight from the head's padded output: one launch instead of six tiny ones
         # ... and DenoisingNet's blend with the input torsion under the fixed mask (denoising_ipa.py:192-193) in the same launch

@@ -157,7 +157,13 @@ class EdgeTransition(nn.Module):
             ce, cb = self._shape[0], self._shape[1]
             w_ab = torch.cat([w1.weight[:, ce:ce + cb], w1.weight[:, ce + cb:]], dim=0).float().contiguous()
             b_ab = torch.cat([w1.bias, torch.zeros_like(w1.bias)]).float().contiguous()
-            return {"init": ops.pack_node_layer(ie.weight, ie.bias), "ab": ops.pack_node_layer(w_ab, b_ab)}
+            # "ab_s": the same vectors straight from s -- W_ab (W_ie s + b_ie) + b_ab = (W_ab W_ie) s + (W_ab b_ie + b_ab), folded in float64 on
+            # the host -- so that both per-node parts read the block's node activations and run in ONE launch with the backbone update
+            w64, ie64 = w_ab.detach().double().cpu(), ie.weight.detach().double().cpu()
+            w_abs = (w64 @ ie64).float().to(w_ab.device)
+            b_abs = (w64 @ ie.bias.detach().double().cpu() + b_ab.detach().double().cpu()).float().to(w_ab.device)
+            return {"init": ops.pack_node_layer(ie.weight, ie.bias), "ab": ops.pack_node_layer(w_ab, b_ab),
+                    "ab_s": ops.pack_node_layer(w_abs, b_abs)}
 
         return self._node_cache.get([w1.weight, w1.bias, ie.weight, ie.bias], build)
 

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 _lib = None
 _tables_loaded = False
@@ -1059,7 +1059,38 @@ class _NodeProblem(ctypes.Structure):   # s2s_node_problem (include/str2str_hip.
                 ("k_in", ctypes.c_int), ("n_out", ctypes.c_int), ("tiles_per_block", ctypes.c_int), ("vfrag_tiles_per_head", ctypes.c_int),
                 ("out_f32", ctypes.c_void_p), ("out_ld", ctypes.c_int), ("out_col0", ctypes.c_int), ("out_xp", ctypes.c_void_p),
                 ("out_xp_ksteps", ctypes.c_int), ("out_xp_kstep0", ctypes.c_int), ("out_vf", ctypes.c_void_p), ("map_pad", ctypes.c_int),
-                ("map_src", ctypes.c_int), ("relu", ctypes.c_int)]
+                ("map_src", ctypes.c_int), ("relu", ctypes.c_int), ("pre_scale", ctypes.c_void_p)]
+
+
+def node_linear_multi(xp, w, bias, pre_scale, dims, out_f32, out_xp):
+    """Up to six node layers that read the same packed planes ``xp``, in ONE launch (s2s_node_linear_multi).  Lists, one entry per
+    layer: ``w`` (packed weights), ``bias``, ``pre_scale`` ([n_rows] row scale or an empty tensor), ``out_f32`` / ``out_xp`` (the
+    caller's output buffers, written in place; an empty tensor = that output is not wanted), and in ``dims`` nine ints per layer:
+    n_rows, k_in, n_out, tiles_per_block, out_ld (row stride of out_f32), out_col0, out_xp_k (width of the planes buffer), out_xp_k0, relu.
+    Bitwise what the separate s2s_node_linear launches give."""
+    lib = load_library()
+    _req(xp, torch.int16, "xp")
+    n = len(w)
+    if not (1 <= n <= 6) or any(len(x) != n for x in (bias, pre_scale, out_f32, out_xp)) or len(dims) != 9 * n:
+        raise HipLibraryError("node_linear_multi: 1 .. 6 layers, one entry per layer in every list, nine ints per layer")
+    arr = (_NodeProblem * n)()
+    for i in range(n):
+        rows, k, nn, tg, ld, c0, xk, xk0, relu = (int(v) for v in dims[9 * i:9 * i + 9])
+        _req(w[i], torch.int16, "w"); _req(bias[i], name="bias")
+        p = arr[i]
+        p.xp, p.w_packed, p.bias = xp.data_ptr(), w[i].data_ptr(), bias[i].data_ptr()
+        p.n_rows, p.k_in, p.n_out, p.tiles_per_block, p.relu = rows, k, nn, tg, relu
+        if pre_scale[i].numel():
+            _req(pre_scale[i], name="pre_scale")
+            p.pre_scale = pre_scale[i].data_ptr()
+        if out_f32[i].numel():
+            _req(out_f32[i], name="out_f32")
+            p.out_f32, p.out_ld, p.out_col0 = out_f32[i].data_ptr(), ld, c0
+        if out_xp[i].numel():
+            _req(out_xp[i], torch.int16, "out_xp")
+            p.out_xp, p.out_xp_ksteps, p.out_xp_kstep0 = out_xp[i].data_ptr(), xk // 16, xk0 // 16
+    range_flag()
+    _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_multi(ctypes.byref(arr), n, _stream())), "s2s_node_linear_multi")
 
 
 def ipa_projections(s_xp, q, k, v, qp, kvp, n_rows: int, n_rows_padded: int, row_map: Optional[tuple] = None, tiles_per_head: int = 8):
@@ -1100,6 +1131,37 @@ def ipa_projections(s_xp, q, k, v, qp, kvp, n_rows: int, n_rows_padded: int, row
     range_flag()
     _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_multi(ctypes.byref(arr), n, _stream())), "s2s_node_linear_multi")
     return q_xp, k_xp, v_vf, qp_o, kvp_o
+
+
+def node_apply_multi(x, specs, n_rows: int):
+    """Several layers of ONE input in one launch: ``specs`` = [(layer, kwargs)], kwargs as for ``node_apply`` restricted to what the
+    multi-problem kernel carries (relu, pre_scale, out_f32 / out_col0 / want_f32, out_xp / out_xp_k / out_xp_k0 / want_xp).
+    -> [(out_f32, out_xp)] like ``node_apply``.  fp32 activations (arithmetic "f32") run the layers one after the other."""
+    if x.dtype != torch.int16 or len(specs) > 6 or len(specs) < 2:
+        return [node_apply(x, layer, n_rows, **kw) for layer, kw in specs]
+    dev = x.device
+    empty_f, empty_i = torch.empty(0, device=dev), torch.empty(0, dtype=torch.int16, device=dev)
+    w, bias, ps, dims, of, ox, res = [], [], [], [], [], [], []
+    for layer, kw in specs:
+        if set(kw) - {"relu", "pre_scale", "out_f32", "out_col0", "want_f32", "out_xp", "out_xp_k", "out_xp_k0", "want_xp"}:
+            raise HipLibraryError(f"node_apply_multi: unsupported epilogue option in {sorted(kw)}")
+        key, tg = small_rows_variant(layer, n_rows)
+        o32, oxp = kw.get("out_f32"), kw.get("out_xp")
+        if o32 is None and kw.get("want_f32", True):
+            o32 = torch.empty(n_rows, layer["n"], device=dev, dtype=torch.float32)
+        xk = kw.get("out_xp_k")
+        if oxp is None and kw.get("want_xp", False):
+            xk = layer["n"] if xk is None else xk
+            oxp = xp_alloc(n_rows, xk, dev)
+        if oxp is not None and xk is None:
+            xk = layer["n"]
+        w.append(layer[key]); bias.append(layer["b"]); ps.append(kw["pre_scale"] if kw.get("pre_scale") is not None else empty_f)
+        dims += [n_rows, layer["k"], layer["n"], tg, o32.shape[-1] if o32 is not None else 0, kw.get("out_col0", 0), xk or 0,
+                 kw.get("out_xp_k0", 0), int(bool(kw.get("relu", False)))]
+        of.append(o32 if o32 is not None else empty_f); ox.append(oxp if oxp is not None else empty_i)
+        res.append((o32, oxp))
+    torch.ops.str2str_amd.node_linear_multi(x, w, bias, ps, dims, of, ox)
+    return res
 
 
 def encoder_attention(qkv: torch.Tensor, key_bias: Optional[torch.Tensor], n_samples: int, n_res: int, n_heads: int = 4,
@@ -1323,6 +1385,8 @@ _TORCH_OPS = {
             m, mo, (mp, ms) if mp else None),
     "embed_assemble(Tensor t_img, Tensor node_const, Tensor fa, Tensor fb, int n_samples, int n_res, bool planes, bool b_col_blocked) "
     "-> (Tensor, Tensor, Tensor)": lambda *a: embed_assemble(*a),
+    "node_linear_multi(Tensor xp, Tensor[] w, Tensor[] bias, Tensor[] pre_scale, int[] dims, Tensor(a!)[] out_f32, Tensor(b!)[] out_xp) -> ()":
+        lambda *a: node_linear_multi(*a),
     "row_layernorm(Tensor x, int n_rows, int n_cols, Tensor gamma, Tensor beta, float eps, Tensor? post_mask=None, Tensor(a!)? out_f32=None, "
     "int out_col0=0, bool want_f32=True, Tensor(b!)? out_xp=None, int out_xp_k=-1, int out_xp_k0=0, bool want_xp=False) -> (Tensor?, Tensor?)":
         lambda x, m, n, g, b, eps, pm=None, of=None, oc=0, wf=True, ox=None, ok=-1, ok0=0, wx=False: row_layernorm(

@@ -696,7 +696,7 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
     names = {sch.split("(")[0] for sch in ops._TORCH_OPS}
     assert names >= {"edge_transition", "edge_transition_f16x3", "edge_transition_f16x3_chain", "edge_embed", "edge_embed_f16x3", "pair_project",
                      "ipa_prep_points", "ipa_attention", "ipa_prep_points_f16", "ipa_prep_points_shared_kv", "ipa_attention_f16w", "encoder_attention", "node_linear",
-                     "node_linear_f32", "node_linear_vfrag", "ipa_projections", "row_layernorm", "embed_assemble", "pack_planes", "se3_step", "forward_marginal", "rigid_compose_update",
+                     "node_linear_f32", "node_linear_vfrag", "ipa_projections", "node_linear_multi", "row_layernorm", "embed_assemble", "pack_planes", "se3_step", "forward_marginal", "rigid_compose_update",
                      "rigid_scale_trans", "torsion_head", "frames_to_backbone"}
     gen = torch.Generator().manual_seed(11)
     rn = lambda *sh: torch.randn(*sh, generator=gen).to(DEV)
@@ -738,6 +738,23 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
     sh_op = K.ipa_prep_points_shared_kv(r7s, five[3], five[4], d["hw"], xp)
     sh_fn = ops.ipa_prep_points_f16(r7s, five[3], five[4], d["hw"], s_xp=xp)
     assert len(sh_op) == 7 and all((a_ is None and b_ is None) or torch.equal(a_, b_) for a_, b_ in zip(sh_op, sh_fn))
+    # layers of one input in one launch (the trunk: four skip_embeds; BackboneUpdate + the EdgeTransition's per-node parts) == the launches
+    nl, tw = et.node_layers(), net_rough.translator._node_weights()
+    dmk = torch.rand(M, generator=gen).to(DEV)
+    xf, xa = torch.zeros(M, 320, device=DEV), torch.zeros_like(ops.xp_alloc(M, 320, DEV))
+    specs = [(tw[0]["bb"], dict(pre_scale=dmk)), (nl["init"], {}), (nl["ab_s"], {}),
+             (tw["tor"]["l1"], dict(relu=True, want_f32=False, want_xp=True)),
+             (tw[0]["skip"], dict(out_f32=xf, out_col0=256, out_xp=xa, out_xp_k=320, out_xp_k0=256))]
+    multi = ops.node_apply_multi(xp, specs, M)
+    xf1, xa1 = torch.zeros(M, 320, device=DEV), torch.zeros_like(xa)
+    specs[4][1].update(out_f32=xf1, out_xp=xa1)
+    for (layer, kw), got in zip(specs, multi):
+        want = ops.node_apply(xp, layer, M, **kw)
+        assert all((a_ is None and b_ is None) or torch.equal(a_, b_) for a_, b_ in zip(got, want))
+    assert torch.equal(xf, xf1) and torch.equal(xa, xa1)
+    # the folded per-node part of the edge transition (W_ab (W_ie s + b_ie) + b_ab as one layer from s) against the two-layer form
+    n_p2, ab2 = et.node_parts(xp, M)
+    assert torch.equal(multi[1][0], n_p2) and rel(multi[2][0], ab2) < 2e-6
     # the embedder's per-evaluation assembly: one launch == the elementwise expressions it replaced, bit for bit (fp32 adds, relu, split)
     Le = 40
     timg, ncst, fa_ = rn(512), rn(B * Le, 256), rn(B, Le, 128)
