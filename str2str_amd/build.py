@@ -32,12 +32,15 @@ UNITS = {
     "ensemble_metrics.hip": ["-ffp-contract=off"],
     # the MFMA chains are fully unrolled on purpose (accumulator tiles must be statically indexed)
     "pair_mlp.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
-    "pair_mlp_f16.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
+    # (no SLP vectorisation in the split-f16 pair kernels: hipcc packs the LayerNorm / epilogue arithmetic into v_pk_*_f32, and a packed
+    #  fp32 instruction issued between MFMAs costs 6-10 matrix-pipe cycles against 2 x 2.3 for the two plain ones it replaces:
+    #  tools/ubench/mfma_valu_overlap.hip; -0.3 .. -1.1 % per edge-transition launch, same-call A/B)
+    "pair_mlp_f16.hip": ["-mllvm", "-pragma-unroll-threshold=10000000", "-fno-slp-vectorize"],
     "ipa_attention.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
     "ipa_attention_f16w.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
-    "node_gemm.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
+    "node_gemm.hip": ["-mllvm", "-pragma-unroll-threshold=10000000", "-fno-slp-vectorize"],   # (as above: node layers -2.4 %)
     # contraction off: the packed-plane output must be the exact split of the SAME rounded value the fp32 output stores
-    "enc_attention.hip": ["-mllvm", "-pragma-unroll-threshold=10000000", "-ffp-contract=off"],
+    "enc_attention.hip": ["-mllvm", "-pragma-unroll-threshold=10000000", "-ffp-contract=off", "-fno-slp-vectorize"],   # (-5 %)
 }
 
 

@@ -595,8 +595,16 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             f16x8 (&P)[2] = ep_blk == 1 ? xq[2 * t + (rq >> 1)] : xpl[2 * t + (rq >> 1)];
             float r0, r1;
             if constexpr (ep_blk == 0) {   // the residual of block 0 is the edge row = x_h + x_l of the planes this piece replaces (to 2^-24 |x|)
+#ifndef S2S_ET_NO_MIXRES
+                // (float) x_h + (float) x_l as ONE v_fma_mix_f32 per value (x_h * 1.0 + x_l with both read as f16: the same single rounding
+                //  as convert, convert, add)
+                const unsigned hw = __builtin_bit_cast(u32x4p, P[0])[e0 / 2], lw = __builtin_bit_cast(u32x4p, P[1])[e0 / 2];
+                asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel_hi:[1,0,1]" : "=v"(r0) : "v"(hw), "v"(lw));
+                asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(r1) : "v"(hw), "v"(lw));
+#else
                 r0 = (float)P[0][e0] + (float)P[1][e0];
                 r1 = (float)P[0][e0 + 1] + (float)P[1][e0 + 1];
+#endif
             } else {
                 const float (&row)[64] = ep_blk == 1 ? rs : rs2;
                 r0 = row[16 * t + j0];

@@ -253,8 +253,18 @@ class DenoisingNet(nn.Module):
         self.translator = translator
         self.backbone_in_forward = True  # the sampler turns this off inside its loop (result unused there)
 
-    def forward(self, batch: dict, as_tensor_7: bool = False) -> dict:
-        """reference :171-211: {'rigids', 'psi', 'atom37', 'atom14'} (+ 'rigids7', the frames as one tensor)."""
+    @staticmethod
+    def blend_psi(psi: torch.Tensor, torsion_angles_sin_cos: torch.Tensor, fixed_mask: torch.Tensor) -> torch.Tensor:
+        """gt_psi * fixed + psi * (1 - fixed) (reference :192-193; the result takes the features' dtype, as there)."""
+        gt_psi = torsion_angles_sin_cos.to(psi.device)[..., 2, :]
+        fixed_mask = fixed_mask.to(psi.device).type(torch.float)
+        return gt_psi * fixed_mask[..., None] + psi * (1 - fixed_mask[..., None])
+
+    def forward(self, batch: dict, as_tensor_7: bool = False, defer_psi_blend: bool = False) -> dict:
+        """reference :171-211: {'rigids', 'psi', 'atom37', 'atom14'} (+ 'rigids7', the frames as one tensor).
+        ``defer_psi_blend`` (the sampler's loop): 'psi' is the torsion head's own output and 'psi_deferred' is set -- the blend with the
+        input torsion under the fixed mask (:192-193; float64 for float64 features) feeds nothing inside the loop, the sampler
+        applies it once to the last evaluation (``blend_psi``)."""
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise ops.HipLibraryError(
@@ -276,13 +286,14 @@ class DenoisingNet(nn.Module):
         tb["rigids_t"] = batch["rigids_t"].to(dev)
         tb["_node_embed_act"] = getattr(self.embedder, "node_embed_act", None)
         model_out = self.translator(node_embed, edge_embed, tb, **({"_first_proj": emb[2]} if fuse else {}))
-        if model_out.get("psi_blended"):     # the torsion head's kernel already blended with the input torsion under the fixed mask
+        if model_out.get("psi_blended") or defer_psi_blend:     # (the torsion head's kernel blends float32 features in its own launch)
             psi_pred = model_out["psi"]
         else:
-            gt_psi = batch["torsion_angles_sin_cos"].to(dev)[..., 2, :]
-            psi_pred = gt_psi * fixed_mask[..., None] + model_out["psi"] * (1 - fixed_mask[..., None])
+            psi_pred = self.blend_psi(model_out["psi"], batch["torsion_angles_sin_cos"], fixed_mask)
         rigids_pred = model_out["out_rigids"]
         out = {"rigids": rigids_pred, "psi": psi_pred, "rigids7": model_out["out_rigids7"]}
+        if defer_psi_blend and not model_out.get("psi_blended"):
+            out["psi_deferred"] = True
         if self.backbone_in_forward:
             aatype = batch["aatype"].to(dev) if "aatype" in batch else None
             bb = compute_backbone(rigids_pred, psi_pred, aatype=aatype, _rigids7=model_out["out_rigids7"])

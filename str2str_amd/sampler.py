@@ -53,11 +53,11 @@ class _GraphedNet:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # warm-up on a side stream (caches, BLAS workspaces), as graph capture requires
             for _ in range(2):
-                net(self.feats, as_tensor_7=False)
+                _net_eval(net, self.feats, True)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out = net(self.feats, as_tensor_7=False)
+            self.out = _net_eval(net, self.feats, True)
         # The captured kernels hold raw pointers to every tensor the evaluation read.  Those allocated INSIDE the capture live in the
         # graph's private pool; the ones built by the warm-up outside it must be kept alive by THIS object, because their only other
         # owner is a single-slot cache that the next evaluation of another shape overwrites: the embedder's per-target tables
@@ -96,6 +96,13 @@ def _graph_read_tensors(net):
             if isinstance(v, ParamCache):
                 tensors(v.pinned(), keep)
     return keep
+
+
+def _net_eval(net, feats, defer_psi: bool):
+    """One evaluation inside the loop: the psi blend is deferred to the last step where the network supports it."""
+    if defer_psi and hasattr(net, "blend_psi"):
+        return net(feats, as_tensor_7=False, defer_psi_blend=True)
+    return net(feats, as_tensor_7=False)
 
 
 _GRAPH_CACHE = {}   # (net id, parameter versions, b, N, feature bytes) -> _GraphedNet; a few entries (one per chunk shape)
@@ -273,8 +280,11 @@ def _denoise_pass(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: fl
     device = rigids_t.device
     b, N = rigids_t.shape[:2]
     feats = dict(feats)
-    mask = feats["residue_mask"].float().contiguous()
-    diffuse_mask = ((1 - feats["fixed_mask"].float()) * mask).contiguous()
+    # the masks as float32 device tensors ONCE per chunk: the network's per-chunk caches (embedder terms, mask terms) key on their identity
+    for k in ("residue_mask", "fixed_mask"):
+        feats[k] = feats[k].to(device).float().contiguous()
+    mask = feats["residue_mask"]
+    diffuse_mask = ((1 - feats["fixed_mask"]) * mask).contiguous()
     t_all = torch.as_tensor(np.ascontiguousarray(ts, dtype=np.float64)).float()  # fl32(t), as `t * torch.ones(B)` gives
     p8_all = diffuser.step_params(t_all).to(device)  # [n, 8]: t is uniform over the chunk
     # timestep embeddings of the whole schedule, uploaded once (same host function the network would call per step)
@@ -293,7 +303,7 @@ def _denoise_pass(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: fl
         if timg_all is not None:
             feats["t_img"] = timg_all[0]
         graphed = _maybe_graph(net, feats, b, N, trace, len(ts))
-        run = graphed if graphed is not None else (lambda f: net(f, as_tensor_7=False))
+        run = graphed if graphed is not None else (lambda f: _net_eval(net, f, trace is None))
         if self_conditioning:
             feats["sc_ca_t"] = run(feats)["rigids7"][..., 4:].clone()
         final = None
@@ -326,6 +336,8 @@ def _denoise_pass(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: fl
                 trace.append(dict(t=t, rigids_t=feats["rigids_t"], sc_ca_t=sc_in, x0=x0_7, psi=out["psi"], rot_score=rs,
                                   trans_score=tsc, next7=nxt))
             feats["rigids_t"] = nxt
+        if final.get("psi_deferred"):   # the blend with the input torsion under the fixed mask, once (DenoisingNet.blend_psi)
+            final = dict(final, psi=net.blend_psi(final["psi"], feats["torsion_angles_sin_cos"], feats["fixed_mask"]))
         atom37 = compute_backbone(final["rigids"], final["psi"], aatype=feats.get("aatype"), _rigids7=final["rigids7"])[0]
     finally:
         if keep_bb is not None:
