@@ -510,6 +510,148 @@ __global__ void __launch_bounds__(256, 2) node_gemm_multi_kernel(MultiArgs ma) {
     }
 }
 
+// A CHAIN of square layers in one launch (s2s_node_chain): x -> relu(W_1 x + b_1) -> ... -> epilogue(W_L h + b_L), width N = K = 32 TG,
+// one column block = the whole row.  The accumulator layout of a layer is the B-operand layout of the next one (header of this file),
+// so the hidden activations never leave the registers: after an inner layer the common epilogue (bias, ReLU) runs on the accumulators
+// and they are split into the f16 planes of the next layer's 2 TG k-steps in place (xr); only the last layer has outputs and the
+// full epilogue (mask, residual, LayerNorm).  Same k-step order, same products, same epilogue code as the single launches: the chain
+// equals them bit for bit.  For NodeTransition (linear_1 -> linear_2 -> linear_3 + residual + LayerNorm, reference layers.py:128-145),
+// the encoder layers' feed-forward (linear1 -> linear2 + residual + norm2, ipa.py:312-317) and the embedder's node MLP
+// (denoising_ipa.py:113-120): at a few thousand rows every launch is one workgroup's latency chain, and at 32 k rows the hidden
+// activations' 4 B per value in each direction were all these layers did besides their MFMAs.
+constexpr int kChainMax = 3;
+struct ChainArgs {
+    GemmArgs a;                      // xp / M / epilogue operands and outputs of the LAST layer
+    const char* w[kChainMax];
+    const float* bias[kChainMax];
+    int relu[kChainMax];
+    int n_layers;
+};
+template <int I> struct CI { static constexpr int value = I; };
+template <int B, int E, class F>
+__device__ __forceinline__ void chain_for(F&& f) {
+    if constexpr (B < E) {
+        f(CI<B>{});
+        chain_for<B + 1, E>(f);
+    }
+}
+
+template <int TG>
+__global__ void __launch_bounds__(256, 1) node_chain_kernel(ChainArgs c) {
+    constexpr int KS = 2 * TG;                 // k-steps of every layer (K = N = 32 TG)
+    constexpr int kStage = 2 * TG * 1024;      // one k-step of weights: TG tiles x 2 planes
+    constexpr int kFrags = 2 * TG, kPieces = (kFrags + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) char s_w[];   // 2 stages
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const GemmArgs& a = c.a;
+    const long long rt = (long long)blockIdx.x * 4 + wave;
+    const long long n_rt = (a.M + 31) / 32;
+    const long long rtc = rt < n_rt ? rt : n_rt - 1;
+    typedef __attribute__((address_space(3))) char lds_char;
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    typedef __attribute__((address_space(3))) f16x8 lds_frag;
+
+    f32x4 wst[kPieces];
+    const char* wsrc = c.w[0] + lane * 16;
+    auto w_load = [&](int ks) {   // (ks < KS: the caller never asks beyond a layer)
+        const char* src = wsrc + (long long)ks * kStage;
+#pragma unroll
+        for (int k = 0; k < kPieces; ++k)
+            if (4 * k + 3 < kFrags || 4 * k + wave < kFrags) wst[k] = *reinterpret_cast<const f32x4*>(src + (4 * k + wave) * 1024);
+    };
+    auto w_store = [&](int par) {
+        lds_char* dst = (lds_char*)s_w + par * kStage + lane * 16;
+#pragma unroll
+        for (int k = 0; k < kPieces; ++k)
+            if (4 * k + 3 < kFrags || 4 * k + wave < kFrags) *(lds_f4*)(dst + (4 * k + wave) * 1024) = wst[k];
+    };
+    f16x8 xr[KS][2];     // the layer's input planes: k-step ks = registers 8u .. 8u+7 of the previous layer's tile t (ks = 2t + u)
+    {
+        const f16x8* xsrc = a.xp + (rtc * KS) * 2 * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { xr[ks][0] = xsrc[(ks * 2) * 64]; xr[ks][1] = xsrc[(ks * 2 + 1) * 64]; }
+    }
+    f32x16 acc[TG];
+    const long long row = rt * 32 + (lane & 31);
+    const bool valid = rt < n_rt && row < a.M;
+    const long long rowc = valid ? row : a.M - 1;
+    auto compute = [&](int par, const f16x8 (&x)[2]) {   // as node_gemm_body: W_l reads first, one W_h read behind each MFMA of the first pass
+        const lds_frag* wl = (const lds_frag*)((lds_char*)s_w + par * kStage) + lane;
+        f16x8 fl[TG], fh[TG];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < TG; ++t) fl[t] = wl[t * 128 + 64];
+#pragma unroll
+        for (int t = 0; t < TG; ++t) fh[t] = wl[t * 128];
+#pragma unroll
+        for (int t = 0; t < TG; ++t) acc[t] = mfma_f16(fl[t], x[0], acc[t]);
+#pragma unroll
+        for (int t = 0; t < TG; ++t) acc[t] = mfma_f16(fh[t], x[1], acc[t]);
+#pragma unroll
+        for (int t = 0; t < TG; ++t) acc[t] = mfma_f16(fh[t], x[0], acc[t]);
+        __builtin_amdgcn_sched_group_barrier(0x100, TG, 0);
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * TG, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    float amax = 0.f;
+    // layer 0's first stages
+    w_load(0);
+    w_store(0);
+    w_load(1);
+    __syncthreads();
+    for (int l = 0; l < c.n_layers; ++l) {
+        const bool last = l == c.n_layers - 1;
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        // k-steps (static: the input planes live in registers); the weight stream runs on into the next layer's first stages
+        chain_for<0, KS>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value, par = ks & 1;
+            compute(par, xr[ks]);
+            if constexpr (ks + 1 < KS) {
+                w_store(par ^ 1);                 // k-step ks + 1 (loaded one stage ago)
+                if constexpr (ks + 2 < KS) w_load(ks + 2);
+                else if (!last) { wsrc = c.w[l + 1] + lane * 16; w_load(0); }
+                __syncthreads();
+            } else if (!last) {                    // ks = KS - 1: wst holds stage 0 of the next layer (KS is even: it goes to buffer 0)
+                __syncthreads();                   // everyone is done reading buffer 0 (k-step KS - 2) ... and buffer 1 after the next barrier
+                w_store(0);
+                w_load(1);
+                __syncthreads();
+            }
+        });
+        if (last) break;
+        // inner layer: bias + ReLU through the common epilogue (no mask, residual, LayerNorm, outputs), then the split into the next
+        // layer's input planes -- exactly the values the single launch would have stored as packed planes
+        GemmArgs inner = a;
+        inner.bias = c.bias[l]; inner.relu = c.relu[l];
+        inner.pre_scale = nullptr; inner.pre_mask = nullptr; inner.residual = nullptr; inner.ln_gamma = nullptr; inner.ln_beta = nullptr;
+        inner.post_mask = nullptr; inner.out_f32 = nullptr; inner.out_xp = nullptr;
+        node_epilogue<TG>(acc, inner, rt, n_rt, lane, 0, kInvWS);
+#pragma unroll
+        for (int t = 0; t < TG; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = valid ? acc[t][8 * u + j] : 0.f;
+                split8_f16(v, xr[2 * t + u][0], xr[2 * t + u][1], amax);
+            }
+    }
+    s2s::range_report(a.range_flag, amax, s2s::kRangeNodeGemm);
+    GemmArgs fin = a;
+    fin.bias = c.bias[c.n_layers - 1]; fin.relu = c.relu[c.n_layers - 1];
+    const float ps = (a.pre_scale ? a.pre_scale[rowc] : 1.0f) * kInvWS;
+    node_epilogue<TG>(acc, fin, rt, n_rt, lane, 0, ps);
+}
+
 // The LayerNorm half of a layer whose GEMM ran WITHOUT it (s2s_row_layernorm): a wave loads its 32 rows of the pre-LayerNorm fp32
 // values into accumulator layout and runs the SAME epilogue function as the fused kernel (scale 1, zero bias: x * 1 + 0 is exact),
 // so the split form equals the fused one bit for bit.  For layers with a long contraction on few rows (linear_out: K = 2688), where
@@ -808,6 +950,38 @@ extern "C" int s2s_node_probe_read(unsigned long long* host_out, int reset) {
 #endif
 
 // Up to six independent layers (bias / ReLU epilogues only) in ONE launch: see node_gemm_multi_kernel.
+extern "C" int s2s_node_chain(const void* xp, const s2s_chain_layer* layers, int n_layers, long long n_rows, int width,
+                              const float* pre_mask, const float* residual, int residual_ld, const float* ln_gamma, const float* ln_beta,
+                              float ln_eps, const float* post_mask, float* out_f32, int out_ld, int out_col0, void* out_xp,
+                              int out_xp_ksteps, int out_xp_kstep0, void* stream) {
+    if (n_rows <= 0) return 0;
+    const int TG = width / 32;
+    if (!xp || !layers || n_layers < 2 || n_layers > kChainMax || width % 32 || (TG != 8 && TG != 10) || (!out_f32 && !out_xp) ||
+        check_epilogue(width, TG, ln_gamma, ln_beta, out_f32, out_ld, out_col0, residual, residual_ld) ||
+        (out_xp && (out_xp_kstep0 < 0 || out_xp_kstep0 % 2 || out_xp_kstep0 + width / 16 > out_xp_ksteps)))
+        return (int)hipErrorInvalidValue;
+    ChainArgs c{};
+    c.a = GemmArgs{(const f16x8*)xp, nullptr, nullptr, nullptr, pre_mask, residual, ln_gamma, ln_beta, post_mask, out_f32, (f16x8*)out_xp,
+                   nullptr, 0, n_rows, width / 16, 1, residual_ld, out_ld, out_col0, out_xp_ksteps, out_xp_kstep0, 0, ln_eps, 0,
+                   s2s::g_range_flag, 0, 0};
+    c.n_layers = n_layers;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!layers[l].w_packed) return (int)hipErrorInvalidValue;
+        c.w[l] = (const char*)layers[l].w_packed; c.bias[l] = layers[l].bias; c.relu[l] = layers[l].relu;
+    }
+    const long long n_rt = (n_rows + 31) / 32;
+    const unsigned grid = (unsigned)((n_rt + 3) / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (TG == 8) {
+        constexpr int lds = 2 * 2 * 8 * 1024;
+        hipLaunchKernelGGL(node_chain_kernel<8>, dim3(grid), dim3(256), lds, st, c);
+    } else {
+        constexpr int lds = 2 * 2 * 10 * 1024;
+        hipLaunchKernelGGL(node_chain_kernel<10>, dim3(grid), dim3(256), lds, st, c);
+    }
+    return (int)hipGetLastError();
+}
+
 extern "C" int s2s_node_linear_multi(const s2s_node_problem* pr, int n, void* stream) {
     if (n <= 0) return 0;
     if (!pr || n > kMultiMax) return (int)hipErrorInvalidValue;

@@ -203,9 +203,8 @@ class EmbeddingModule(nn.Module):
         # layers 2, 3 + LayerNorm (+ DenoisingNet's node mask) on the fused node kernels; the packed planes of the result are
         # what the trunk's first projections and every skip_embed read
         nw = w["node_mlp"]
-        _, h2 = ops.node_apply(h_act, nw[0], M, relu=True, want_f32=False, want_xp=True)
-        node_embed, self.node_embed_act = ops.node_apply(h2, nw[1], M, ln=(ne[5].weight, ne[5].bias, ne[5].eps),
-                                                         post_mask=None if mask is None else mask.reshape(M), want_xp=True)
+        node_embed, self.node_embed_act = ops.node_apply_chain(h_act, nw, M, (True, False), ln=(ne[5].weight, ne[5].bias, ne[5].eps),
+                                                               post_mask=None if mask is None else mask.reshape(M), want_xp=True)
         node_embed = node_embed.view(B, L, -1)
         if not single_t:
             node_a = (tl(w["w_row_t"], w["b0"])[:, None, :] + fixed * w["w_row_f"]).expand(B, L, -1).contiguous()

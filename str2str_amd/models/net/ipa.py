@@ -375,14 +375,14 @@ class TranslationIPA(nn.Module):
                 sa_f32, sa_xp = torch.ops.str2str_amd.encoder_attention(qkv, key_bias, B, N, layer.self_attn.num_heads, not f16, f16, self.arith)
                 x1, x1a = lin(sa_xp if f16 else sa_f32, lw["o"], residual=xf, ln=(layer.norm1.weight, layer.norm1.bias, layer.norm1.eps),
                               want_xp=True)
-                _, ha = lin(x1a, lw["l1"], relu=True, want_f32=False, want_xp=True)
-                xf, xx = lin(ha, lw["l2"], residual=x1, ln=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), want_xp=True)
+                # feed-forward linear1 -> relu -> linear2 (+ residual, norm2): one launch, the hidden activations stay in registers
+                xf, xx = ops.node_apply_chain(x1a, [lw["l1"], lw["l2"]], M, (True, False), residual=x1,
+                                              ln=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), want_xp=True)
             # ---- node_embed + linear(tr) (:358), NodeTransition (:359, layers.py:128-145), mask (:360)
             n_f32, n_a = lin(xx, w["lin"], residual=x_f32, want_xp=True)
-            _, h1 = lin(n_a, w["nt1"], relu=True, want_f32=False, want_xp=True)
-            _, h2 = lin(h1, w["nt2"], relu=True, want_f32=False, want_xp=True)
             nt = T[f"node_transition_{b}"]
-            s_f32, s_a = lin(h2, w["nt3"], residual=n_f32, ln=(nt.ln.weight, nt.ln.bias, nt.ln.eps), post_mask=nm, want_xp=True)
+            s_f32, s_a = ops.node_apply_chain(n_a, [w["nt1"], w["nt2"], w["nt3"]], M, (True, True, False), residual=n_f32,
+                                              ln=(nt.ln.weight, nt.ln.bias, nt.ln.eps), post_mask=nm, want_xp=True)
             # ---- backbone update (:361-365) and the layers that read the same s: the EdgeTransition's per-node parts (:367-372; their
             #      pair MLP runs in its own kernel below), after the last block the torsion head's first layer -- ONE launch
             has_et = b < self.num_blocks - 1

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 _lib = None
 _tables_loaded = False
@@ -47,6 +47,7 @@ _SIGNATURES = {
     "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "s2s_node_linear_f32": [_vp, _i, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "s2s_node_linear_multi": [_vp, _i, _vp],
+    "s2s_node_chain": [_vp, _vp, _i, _ll, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
     "s2s_embed_assemble": [_vp, _vp, _ll, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "s2s_row_layernorm": [_vp, _i, _ll, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
     "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _i, _vp],
@@ -833,6 +834,8 @@ class _NodeLayer(dict):
             self[key] = pack_node_weight(self._w.float(), self["tg"])
         elif key == "w_s":
             self[key] = self["w"] if self["tg_s"] == self["tg"] else pack_node_weight(self._w.float(), self["tg_s"])
+        elif key == "w_row":   # one column block = the whole row (s2s_node_chain)
+            self[key] = self["w"] if self["tg"] == self["n"] // 32 else pack_node_weight(self._w.float(), self["n"] // 32)
         elif key == "w32":
             self[key] = pack_node_weight_f32(self._w.float(), self["tg"])
         else:
@@ -1133,6 +1136,77 @@ def ipa_projections(s_xp, q, k, v, qp, kvp, n_rows: int, n_rows_padded: int, row
     return q_xp, k_xp, v_vf, qp_o, kvp_o
 
 
+class _ChainLayer(ctypes.Structure):   # s2s_chain_layer (include/str2str_hip.h)
+    _fields_ = [("w_packed", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("relu", ctypes.c_int)]
+
+
+CHAIN_WIDTHS = (256, 320)
+
+
+def node_chain(xp, w_row, bias, relu, n_rows: int, width: int, pre_mask=None, residual=None, ln_gamma=None, ln_beta=None, ln_eps: float = 0.0,
+               post_mask=None, out_f32=None, out_col0: int = 0, want_f32=True, out_xp=None, out_xp_k: Optional[int] = None,
+               out_xp_k0: int = 0, want_xp=False):
+    """2 or 3 square layers (``width`` = 256 | 320) in one launch (s2s_node_chain): relu?(W x + b) between, the last layer with
+    ``node_linear``'s epilogue and outputs; hidden activations stay in registers.  ``w_row``: per layer the weights packed with one
+    column block (pack_node_layer(..)["w_row"]), ``bias`` / ``relu`` per layer.  Bit for bit the separate launches.
+    -> (out_f32, out_xp) like ``node_linear``."""
+    lib = load_library()
+    _req(xp, torch.int16, "xp")
+    n = len(w_row)
+    if n not in (2, 3) or len(bias) != n or len(relu) != n or width not in CHAIN_WIDTHS:
+        raise HipLibraryError("node_chain: 2 or 3 layers of width 256 or 320")
+    dev = xp.device
+    arr = (_ChainLayer * n)()
+    for i in range(n):
+        _req(w_row[i], torch.int16, "w_row"); _req(bias[i], name="bias")
+        if w_row[i].numel() != width * width * 2 or bias[i].numel() < width:
+            raise HipLibraryError("node_chain: weights must be packed with one column block of the layer's width")
+        arr[i].w_packed, arr[i].bias, arr[i].relu = w_row[i].data_ptr(), bias[i].data_ptr(), int(bool(relu[i]))
+    for nme, t in (("pre_mask", pre_mask), ("residual", residual), ("ln_gamma", ln_gamma), ("ln_beta", ln_beta), ("post_mask", post_mask)):
+        if t is not None:
+            _req(t, name=nme)
+    if out_f32 is None and want_f32:
+        out_f32 = torch.empty(n_rows, width, device=dev, dtype=torch.float32)
+    if out_xp is None and want_xp:
+        out_xp_k = width if out_xp_k is None else out_xp_k
+        out_xp = xp_alloc(n_rows, out_xp_k, dev)
+    if out_xp is not None:
+        out_xp_k = width if out_xp_k is None else out_xp_k
+    range_flag()
+    _check(_timed("s2s_node_linear", lambda: lib.s2s_node_chain(
+        _p(xp), ctypes.byref(arr), n, n_rows, width, _p(pre_mask), _p(residual), residual.shape[-1] if residual is not None else 0,
+        _p(ln_gamma), _p(ln_beta), float(ln_eps), _p(post_mask), _p(out_f32), out_f32.shape[-1] if out_f32 is not None else 0, out_col0,
+        _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16, _stream())), "s2s_node_chain")
+    return out_f32, out_xp
+
+
+def node_apply_chain(x, layers, n_rows: int, relu, **kw):
+    """``node_apply`` for a chain of square layers: ONE launch (s2s_node_chain) for packed-plane activations of a supported width,
+    the layers one after the other otherwise (fp32 activations of the "f32" arithmetic; other widths).  ``relu``: per layer;
+    ``kw``: the LAST layer's epilogue / outputs as for ``node_apply`` (residual, ln, pre_mask, post_mask, out_*, want_*)."""
+    width = layers[0]["n"]
+    ok = (x.dtype == torch.int16 and len(layers) in (2, 3) and width in CHAIN_WIDTHS
+          and all(L["n"] == width and L["k"] == width for L in layers) and "pre_scale" not in kw and "row_map" not in kw)
+    # 320-wide chains (10 tiles: 512 registers, one workgroup per CU) win only between ~64 and ~384 workgroups: below, the first layer
+    # is faster in narrow column blocks; above, two co-resident workgroups of the single launches overlap (tools/node_chain_bench.py:
+    # 2 x 320: 38 -> 47 us at 1260 rows, 78 -> 70 at 32768, 182 -> 194 at 80000; 3 x 256: 55 -> 44, 74 -> 63, 201 -> 176)
+    if ok and width == 320 and not (64 <= (n_rows + 127) // 128 <= 384):
+        ok = False
+    if not ok:
+        act = x
+        for i, L in enumerate(layers[:-1]):
+            _, act = node_apply(act, L, n_rows, relu=relu[i], want_f32=False, want_xp=True)
+        return node_apply(act, layers[-1], n_rows, relu=relu[-1], **kw)
+    kw = dict(kw)
+    ln = kw.pop("ln", None)
+    g, b, eps = ln if ln is not None else (None, None, 0.0)
+    return torch.ops.str2str_amd.node_chain(x, [L["w_row"] for L in layers], [L["b"] for L in layers], [bool(r) for r in relu], n_rows, width,
+                                            kw.pop("pre_mask", None), kw.pop("residual", None), g, b, float(eps), kw.pop("post_mask", None),
+                                            kw.pop("out_f32", None), kw.pop("out_col0", 0), kw.pop("want_f32", True), kw.pop("out_xp", None),
+                                            -1 if kw.get("out_xp_k") is None else kw.pop("out_xp_k"), kw.pop("out_xp_k0", 0),
+                                            kw.pop("want_xp", False))
+
+
 def node_apply_multi(x, specs, n_rows: int):
     """Several layers of ONE input in one launch: ``specs`` = [(layer, kwargs)], kwargs as for ``node_apply`` restricted to what the
     multi-problem kernel carries (relu, pre_scale, out_f32 / out_col0 / want_f32, out_xp / out_xp_k / out_xp_k0 / want_xp).
@@ -1387,6 +1461,11 @@ _TORCH_OPS = {
     "-> (Tensor, Tensor, Tensor)": lambda *a: embed_assemble(*a),
     "node_linear_multi(Tensor xp, Tensor[] w, Tensor[] bias, Tensor[] pre_scale, int[] dims, Tensor(a!)[] out_f32, Tensor(b!)[] out_xp) -> ()":
         lambda *a: node_linear_multi(*a),
+    "node_chain(Tensor xp, Tensor[] w_row, Tensor[] bias, bool[] relu, int n_rows, int width, Tensor? pre_mask=None, Tensor? residual=None, "
+    "Tensor? ln_gamma=None, Tensor? ln_beta=None, float ln_eps=0.0, Tensor? post_mask=None, Tensor(a!)? out_f32=None, int out_col0=0, "
+    "bool want_f32=True, Tensor(b!)? out_xp=None, int out_xp_k=-1, int out_xp_k0=0, bool want_xp=False) -> (Tensor?, Tensor?)":
+        lambda xp, w, b, r, m, wd, pm=None, res=None, g=None, be=None, eps=0.0, pom=None, of=None, oc=0, wf=True, ox=None, ok=-1, ok0=0, wx=False:
+            node_chain(xp, w, b, r, m, wd, pm, res, g, be, eps, pom, of, oc, wf, ox, _opt_int(ok), ok0, wx),
     "row_layernorm(Tensor x, int n_rows, int n_cols, Tensor gamma, Tensor beta, float eps, Tensor? post_mask=None, Tensor(a!)? out_f32=None, "
     "int out_col0=0, bool want_f32=True, Tensor(b!)? out_xp=None, int out_xp_k=-1, int out_xp_k0=0, bool want_xp=False) -> (Tensor?, Tensor?)":
         lambda x, m, n, g, b, eps, pm=None, of=None, oc=0, wf=True, ox=None, ok=-1, ok0=0, wx=False: row_layernorm(

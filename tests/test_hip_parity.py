@@ -696,7 +696,7 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
     names = {sch.split("(")[0] for sch in ops._TORCH_OPS}
     assert names >= {"edge_transition", "edge_transition_f16x3", "edge_transition_f16x3_chain", "edge_embed", "edge_embed_f16x3", "pair_project",
                      "ipa_prep_points", "ipa_attention", "ipa_prep_points_f16", "ipa_prep_points_shared_kv", "ipa_attention_f16w", "encoder_attention", "node_linear",
-                     "node_linear_f32", "node_linear_vfrag", "ipa_projections", "node_linear_multi", "row_layernorm", "embed_assemble", "pack_planes", "se3_step", "forward_marginal", "rigid_compose_update",
+                     "node_linear_f32", "node_linear_vfrag", "ipa_projections", "node_linear_multi", "node_chain", "row_layernorm", "embed_assemble", "pack_planes", "se3_step", "forward_marginal", "rigid_compose_update",
                      "rigid_scale_trans", "torsion_head", "frames_to_backbone"}
     gen = torch.Generator().manual_seed(11)
     rn = lambda *sh: torch.randn(*sh, generator=gen).to(DEV)
@@ -755,6 +755,26 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
     # the folded per-node part of the edge transition (W_ab (W_ie s + b_ie) + b_ab as one layer from s) against the two-layer form
     n_p2, ab2 = et.node_parts(xp, M)
     assert torch.equal(multi[1][0], n_p2) and rel(multi[2][0], ab2) < 2e-6
+    # a chain of square layers in one launch (hidden activations in registers) == the launches, bit for bit: NodeTransition (3 x 256,
+    # residual + LayerNorm + mask), an encoder layer's feed-forward (2 x 320, residual + LayerNorm); several workgroups + a ragged last tile
+    for Mc in (M, 5 * 128 + 40):
+        xc, resc, pmc = ops.pack_planes(rn(Mc, 256)), rn(Mc, 256), (torch.rand(Mc, generator=gen) > 0.2).float().to(DEV)
+        ntm = tr["node_transition_0"]
+        lyr = [tw[0]["nt1"], tw[0]["nt2"], tw[0]["nt3"]]
+        kwc = dict(residual=resc, ln=(ntm.ln.weight, ntm.ln.bias, ntm.ln.eps), post_mask=pmc, want_xp=True)
+        _, h1_ = ops.node_apply(xc, lyr[0], Mc, relu=True, want_f32=False, want_xp=True)
+        _, h2_ = ops.node_apply(h1_, lyr[1], Mc, relu=True, want_f32=False, want_xp=True)
+        want = ops.node_apply(h2_, lyr[2], Mc, **kwc)
+        got = ops.node_apply_chain(xc, lyr, Mc, (True, True, False), **kwc)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), Mc
+        enc = tr["transformer_0"].layers[0]
+        lw0 = tw[0]["layers"][0]
+        xe, rese = ops.pack_planes(rn(Mc, 320)), rn(Mc, 320)
+        kwe = dict(residual=rese, ln=(enc.norm2.weight, enc.norm2.bias, enc.norm2.eps), want_xp=True)
+        _, ha_ = ops.node_apply(xe, lw0["l1"], Mc, relu=True, want_f32=False, want_xp=True)
+        want = ops.node_apply(ha_, lw0["l2"], Mc, **kwe)
+        got = ops.node_apply_chain(xe, [lw0["l1"], lw0["l2"]], Mc, (True, False), **kwe)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), Mc
     # the embedder's per-evaluation assembly: one launch == the elementwise expressions it replaced, bit for bit (fp32 adds, relu, split)
     Le = 40
     timg, ncst, fa_ = rn(512), rn(B * Le, 256), rn(B, Le, 128)

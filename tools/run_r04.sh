@@ -24,4 +24,12 @@ bash tools/pmc_ipa.sh gpurun_out/${T}_pmc_ipa_traffic.json > $O/pmc_ipa.log 2>&1
 bash tools/pmc_kernel.sh ${T}_et edge_transition_f16 -- python tools/et_only.py --B 64 --N 256 --iters 2 --proj --layout tiled > gpurun_out/${T}_pmc_et_f16_counters.txt 2>&1
 bash tools/pmc_kernel.sh ${T}_ipa ipa_attention_f16w -- python tools/ipa_loop.py --seconds 0.5 > gpurun_out/${T}_pmc_ipa_f16w_counters.txt 2>&1
 rm -rf gpurun_out/pmc_${T}_et gpurun_out/pmc_${T}_ipa
+python bench.py --config ref_default --no-cpu-baseline > gpurun_out/${T}_bench_ref_default.json 2> $O/ref_default.err
+python tools/ipa_fold_ab.py > gpurun_out/${T}_ipa_fold_ab.txt 2>&1
+python tools/range_stress_time.py > gpurun_out/${T}_range_stress_time.txt 2>&1
+python - <<PY
+import json
+l=json.loads(open("gpurun_out/${T}_bench_ref_default.json").read().strip().splitlines()[-1]); print("ref_default", round(l["value"],2), l["unit"])
+PY
+tail -3 gpurun_out/${T}_range_stress_time.txt | cut -c1-250
 tail -22 gpurun_out/${T}_pmc_et_f16_counters.txt
