@@ -5,9 +5,10 @@ T=${1:-r04}
 O=gpurun_out/$T; mkdir -p $O
 python tools/et_only.py --B 128 --N 256 --iters 20 --proj --layout tiled 2>/dev/null | tail -1 > $O/box_calibration.txt
 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/pytest.log
+python __graft_entry__.py --smoke 2>&1 | tail -1 > $O/smoke.txt
 python bench.py > $O/bench_cfg2.json 2> $O/bench_cfg2.err
 bash tools/prof_bench.sh $T > $O/prof.log 2>&1
-cat $O/box_calibration.txt $O/pytest.log
+cat $O/box_calibration.txt $O/pytest.log $O/smoke.txt
 for c in cfg2; do python - <<PY
 import json
 l=json.loads(open("$O/bench_$c.json").read().strip().splitlines()[-1])
@@ -27,6 +28,7 @@ rm -rf gpurun_out/pmc_${T}_et gpurun_out/pmc_${T}_ipa
 python bench.py --config ref_default --no-cpu-baseline > gpurun_out/${T}_bench_ref_default.json 2> $O/ref_default.err
 python tools/ipa_fold_ab.py > gpurun_out/${T}_ipa_fold_ab.txt 2>&1
 python tools/range_stress_time.py > gpurun_out/${T}_range_stress_time.txt 2>&1
+python tools/node_chain_bench.py > gpurun_out/${T}_node_chain_bench.txt 2>&1
 python - <<PY
 import json
 l=json.loads(open("gpurun_out/${T}_bench_ref_default.json").read().strip().splitlines()[-1]); print("ref_default", round(l["value"],2), l["unit"])
