@@ -59,6 +59,56 @@ def atom37_to_pdb(save_to: str, atom_positions: np.ndarray, aatype: Optional[np.
     return save_to
 
 
+class AsyncPdbWriter:
+    """Multi-MODEL PDB files written BEHIND the sampler: ``submit`` starts the device -> pinned-host copy of a coordinate tensor on the
+    current stream and hands copy + ``atom37_to_pdb`` to one background thread, so the caller goes straight on to the next trajectory
+    (the native writer releases the GIL; the reference writes synchronously, src/models/diffusion_module.py:353-360, and its GPU idles
+    meanwhile).  ``results()`` waits for every file, in submission order, and re-raises a writer's exception."""
+
+    def __init__(self):
+        from concurrent.futures import ThreadPoolExecutor
+
+        self._pool = ThreadPoolExecutor(max_workers=1)
+        self._futs = []
+        self._pinned = {}
+
+    def submit(self, atom_positions, save_to: str, **kw):
+        import torch
+
+        if os.environ.get("S2S_ASYNC_PDB", "1") == "0":      # the reference's order of events: copy, write, then go on
+            arr = atom_positions.cpu().numpy() if torch.is_tensor(atom_positions) else atom_positions
+            res = atom37_to_pdb(atom_positions=arr, save_to=save_to, **kw)
+            self._futs.append(self._pool.submit(lambda: res))
+            return
+        if not (torch.is_tensor(atom_positions) and atom_positions.is_cuda):
+            arr = atom_positions.cpu().numpy() if torch.is_tensor(atom_positions) else atom_positions
+            self._futs.append(self._pool.submit(atom37_to_pdb, atom_positions=arr, save_to=save_to, **kw))
+            return
+        key = (tuple(atom_positions.shape), atom_positions.dtype, len(self._futs) & 1)    # two buffers per shape: copy k + 1 while file k is written
+        host = self._pinned.get(key)
+        if host is None:
+            host = self._pinned[key] = torch.empty(atom_positions.shape, dtype=atom_positions.dtype, pin_memory=True)
+        if len(self._futs) >= 2:
+            self._futs[-2].result()          # the writer is done with this buffer
+        host.copy_(atom_positions, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+
+        def job():
+            done.synchronize()
+            return atom37_to_pdb(atom_positions=host.numpy(), save_to=save_to, **kw)
+
+        self._futs.append(self._pool.submit(job))
+
+    def results(self):
+        out = [f.result() for f in self._futs]
+        self._futs = []
+        return out
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+
+
 def merge_pdbfiles(input, output_file: str, verbose: bool = True) -> None:
     files = [os.path.join(input, f) for f in os.listdir(input) if f.endswith(".pdb")] if isinstance(input, str) else list(input)
     os.makedirs(os.path.dirname(output_file), exist_ok=True)

@@ -24,7 +24,7 @@ from typing import Any, Optional
 import numpy as np
 import torch
 
-from ..common.pdb_utils import atom37_to_pdb, merge_pdbfiles
+from ..common.pdb_utils import AsyncPdbWriter, atom37_to_pdb, merge_pdbfiles
 from ..common.rigid_utils import Rigid
 from ..sampler import forward_backward, plan_mixed_work, rank_chunk_slices, sample_mixed_lengths, shard_range
 
@@ -109,7 +109,7 @@ class DiffusionLitModule(_Base):
         extra = {k: batch[k][0].detach().cpu().numpy() for k in ("aatype", "chain_index", "residue_index")}
         kw = dict(num_timesteps=inf.num_timesteps, min_t=inf.min_t, noise_scale=inf.noise_scale,
                   probability_flow=inf.probability_flow, self_conditioning=self_cond, device=device, rng=self.rng_mode)
-        saved = []
+        writer = AsyncPdbWriter()   # files are written behind the sampler (the GPU goes on with the next t_delta meanwhile)
         self.last_samples = {}   # t_delta -> atom37 [n_replica, N, 37, 3] device tensor of the last target (rank 0; programmatic callers)
         for t_delta in delta_range:
             gt4 = batch["rigidgroups_gt_frames"][..., 0, :, :].clone()
@@ -128,9 +128,10 @@ class DiffusionLitModule(_Base):
                 self.last_samples[float(t_delta)] = a37
                 t_dir = os.path.join(output_dir, f"{t_delta}")
                 os.makedirs(t_dir, exist_ok=True)
-                saved.append(atom37_to_pdb(atom_positions=a37.cpu().numpy(),
-                                           save_to=os.path.join(t_dir, f"{accession_code}.pdb"), **extra))
+                writer.submit(a37, os.path.join(t_dir, f"{accession_code}.pdb"), **extra)
         all_dir = os.path.join(output_dir, "all_delta")
+        saved = writer.results()
+        writer.close()
         if shard[0] == 0:
             os.makedirs(all_dir, exist_ok=True)
             merge_pdbfiles(saved, os.path.join(all_dir, f"{accession_code}.pdb"), verbose=False)
