@@ -204,3 +204,34 @@ def test_extract_backbone_coords_altloc_and_nonstandard(tmp_path):
     (tmp_path / "ragged.pdb").write_text("\n".join(["MODEL        1"] + model + ["ENDMDL", "MODEL        2"] + model[:3]))
     with pytest.raises(ValueError):
         extract_backbone_coords(str(tmp_path / "ragged.pdb"))
+
+
+def test_async_writer_gives_the_same_files_in_submission_order(tmp_path, monkeypatch):
+    """AsyncPdbWriter (the writer predict_step hands its ensembles to): same bytes as atom37_to_pdb called directly, results in
+    submission order, a failing write surfaces in results(); host arrays and host tensors take the same path as device tensors
+    minus the pinned copy (no GPU here)."""
+    import torch
+
+    g = golden("io_writer_inputs.npz")
+    kw = dict(aatype=g["aatype"], chain_index=g["chain_index"], residue_index=g["residue_index"])
+    for mode in ("1", "0"):
+        monkeypatch.setenv("S2S_ASYNC_PDB", mode)
+        d = tmp_path / mode
+        os.makedirs(d)
+        w = pdb_utils.AsyncPdbWriter()
+        w.submit(g["pos"], str(d / "a.pdb"), **kw)
+        w.submit(torch.as_tensor(g["pos"][:1] + 1.0), str(d / "b.pdb"), **kw)
+        w.submit(g["pos"], str(d / "c.pdb"), **kw)
+        assert w.results() == [str(d / "a.pdb"), str(d / "b.pdb"), str(d / "c.pdb")]
+        assert open(d / "a.pdb").read() == _read("io_atom37_two_models.pdb.txt") == open(d / "c.pdb").read()
+        want = pdb_utils.atom37_to_pdb(save_to=str(d / "b_direct.pdb"), atom_positions=g["pos"][:1] + 1.0, **kw)
+        assert open(d / "b.pdb").read() == open(want).read()
+        w.close()
+    monkeypatch.setenv("S2S_ASYNC_PDB", "1")
+    w = pdb_utils.AsyncPdbWriter()
+    w.submit(g["pos"], str(tmp_path / "no_such_dir" / "x.pdb"), **kw)
+    import pytest
+
+    with pytest.raises(Exception):
+        w.results()
+    w.close()
