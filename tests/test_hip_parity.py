@@ -1895,7 +1895,7 @@ def test_ipa_folded_projections_equal_the_per_head_path(B, N):
     with torch.no_grad():
         ipa.arith = "f32"
         ref = block(s)
-        ipa.arith = "f16x3"
+        ipa.arith, ipa.fold = "f16x3", True
         assert ipa.folded
         out_f = block(s_xp)
         ipa.fold = False
