@@ -87,7 +87,13 @@ class AsyncPdbWriter:
         key = (tuple(atom_positions.shape), atom_positions.dtype, len(self._futs) & 1)    # two buffers per shape: copy k + 1 while file k is written
         host = self._pinned.get(key)
         if host is None:
-            host = self._pinned[key] = torch.empty(atom_positions.shape, dtype=atom_positions.dtype, pin_memory=True)
+            try:
+                host = torch.empty(atom_positions.shape, dtype=atom_positions.dtype, pin_memory=True)
+            except RuntimeError:     # no page-locked memory to be had: the reference's order for this file
+                arr = atom_positions.cpu().numpy()
+                self._futs.append(self._pool.submit(atom37_to_pdb, atom_positions=arr, save_to=save_to, **kw))
+                return
+            self._pinned[key] = host
         if len(self._futs) >= 2:
             self._futs[-2].result()          # the writer is done with this buffer
         host.copy_(atom_positions, non_blocking=True)
