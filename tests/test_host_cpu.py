@@ -334,3 +334,28 @@ def test_every_global_name_the_package_uses_resolves():
                     if ins.opname == "LOAD_GLOBAL" and ins.argval not in f.__globals__ and not hasattr(builtins, ins.argval):
                         missing.add((info.name, f.__name__, ins.argval))
     assert not missing, sorted(missing)
+
+
+def test_edge_prescale_ladder():
+    """The sampler's answer to an edge-transition range flag (sampler._raise_edge_prescale): the block exponent of EVERY f16x3
+    EdgeTransition goes 0 -> 5 -> 10 -> 15 and then reports that nothing is left (the family is demoted to fp32); modules on the exact
+    arithmetic are not touched."""
+    import torch.nn as nn
+
+    from str2str_amd.sampler import _raise_edge_prescale
+
+    class ET(nn.Module):
+        def __init__(self, arith):
+            super().__init__()
+            self.arith, self.prescale_exp = arith, 0
+
+    net = nn.ModuleList([ET("f16x3"), ET("f16x3"), ET("f32")])
+    seen = []
+    while True:
+        e = _raise_edge_prescale(net)
+        if not e:
+            break
+        seen.append(e)
+        assert [m.prescale_exp for m in net] == [e, e, 0]
+    assert seen == [5, 10, 15]
+    assert _raise_edge_prescale(nn.ModuleList([ET("f32")])) == 0
