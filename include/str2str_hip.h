@@ -172,6 +172,9 @@ int s2s_ipa_attention(const float* q, const float* kv, const float* q_pts, const
  * b_v move into linear_out's weight and bias), and the kernel aggregates s instead of v.  n_kv_heads = 1 selects that operand
  * layout: k_xp = packed planes of s [rows/32][16][2][64][8] (s itself when n_res % 32 == 0, else k_shared below), v_vf =
  * [rows/32][8][2][2][64][8] (v_shared below); n_kv_heads = n_heads is the per-head layout above.
+ * Short chains with the shared operands (n_pad <= 64: one or two key tiles per sample) run on a second kernel behind the same entry
+ * point: one wave per (sample, head, query tile), no LDS and no barriers -- the streaming kernel's workgroup of four query tiles of
+ * one (sample, head) repeats work on three / two of its waves there; S2S_IPA_SHORT=0 keeps the streaming kernel for every length.
  * s2s_ipa_prep_points_f16 with s_xp != NULL (n_heads = 8) writes those shared operands in the same launch: v_shared always,
  * k_shared (rows gathered into the padded per-sample layout) when n_res % 32 != 0; NULL s_xp skips the step. */
 int s2s_ipa_prep_points_f16(const float* rigids7, const float* q_pts_lin, const float* kv_pts_lin, const float* head_w_scaled,

@@ -799,6 +799,206 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// SHORT CHAINS (n_pad <= 64: one or two key tiles) with the shared K / V operands of the folded projections.  The streaming kernel above
+// gives a workgroup four query tiles of one (sample, head): with one or two tiles per sample, three or two of its waves repeat work
+// (the Science2011 targets, the reference's default inference block).  Here a wave is one (sample, head, query tile) on its own -- no
+// LDS, no barriers, no image stream: the K / V fragments of the whole sample are 64 + 72 fragment loads that every head and query
+// tile of the sample repeats (L1 / L2 hits), the logits of both key tiles stay in registers between the two phases (they are still
+// written for s2s_ipa_opair), and four heads of one query tile share a workgroup.  Same operands, same products, same logit
+// arithmetic as the kernel above; the sums differ in order only.
+template <bool RAGGED, int NT>
+__global__ void __launch_bounds__(256, 1) ipa_attention_short_kernel(PlaneArgs a) {
+    const int lane = threadIdx.x & 63, h = lane >> 5, c = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int N = a.N, H = a.H;
+    const int NP = RAGGED ? a.NP : N;
+    const float c1 = sqrtf(1.0f / (3 * 256)), c2 = sqrtf(1.0f / 3);
+    // workgroup = (sample, query tile, half of the heads); wave = head
+    int bid = blockIdx.x;
+    const int hg = bid % (H / 4); bid /= (H / 4);
+    const int qt = bid % NT;
+    const int b = bid / NT;
+    const int head = hg * 4 + wave;
+    const long long rt_q = (long long)b * NT + qt;
+    const int i = qt * 32 + c;
+    const int ic = RAGGED ? min(i, N - 1) : i;
+    const long long row_i = (long long)b * N + ic;
+    const long long brow0 = (((long long)b * H + head) * N + ic) * N + 4 * h;
+    const float q2_i = a.q2[(rt_q * H + head) * 32 + c];
+    float mask_i = a.mask[row_i];
+    if constexpr (RAGGED) mask_i = i < N ? mask_i : 0.f;
+    const __amdgpu_buffer_rsrc_t r_bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.attn_bias, 0, RAGGED ? (int)((long long)a.B * H * N * N * 4) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.logits + ((long long)b * H + head) * NP * NP), 0, NP * NP * 4, 0x00020000);
+    const int loff0 = (i * NP + 4 * h) * 4;
+
+    // ---- phase 1: S^T = K . Q'^T (+ point cross term) for every key tile, logits in registers
+    f16x8 qf[KQ][2];
+    {
+        const f16x8* qs = a.q_xp + ((rt_q * (16 * H) + 16 * head) * 2) * 64 + lane;
+        const f16x8* ps = a.qp_xp + ((rt_q * H + head) * 4) * 64 + lane;
+#pragma unroll
+        for (int x = 0; x < KQ; ++x)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) qf[x][p] = x < 16 ? qs[(x * 2 + p) * 64] : ps[((x - 16) * 2 + p) * 64];
+    }
+    float sl[NT][16];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const long long rt_k = (long long)b * NT + t;
+        const f16x8* ks_ = a.k_xp + ((rt_k * 16) * 2) * 64 + lane;
+        const f16x8* kp_ = a.kp_xp + ((rt_k * H + head) * 4) * 64 + lane;
+        f16x8 kf[KQ][2];
+#pragma unroll
+        for (int x = 0; x < KQ; ++x)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) kf[x][p] = x < 16 ? ks_[(x * 2 + p) * 64] : kp_[((x - 16) * 2 + p) * 64];
+        float4 bias4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if constexpr (RAGGED) {
+                const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(r_bias, (int)(brow0 * 4) + (t * 32 + 8 * g) * 4, 0, 0);
+                bias4[g] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+            } else {
+                bias4[g] = *reinterpret_cast<const float4*>(a.attn_bias + brow0 + t * 32 + 8 * g);
+            }
+        }
+        f32x16 S0, S1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S0[r] = 0.f, S1[r] = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int x = 0; x < KQ; ++x) {
+            S0 = mfma_f16(kf[x][1], qf[x][0], S0); S1 = mfma_f16(kf[x][0], qf[x][1], S1);   // k_l q_h, k_h q_l
+            if (x & 1) S1 = mfma_f16(kf[x][0], qf[x][0], S1); else S0 = mfma_f16(kf[x][0], qf[x][0], S0);   // k_h q_h
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 k2g = *reinterpret_cast<const float4*>(a.k2 + (rt_k * H + head) * 32 + 8 * g + 4 * h);
+            float kmv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int j = t * 32 + 8 * g + 4 * h + e;
+                kmv[e] = (!RAGGED || j < N) ? a.mask[(long long)b * N + min(j, N - 1)] : 0.f;
+            }
+            const float k2v[4] = {k2g.x, k2g.y, k2g.z, k2g.w};
+            const float bv[4] = {bias4[g].x, bias4[g].y, bias4[g].z, bias4[g].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                float x = (S0[r] + S1[r]) * c1 + c2 * bv[e];
+                x = x + (q2_i + k2v[e]);
+                x = x + a.inf * (mask_i * kmv[e] - 1.0f);
+                sl[t][r] = x;
+                tmax = fmaxf(tmax, x);
+            }
+            if constexpr (RAGGED)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(sl[t][4 * g]), __float_as_uint(sl[t][4 * g + 1]), __float_as_uint(sl[t][4 * g + 2]),
+                                                             __float_as_uint(sl[t][4 * g + 3])}, lrsrc, loff0 + t * 128 + 32 * g, 0, 0);
+            else
+                *reinterpret_cast<float4*>(a.logits + brow0 + t * 32 + 8 * g) = make_float4(sl[t][4 * g], sl[t][4 * g + 1], sl[t][4 * g + 2], sl[t][4 * g + 3]);
+        }
+    }
+    const float m_run = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+
+    // ---- phase 2: probabilities and value aggregation
+    f32x16 O[OT];
+#pragma unroll
+    for (int x = 0; x < OT; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[x][r] = 0.f;
+    float l_run = 0.f;
+    constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};   // (V plane, P plane) = (l,h) (h,l) (h,h): small terms first
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const long long rt_k = (long long)b * NT + t;
+        float ps[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pe = exp_neg(sl[t][r] - m_run);
+            l_run += pe;
+            ps[r] = pe * 1024.0f;
+        }
+        f16x8 pc[2][2];
+        split8(ps, pc[0][0], pc[0][1]);
+        split8(ps + 8, pc[1][0], pc[1][1]);
+        const f16x8* vs_ = a.v_vf + ((rt_k * 8) * 4) * 64 + lane;                 // [8 tiles][u][plane][lane]
+        const f16x8* vp_ = a.vp_vf + ((rt_k * H + head) * 8) * 64 + lane;        // [2 tiles][u][plane][lane]
+        // every V fragment of the key tile is requested before the first product (the query fragments are dead: 160 registers)
+        f16x8 vf[OT][2][2];
+#pragma unroll
+        for (int x = 0; x < OT; ++x)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) vf[x][u][p] = x < CT ? vs_[((x * 2 + u) * 2 + p) * 64] : vp_[(((x - CT) * 2 + u) * 2 + p) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int x = 0; x < OT; ++x)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) O[x] = mfma_f16(vf[x][u][PA[k]], pc[u][PB[k]], O[x]);
+    }
+
+    // ---- epilogue (as above)
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = (1.0f / l_tot) * (1.0f / 1024.0f);
+    const bool row_ok = !RAGGED || i < N;
+    {
+        f16x8* o = RAGGED ? a.out_xp + (((row_i >> 5) * a.xp_ksteps + 16 * head) * 2) * 64 + ((int)(row_i & 31) + 32 * h)
+                           : a.out_xp + ((rt_q * a.xp_ksteps + 16 * head) * 2) * 64 + lane;
+#pragma unroll
+        for (int T = 0; T < CT; ++T)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = O[T][8 * u + j] * inv;
+                f16x8 ph, pl;
+                split8(v, ph, pl);
+                f16x8* q = o + ((2 * T + u) * 2) * 64;
+                if (row_ok) { q[0] = ph; q[64] = pl; }
+            }
+    }
+    {
+        const int feat = H * (256 + 4 * PV + 32);
+        const float* f = a.rigids7 + row_i * 7;
+        const float qa = f[0], qb_ = f[1], qc = f[2], qd = f[3];
+        const float tx = f[4], ty = f[5], tz = f[6];
+        const float r00 = qa * qa + qb_ * qb_ - qc * qc - qd * qd, r01 = 2 * qb_ * qc - 2 * qa * qd, r02 = 2 * qb_ * qd + 2 * qa * qc;
+        const float r10 = 2 * qb_ * qc + 2 * qa * qd, r11 = qa * qa - qb_ * qb_ + qc * qc - qd * qd, r12 = 2 * qc * qd - 2 * qa * qb_;
+        const float r20 = 2 * qb_ * qd - 2 * qa * qc, r21 = 2 * qc * qd + 2 * qa * qb_, r22 = qa * qa - qb_ * qb_ - qc * qc + qd * qd;
+        float* ox = a.out + row_i * feat + H * 256 + head * PV;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int pt_idx = 8 * t + 2 * rq + h;
+                const f32x16& ov = O[CT + t];
+                const float dx = ov[4 * rq + 0] * inv - tx;
+                const float dy = ov[4 * rq + 1] * inv - ty;
+                const float dz = ov[4 * rq + 2] * inv - tz;
+                const float lx = r00 * dx + r10 * dy + r20 * dz;
+                const float ly = r01 * dx + r11 * dy + r21 * dz;
+                const float lz = r02 * dx + r12 * dy + r22 * dz;
+                const float nr = sqrtf(lx * lx + ly * ly + lz * lz + a.eps);
+                if (pt_idx < PV && row_ok) {
+                    ox[pt_idx] = lx;
+                    ox[H * PV + pt_idx] = ly;
+                    ox[2 * H * PV + pt_idx] = lz;
+                    ox[3 * H * PV + pt_idx] = nr;
+                }
+            }
+    }
+    if (h == 0 && row_ok) {
+        float* st2 = a.stats + ((((long long)b * H + head) * N) + i) * 2;
+        st2[0] = m_run;
+        st2[1] = l_tot;
+    }
+}
+
 }  // namespace
 
 #ifdef S2S_IPA_PROBE
@@ -855,6 +1055,22 @@ extern "C" int s2s_ipa_attention_f16w(const void* q_xp, const void* k_xp, const 
     PlaneArgs a{(const f16x8*)q_xp, (const f16x8*)k_xp, (const f16x8*)v_vf, (const f16x8*)qp_xp, (const f16x8*)kp_xp,
                 (const f16x8*)vp_vf, q2, k2, attn_bias, logits_out, stats_out, mask, rigids7, out, (f16x8*)out_xp, out_xp_ksteps,
                 n_samples, n_res, n_heads, n_pad, inf, eps, (remap_env && items % 8 == 0 && blocks % 8 == 0 && n_qb > 1) ? 1 : 0, n_kv_heads};
+    static const int short_env = getenv("S2S_IPA_SHORT") ? atoi(getenv("S2S_IPA_SHORT")) : 1;
+    if (short_env && n_kv_heads == 1 && n_heads % 4 == 0 && n_pad <= 64) {   // one wave per (sample, head, query tile): see the short kernel
+        const int nt = n_pad / 32;
+        const long long wgs = (long long)n_samples * nt * (n_heads / 4);
+        if (wgs < (1ll << 31)) {
+            hipStream_t st = (hipStream_t)stream;
+            if (nt == 1) {
+                if (ragged) hipLaunchKernelGGL((ipa_attention_short_kernel<true, 1>), dim3((unsigned)wgs), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((ipa_attention_short_kernel<false, 1>), dim3((unsigned)wgs), dim3(256), 0, st, a);
+            } else {
+                if (ragged) hipLaunchKernelGGL((ipa_attention_short_kernel<true, 2>), dim3((unsigned)wgs), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL((ipa_attention_short_kernel<false, 2>), dim3((unsigned)wgs), dim3(256), 0, st, a);
+            }
+            return (int)hipGetLastError();
+        }
+    }
     if (ragged)
         hipLaunchKernelGGL(ipa_attention_f16w_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     else
