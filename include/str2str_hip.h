@@ -319,13 +319,16 @@ typedef struct s2s_node_problem {
 } s2s_node_problem;
 int s2s_node_linear_multi(const s2s_node_problem* problems, int n_problems, void* stream);
 
-/* A chain of 2 or 3 SQUARE layers (width = k_in = n_out = 256 or 320) in one launch: every layer but the last is relu?(W x + b), the
- * last one has the epilogue and outputs of s2s_node_linear.  The hidden activations stay in registers (the accumulator layout of a
- * layer is the operand layout of the next); bit for bit the separate launches.  w_packed: ops.pack_node_weight(W, width / 32).
- * NodeTransition (src/models/net/layers.py:128-145), the encoder layers' feed-forward (src/models/net/ipa.py:312-317), the embedder's
- * node MLP (src/models/net/denoising_ipa.py:113-120). */
+/* A chain of 2 .. 4 layers of one output width (256 or 320) in one launch: every layer but the last is relu?(W x + b), the last one
+ * has the epilogue and outputs of s2s_node_linear.  The hidden activations stay in registers (the accumulator layout of a layer is the
+ * operand layout of the next); bit for bit the separate launches.  w_packed: ops.pack_node_weight(W, width / 32).
+ * The FIRST layer may contract over k_in0 != width columns (320 -> 256) and may add a residual (mid_residual [n_rows, ld]) and store its
+ * fp32 result (mid_out_f32 [n_rows, ld]) -- which may then be the last layer's ``residual``: trunk.linear + NodeTransition
+ * (src/models/net/ipa.py:358-359, layers.py:128-145) as one launch.  Also: the encoder layers' feed-forward (ipa.py:312-317), the
+ * embedder's node MLP (denoising_ipa.py:113-120). */
 typedef struct s2s_chain_layer { const void* w_packed; const float* bias; int relu; } s2s_chain_layer;
-int s2s_node_chain(const void* xp, const s2s_chain_layer* layers, int n_layers, long long n_rows, int width, const float* pre_mask,
+int s2s_node_chain(const void* xp, const s2s_chain_layer* layers, int n_layers, long long n_rows, int width, int k_in0,
+                   const float* mid_residual, int mid_residual_ld, float* mid_out_f32, int mid_out_ld, const float* pre_mask,
                    const float* residual, int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps,
                    const float* post_mask, float* out_f32, int out_ld, int out_col0, void* out_xp, int out_xp_ksteps,
                    int out_xp_kstep0, void* stream);

@@ -519,13 +519,17 @@ __global__ void __launch_bounds__(256, 2) node_gemm_multi_kernel(MultiArgs ma) {
 // the encoder layers' feed-forward (linear1 -> linear2 + residual + norm2, ipa.py:312-317) and the embedder's node MLP
 // (denoising_ipa.py:113-120): at a few thousand rows every launch is one workgroup's latency chain, and at 32 k rows the hidden
 // activations' 4 B per value in each direction were all these layers did besides their MFMAs.
-constexpr int kChainMax = 3;
+constexpr int kChainMax = 4;
 struct ChainArgs {
     GemmArgs a;                      // xp / M / epilogue operands and outputs of the LAST layer
     const char* w[kChainMax];
     const float* bias[kChainMax];
     int relu[kChainMax];
     int n_layers;
+    // the FIRST layer may also add a residual and store its fp32 result (trunk.linear in front of NodeTransition: its output is the
+    // residual of the chain's last layer -- read back from memory by the lanes that wrote it)
+    const float* mid_residual; int mid_res_ld;
+    float* mid_out; int mid_out_ld;
 };
 template <int I> struct CI { static constexpr int value = I; };
 template <int B, int E, class F>
@@ -536,9 +540,10 @@ __device__ __forceinline__ void chain_for(F&& f) {
     }
 }
 
-template <int TG>
+template <int TG, int KS0>
 __global__ void __launch_bounds__(256, 1) node_chain_kernel(ChainArgs c) {
-    constexpr int KS = 2 * TG;                 // k-steps of every layer (K = N = 32 TG)
+    constexpr int KS = 2 * TG;                 // k-steps of every layer but the first (K = N = 32 TG); the first: KS0 (K_0 = 16 KS0, even)
+    constexpr int KSX = KS0 > KS ? KS0 : KS;
     constexpr int kStage = 2 * TG * 1024;      // one k-step of weights: TG tiles x 2 planes
     constexpr int kFrags = 2 * TG, kPieces = (kFrags + 3) / 4;
     extern __shared__ __attribute__((aligned(16))) char s_w[];   // 2 stages
@@ -566,11 +571,11 @@ __global__ void __launch_bounds__(256, 1) node_chain_kernel(ChainArgs c) {
         for (int k = 0; k < kPieces; ++k)
             if (4 * k + 3 < kFrags || 4 * k + wave < kFrags) *(lds_f4*)(dst + (4 * k + wave) * 1024) = wst[k];
     };
-    f16x8 xr[KS][2];     // the layer's input planes: k-step ks = registers 8u .. 8u+7 of the previous layer's tile t (ks = 2t + u)
+    f16x8 xr[KSX][2];    // the layer's input planes: k-step ks = registers 8u .. 8u+7 of the previous layer's tile t (ks = 2t + u)
     {
-        const f16x8* xsrc = a.xp + (rtc * KS) * 2 * 64 + lane;
+        const f16x8* xsrc = a.xp + (rtc * KS0) * 2 * 64 + lane;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) { xr[ks][0] = xsrc[(ks * 2) * 64]; xr[ks][1] = xsrc[(ks * 2 + 1) * 64]; }
+        for (int ks = 0; ks < KS0; ++ks) { xr[ks][0] = xsrc[(ks * 2) * 64]; xr[ks][1] = xsrc[(ks * 2 + 1) * 64]; }
     }
     f32x16 acc[TG];
     const long long row = rt * 32 + (lane & 31);
@@ -605,36 +610,42 @@ __global__ void __launch_bounds__(256, 1) node_chain_kernel(ChainArgs c) {
     w_store(0);
     w_load(1);
     __syncthreads();
-    for (int l = 0; l < c.n_layers; ++l) {
-        const bool last = l == c.n_layers - 1;
+    // the k-steps of one layer (static: the input planes live in registers); the weight stream runs on into the next layer's first stages
+    auto run_layer = [&](auto nkc, int l, bool last) {
+        constexpr int NK = decltype(nkc)::value;
 #pragma unroll
         for (int t = 0; t < TG; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        // k-steps (static: the input planes live in registers); the weight stream runs on into the next layer's first stages
-        chain_for<0, KS>([&](auto kc) {
+        chain_for<0, NK>([&](auto kc) {
             constexpr int ks = decltype(kc)::value, par = ks & 1;
             compute(par, xr[ks]);
-            if constexpr (ks + 1 < KS) {
+            if constexpr (ks + 1 < NK) {
                 w_store(par ^ 1);                 // k-step ks + 1 (loaded one stage ago)
-                if constexpr (ks + 2 < KS) w_load(ks + 2);
+                if constexpr (ks + 2 < NK) w_load(ks + 2);
                 else if (!last) { wsrc = c.w[l + 1] + lane * 16; w_load(0); }
                 __syncthreads();
-            } else if (!last) {                    // ks = KS - 1: wst holds stage 0 of the next layer (KS is even: it goes to buffer 0)
-                __syncthreads();                   // everyone is done reading buffer 0 (k-step KS - 2) ... and buffer 1 after the next barrier
+            } else if (!last) {                    // ks = NK - 1: wst holds stage 0 of the next layer (NK is even: it goes to buffer 0)
+                __syncthreads();                   // everyone is done reading buffer 0 (k-step NK - 2) ... and buffer 1 after the next barrier
                 w_store(0);
                 w_load(1);
                 __syncthreads();
             }
         });
-        if (last) break;
-        // inner layer: bias + ReLU through the common epilogue (no mask, residual, LayerNorm, outputs), then the split into the next
-        // layer's input planes -- exactly the values the single launch would have stored as packed planes
+    };
+    // inner layer: bias + ReLU (the first layer: + residual, fp32 output) through the common epilogue, then the split into the next
+    // layer's input planes -- exactly the values the single launch would have stored as packed planes
+    auto inner_epilogue = [&](int l) {
         GemmArgs inner = a;
         inner.bias = c.bias[l]; inner.relu = c.relu[l];
         inner.pre_scale = nullptr; inner.pre_mask = nullptr; inner.residual = nullptr; inner.ln_gamma = nullptr; inner.ln_beta = nullptr;
         inner.post_mask = nullptr; inner.out_f32 = nullptr; inner.out_xp = nullptr;
+        if (l == 0) {
+            inner.residual = c.mid_residual; inner.res_ld = c.mid_res_ld;
+            inner.out_f32 = c.mid_out; inner.out_ld = c.mid_out_ld; inner.out_col0 = 0;
+        }
         node_epilogue<TG>(acc, inner, rt, n_rt, lane, 0, kInvWS);
+        if (l == 0 && c.mid_out) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows are read back as the last layer's residual
 #pragma unroll
         for (int t = 0; t < TG; ++t)
 #pragma unroll
@@ -644,6 +655,11 @@ __global__ void __launch_bounds__(256, 1) node_chain_kernel(ChainArgs c) {
                 for (int j = 0; j < 8; ++j) v[j] = valid ? acc[t][8 * u + j] : 0.f;
                 split8_f16(v, xr[2 * t + u][0], xr[2 * t + u][1], amax);
             }
+    };
+    run_layer(CI<KS0>{}, 0, c.n_layers == 1);
+    for (int l = 1; l < c.n_layers; ++l) {
+        inner_epilogue(l - 1);
+        run_layer(CI<KS>{}, l, l == c.n_layers - 1);
     }
     s2s::range_report(a.range_flag, amax, s2s::kRangeNodeGemm);
     GemmArgs fin = a;
@@ -950,7 +966,8 @@ extern "C" int s2s_node_probe_read(unsigned long long* host_out, int reset) {
 #endif
 
 // Up to six independent layers (bias / ReLU epilogues only) in ONE launch: see node_gemm_multi_kernel.
-extern "C" int s2s_node_chain(const void* xp, const s2s_chain_layer* layers, int n_layers, long long n_rows, int width,
+extern "C" int s2s_node_chain(const void* xp, const s2s_chain_layer* layers, int n_layers, long long n_rows, int width, int k_in0,
+                              const float* mid_residual, int mid_residual_ld, float* mid_out_f32, int mid_out_ld,
                               const float* pre_mask, const float* residual, int residual_ld, const float* ln_gamma, const float* ln_beta,
                               float ln_eps, const float* post_mask, float* out_f32, int out_ld, int out_col0, void* out_xp,
                               int out_xp_ksteps, int out_xp_kstep0, void* stream) {
@@ -958,13 +975,15 @@ extern "C" int s2s_node_chain(const void* xp, const s2s_chain_layer* layers, int
     const int TG = width / 32;
     if (!xp || !layers || n_layers < 2 || n_layers > kChainMax || width % 32 || (TG != 8 && TG != 10) || (!out_f32 && !out_xp) ||
         check_epilogue(width, TG, ln_gamma, ln_beta, out_f32, out_ld, out_col0, residual, residual_ld) ||
-        (out_xp && (out_xp_kstep0 < 0 || out_xp_kstep0 % 2 || out_xp_kstep0 + width / 16 > out_xp_ksteps)))
+        (out_xp && (out_xp_kstep0 < 0 || out_xp_kstep0 % 2 || out_xp_kstep0 + width / 16 > out_xp_ksteps)) ||
+        (k_in0 != width && !(TG == 8 && k_in0 == 320)) || (mid_residual && mid_residual_ld % 4) || (mid_out_f32 && (mid_out_ld % 4 || mid_out_ld < width)))
         return (int)hipErrorInvalidValue;
     ChainArgs c{};
     c.a = GemmArgs{(const f16x8*)xp, nullptr, nullptr, nullptr, pre_mask, residual, ln_gamma, ln_beta, post_mask, out_f32, (f16x8*)out_xp,
                    nullptr, 0, n_rows, width / 16, 1, residual_ld, out_ld, out_col0, out_xp_ksteps, out_xp_kstep0, 0, ln_eps, 0,
                    s2s::g_range_flag, 0, 0};
     c.n_layers = n_layers;
+    c.mid_residual = mid_residual; c.mid_res_ld = mid_residual_ld; c.mid_out = mid_out_f32; c.mid_out_ld = mid_out_ld;
     for (int l = 0; l < n_layers; ++l) {
         if (!layers[l].w_packed) return (int)hipErrorInvalidValue;
         c.w[l] = (const char*)layers[l].w_packed; c.bias[l] = layers[l].bias; c.relu[l] = layers[l].relu;
@@ -972,12 +991,15 @@ extern "C" int s2s_node_chain(const void* xp, const s2s_chain_layer* layers, int
     const long long n_rt = (n_rows + 31) / 32;
     const unsigned grid = (unsigned)((n_rt + 3) / 4);
     hipStream_t st = (hipStream_t)stream;
-    if (TG == 8) {
+    if (TG == 8 && k_in0 == 320) {
         constexpr int lds = 2 * 2 * 8 * 1024;
-        hipLaunchKernelGGL(node_chain_kernel<8>, dim3(grid), dim3(256), lds, st, c);
+        hipLaunchKernelGGL((node_chain_kernel<8, 20>), dim3(grid), dim3(256), lds, st, c);
+    } else if (TG == 8) {
+        constexpr int lds = 2 * 2 * 8 * 1024;
+        hipLaunchKernelGGL((node_chain_kernel<8, 16>), dim3(grid), dim3(256), lds, st, c);
     } else {
         constexpr int lds = 2 * 2 * 10 * 1024;
-        hipLaunchKernelGGL(node_chain_kernel<10>, dim3(grid), dim3(256), lds, st, c);
+        hipLaunchKernelGGL((node_chain_kernel<10, 20>), dim3(grid), dim3(256), lds, st, c);
     }
     return (int)hipGetLastError();
 }

@@ -26,6 +26,7 @@ import torch.nn.functional as F
 from ... import ops
 from ...arith import default_arith
 from ...common.rigid_utils import Rigid, Rotation
+_CHAIN4 = os.environ.get("S2S_CHAIN4", "1") != "0"   # trunk.linear + NodeTransition as one launch (s2s_node_chain)
 from .layers import BackboneUpdate, EdgeTransition, Linear, NodeTransition, ParamCache, TorsionAngleHead
 
 
@@ -379,10 +380,17 @@ class TranslationIPA(nn.Module):
                 xf, xx = ops.node_apply_chain(x1a, [lw["l1"], lw["l2"]], M, (True, False), residual=x1,
                                               ln=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), want_xp=True)
             # ---- node_embed + linear(tr) (:358), NodeTransition (:359, layers.py:128-145), mask (:360)
-            n_f32, n_a = lin(xx, w["lin"], residual=x_f32, want_xp=True)
+            # ... as ONE launch: trunk.linear's fp32 result is stored and read back as NodeTransition's residual (s2s_node_chain)
             nt = T[f"node_transition_{b}"]
-            s_f32, s_a = ops.node_apply_chain(n_a, [w["nt1"], w["nt2"], w["nt3"]], M, (True, True, False), residual=n_f32,
-                                              ln=(nt.ln.weight, nt.ln.bias, nt.ln.eps), post_mask=nm, want_xp=True)
+            if _CHAIN4:
+                n_f32 = torch.empty(M, C, device=dev, dtype=torch.float32)
+                s_f32, s_a = ops.node_apply_chain(xx, [w["lin"], w["nt1"], w["nt2"], w["nt3"]], M, (False, True, True, False),
+                                                  first_residual=x_f32, first_out_f32=n_f32, residual=n_f32,
+                                                  ln=(nt.ln.weight, nt.ln.bias, nt.ln.eps), post_mask=nm, want_xp=True)
+            else:
+                n_f32, n_a = lin(xx, w["lin"], residual=x_f32, want_xp=True)
+                s_f32, s_a = ops.node_apply_chain(n_a, [w["nt1"], w["nt2"], w["nt3"]], M, (True, True, False), residual=n_f32,
+                                                  ln=(nt.ln.weight, nt.ln.bias, nt.ln.eps), post_mask=nm, want_xp=True)
             # ---- backbone update (:361-365) and the layers that read the same s: the EdgeTransition's per-node parts (:367-372; their
             #      pair MLP runs in its own kernel below), after the last block the torsion head's first layer -- ONE launch
             has_et = b < self.num_blocks - 1

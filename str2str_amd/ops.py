@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 _lib = None
 _tables_loaded = False
@@ -47,7 +47,7 @@ _SIGNATURES = {
     "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "s2s_node_linear_f32": [_vp, _i, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "s2s_node_linear_multi": [_vp, _i, _vp],
-    "s2s_node_chain": [_vp, _vp, _i, _ll, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
+    "s2s_node_chain": [_vp, _vp, _i, _ll, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
     "s2s_embed_assemble": [_vp, _vp, _ll, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "s2s_row_layernorm": [_vp, _i, _ll, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
     "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _i, _vp],
@@ -1145,24 +1145,27 @@ CHAIN_WIDTHS = (256, 320)
 
 def node_chain(xp, w_row, bias, relu, n_rows: int, width: int, pre_mask=None, residual=None, ln_gamma=None, ln_beta=None, ln_eps: float = 0.0,
                post_mask=None, out_f32=None, out_col0: int = 0, want_f32=True, out_xp=None, out_xp_k: Optional[int] = None,
-               out_xp_k0: int = 0, want_xp=False):
-    """2 or 3 square layers (``width`` = 256 | 320) in one launch (s2s_node_chain): relu?(W x + b) between, the last layer with
+               out_xp_k0: int = 0, want_xp=False, k_in0: Optional[int] = None, mid_residual=None, mid_out_f32=None):
+    """2 .. 4 layers of one output width (``width`` = 256 | 320) in one launch (s2s_node_chain): relu?(W x + b) between, the last layer with
     ``node_linear``'s epilogue and outputs; hidden activations stay in registers.  ``w_row``: per layer the weights packed with one
     column block (pack_node_layer(..)["w_row"]), ``bias`` / ``relu`` per layer.  Bit for bit the separate launches.
-    -> (out_f32, out_xp) like ``node_linear``."""
+    The FIRST layer may contract over ``k_in0`` != width columns (320 -> 256), add ``mid_residual`` and store its fp32 result in
+    ``mid_out_f32`` (which may be the last layer's ``residual``).  -> (out_f32, out_xp) like ``node_linear``."""
     lib = load_library()
     _req(xp, torch.int16, "xp")
     n = len(w_row)
-    if n not in (2, 3) or len(bias) != n or len(relu) != n or width not in CHAIN_WIDTHS:
-        raise HipLibraryError("node_chain: 2 or 3 layers of width 256 or 320")
+    k0 = width if k_in0 is None or k_in0 < 0 else int(k_in0)
+    if n not in (2, 3, 4) or len(bias) != n or len(relu) != n or width not in CHAIN_WIDTHS or (k0 != width and (width, k0) != (256, 320)):
+        raise HipLibraryError("node_chain: 2 .. 4 layers of width 256 or 320 (first layer: 320 -> 256 allowed)")
     dev = xp.device
     arr = (_ChainLayer * n)()
     for i in range(n):
         _req(w_row[i], torch.int16, "w_row"); _req(bias[i], name="bias")
-        if w_row[i].numel() != width * width * 2 or bias[i].numel() < width:
+        if w_row[i].numel() != width * (k0 if i == 0 else width) * 2 or bias[i].numel() < width:
             raise HipLibraryError("node_chain: weights must be packed with one column block of the layer's width")
         arr[i].w_packed, arr[i].bias, arr[i].relu = w_row[i].data_ptr(), bias[i].data_ptr(), int(bool(relu[i]))
-    for nme, t in (("pre_mask", pre_mask), ("residual", residual), ("ln_gamma", ln_gamma), ("ln_beta", ln_beta), ("post_mask", post_mask)):
+    for nme, t in (("pre_mask", pre_mask), ("residual", residual), ("ln_gamma", ln_gamma), ("ln_beta", ln_beta), ("post_mask", post_mask),
+                   ("mid_residual", mid_residual), ("mid_out_f32", mid_out_f32)):
         if t is not None:
             _req(t, name=nme)
     if out_f32 is None and want_f32:
@@ -1174,7 +1177,8 @@ def node_chain(xp, w_row, bias, relu, n_rows: int, width: int, pre_mask=None, re
         out_xp_k = width if out_xp_k is None else out_xp_k
     range_flag()
     _check(_timed("s2s_node_linear", lambda: lib.s2s_node_chain(
-        _p(xp), ctypes.byref(arr), n, n_rows, width, _p(pre_mask), _p(residual), residual.shape[-1] if residual is not None else 0,
+        _p(xp), ctypes.byref(arr), n, n_rows, width, k0, _p(mid_residual), mid_residual.shape[-1] if mid_residual is not None else 0,
+        _p(mid_out_f32), mid_out_f32.shape[-1] if mid_out_f32 is not None else 0, _p(pre_mask), _p(residual), residual.shape[-1] if residual is not None else 0,
         _p(ln_gamma), _p(ln_beta), float(ln_eps), _p(post_mask), _p(out_f32), out_f32.shape[-1] if out_f32 is not None else 0, out_col0,
         _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16, _stream())), "s2s_node_chain")
     return out_f32, out_xp
@@ -1185,8 +1189,11 @@ def node_apply_chain(x, layers, n_rows: int, relu, **kw):
     the layers one after the other otherwise (fp32 activations of the "f32" arithmetic; other widths).  ``relu``: per layer;
     ``kw``: the LAST layer's epilogue / outputs as for ``node_apply`` (residual, ln, pre_mask, post_mask, out_*, want_*)."""
     width = layers[0]["n"]
-    ok = (x.dtype == torch.int16 and len(layers) in (2, 3) and width in CHAIN_WIDTHS
-          and all(L["n"] == width and L["k"] == width for L in layers) and "pre_scale" not in kw and "row_map" not in kw)
+    first_res, first_out = kw.pop("first_residual", None), kw.pop("first_out_f32", None)
+    k0 = layers[0]["k"]
+    ok = (x.dtype == torch.int16 and len(layers) in (2, 3, 4) and width in CHAIN_WIDTHS and (k0 == width or (width, k0) == (256, 320))
+          and all(L["n"] == width for L in layers) and all(L["k"] == width for L in layers[1:])
+          and "pre_scale" not in kw and "row_map" not in kw)
     # 320-wide chains (10 tiles: 512 registers, one workgroup per CU) win only between ~64 and ~384 workgroups: below, the first layer
     # is faster in narrow column blocks; above, two co-resident workgroups of the single launches overlap (tools/node_chain_bench.py:
     # 2 x 320: 38 -> 47 us at 1260 rows, 78 -> 70 at 32768, 182 -> 194 at 80000; 3 x 256: 55 -> 44, 74 -> 63, 201 -> 176)
@@ -1195,7 +1202,8 @@ def node_apply_chain(x, layers, n_rows: int, relu, **kw):
     if not ok:
         act = x
         for i, L in enumerate(layers[:-1]):
-            _, act = node_apply(act, L, n_rows, relu=relu[i], want_f32=False, want_xp=True)
+            fk = dict(residual=first_res, out_f32=first_out, want_f32=first_out is not None) if i == 0 else dict(want_f32=False)
+            _, act = node_apply(act, L, n_rows, relu=relu[i], want_xp=True, **fk)
         return node_apply(act, layers[-1], n_rows, relu=relu[-1], **kw)
     kw = dict(kw)
     ln = kw.pop("ln", None)
@@ -1204,7 +1212,7 @@ def node_apply_chain(x, layers, n_rows: int, relu, **kw):
                                             kw.pop("pre_mask", None), kw.pop("residual", None), g, b, float(eps), kw.pop("post_mask", None),
                                             kw.pop("out_f32", None), kw.pop("out_col0", 0), kw.pop("want_f32", True), kw.pop("out_xp", None),
                                             -1 if kw.get("out_xp_k") is None else kw.pop("out_xp_k"), kw.pop("out_xp_k0", 0),
-                                            kw.pop("want_xp", False))
+                                            kw.pop("want_xp", False), k0, first_res, first_out)
 
 
 def node_apply_multi(x, specs, n_rows: int):
@@ -1463,9 +1471,10 @@ _TORCH_OPS = {
         lambda *a: node_linear_multi(*a),
     "node_chain(Tensor xp, Tensor[] w_row, Tensor[] bias, bool[] relu, int n_rows, int width, Tensor? pre_mask=None, Tensor? residual=None, "
     "Tensor? ln_gamma=None, Tensor? ln_beta=None, float ln_eps=0.0, Tensor? post_mask=None, Tensor(a!)? out_f32=None, int out_col0=0, "
-    "bool want_f32=True, Tensor(b!)? out_xp=None, int out_xp_k=-1, int out_xp_k0=0, bool want_xp=False) -> (Tensor?, Tensor?)":
-        lambda xp, w, b, r, m, wd, pm=None, res=None, g=None, be=None, eps=0.0, pom=None, of=None, oc=0, wf=True, ox=None, ok=-1, ok0=0, wx=False:
-            node_chain(xp, w, b, r, m, wd, pm, res, g, be, eps, pom, of, oc, wf, ox, _opt_int(ok), ok0, wx),
+    "bool want_f32=True, Tensor(b!)? out_xp=None, int out_xp_k=-1, int out_xp_k0=0, bool want_xp=False, int k_in0=-1, "
+    "Tensor? mid_residual=None, Tensor(c!)? mid_out_f32=None) -> (Tensor?, Tensor?)":
+        lambda xp, w, b, r, m, wd, pm=None, res=None, g=None, be=None, eps=0.0, pom=None, of=None, oc=0, wf=True, ox=None, ok=-1, ok0=0, wx=False,
+        k0=-1, mr=None, mo=None: node_chain(xp, w, b, r, m, wd, pm, res, g, be, eps, pom, of, oc, wf, ox, _opt_int(ok), ok0, wx, k0, mr, mo),
     "row_layernorm(Tensor x, int n_rows, int n_cols, Tensor gamma, Tensor beta, float eps, Tensor? post_mask=None, Tensor(a!)? out_f32=None, "
     "int out_col0=0, bool want_f32=True, Tensor(b!)? out_xp=None, int out_xp_k=-1, int out_xp_k0=0, bool want_xp=False) -> (Tensor?, Tensor?)":
         lambda x, m, n, g, b, eps, pm=None, of=None, oc=0, wf=True, ox=None, ok=-1, ok0=0, wx=False: row_layernorm(

@@ -767,6 +767,17 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
         want = ops.node_apply(h2_, lyr[2], Mc, **kwc)
         got = ops.node_apply_chain(xc, lyr, Mc, (True, True, False), **kwc)
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), Mc
+        # ... and with trunk.linear (320 -> 256, + residual, fp32 result stored and read back as the last layer's residual) in front
+        x4, res4 = ops.pack_planes(rn(Mc, 320)), rn(Mc, 320)
+        n_want, n_a_ = ops.node_apply(x4, tw[0]["lin"], Mc, residual=res4, want_xp=True)
+        _, h1_ = ops.node_apply(n_a_, lyr[0], Mc, relu=True, want_f32=False, want_xp=True)
+        _, h2_ = ops.node_apply(h1_, lyr[1], Mc, relu=True, want_f32=False, want_xp=True)
+        kw4 = dict(ln=(ntm.ln.weight, ntm.ln.bias, ntm.ln.eps), post_mask=pmc, want_xp=True)
+        want = ops.node_apply(h2_, lyr[2], Mc, residual=n_want, **kw4)
+        n_got = torch.full((Mc, 256), float("nan"), device=DEV)
+        got = ops.node_apply_chain(x4, [tw[0]["lin"]] + lyr, Mc, (False, True, True, False), first_residual=res4, first_out_f32=n_got,
+                                   residual=n_got, **kw4)
+        assert torch.equal(n_got, n_want) and torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), Mc
         enc = tr["transformer_0"].layers[0]
         lw0 = tw[0]["layers"][0]
         xe, rese = ops.pack_planes(rn(Mc, 320)), rn(Mc, 320)
