@@ -13,6 +13,7 @@ ap.add_argument("--B", type=int, default=128)
 ap.add_argument("--N", type=int, default=256)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--sigma", type=float, default=0.05)
+ap.add_argument("--only-folded", action="store_true", help="run the folded (production) form alone: what a PMC pass should see")
 a = ap.parse_args()
 from str2str_amd import ops  # noqa: E402
 from str2str_amd.arith import use_arith  # noqa: E402
@@ -56,6 +57,10 @@ def timed(name, fn):
 
 with torch.no_grad():
     print(f"B={B} N={N} sigma={a.sigma}")
+    if a.only_folded:
+        ipa.arith, ipa.fold = "f16x3", True
+        timed("folded (K = V = s)", lambda: block(s_xp))
+        sys.exit(0)
     ipa.arith = "f32"
     ref = timed("exact fp32 path", lambda: block(s)).double()
     ipa.arith = "f16x3"
