@@ -98,11 +98,19 @@ def traffic_from_profiles(pairs, mode):
     """HBM bytes per launch of the dominant kernel.  NOT measured in this run: PMC counters need rocprofv3 around the
     process (separate --pmc passes, tools/pmc_hbm_traffic.sh), so the committed pass at B = 16, N = 256 is scaled by the
     pairs of this launch and labelled as such.  (None, None) if the file is absent."""
-    for name in ("r04_pmc_hbm_traffic.json", "r03h_pmc_hbm_traffic.json", "r03g_pmc_hbm_traffic.json", "r03f_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02m_pmc_hbm_traffic.json", "r02l_pmc_hbm_traffic.json", "r02k_pmc_hbm_traffic.json", "r02i_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01i_pmc_hbm_traffic.json"):
-        key = {"f16x3": "edge_transition_f16x3"}.get(mode, "edge_transition")
+    import glob
+    import re
+
+    def _order(path):   # newest evidence run first: round number, then the run's letter (r04l > r04a > r03h ...)
+        m = re.match(r"r(\d+)([a-z]*)_pmc_hbm_traffic\.json$", os.path.basename(path))
+        return (int(m.group(1)), m.group(2)) if m else (-1, "")
+
+    key = {"f16x3": "edge_transition_f16x3"}.get(mode, "edge_transition")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), key=_order, reverse=True):
         try:
-            with open(os.path.join(ROOT, "profiles", name)) as f:
-                return json.load(f)["kernels"][key]["bytes_per_pair_corrected"] * pairs, f"profiles/{name} (PMC pass at B=16, N=256, scaled per pair)"
+            with open(path) as f:
+                return (json.load(f)["kernels"][key]["bytes_per_pair_corrected"] * pairs,
+                        f"profiles/{os.path.basename(path)} (PMC pass at B=16, N=256, scaled per pair)")
         except Exception:
             continue
     return None, None
