@@ -137,7 +137,7 @@ def main():
     from str2str_amd import ops
     from str2str_amd.common.rigid_utils import Rigid
     from str2str_amd.factory import build_diffuser, build_synthetic_net
-    from str2str_amd.sampler import forward_backward, plan_mixed_work, sample_mixed_lengths
+    from str2str_amd.sampler import forward_backward, forward_backward_chunks, merge_chunk_groups, plan_mixed_work, sample_mixed_lengths
     from str2str_amd.synth import synth_chain
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -261,7 +261,9 @@ def main():
                     f"t_delta {deltas[0]} .. {deltas[-1]} ({len(deltas)} values), num_timesteps {S}: {n_eval} network evaluations per chunk")
         pairs_main = 64 * max(lens) ** 2
         eval_pairs = eval_ipa_bytes = 0
-        extra["evaluations_per_step"] = n_eval * len(chunks) * len(targets)
+        groups = {n: [[c[0] for c in g] for g in merge_chunk_groups([(c, 0, c) for c in chunks], n)] for n in lens}
+        extra["evaluations_per_step"] = n_eval * sum(len(g) for g in groups.values())
+        extra["trajectories_per_t_delta"] = {str(n): g for n, g in groups.items()}   # chunks sampled as one trajectory each
         extra["hip_graph"] = os.environ.get("S2S_HIP_GRAPH", "auto")
 
         def one_step(seed):
@@ -270,10 +272,12 @@ def main():
             res = None
             for tg in targets:
                 for d in deltas:
-                    for c in chunks:
-                        rig0 = Rigid.from_tensor_4x4(tg["rigidgroups_gt_frames"][..., 0, :, :].repeat(c, 1, 1, 1))
-                        a37 = forward_backward(net, diff, tg, rig0, d, num_timesteps=S, min_t=0.01, probability_flow=True,
-                                               self_conditioning=True, device=dev, rng=a.rng)
+                    # as DiffusionLitModule.predict_step runs it: the chunks are the unit of the reference's noise stream; those that fit
+                    # the pair budget are sampled as one trajectory (sampler.forward_backward_chunks; S2S_MERGE_CHUNKS=0: one per chunk)
+                    if True:
+                        a37 = forward_backward_chunks(net, diff, tg, tg["rigidgroups_gt_frames"][..., 0, :, :], [(c, 0, c) for c in chunks], d,
+                                                      num_timesteps=S, min_t=0.01, probability_flow=True, self_conditioning=True,
+                                                      device=dev, rng=a.rng)
                         res = a37[..., :5, :]
             return res.cpu() if rank == 0 else None
     else:  # cfg5

@@ -26,7 +26,7 @@ import torch
 
 from ..common.pdb_utils import AsyncPdbWriter, atom37_to_pdb, merge_pdbfiles
 from ..common.rigid_utils import Rigid
-from ..sampler import forward_backward, plan_mixed_work, rank_chunk_slices, sample_mixed_lengths, shard_range
+from ..sampler import forward_backward, forward_backward_chunks, plan_mixed_work, rank_chunk_slices, sample_mixed_lengths, shard_range
 
 try:  # pragma: no cover - depends on the environment
     from lightning import LightningModule as _Base
@@ -113,15 +113,11 @@ class DiffusionLitModule(_Base):
         self.last_samples = {}   # t_delta -> atom37 [n_replica, N, 37, 3] device tensor of the last target (rank 0; programmatic callers)
         for t_delta in delta_range:
             gt4 = batch["rigidgroups_gt_frames"][..., 0, :, :].clone()
-            mine = []
-            for bsz, lo, hi in rank_chunk_slices(n_replica, replica_per_batch, *shard):
-                # the reference's chunks are the unit of its host noise stream: an empty slice still advances the host
-                # generator in lock-step with the ranks that sample the chunk
-                if hi > lo or self.rng_mode == "host":
-                    rig0 = Rigid.from_tensor_4x4(gt4.repeat(bsz, *(1,) * (gt4.ndim - 1)))
-                    mine.append(forward_backward(self.net, self.diffuser, batch, rig0, float(t_delta),
-                                                 replica_slice=(lo, hi), **kw))
-            a37 = torch.cat(mine, dim=0) if mine else torch.zeros(0, gt4.shape[-3], 37, 3, device=device)
+            # the reference's chunks are the unit of its host noise stream, not of the arithmetic: chunks that fit a pair budget are
+            # sampled as one trajectory (sampler.forward_backward_chunks: same samples, fewer launches; S2S_MERGE_CHUNKS=0 = one
+            # trajectory per chunk); an empty slice still advances the host generator in lock-step with the other ranks
+            a37 = forward_backward_chunks(self.net, self.diffuser, batch, gt4, rank_chunk_slices(n_replica, replica_per_batch, *shard),
+                                          float(t_delta), **kw)
             if distributed:
                 a37 = gather_replicas(a37, n_replica)   # ONE collective per (target, t_delta)
             if shard[0] == 0:

@@ -345,6 +345,46 @@ def _denoise_pass(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: fl
     return atom37, final["rigids7"], final["psi"]
 
 
+def _require_hip_device(device, net) -> torch.device:
+    device = torch.device(device) if device is not None else next(net.parameters()).device
+    if device.type != "cuda":
+        raise ops.HipLibraryError("the sampler needs the HIP device (MI355X); there is no CPU fallback")
+    return device
+
+
+def _start_frames(diffuser, batch: dict, rigids_0: Rigid, t_delta: float, lo: int, hi: int, rng: str, device):
+    """The noised frames a chunk's trajectory starts from, for the replicas [lo, hi) of the chunk ``rigids_0`` -> [hi - lo, N, 7]
+    float32 device tensor, or None for an empty slice.  ``rng="host"``: drawn once per trajectory on the host generators for the
+    WHOLE chunk, in the reference's order (diffusion_module.py:277-296 there) -- also for an empty slice; ``rng="device"``
+    (throughput mode): for the slice only, drawn and applied on the device (s2s_forward_marginal)."""
+    B_total, N = rigids_0.shape[0], rigids_0.shape[1]
+    b = hi - lo
+    if rng == "device":
+        if b == 0:
+            return None
+        if t_delta > 0:
+            dmask = batch["residue_mask"].to(device).float().reshape(1, N).expand(b, N).contiguous()
+            return diffuser.forward_marginal_device(rigids_0[lo:hi].to_tensor_4x4().to(device), t_delta, dmask)
+        return diffuser.forward_marginal_device(None, None, shape=(b, N))
+    if t_delta > 0:
+        rigids_t = diffuser.forward_marginal(rigids_0=rigids_0.to(device="cpu"), t=t_delta * torch.ones(B_total),
+                                             diffuse_mask=batch["residue_mask"].cpu().repeat(B_total, 1),
+                                             as_tensor_7=True)["rigids_t"]
+    else:
+        rigids_t = diffuser.sample_prior(shape=rigids_0.shape, device="cpu", as_tensor_7=True)["rigids_t"]
+    if b == 0:
+        return None
+    return rigids_t[lo:hi].to(device).float().contiguous()
+
+
+def _burn_step_draws(B_total: int, N: int, n_draw_steps: int):
+    """The reference consumes two float64 normal draws of the whole chunk per step even under the probability-flow ODE
+    (so3.py:360, r3.py:109): consume them so that the host generator is where the reference's is for the next chunk."""
+    for _ in range(n_draw_steps):
+        torch.randn(B_total, N, 3, dtype=torch.float64)
+        torch.randn(B_total, N, 3, dtype=torch.float64)
+
+
 @torch.no_grad()
 def forward_backward(net, diffuser, batch: dict, rigids_0: Rigid, t_delta: float, *, num_timesteps: int,
                      min_t: float = 0.01, noise_scale: float = 1.0, probability_flow: bool = True,
@@ -359,9 +399,7 @@ def forward_backward(net, diffuser, batch: dict, rigids_0: Rigid, t_delta: float
     including a process whose slice is empty -- so the union over processes equals the single-process run sample for
     sample and every generator stays in lock-step for later chunks.  ``rng="device"`` (throughput mode) draws the
     forward-marginal and step noise on the device generator for the slice only."""
-    device = torch.device(device) if device is not None else next(net.parameters()).device
-    if device.type != "cuda":
-        raise ops.HipLibraryError("the sampler needs the HIP device (MI355X); there is no CPU fallback")
+    device = _require_hip_device(device, net)
     B_total = rigids_0.shape[0]
     lo, hi = replica_slice if replica_slice is not None else shard_range(B_total, *shard)
     if not (0 <= lo <= hi <= B_total):
@@ -370,31 +408,11 @@ def forward_backward(net, diffuser, batch: dict, rigids_0: Rigid, t_delta: float
     T, n, dt, ts = schedule(t_delta, num_timesteps, min_t)
     N = rigids_0.shape[1]
 
-    if rng == "device":
-        # ---- throughput mode: noise for this slice only, drawn and applied on the device (s2s_forward_marginal)
-        if b == 0:
-            return torch.zeros(0, N, 37, 3, device=device)
-        if t_delta > 0:
-            dmask = batch["residue_mask"].to(device).float().reshape(1, N).expand(b, N).contiguous()
-            rigids_t = diffuser.forward_marginal_device(rigids_0[lo:hi].to_tensor_4x4().to(device), t_delta, dmask)
-        else:
-            rigids_t = diffuser.forward_marginal_device(None, None, shape=(b, N))
-    else:
-        # ---- once per trajectory, on the host generator, for the WHOLE chunk (reference order)
-        if t_delta > 0:
-            rigids_t = diffuser.forward_marginal(rigids_0=rigids_0.to(device="cpu"), t=t_delta * torch.ones(B_total),
-                                                 diffuse_mask=batch["residue_mask"].cpu().repeat(B_total, 1),
-                                                 as_tensor_7=True)["rigids_t"]
-        else:
-            rigids_t = diffuser.sample_prior(shape=rigids_0.shape, device="cpu", as_tensor_7=True)["rigids_t"]
-        if b == 0:
-            # nothing to sample here, but the reference's per-step draws (two float64 normals per step, see host_noise
-            # below) must still be consumed so that this process' generator matches every other process' afterwards
-            for _ in range(len(ts) - 1):
-                torch.randn(B_total, N, 3, dtype=torch.float64)
-                torch.randn(B_total, N, 3, dtype=torch.float64)
-            return torch.zeros(0, N, 37, 3, device=device)
-        rigids_t = rigids_t[lo:hi].to(device).float().contiguous()
+    rigids_t = _start_frames(diffuser, batch, rigids_0, t_delta, lo, hi, rng, device)
+    if rigids_t is None:
+        if rng == "host":
+            _burn_step_draws(B_total, N, len(ts) - 1)
+        return torch.zeros(0, N, 37, 3, device=device)
     feats = {k: batch[k].to(device).repeat(b, *(1,) * (batch[k].ndim - 1)) for k in _REPEAT_KEYS if k in batch}
 
     def host_noise():
@@ -412,6 +430,77 @@ def forward_backward(net, diffuser, batch: dict, rigids_0: Rigid, t_delta: float
     if return_rigids:
         return atom37, r7, psi
     return atom37
+
+
+_MERGE_MAX_PAIRS = 8 << 20   # a merged trajectory stays within the working set of BASELINE configs[1] (128 x 256^2 pairs, ~11 GB)
+
+
+def merge_chunk_groups(chunks, N: int, *, mergeable: bool = True, max_pairs: int = None):
+    """Consecutive replica chunks ``[(chunk_size, lo, hi)]`` (``rank_chunk_slices``) -> groups that are sampled as ONE trajectory each.
+    A group grows while this rank's replicas in it stay below ``max_pairs`` pairs; ``S2S_MERGE_CHUNKS=0`` (or ``mergeable=False``:
+    host noise under the SDE, where a chunk's per-step draws interleave with its trajectory) keeps one chunk per group."""
+    max_pairs = _MERGE_MAX_PAIRS if max_pairs is None else max_pairs
+    if not mergeable or os.environ.get("S2S_MERGE_CHUNKS", "1") == "0":
+        return [[c] for c in chunks]
+    groups, cur, cur_b = [], [], 0
+    for c in chunks:
+        b = c[2] - c[1]
+        if cur and (cur_b + b) * N * N > max_pairs:
+            groups.append(cur)
+            cur, cur_b = [], 0
+        cur.append(c)
+        cur_b += b
+    if cur:
+        groups.append(cur)
+    return groups
+
+
+@torch.no_grad()
+def forward_backward_chunks(net, diffuser, batch: dict, gt_frames_4x4: torch.Tensor, chunks, t_delta: float, *, num_timesteps: int,
+                            min_t: float = 0.01, noise_scale: float = 1.0, probability_flow: bool = True,
+                            self_conditioning: bool = True, device=None, rng: str = "host", max_pairs: int = None):
+    """All replica chunks of one (target, t_delta) -> atom37 [sum(hi - lo), N, 37, 3] in replica order.
+
+    The reference samples ``n_replica`` replicas in chunks of ``replica_per_batch`` (diffusion_module.py:341-351), one trajectory per
+    chunk; its default block (100 replicas in chunks of 64 + 36 on chains of 35 .. 80 residues) leaves the GPU launch-bound -- an
+    evaluation of 64 x 35^2 pairs costs what one of 100 x 35^2 costs.  The chunk is only the unit of the reference's HOST NOISE
+    stream: every replica's trajectory is independent of its batch (the kernels are batch-invariant: sharded == single is tested
+    bit for bit).  So the chunks' start frames are drawn chunk by chunk in the reference's order (and, in ``rng="host"`` mode, the
+    two float64 draws per step the reference consumes even under the ODE are consumed per chunk), and the chunks that fit a pair
+    budget run as ONE trajectory: same samples, file for file, in fewer launches.  Under the SDE with host noise the per-step draws
+    are part of the trajectory: one chunk per trajectory, as before.  ``chunks`` = ``rank_chunk_slices(...)`` of this rank."""
+    device = _require_hip_device(device, net)
+    N = gt_frames_4x4.shape[-3]
+    T, n, dt, ts = schedule(t_delta, num_timesteps, min_t)
+    kw = dict(num_timesteps=num_timesteps, min_t=min_t, noise_scale=noise_scale, probability_flow=probability_flow,
+              self_conditioning=self_conditioning, device=device, rng=rng)
+    rig0 = lambda bsz: Rigid.from_tensor_4x4(gt_frames_4x4.repeat(bsz, *(1,) * (gt_frames_4x4.ndim - 1)))  # noqa: E731
+    out = []
+    for group in merge_chunk_groups(chunks, N, mergeable=probability_flow or rng == "device", max_pairs=max_pairs):
+        if len(group) == 1:
+            bsz, lo, hi = group[0]
+            if hi > lo or rng == "host":   # an empty slice still advances the host generators in lock-step with the other ranks
+                out.append(forward_backward(net, diffuser, batch, rig0(bsz), float(t_delta), replica_slice=(lo, hi), **kw))
+            continue
+        starts = []
+        for bsz, lo, hi in group:
+            if hi > lo or rng == "host":
+                r = _start_frames(diffuser, batch, rig0(bsz), float(t_delta), lo, hi, rng, device)
+                if rng == "host":
+                    _burn_step_draws(bsz, N, len(ts) - 1)
+                if r is not None:
+                    starts.append(r)
+        if not starts:
+            continue
+        rigids_t = torch.cat(starts, dim=0) if len(starts) > 1 else starts[0]
+        b = rigids_t.shape[0]
+        feats = {k: batch[k].to(device).repeat(b, *(1,) * (batch[k].ndim - 1)) for k in _REPEAT_KEYS if k in batch}
+        out.append(denoise_loop(net, diffuser, feats, rigids_t, ts, dt, min_t=min_t, noise_scale=noise_scale,
+                                probability_flow=probability_flow, self_conditioning=self_conditioning, center_mode=1,
+                                host_noise=None)[0])
+    if not out:
+        return torch.zeros(0, N, 37, 3, device=device)
+    return torch.cat(out, dim=0) if len(out) > 1 else out[0]
 
 
 def forward_flops(n_res: int) -> float:

@@ -38,18 +38,22 @@ def test_rank_chunk_slices_partition_the_replica_range():
     assert sorted(hi - lo for _, lo, hi in rank_chunk_slices(1000, 64, 0, 8) if hi > lo) == [61, 64]
 
 
-def _fake_forward_backward(net, diffuser, batch, rigids_0, t_delta, *, replica_slice, num_timesteps, **kw):
-    """Generator behaviour of sampler.forward_backward in rng='host' mode: the WHOLE chunk's forward-marginal noise and two
-    float64 normal draws per step are consumed whatever the slice; returns, per replica of the slice, its forward-marginal
-    noise value (so a wrong slice / a generator out of lock-step shows up in the gathered file)."""
+def _fake_start_frames(diffuser, batch, rigids_0, t_delta, lo, hi, rng, device):
+    """Generator behaviour of sampler._start_frames in rng='host' mode: the WHOLE chunk's forward-marginal noise is consumed whatever
+    the slice; the "frames" of the slice are that noise (so a wrong slice / a generator out of lock-step shows up in the file)."""
     B, N = rigids_0.shape
     z = torch.randn(B, N, 3)              # stands for the chunk's forward-marginal draws
-    for _ in range(num_timesteps - 1):
-        torch.randn(B, N, 3, dtype=torch.float64); torch.randn(B, N, 3, dtype=torch.float64)
-    lo, hi = replica_slice
-    out = torch.zeros(hi - lo, N, 37, 3)
-    out[:, :, 1, :] = z[lo:hi]
-    return out
+    return z[lo:hi] if hi > lo else None
+
+
+def _fake_denoise_loop(net, diffuser, feats, rigids_t, ts, dt, *, host_noise=None, **kw):
+    """A trajectory that returns its start: per step the host draws of the chunk are consumed when the caller hands them in."""
+    for _ in range(len(ts) - 1):
+        if host_noise is not None:
+            host_noise()
+    out = torch.zeros(rigids_t.shape[0], rigids_t.shape[1], 37, 3)
+    out[:, :, 1, :] = rigids_t
+    return out, None, None
 
 
 class _Net(torch.nn.Module):
@@ -67,7 +71,12 @@ def _predict(rank, world, port, n_replica, rpb, out_dir, q):
     from str2str_amd.models import diffusion_module as DM
     from str2str_amd.synth import synth_chain
 
-    DM.forward_backward = _fake_forward_backward
+    from str2str_amd import sampler as SM
+
+    # the sampler's control flow (chunks -> groups -> trajectories, slices, host-generator lock-step) runs as shipped; only the three
+    # functions that need the device are replaced
+    SM._start_frames, SM.denoise_loop = _fake_start_frames, _fake_denoise_loop
+    SM._require_hip_device = lambda device, net: torch.device("cpu")
     inf = dict(n_replica=n_replica, replica_per_batch=rpb, delta_min=0.5, delta_max=0.6, delta_step=0.1, num_timesteps=4,
                noise_scale=1.0, probability_flow=True, self_conditioning=True, min_t=0.01, output_dir=out_dir, backward_only=False)
     model = DM.DiffusionLitModule(net=_Net(), diffuser=None, inference=inf)
@@ -106,6 +115,13 @@ def test_predict_step_multi_rank_files_equal_single_process(tmp_path):
         for world in (2, 3):
             multi = _run_predict(world, n_replica, rpb, str(tmp_path / f"w{world}_{n_replica}"))
             assert multi == single, (n_replica, rpb, world)
+        # the chunks of a (target, t_delta) sampled as one trajectory (the default) against one trajectory per chunk
+        os.environ["S2S_MERGE_CHUNKS"] = "0"   # (inherited by the spawned ranks)
+        try:
+            assert _run_predict(1, n_replica, rpb, str(tmp_path / f"w1_{n_replica}_chunkwise")) == single
+            assert _run_predict(2, n_replica, rpb, str(tmp_path / f"w2_{n_replica}_chunkwise")) == single
+        finally:
+            del os.environ["S2S_MERGE_CHUNKS"]
 
 
 def _gather_worker(rank, world, port, total, q):

@@ -1194,6 +1194,45 @@ def test_free_running_trajectory_rmsd(net_smooth, diffuser, tag):
     assert rmsd < 1e-4, (tag, rmsd)
 
 
+def test_merged_chunks_equal_chunk_by_chunk(net_smooth, diffuser, monkeypatch):
+    """The reference's replica chunks (diffusion_module.py:341-351) are the unit of its host noise stream, not of the arithmetic:
+    ``forward_backward_chunks`` draws chunk by chunk in the reference's order and samples the chunks that fit the pair budget as ONE
+    trajectory.  Bit for bit the chunk-by-chunk run (S2S_MERGE_CHUNKS=0 = the reference's control flow), the host generator ends
+    where that run leaves it, and a rank's part of the merged run is the matching part of the single-process run."""
+    from str2str_amd.sampler import forward_backward_chunks, merge_chunk_groups, rank_chunk_slices
+    from str2str_amd.synth import synth_chain
+
+    for n_res, t_delta in ((20, 0.5), (40, 1.0)):
+        feats = synth_chain(n_res)
+        gt4 = feats["rigidgroups_gt_frames"][..., 0, :, :]
+        kw = dict(num_timesteps=8, device=DEV, rng="host", probability_flow=True)
+        chunks = rank_chunk_slices(7, 3, 0, 1)                      # 3 + 3 + 1 replicas
+        assert len(merge_chunk_groups(chunks, n_res)) == 1
+        monkeypatch.setenv("S2S_MERGE_CHUNKS", "0")
+        torch.manual_seed(21)
+        ref = forward_backward_chunks(net_smooth, diffuser, feats, gt4, chunks, t_delta, **kw)
+        state_ref = torch.get_rng_state()
+        monkeypatch.setenv("S2S_MERGE_CHUNKS", "1")
+        torch.manual_seed(21)
+        got = forward_backward_chunks(net_smooth, diffuser, feats, gt4, chunks, t_delta, **kw)
+        assert got.shape == ref.shape == (7, n_res, 37, 3)
+        assert torch.equal(got.cpu(), ref.cpu())
+        assert torch.equal(torch.get_rng_state(), state_ref)
+        # a pair budget in between: (3 + 3) | 1
+        torch.manual_seed(21)
+        two = forward_backward_chunks(net_smooth, diffuser, feats, gt4, chunks, t_delta, max_pairs=6 * n_res * n_res, **kw)
+        assert torch.equal(two.cpu(), ref.cpu())
+        # two ranks, back to back on this GPU: rank-major concatenation of the merged runs == the single-process run
+        parts = []
+        for r in range(2):
+            torch.manual_seed(21)
+            parts.append(forward_backward_chunks(net_smooth, diffuser, feats, gt4, rank_chunk_slices(7, 3, r, 2), t_delta, **kw))
+        assert parts[0].shape[0] == 4 and parts[1].shape[0] == 3
+        assert torch.equal(torch.cat(parts).cpu(), ref.cpu())
+    # the SDE with host noise keeps one trajectory per chunk (its per-step draws are part of the trajectory)
+    assert len(merge_chunk_groups(chunks, 20, mergeable=False)) == 3
+
+
 def test_sharded_sampler_equals_single(net_smooth, diffuser):
     """Replica sharding (2 'ranks' run back to back on one GPU) reproduces the unsharded chunk."""
     from str2str_amd.common.rigid_utils import Rigid

@@ -359,3 +359,26 @@ def test_edge_prescale_ladder():
         assert [m.prescale_exp for m in net] == [e, e, 0]
     assert seen == [5, 10, 15]
     assert _raise_edge_prescale(nn.ModuleList([ET("f32")])) == 0
+
+
+def test_chunk_merging_groups(monkeypatch):
+    """sampler.merge_chunk_groups: consecutive replica chunks are sampled as one trajectory while this rank's replicas in the group
+    stay below the pair budget; order and membership are untouched; the switch and the SDE-with-host-noise case keep single chunks."""
+    from str2str_amd.sampler import merge_chunk_groups, rank_chunk_slices
+
+    monkeypatch.delenv("S2S_MERGE_CHUNKS", raising=False)
+    ref_default = rank_chunk_slices(100, 64, 0, 1)
+    assert ref_default == [(64, 0, 64), (36, 0, 36)]
+    assert merge_chunk_groups(ref_default, 35) == [ref_default] and merge_chunk_groups(ref_default, 80) == [ref_default]
+    assert merge_chunk_groups(ref_default, 512) == [[c] for c in ref_default]              # 64 x 512^2 alone exceeds the budget
+    assert merge_chunk_groups(rank_chunk_slices(256, 128, 0, 1), 256) == [[(128, 0, 128)], [(128, 0, 128)]]   # cfg2-sized chunks stay
+    for n, rpb, world, N in [(1000, 64, 8, 80), (100, 64, 3, 35), (9, 4, 8, 20), (130, 64, 4, 300)]:
+        for r in range(world):
+            chunks = rank_chunk_slices(n, rpb, r, world)
+            groups = merge_chunk_groups(chunks, N)
+            assert [c for g in groups for c in g] == chunks
+            for g in groups:
+                assert len(g) == 1 or sum(hi - lo for _, lo, hi in g) * N * N <= 8 << 20
+    assert merge_chunk_groups(ref_default, 35, mergeable=False) == [[c] for c in ref_default]
+    monkeypatch.setenv("S2S_MERGE_CHUNKS", "0")
+    assert merge_chunk_groups(ref_default, 35) == [[c] for c in ref_default]
