@@ -482,22 +482,33 @@ def forward_backward_chunks(net, diffuser, batch: dict, gt_frames_4x4: torch.Ten
             if hi > lo or rng == "host":   # an empty slice still advances the host generators in lock-step with the other ranks
                 out.append(forward_backward(net, diffuser, batch, rig0(bsz), float(t_delta), replica_slice=(lo, hi), **kw))
             continue
-        starts = []
-        for bsz, lo, hi in group:
+        starts, tail_burn = [], None
+        for i, (bsz, lo, hi) in enumerate(group):
             if hi > lo or rng == "host":
                 r = _start_frames(diffuser, batch, rig0(bsz), float(t_delta), lo, hi, rng, device)
                 if rng == "host":
-                    _burn_step_draws(bsz, N, len(ts) - 1)
+                    if i + 1 < len(group):
+                        _burn_step_draws(bsz, N, len(ts) - 1)   # the next chunk's start frames come after this chunk's step draws
+                    else:
+                        tail_burn = bsz                          # the last chunk's ride in the loop, behind the GPU (as in forward_backward)
                 if r is not None:
                     starts.append(r)
         if not starts:
+            if tail_burn is not None:
+                _burn_step_draws(tail_burn, N, len(ts) - 1)
             continue
         rigids_t = torch.cat(starts, dim=0) if len(starts) > 1 else starts[0]
         b = rigids_t.shape[0]
         feats = {k: batch[k].to(device).repeat(b, *(1,) * (batch[k].ndim - 1)) for k in _REPEAT_KEYS if k in batch}
+
+        def host_noise(bsz=tail_burn):   # (a mergeable group in host mode runs the ODE: the draws are consumed, not used)
+            torch.randn(bsz, N, 3, dtype=torch.float64)
+            torch.randn(bsz, N, 3, dtype=torch.float64)
+            return None
+
         out.append(denoise_loop(net, diffuser, feats, rigids_t, ts, dt, min_t=min_t, noise_scale=noise_scale,
                                 probability_flow=probability_flow, self_conditioning=self_conditioning, center_mode=1,
-                                host_noise=None)[0])
+                                host_noise=host_noise if tail_burn is not None else None)[0])
     if not out:
         return torch.zeros(0, N, 37, 3, device=device)
     return torch.cat(out, dim=0) if len(out) > 1 else out[0]
