@@ -437,13 +437,14 @@ def main():
         if world == 1 and not a.no_cpu_baseline and a.config == "cfg2":
             line["cpu_baseline"] = cpu_baseline(N, S, steps_sampled=a.cpu_steps)
         if world == 1 and a.config == "cfg2" and not a.no_other_configs and a.n_res is None and a.replicas is None and a.denoise_steps is None:
-            # the other single-GPU workloads of BASELINE.json, ONE step each (their own processes, after the timed region and the CPU
-            # baseline): driver-visible numbers for cfg3 / cfg4 / cfg5 beside the headline
+            # the other single-GPU workloads of BASELINE.json and the reference's default inference block (configs/model/diffusion.yaml:88-100
+            # there: the workload its users run), ONE step each (their own processes, after the timed region and the CPU baseline):
+            # driver-visible numbers for cfg3 / cfg4 / cfg5 / ref_default beside the headline
             import subprocess
 
             torch.cuda.empty_cache()
             line["other_configs"] = {}
-            for cfg in ("cfg3", "cfg4", "cfg5"):
+            for cfg in ("cfg3", "cfg4", "cfg5", "ref_default"):
                 t_sub = time.perf_counter()
                 try:
                     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", "1", "--warmup", "0",
