@@ -531,7 +531,7 @@ def plan_mixed_work(lengths, replicas: int, world: int = 1, *, max_pairs: int = 
       3. per rank, items in decreasing length are packed into padded batches (n_pad = the longest chain of the batch; the
          kernels take ragged N, so there is no tile rounding).  An item joins the open batch when that is cheaper than a
          batch of its own (within 5 %) under  cost(batch) = max(launch_floor_ms, ms_per_mpair x padded Mpairs)  per network evaluation
-         -- one evaluation is ~330 launches, so small batches are launch-bound and padding them into a neighbour is free,
+         -- one evaluation is ~83 dependent launches, so small batches are launch-bound and padding them into a neighbour is free,
          while large ones pay for every padded pair (measured: 10.7 ms per 2^20 pairs at cfg2) -- and the batch stays
          below ``max_pairs`` (device memory: ~1.3 KB per pair).
     -> plan[rank] = [ {"n_pad": int, "items": [(chain, replica_lo, replica_hi), ...]}, ... ]"""
