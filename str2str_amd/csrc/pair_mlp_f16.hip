@@ -285,12 +285,14 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     const long long n_wt = (M + 127) / 128;
     long long wt = blockIdx.x;
 #ifndef S2S_ET_PHASES
-#define S2S_ET_PHASES 16
+#define S2S_ET_PHASES 1
 #endif
-    // Phase stagger.  Every workgroup runs the same schedule on equal tiles: left alone they stay in lockstep, and all 256 of them
-    // ask HBM for their next 64 KiB tile in the same microsecond (16 MiB: ~3.5 us at the achievable rate, which every workgroup
-    // then waits for -- the tile's edge row is needed 4 slots after it is requested).  Workgroups of one XCD start S2S_ET_PHASES
-    // different fractions of a tile apart (a tile is ~100 k cycles), so the requests arrive spread over the tile time.
+    // Phase stagger (OFF since the end of round 4; -DS2S_ET_PHASES=16 restores it).  Every workgroup runs the same schedule on equal
+    // tiles: left alone they stay in lockstep and ask HBM for their next 64 KiB tile in the same microsecond.  Starting the workgroups
+    // of one XCD S2S_ET_PHASES different fractions of a tile apart was meant to spread those requests over the tile time -- but since
+    // the edge row is requested two loads per slot, 16+ slots ahead of its use (kXv0 below), lockstep costs nothing, while the start
+    // delay (up to 15/16 of a tile: ~45 us) is added to every launch: same-call A/B (profiles/r04t_et_phase_stagger_ab.txt)
+    // 11.290 -> 11.274 ms at cfg2, 0.245 -> 0.215 ms at 100 x 35^2 pairs (3.7 tiles per workgroup), 1.019 -> 1.002 at 100 x 80^2.
     if constexpr (S2S_ET_PHASES > 1) {
         const int phase = (blockIdx.x >> 3) % S2S_ET_PHASES;
         for (int i = 0; i < phase * (16 / (S2S_ET_PHASES > 16 ? 16 : S2S_ET_PHASES)); ++i) __builtin_amdgcn_s_sleep(98);   // 98 x 64 cycles = 1/16 tile
