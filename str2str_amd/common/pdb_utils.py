@@ -111,8 +111,19 @@ class AsyncPdbWriter:
         self._futs = []
         return out
 
-    def close(self):
-        self._pool.shutdown(wait=True)
+    def close(self, cancel_pending: bool = False):
+        """Stop the worker thread and drop the page-locked buffers.  ``cancel_pending``: files still queued are not written (the
+        error path: a sampler failure must not leave a worker writing behind the exception)."""
+        self._pool.shutdown(wait=True, cancel_futures=cancel_pending)
+        self._futs = []
+        self._pinned = {}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        self.close(cancel_pending=exc_type is not None)
+        return False
 
 
 def merge_pdbfiles(input, output_file: str, verbose: bool = True) -> None:
@@ -154,6 +165,18 @@ def merge_pdbfiles(input, output_file: str, verbose: bool = True) -> None:
 
 
 _AMINO_ACIDS = frozenset("ALA ARG ASN ASP CYS GLN GLU GLY HIS ILE LEU LYS MET PHE PRO SER THR TRP TYR VAL".split())
+# Peptide-linking components of the CCD that occur in experimental / reference structures (biotite's filter_amino_acids, which the
+# reference's reader applies, accepts every such component, as ATOM or HETATM records): the common modified residues with the
+# standard residue each derives from.  Only membership matters for the C-alpha trace; a residue in neither table is an error.
+_MODIFIED_AMINO_ACIDS = {
+    "MSE": "MET", "SEC": "CYS", "PYL": "LYS", "HYP": "PRO", "SEP": "SER", "TPO": "THR", "PTR": "TYR", "TYS": "TYR", "CSO": "CYS",
+    "CSD": "CYS", "CME": "CYS", "OCS": "CYS", "CSS": "CYS", "CSX": "CYS", "SMC": "CYS", "CAS": "CYS", "KCX": "LYS", "MLY": "LYS",
+    "MLZ": "LYS", "M3L": "LYS", "ALY": "LYS", "LLP": "LYS", "PCA": "GLU", "CGU": "GLU", "HIC": "HIS", "NEP": "HIS", "MHS": "HIS",
+    "NLE": "LEU", "MLE": "LEU", "ABA": "ALA", "AIB": "ALA", "DAL": "ALA", "ORN": "LYS", "FME": "MET", "MHO": "MET", "SAC": "SER",
+    "DSN": "SER", "DTH": "THR", "DVA": "VAL", "DLE": "LEU", "DPR": "PRO", "DPN": "PHE", "DTR": "TRP", "DTY": "TYR", "DAR": "ARG",
+    "DAS": "ASP", "DGL": "GLU", "DGN": "GLN", "DLY": "LYS", "DCY": "CYS", "DHI": "HIS", "DIL": "ILE", "MED": "MET", "DSG": "ASN",
+    "TRO": "TRP", "HTR": "TRP", "PHI": "PHE", "YCM": "CYS", "AGM": "ARG", "ASX": "ASP", "GLX": "GLU", "UNK": "ALA",
+}
 
 
 def extract_backbone_coords(input_path: str, max_n_model: Optional[int] = None) -> np.ndarray:
@@ -172,13 +195,13 @@ def extract_backbone_coords(input_path: str, max_n_model: Optional[int] = None) 
         with open(input_path) as fh:
             for ln in fh:
                 if ln.startswith(("ATOM", "HETATM")) and ln[12:16] == " CA ":      # a C-alpha (a calcium ion is "CA  ")
-                    if ln[17:20] not in _AMINO_ACIDS:
-                        # biotite's filter_amino_acids accepts every peptide-linking component of the CCD (MSE, SEC, HYP, ...), a
-                        # table this reader does not carry: such a residue is an error here, not a silently shorter chain
-                        raise ValueError(f"{input_path}: C-alpha of non-standard residue {ln[17:20]!r} {ln[21]}{ln[22:27].strip()}: "
-                                         "only the 20 standard amino acids are read (convert the residue or extend _AMINO_ACIDS)")
-                    if not ln.startswith("ATOM"):
-                        continue
+                    if ln[17:20] not in _AMINO_ACIDS and ln[17:20] not in _MODIFIED_AMINO_ACIDS:
+                        # biotite's filter_amino_acids accepts every peptide-linking component of the CCD; this reader carries the
+                        # standard twenty + the common modified residues (selenomethionine, phosphoserine, ...), as ATOM or HETATM
+                        # records like biotite (which does not filter on the record type).  A residue in neither table is an error
+                        # here, not a silently shorter chain
+                        raise ValueError(f"{input_path}: C-alpha of unknown residue {ln[17:20]!r} {ln[21]}{ln[22:27].strip()}: "
+                                         "not one of the standard or common modified amino acids (extend _MODIFIED_AMINO_ACIDS)")
                     key = (ln[21], ln[22:27])          # chain id, resSeq + iCode
                     if key not in seen:                 # later altlocs of a residue already taken are skipped
                         seen.add(key)

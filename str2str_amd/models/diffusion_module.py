@@ -109,25 +109,26 @@ class DiffusionLitModule(_Base):
         extra = {k: batch[k][0].detach().cpu().numpy() for k in ("aatype", "chain_index", "residue_index")}
         kw = dict(num_timesteps=inf.num_timesteps, min_t=inf.min_t, noise_scale=inf.noise_scale,
                   probability_flow=inf.probability_flow, self_conditioning=self_cond, device=device, rng=self.rng_mode)
-        writer = AsyncPdbWriter()   # files are written behind the sampler (the GPU goes on with the next t_delta meanwhile)
         self.last_samples = {}   # t_delta -> atom37 [n_replica, N, 37, 3] device tensor of the last target (rank 0; programmatic callers)
-        for t_delta in delta_range:
-            gt4 = batch["rigidgroups_gt_frames"][..., 0, :, :].clone()
-            # the reference's chunks are the unit of its host noise stream, not of the arithmetic: chunks that fit a pair budget are
-            # sampled as one trajectory (sampler.forward_backward_chunks: same samples, fewer launches; S2S_MERGE_CHUNKS=0 = one
-            # trajectory per chunk); an empty slice still advances the host generator in lock-step with the other ranks
-            a37 = forward_backward_chunks(self.net, self.diffuser, batch, gt4, rank_chunk_slices(n_replica, replica_per_batch, *shard),
-                                          float(t_delta), **kw)
-            if distributed:
-                a37 = gather_replicas(a37, n_replica)   # ONE collective per (target, t_delta)
-            if shard[0] == 0:
-                self.last_samples[float(t_delta)] = a37
-                t_dir = os.path.join(output_dir, f"{t_delta}")
-                os.makedirs(t_dir, exist_ok=True)
-                writer.submit(a37, os.path.join(t_dir, f"{accession_code}.pdb"), **extra)
+        # files are written behind the sampler (the GPU goes on with the next t_delta meanwhile); the context manager stops the worker
+        # and frees its page-locked buffers on every path -- after an exception the files still queued are dropped, not written
+        with AsyncPdbWriter() as writer:
+            for t_delta in delta_range:
+                gt4 = batch["rigidgroups_gt_frames"][..., 0, :, :].clone()
+                # the reference's chunks are the unit of its host noise stream, not of the arithmetic: chunks that fit a pair budget are
+                # sampled as one trajectory (sampler.forward_backward_chunks: same samples, fewer launches; S2S_MERGE_CHUNKS=0 = one
+                # trajectory per chunk); an empty slice still advances the host generator in lock-step with the other ranks
+                a37 = forward_backward_chunks(self.net, self.diffuser, batch, gt4, rank_chunk_slices(n_replica, replica_per_batch, *shard),
+                                              float(t_delta), **kw)
+                if distributed:
+                    a37 = gather_replicas(a37, n_replica)   # ONE collective per (target, t_delta)
+                if shard[0] == 0:
+                    self.last_samples[float(t_delta)] = a37
+                    t_dir = os.path.join(output_dir, f"{t_delta}")
+                    os.makedirs(t_dir, exist_ok=True)
+                    writer.submit(a37, os.path.join(t_dir, f"{accession_code}.pdb"), **extra)
+            saved = writer.results()
         all_dir = os.path.join(output_dir, "all_delta")
-        saved = writer.results()
-        writer.close()
         if shard[0] == 0:
             os.makedirs(all_dir, exist_ok=True)
             merge_pdbfiles(saved, os.path.join(all_dir, f"{accession_code}.pdb"), verbose=False)

@@ -1499,7 +1499,8 @@ def register_torch_ops():
     """Expose every tensor entry point of the library as ``torch.ops.str2str_amd.<name>`` (CUDA/HIP dispatch key only).
     The model's modules reach their kernels through these ops (``node_apply``, ``encoder_attention``, the attention and
     edge-transition call sites below and in models/net): ``torch.ops.str2str_amd`` is the operator surface, this module its
-    implementation over the C ABI.  Called by ``load_library``."""
+    implementation over the C ABI.  Called once at import time (bottom of this module): defining the schemas needs no GPU and no
+    library; the kernels behind them load the shared object on first use."""
     global _registered
     if _registered:
         return

@@ -122,6 +122,7 @@ def _graph_key(net, feats, b, N):
     # which kernels were captured: the arithmetic / kernel selectors of the modules
     modes = tuple(str(getattr(m, a)) for m, a in family_slots(net))   # per switch, in module order: a mixed network has many forms
     modes += tuple(int(m.prescale_exp) for m in net.modules() if hasattr(m, "prescale_exp"))   # block exponents are launch arguments
+    modes += tuple(bool(m.fold) for m in net.modules() if hasattr(m, "fold"))                 # folded / per-head attention operands (A/B switch)
     return (id(net), sum(p._version for p in net.parameters()), b, N, bool(getattr(tr, "exact_padding", False)),
             bool(getattr(tr, "fuse_pair_projection", False)), modes, h.hexdigest())
 
@@ -241,6 +242,8 @@ def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: flo
                         continue
         except ops.WeightRangeError as e:   # |32 w| >= 65504: the weights themselves cannot be packed for the f16 kernels
             new = set(FAMILIES) - demoted
+            if not new:     # every family already runs its exact fp32 kernels (which pack nothing): not a range event, the caller's error
+                raise
             why = f"a weight does not fit the split-f16 packing ({e})"
         if not new:
             if len(demoted) == len(FAMILIES):
@@ -569,7 +572,6 @@ def plan_mixed_work(lengths, replicas: int, world: int = 1, *, max_pairs: int = 
     return plan
 
 
-@torch.no_grad()
 def mixed_batch_seed(base_seed: int, t_delta: float, chain: int, replica_lo: int) -> int:
     """Seed of the host generators for the padded batch whose first item is (chain, replica_lo): a function of the run seed and the
     work item only, so no two batches of a run -- on one rank or on different ranks -- share a noise stream."""
@@ -577,6 +579,7 @@ def mixed_batch_seed(base_seed: int, t_delta: float, chain: int, replica_lo: int
             + 12345) % (2 ** 63 - 1)
 
 
+@torch.no_grad()
 def sample_mixed_lengths(net, diffuser, targets, replicas: int, t_delta: float, *, num_timesteps: int,
                          min_t: float = 0.01, noise_scale: float = 1.0, probability_flow: bool = True,
                          self_conditioning: bool = True, device=None, rigids_t_init=None, shard: Tuple[int, int] = (0, 1),
@@ -602,7 +605,11 @@ def sample_mixed_lengths(net, diffuser, targets, replicas: int, t_delta: float, 
     tr = net.translator
     keep = tr.exact_padding
     tr.exact_padding = True
-    base_seed = int(torch.initial_seed()) if seed_base is None else int(seed_base)   # (callers that loop over t_delta pass the run's seed: the per-batch seeding below replaces the generator's)
+    base_seed = int(torch.initial_seed()) if seed_base is None else int(seed_base)
+    # The per-batch seeding below re-seeds the process-global host generators; their states are put back on the way out, so that the
+    # call leaves no trace in them: `torch.initial_seed()` stays the run seed for the next call (a loop over t_delta without
+    # ``seed_base`` sees the same base every time) and whatever the caller samples afterwards continues ITS stream.
+    host_states = (torch.get_rng_state(), np.random.get_state()) if rng == "host" else None
     try:
         for batch in plan[rank]:
             n_pad = batch["n_pad"]
@@ -653,4 +660,7 @@ def sample_mixed_lengths(net, diffuser, targets, replicas: int, t_delta: float, 
                 o += hi - lo
     finally:
         tr.exact_padding = keep
+        if host_states is not None:
+            torch.set_rng_state(host_states[0])
+            np.random.set_state(host_states[1])
     return [sorted(p, key=lambda x: x[0]) for p in pieces]

@@ -1485,6 +1485,11 @@ def test_eval_entry_mixed_batch(tmp_path, monkeypatch):
     model.predict_mixed(batches)
     torch.manual_seed(3)
     want = sample_mixed_lengths(model.net, model.diffuser, batches, 3, 0.5, num_timesteps=6, device=DEV)
+    # the per-batch host seeding leaves no trace in the process-global generators: the run seed is still the seed, and the
+    # caller's stream continues where it was
+    after = (torch.initial_seed(), float(torch.rand(1)), float(np.random.get_state()[1][0]))
+    torch.manual_seed(3)
+    assert after[:2] == (3, float(torch.rand(1)))
     for k, b in enumerate(batches):
         code = b["accession_code"][0]
         got = model.last_samples[(code, 0.5)]

@@ -178,7 +178,7 @@ def test_native_writer_byte_identical_to_reference_text(tmp_path, monkeypatch):
 
 def test_extract_backbone_coords_altloc_and_nonstandard(tmp_path):
     """Reference reader semantics (biotite, altloc='first' + filter_backbone, pdb_utils.py:255-317): the first alternate location of
-    a residue, amino-acid residues only (a non-standard one is an error here), equal model lengths (a ragged file is an error, not a
+    a residue, amino-acid residues only (standard + common modified ones; an unknown one is an error here), equal model lengths (a ragged file is an error, not a
     silent ragged array)."""
     import pytest
 
@@ -196,11 +196,15 @@ def test_extract_backbone_coords_altloc_and_nonstandard(tmp_path):
     p.write_text(txt)
     ca = extract_backbone_coords(str(p))
     assert ca.shape == (2, 3, 3) and ca[0, :, 0].tolist() == [1.0, 2.0, 3.0]
-    # a C-alpha of a residue outside the 20 standard names (biotite would keep MSE: its amino-acid table is the CCD's) is an error,
-    # not a silently shorter chain
+    # a modified residue (selenomethionine as a HETATM record, as experimental files carry it) is part of the chain, as in biotite's
+    # amino-acid filter (CCD peptide-linking components, any record type); a residue in neither table is an error, not a silently
+    # shorter chain
     (tmp_path / "mse.pdb").write_text("\n".join(model[:3] + [atom(4, "CA", " ", "MSE", "A", 3, 7.0).replace("ATOM  ", "HETATM")] + ["END"]))
-    with pytest.raises(ValueError, match="MSE"):
-        extract_backbone_coords(str(tmp_path / "mse.pdb"))
+    ca = extract_backbone_coords(str(tmp_path / "mse.pdb"))
+    assert ca.shape == (1, 3, 3) and ca[0, :, 0].tolist() == [1.0, 2.0, 7.0]
+    (tmp_path / "xyz.pdb").write_text("\n".join(model[:3] + [atom(4, "CA", " ", "XYZ", "A", 3, 7.0)] + ["END"]))
+    with pytest.raises(ValueError, match="XYZ"):
+        extract_backbone_coords(str(tmp_path / "xyz.pdb"))
     (tmp_path / "ragged.pdb").write_text("\n".join(["MODEL        1"] + model + ["ENDMDL", "MODEL        2"] + model[:3]))
     with pytest.raises(ValueError):
         extract_backbone_coords(str(tmp_path / "ragged.pdb"))
