@@ -137,7 +137,8 @@ def main():
     from str2str_amd import ops
     from str2str_amd.common.rigid_utils import Rigid
     from str2str_amd.factory import build_diffuser, build_synthetic_net
-    from str2str_amd.sampler import forward_backward, forward_backward_chunks, merge_chunk_groups, plan_mixed_work, sample_mixed_lengths
+    from str2str_amd.sampler import (forward_backward, forward_backward_chunks, forward_backward_deltas, merge_chunk_groups, merge_delta_groups,
+                                     plan_mixed_work, sample_mixed_lengths, schedule)
     from str2str_amd.synth import synth_chain
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -265,20 +266,24 @@ def main():
         extra["evaluations_per_step"] = n_eval * sum(len(g) for g in groups.values())
         extra["trajectories_per_t_delta"] = {str(n): g for n, g in groups.items()}   # chunks sampled as one trajectory each
         extra["hip_graph"] = os.environ.get("S2S_HIP_GRAPH", "auto")
+        dsteps = [schedule(d, S, 0.01)[1] for d in deltas]
+        dgroups = {n: merge_delta_groups(dsteps, B, n) for n in lens}
+        extra["t_deltas_per_batch"] = {str(n): [[deltas[i] for i in g] for g in dg] for n, dg in dgroups.items()}   # t_deltas sampled as one growing batch
+        extra["evaluations_per_step_merged"] = sum(max(dsteps[i] for i in g) + len(g) if len(g) > 1 else (dsteps[g[0]] + 1) * len(groups[n])
+                                                   for n, dg in dgroups.items() for g in dg)
 
         def one_step(seed):
             torch.manual_seed(seed * 1000 + rank)
             torch.cuda.manual_seed(seed * 1000 + rank)
             res = None
             for tg in targets:
-                for d in deltas:
-                    # as DiffusionLitModule.predict_step runs it: the chunks are the unit of the reference's noise stream; those that fit
-                    # the pair budget are sampled as one trajectory (sampler.forward_backward_chunks; S2S_MERGE_CHUNKS=0: one per chunk)
-                    if True:
-                        a37 = forward_backward_chunks(net, diff, tg, tg["rigidgroups_gt_frames"][..., 0, :, :], [(c, 0, c) for c in chunks], d,
-                                                      num_timesteps=S, min_t=0.01, probability_flow=True, self_conditioning=True,
-                                                      device=dev, rng=a.rng)
-                        res = a37[..., :5, :]
+                # as DiffusionLitModule.predict_step runs it: the chunks are the unit of the reference's noise stream; the chunks and the
+                # t_deltas of a target whose replicas fit the pair budget are sampled as ONE growing batch (sampler.forward_backward_deltas;
+                # S2S_MERGE_DELTAS=0: one t_delta at a time, S2S_MERGE_CHUNKS=0: one chunk at a time -- the reference's control flow)
+                a37 = forward_backward_deltas(net, diff, tg, tg["rigidgroups_gt_frames"][..., 0, :, :], [(c, 0, c) for c in chunks], deltas,
+                                              num_timesteps=S, min_t=0.01, probability_flow=True, self_conditioning=True,
+                                              device=dev, rng=a.rng)
+                res = a37[-1][..., :5, :]
             return res.cpu() if rank == 0 else None
     else:  # cfg5
         lens = [int(x) for x in np.random.default_rng(5).integers(64, 385, size=32)]

@@ -236,22 +236,25 @@ int s2s_frames_to_backbone(const float* rigids7, const float* psi_sincos, const 
  *   these are used (FrameDiffuser.reverse called with caller-provided scores; x0_7 may be NULL),
  *   next7 [B,N,7] or NULL (score only); rot_score_out/trans_score_out [B,N,3] double or NULL.
  *   center_trans: 0 = off, 1 = centre of mass over all N residues (reference behaviour), 2 = over the
- *   residues with mask > 0 only (padded mixed-length batches). */
+ *   residues with mask > 0 only (padded mixed-length batches).
+ *   dt = 1 / int(num_timesteps * T) of the trajectory (diffusion_module.py:267); dt_per_sample [B] double or NULL: one step size
+ *   per sample instead, for batches that hold trajectories of different t_delta (sampler.forward_backward_deltas). */
 int s2s_se3_step(const float* x0_7, const float* xt_7, const float* mask, const float* diffuse_mask,
                  const float* params8, const double* z_rot, const double* z_trans,
                  const double* rot_score_in, const double* trans_score_in, float* next7,
                  double* rot_score_out, double* trans_score_out, int n_samples, int n_res, double dt,
-                 double coordinate_scaling, int probability_flow, int center_trans, double noise_scale,
-                 void* stream);
+                 const double* dt_per_sample, double coordinate_scaling, int probability_flow, int center_trans,
+                 double noise_scale, void* stream);
 
 /* The embedder's per-evaluation assembly in one launch (EmbeddingModule.forward, src/models/net/denoising_ipa.py:107-136: the first
  * Linear of the node MLP and of the edge MLP on [timestep embedding | fixed-mask column | positional block]).
- *   t_img [512] = first-layer image of the chunk's timestep embedding + bias: [node MLP 256 | edge row part 128 | edge column part 128]
+ *   t_img [t_img_rows, 512] = first-layer image of the timestep embedding + bias: [node MLP 256 | edge row part 128 | edge column part 128];
+ *          t_img_rows = 1: one timestep for the whole chunk, = n_rows / n_res: one row per sample (trajectories of different t in a batch)
  *   node_const [node_const_rows, 256] (rows = n_rows, or n_res when every sample shares it): fixed-mask + positional terms of the node MLP
  *   fa [n_rows,128], fb (column-blocked [B,32,n_res,4] when b_col_blocked, else [n_rows,128]): fixed-mask terms of the edge MLP
  *   -> h = relu(t_img[0:256] + node_const) as packed planes (h_xp) or fp32 [n_rows,256] (h_f32; exactly one of the two),
  *      node_a = t_img[256:384] + fa, node_b = t_img[384:512] + fb: the operands of s2s_node_linear / s2s_edge_embed(_f16x3). */
-int s2s_embed_assemble(const float* t_img, const float* node_const, long long node_const_rows, const float* fa, const float* fb,
+int s2s_embed_assemble(const float* t_img, long long t_img_rows, const float* node_const, long long node_const_rows, const float* fa, const float* fb,
                        long long n_rows, int n_res, void* h_xp, float* h_f32, float* node_a, float* node_b, int b_col_blocked,
                        void* stream);
 

@@ -796,7 +796,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
 //   node_b = t_img[384:512] + fb[...]                         -> column part, column-blocked [B,32,L,4] (f16x3 kernel) or row-major
 // which were ~14 elementwise launches.  Blocks [0, nh): h (a wave per (row tile, k-step) like pack_planes); then node_a, then node_b,
 // 256 float4 per block.
-__global__ void __launch_bounds__(256) embed_assemble_kernel(const float* __restrict__ t_img, const float* __restrict__ node_const,
+__global__ void __launch_bounds__(256) embed_assemble_kernel(const float* __restrict__ t_img_all, int t_img_stride, const float* __restrict__ node_const,
                                                              long long nc_rows, const float* __restrict__ fa, const float* __restrict__ fb,
                                                              long long M, int L, f16x8* __restrict__ h_xp, float* __restrict__ h_f32,
                                                              float* __restrict__ node_a, float* __restrict__ node_b, int b_col_blocked,
@@ -815,6 +815,7 @@ __global__ void __launch_bounds__(256) embed_assemble_kernel(const float* __rest
             if (row < M) {
                 const int c0 = 32 * (ks >> 1) + 16 * (ks & 1) + 4 * g;
                 const float* p = node_const + (row % nc_rows) * 256 + c0;
+                const float* t_img = t_img_all + (row / L) * t_img_stride;   // the sample's own timestep image, or the chunk's (stride 0)
                 const float4 lo = *reinterpret_cast<const float4*>(p), hi = *reinterpret_cast<const float4*>(p + 8);
                 const float4 tl = *reinterpret_cast<const float4*>(t_img + c0), th = *reinterpret_cast<const float4*>(t_img + c0 + 8);
                 v[0] = fmaxf(tl.x + lo.x, 0.f); v[1] = fmaxf(tl.y + lo.y, 0.f); v[2] = fmaxf(tl.z + lo.z, 0.f); v[3] = fmaxf(tl.w + lo.w, 0.f);
@@ -829,7 +830,7 @@ __global__ void __launch_bounds__(256) embed_assemble_kernel(const float* __rest
                 const long long row = i >> 6;
                 const int c = (int)(i & 63) * 4;
                 const float4 x = *reinterpret_cast<const float4*>(node_const + (row % nc_rows) * 256 + c);
-                const float4 t = *reinterpret_cast<const float4*>(t_img + c);
+                const float4 t = *reinterpret_cast<const float4*>(t_img_all + (row / L) * t_img_stride + c);
                 *reinterpret_cast<float4*>(h_f32 + i * 4) = make_float4(fmaxf(t.x + x.x, 0.f), fmaxf(t.y + x.y, 0.f), fmaxf(t.z + x.z, 0.f), fmaxf(t.w + x.w, 0.f));
             }
         }
@@ -843,21 +844,22 @@ __global__ void __launch_bounds__(256) embed_assemble_kernel(const float* __rest
     else c = (int)((i / L) & 31) * 4;                        // [B][32 chunks][L][4]: float4 index = (b 32 + chunk) L + l
     const float* src = is_a ? fa : fb;
     const float4 x = *reinterpret_cast<const float4*>(src + i * 4);
+    const float* t_img = t_img_all + (i / (32ll * L)) * t_img_stride;   // either layout holds 32 L float4 per sample
     const float4 t = *reinterpret_cast<const float4*>(t_img + (is_a ? 256 : 384) + c);
     *reinterpret_cast<float4*>((is_a ? node_a : node_b) + i * 4) = make_float4(t.x + x.x, t.y + x.y, t.z + x.z, t.w + x.w);
 }
 
-extern "C" int s2s_embed_assemble(const float* t_img, const float* node_const, long long node_const_rows, const float* fa, const float* fb,
+extern "C" int s2s_embed_assemble(const float* t_img, long long t_img_rows, const float* node_const, long long node_const_rows, const float* fa, const float* fb,
                                   long long n_rows, int n_res, void* h_xp, float* h_f32, float* node_a, float* node_b, int b_col_blocked,
                                   void* stream) {
     if (n_rows <= 0) return 0;
     if (!t_img || !node_const || !fa || !fb || !node_a || !node_b || (!h_xp == !h_f32) || n_res <= 0 || node_const_rows <= 0 ||
-        n_rows % n_res || (node_const_rows != n_rows && node_const_rows != n_res))
+        n_rows % n_res || (node_const_rows != n_rows && node_const_rows != n_res) || (t_img_rows != 1 && t_img_rows != n_rows / n_res))
         return (int)hipErrorInvalidValue;
     const long long nh = h_xp ? (((n_rows + 31) / 32) * 16 + 3) / 4 : (n_rows * 64 + 255) / 256;
     const long long na = (n_rows * 32 + 255) / 256;
     if (nh + 2 * na >= (1ll << 31)) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(embed_assemble_kernel, dim3((unsigned)(nh + 2 * na)), dim3(256), 0, (hipStream_t)stream, t_img, node_const,
+    hipLaunchKernelGGL(embed_assemble_kernel, dim3((unsigned)(nh + 2 * na)), dim3(256), 0, (hipStream_t)stream, t_img, t_img_rows == 1 ? 0 : 512, node_const,
                        node_const_rows, fa, fb, n_rows, n_res, (f16x8*)h_xp, h_f32, node_a, node_b, b_col_blocked, (unsigned)nh, (unsigned)na,
                        s2s::g_range_flag);
     return (int)hipGetLastError();

@@ -39,8 +39,8 @@ __global__ void __launch_bounds__(kThreads) se3_step_kernel(
     const float* __restrict__ diffuse_mask, const float* __restrict__ params, const double* __restrict__ z_rot,
     const double* __restrict__ z_trans, const double* __restrict__ rot_score_in,
     const double* __restrict__ trans_score_in, float* __restrict__ next7, double* __restrict__ rot_score_out,
-    double* __restrict__ trans_score_out, int N, double dt, double coord_scale_d, int probability_flow, int center,
-    double noise_scale) {
+    double* __restrict__ trans_score_out, int N, double dt_all, const double* __restrict__ dt_per_sample, double coord_scale_d,
+    int probability_flow, int center, double noise_scale) {
     __shared__ double s_cw[kL];      // (2l+1) * exp(-l(l+1) sigma^2 / 2) in float64 (sigma = the float32 bin value)
     __shared__ int s_leff;
     __shared__ double s_red[4][kThreads / 64];
@@ -48,6 +48,9 @@ __global__ void __launch_bounds__(kThreads) se3_step_kernel(
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
+    // the step size is a property of a trajectory (1 / int(num_timesteps T), diffusion_module.py:267 of the reference): one value
+    // for the batch, or one per sample when trajectories of different length share a batch
+    const double dt = dt_per_sample ? dt_per_sample[b] : dt_all;
     // x * 0.1 on a float32 tensor uses float32(0.1); x / 0.1 on the float64 tensor uses the double 0.1
     const float coord_scale = (float)coord_scale_d;
     const float* P = params + (long long)b * 8;
@@ -214,8 +217,8 @@ extern "C" int s2s_se3_step(const float* x0_7, const float* xt_7, const float* m
                             const float* params8, const double* z_rot, const double* z_trans,
                             const double* rot_score_in, const double* trans_score_in, float* next7,
                             double* rot_score_out, double* trans_score_out, int n_samples, int n_res, double dt,
-                            double coordinate_scaling, int probability_flow, int center_trans, double noise_scale,
-                            void* stream) {
+                            const double* dt_per_sample, double coordinate_scaling, int probability_flow, int center_trans,
+                            double noise_scale, void* stream) {
     if (n_samples <= 0 || n_res <= 0) return 0;
     if (n_res > kThreads * kMaxPerThread) return (int)hipErrorInvalidValue;
     if (!probability_flow && (!z_rot || !z_trans)) return (int)hipErrorInvalidValue;
@@ -223,6 +226,6 @@ extern "C" int s2s_se3_step(const float* x0_7, const float* xt_7, const float* m
     if (!rot_score_in && !x0_7) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(se3_step_kernel, dim3(n_samples), dim3(kThreads), 0, (hipStream_t)stream, x0_7, xt_7, mask,
                        diffuse_mask, params8, z_rot, z_trans, rot_score_in, trans_score_in, next7, rot_score_out, trans_score_out, n_res, dt,
-                       coordinate_scaling, probability_flow, center_trans, noise_scale);
+                       dt_per_sample, coordinate_scaling, probability_flow, center_trans, noise_scale);
     return (int)hipGetLastError();
 }

@@ -26,7 +26,8 @@ import torch
 
 from ..common.pdb_utils import AsyncPdbWriter, atom37_to_pdb, merge_pdbfiles
 from ..common.rigid_utils import Rigid
-from ..sampler import forward_backward, forward_backward_chunks, plan_mixed_work, rank_chunk_slices, sample_mixed_lengths, shard_range
+from ..sampler import (forward_backward, forward_backward_chunks, forward_backward_deltas, plan_mixed_work, rank_chunk_slices,
+                       sample_mixed_lengths, shard_range)
 
 try:  # pragma: no cover - depends on the environment
     from lightning import LightningModule as _Base
@@ -113,13 +114,14 @@ class DiffusionLitModule(_Base):
         # files are written behind the sampler (the GPU goes on with the next t_delta meanwhile); the context manager stops the worker
         # and frees its page-locked buffers on every path -- after an exception the files still queued are dropped, not written
         with AsyncPdbWriter() as writer:
-            for t_delta in delta_range:
-                gt4 = batch["rigidgroups_gt_frames"][..., 0, :, :].clone()
-                # the reference's chunks are the unit of its host noise stream, not of the arithmetic: chunks that fit a pair budget are
-                # sampled as one trajectory (sampler.forward_backward_chunks: same samples, fewer launches; S2S_MERGE_CHUNKS=0 = one
-                # trajectory per chunk); an empty slice still advances the host generator in lock-step with the other ranks
-                a37 = forward_backward_chunks(self.net, self.diffuser, batch, gt4, rank_chunk_slices(n_replica, replica_per_batch, *shard),
-                                              float(t_delta), **kw)
+            gt4 = batch["rigidgroups_gt_frames"][..., 0, :, :].clone()
+            # The reference's chunks (and its loop over t_delta) are units of its host noise stream, not of the arithmetic: the chunks --
+            # and the t_deltas -- of a target whose replicas fit a pair budget are sampled as ONE batch (sampler.forward_backward_deltas:
+            # same samples file for file, far fewer launches; S2S_MERGE_DELTAS=0 = one t_delta at a time, S2S_MERGE_CHUNKS=0 = one
+            # trajectory per chunk); an empty slice still advances the host generator in lock-step with the other ranks
+            samples = forward_backward_deltas(self.net, self.diffuser, batch, gt4, rank_chunk_slices(n_replica, replica_per_batch, *shard),
+                                              [float(t) for t in delta_range], **kw)
+            for t_delta, a37 in zip(delta_range, samples):
                 if distributed:
                     a37 = gather_replicas(a37, n_replica)   # ONE collective per (target, t_delta)
                 if shard[0] == 0:

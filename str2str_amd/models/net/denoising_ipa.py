@@ -191,7 +191,10 @@ class EmbeddingModule(nn.Module):
             # positional terms do not depend on t and are cached.  What is left per evaluation -- relu(t + const) into the node
             # stream's format and the two operand arrays of the edge embedding -- is ONE launch (s2s_embed_assemble; a network
             # evaluation of a small chunk is launch-latency bound: 22 tiny launches here in round 3)
-            img = t_img.reshape(-1) if t_img is not None else (w["w_t_cat"] * t_emb).sum(-1) + w["b_t_cat"]
+            # (t_img [B, 512]: one image per sample -- trajectories of different t_delta in one batch, sampler.forward_backward_deltas;
+            #  the kernel adds row sample of it instead of the one shared row: the same sums per element)
+            per_sample = t_img is not None and t_img.ndim == 2 and t_img.shape[0] == B and B > 1
+            img = (t_img if per_sample else t_img.reshape(-1)) if t_img is not None else (w["w_t_cat"] * t_emb).sum(-1) + w["b_t_cat"]
             Fn, Fa, Fb = self._fixed_terms(fixed_mask, w, dev, node_pos)
             h_act, node_a, node_b = torch.ops.str2str_amd.embed_assemble(img.contiguous(), Fn, Fa, Fb[0] if f16 else Fb[1], B, L,
                                                                          self.node_arith == "f16x3", f16)

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 _lib = None
 _tables_loaded = False
@@ -41,14 +41,14 @@ _SIGNATURES = {
     "s2s_rigid_scale_trans": [_vp, _vp, _ll, _f, _i, _vp],
     "s2s_set_backbone_tables": [_vp] * 4,
     "s2s_frames_to_backbone": [_vp] * 5 + [_ll, _vp],
-    "s2s_se3_step": [_vp] * 12 + [_i, _i, _d, _d, _i, _i, _d, _vp],
+    "s2s_se3_step": [_vp] * 12 + [_i, _i, _d, _vp, _d, _i, _i, _d, _vp],
     "s2s_forward_marginal": [_vp] * 7 + [_i, _vp, _vp, _f, _vp, _i, _i, _vp],
     "s2s_pack_planes": [_vp, _ll, _i, _i, _i, _vp, _i, _i, _vp, _vp],
     "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "s2s_node_linear_f32": [_vp, _i, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "s2s_node_linear_multi": [_vp, _i, _vp],
     "s2s_node_chain": [_vp, _vp, _i, _ll, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
-    "s2s_embed_assemble": [_vp, _vp, _ll, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "s2s_embed_assemble": [_vp, _ll, _vp, _ll, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "s2s_row_layernorm": [_vp, _i, _ll, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
     "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _i, _vp],
     "s2s_encoder_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -712,11 +712,19 @@ def frames_to_backbone(rigids7, psi, aatype=None, want_atom37=True, want_atom14=
     return a37, a14
 
 
-def se3_step(x0_7, xt_7, mask, diffuse_mask, params8, dt: float, coordinate_scaling: float = 0.1, probability_flow=True,
+def se3_step(x0_7, xt_7, mask, diffuse_mask, params8, dt, coordinate_scaling: float = 0.1, probability_flow=True,
              center=True, noise_scale: float = 1.0, z_rot=None, z_trans=None, want_next=True, want_scores=False,
              rot_score_in=None, trans_score_in=None):
+    """``dt``: the trajectory's step size (a float), or a float64 device tensor [B] with one step size per sample (a batch that holds
+    trajectories of different t_delta)."""
     lib = load_library()
     B, N = mask.shape
+    dt_vec = None
+    if torch.is_tensor(dt):
+        dt_vec = _req(dt, torch.float64, "dt")
+        if dt_vec.shape != (B,):
+            raise HipLibraryError("se3_step: a per-sample dt must be [B] float64")
+        dt = 0.0
     for n, t in (("xt_7", xt_7), ("mask", mask), ("diffuse_mask", diffuse_mask), ("params8", params8)):
         _req(t, name=n)
     if rot_score_in is not None:
@@ -733,7 +741,7 @@ def se3_step(x0_7, xt_7, mask, diffuse_mask, params8, dt: float, coordinate_scal
     ts = torch.empty(B, N, 3, device=dev, dtype=torch.float64) if want_scores else None
     _check(lib.s2s_se3_step(_p(x0_7), _p(xt_7), _p(mask), _p(diffuse_mask), _p(params8), _p(z_rot), _p(z_trans), _p(rot_score_in),
                             _p(trans_score_in), _p(nxt),
-                            _p(rs), _p(ts), B, N, float(dt), float(coordinate_scaling), int(bool(probability_flow)),
+                            _p(rs), _p(ts), B, N, float(dt), _p(dt_vec), float(coordinate_scaling), int(bool(probability_flow)),
                             int(center), float(noise_scale), _stream()), "s2s_se3_step")
     return nxt, rs, ts
 
@@ -955,17 +963,18 @@ def small_rows_variant(layer: dict, n_rows: int):
 
 def embed_assemble(t_img, node_const, fa, fb, n_samples: int, n_res: int, planes: bool, b_col_blocked: bool):
     """The embedder's per-evaluation assembly (s2s_embed_assemble): -> (h as packed planes [M,256] or fp32, node_a [B,L,128], node_b in
-    ``fb``'s layout) from the chunk's timestep image ``t_img`` [512] and the cached per-target terms."""
+    ``fb``'s layout) from the chunk's timestep image ``t_img`` [512] -- or one image per sample, [n_samples, 512] -- and the cached
+    per-target terms."""
     lib = load_library()
     for n, t in (("t_img", t_img), ("node_const", node_const), ("fa", fa), ("fb", fb)):
         _req(t, name=n)
     M, dev = n_samples * n_res, t_img.device
-    if t_img.numel() != 512 or node_const.numel() not in (M * 256, n_res * 256) or fa.numel() != M * 128 or fb.numel() != M * 128:
+    if t_img.numel() not in (512, 512 * n_samples) or node_const.numel() not in (M * 256, n_res * 256) or fa.numel() != M * 128 or fb.numel() != M * 128:
         raise HipLibraryError("embed_assemble: bad shapes")
     h = xp_alloc(M, 256, dev) if planes else torch.empty(M, 256, device=dev, dtype=torch.float32)
     node_a, node_b = torch.empty(n_samples, n_res, 128, device=dev, dtype=torch.float32), torch.empty_like(fb)
     range_flag()
-    _check(lib.s2s_embed_assemble(_p(t_img), _p(node_const), node_const.numel() // 256, _p(fa), _p(fb), M, n_res, _p(h) if planes else None,
+    _check(lib.s2s_embed_assemble(_p(t_img), t_img.numel() // 512 if t_img.numel() != 512 else 1, _p(node_const), node_const.numel() // 256, _p(fa), _p(fb), M, n_res, _p(h) if planes else None,
                                   None if planes else _p(h), _p(node_a), _p(node_b), int(b_col_blocked), _stream()), "s2s_embed_assemble")
     return h, node_a, node_b
 

@@ -202,24 +202,33 @@ def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: flo
     and at the same speed, include/str2str_hip.h) and only go to fp32 when 2^30 is not enough; ``net.range_prescale`` records it."""
     kw = dict(min_t=min_t, noise_scale=noise_scale, probability_flow=probability_flow, self_conditioning=self_conditioning,
               center_mode=center_mode, trace=trace)
+    return _range_guarded(net, lambda: _denoise_pass(net, diffuser, feats, rigids_t, ts, dt, host_noise=host_noise, **kw),
+                          rigids_t.device, host_draws=host_noise is not None, device_draws=host_noise is None and not probability_flow,
+                          trace=trace)
+
+
+def _range_guarded(net, run_pass, device, *, host_draws: bool, device_draws: bool, trace: Optional[list] = None):
+    """``run_pass()`` (one complete pass over a batch of trajectories from their starting frames -> a tuple whose element 1 holds the
+    final frames) under the range guard described in ``denoise_loop``: repeated with the flagged kernel families demoted (or the
+    edge transitions' block exponent raised) until no flag is raised; every repetition sees the same noise (generator states
+    restored)."""
     if net_arith(net) == "f32":
-        out = _denoise_pass(net, diffuser, feats, rigids_t, ts, dt, host_noise=host_noise, **kw)
+        out = run_pass()
         _require_finite(out[1], "fp32")
         return out
     demoted = set(getattr(net, "range_fallback", None) or ())
-    device_draws = host_noise is None and not probability_flow
-    rng_state = torch.cuda.get_rng_state(rigids_t.device) if device_draws else None
+    rng_state = torch.cuda.get_rng_state(device) if device_draws else None
     # Host noise (parity mode) comes from the global CPU generator (forward_backward.host_noise): a replay re-draws it from the
     # generator state saved here -- nothing is recorded (the draws of a long SDE trajectory at b = 128, N = 512 are ~0.6 GB), and
     # every pass leaves the generator where one completed pass leaves it.
-    host_state = torch.get_rng_state() if host_noise is not None else None
+    host_state = torch.get_rng_state() if host_draws else None
     while True:
         if host_state is not None:
             torch.set_rng_state(host_state)
         ops.range_flag_reset()
         try:
             with use_arith(net, "f32", families=tuple(demoted)):
-                out = _denoise_pass(net, diffuser, feats, rigids_t, ts, dt, host_noise=host_noise, **kw)
+                out = run_pass()
             finite = bool(torch.isfinite(out[1]).all())     # (the synchronisation point of the chunk)
             bits = ops.range_flag_read()
             if bits == 0 and finite:
@@ -238,7 +247,7 @@ def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: flo
                         if trace is not None:
                             del trace[:]
                         if rng_state is not None:
-                            torch.cuda.set_rng_state(rng_state, rigids_t.device)
+                            torch.cuda.set_rng_state(rng_state, device)
                         continue
         except ops.WeightRangeError as e:   # |32 w| >= 65504: the weights themselves cannot be packed for the f16 kernels
             new = set(FAMILIES) - demoted
@@ -257,7 +266,7 @@ def denoise_loop(net, diffuser, feats: dict, rigids_t: torch.Tensor, ts, dt: flo
         if trace is not None:
             del trace[:]
         if rng_state is not None:
-            torch.cuda.set_rng_state(rng_state, rigids_t.device)
+            torch.cuda.set_rng_state(rng_state, device)
 
 
 def _raise_edge_prescale(net, step: int = 5, top: int = 15) -> int:
@@ -515,6 +524,177 @@ def forward_backward_chunks(net, diffuser, batch: dict, gt_frames_4x4: torch.Ten
     if not out:
         return torch.zeros(0, N, 37, 3, device=device)
     return torch.cat(out, dim=0) if len(out) > 1 else out[0]
+
+
+def _denoise_pass_deltas(net, diffuser, batch: dict, groups, *, min_t: float, noise_scale: float, probability_flow: bool,
+                         self_conditioning: bool, center_mode: int, host_noise, device):
+    """One pass over SEVERAL trajectories of one target with different schedules (the t_deltas of the reference's inference block)
+    as ONE growing batch.  ``groups`` = [dict(rigids_t [b_k,N,7], ts (descending), dt)] in output order.  The trajectories are
+    aligned at their END: group k (n_k steps) joins at global step n_max - n_k, after its own self-conditioning evaluation, and
+    every sample carries its own timestep image (``t_img`` [b,512]), SE(3) step parameters and step size (s2s_se3_step
+    dt_per_sample) -- so each sample sees exactly the evaluations of its single-t_delta run (the kernels are batch-invariant).
+    -> (atom37 per group, rigids7 of the whole batch, psi per group)."""
+    emb = net.embedder
+    order = sorted(range(len(groups)), key=lambda k: -len(groups[k]["ts"]))     # join order (stable: equal lengths keep output order)
+    n_max = len(groups[order[0]]["ts"])
+    N = groups[0]["rigids_t"].shape[1]
+    timg, p8s, base, o = [], [], {}, 0
+    for k in order:
+        t_all = torch.as_tensor(np.ascontiguousarray(groups[k]["ts"], dtype=np.float64)).float()   # fl32(t), as `t * torch.ones(B)` gives
+        p8s.append(diffuser.step_params(t_all).to(device))
+        timg.append(emb.time_images(emb.time_embed(t_all).to(device)))
+        base[k] = o
+        o += len(t_all)
+    TIMG, P8 = torch.cat(timg).contiguous(), torch.cat(p8s).contiguous()
+    one = {k: batch[k].to(device) for k in _REPEAT_KEYS if k in batch}
+
+    def expand(b):
+        f = {k: v.repeat(b, *(1,) * (v.ndim - 1)) for k, v in one.items()}
+        for k in ("residue_mask", "fixed_mask"):     # float32 device tensors once per batch composition (the network's caches key on them)
+            f[k] = f[k].float().contiguous()
+        return f
+
+    keep_bb = getattr(net, "backbone_in_forward", None)
+    if keep_bb is not None:
+        net.backbone_in_forward = False
+    try:
+        rig = sc = idx = dtv = feats = mask = diffuse_mask = None
+        members, final = [], None
+        for g in range(n_max):
+            joined = False
+            for k in order:
+                if n_max - len(groups[k]["ts"]) != g:
+                    continue
+                rk = groups[k]["rigids_t"]
+                bk = rk.shape[0]
+                sck = torch.zeros(bk, N, 3, device=device)
+                if self_conditioning:      # the group's extra evaluation at its first t with an empty self-conditioning input, on its own
+                    fk = expand(bk)
+                    fk.update(rigids_t=rk, sc_ca_t=sck, t=torch.full((bk,), float(groups[k]["ts"][0]), dtype=torch.float32),
+                              t_img=TIMG[base[k]])
+                    sck = _net_eval(net, fk, True)["rigids7"][..., 4:].clone()
+                ik = torch.full((bk,), base[k], dtype=torch.int64, device=device)
+                dk = torch.full((bk,), float(groups[k]["dt"]), dtype=torch.float64, device=device)
+                rig = rk if rig is None else torch.cat([rig, rk])
+                sc = sck if sc is None else torch.cat([sc, sck])
+                idx = ik if idx is None else torch.cat([idx, ik])
+                dtv = dk if dtv is None else torch.cat([dtv, dk])
+                members.append((k, bk))
+                joined = True
+            b = rig.shape[0]
+            if joined:
+                feats = expand(b)
+                mask = feats["residue_mask"]
+                diffuse_mask = ((1 - feats["fixed_mask"]) * mask).contiguous()
+                feats["t"] = torch.zeros(b)     # (not read: every sample's timestep enters through its t_img row)
+            feats["rigids_t"], feats["sc_ca_t"] = rig, sc
+            feats["t_img"] = TIMG.index_select(0, idx)
+            out = _net_eval(net, feats, True)
+            x0_7 = out["rigids7"]
+            if g == n_max - 1:           # every trajectory's last evaluation (t == min_t): the x0 prediction is the sample
+                final = out
+                break
+            if self_conditioning:
+                sc = x0_7[..., 4:]
+            z = host_noise() if host_noise is not None else None
+            z_rot, z_trans = z if z is not None else (None, None)
+            if not probability_flow and z_rot is None:
+                z_rot = torch.randn(b, N, 3, dtype=torch.float64, device=device)
+                z_trans = torch.randn(b, N, 3, dtype=torch.float64, device=device)
+            rig, _, _ = diffuser.step(x0_7, rig, P8.index_select(0, idx), dtv, mask, diffuse_mask, center_trans=center_mode,
+                                      noise_scale=noise_scale, probability_flow=probability_flow, z_rot=z_rot, z_trans=z_trans)
+            idx = idx + 1
+        if final.get("psi_deferred"):
+            final = dict(final, psi=net.blend_psi(final["psi"], feats["torsion_angles_sin_cos"], feats["fixed_mask"]))
+        atom37 = compute_backbone(final["rigids"], final["psi"], aatype=feats.get("aatype"), _rigids7=final["rigids7"])[0]
+    finally:
+        if keep_bb is not None:
+            net.backbone_in_forward = keep_bb
+    a_out, p_out, o = [None] * len(groups), [None] * len(groups), 0
+    for k, bk in members:
+        a_out[k], p_out[k] = atom37[o:o + bk], final["psi"][o:o + bk]
+        o += bk
+    return a_out, final["rigids7"], p_out
+
+
+def merge_delta_groups(steps, b: int, N: int, max_pairs: int = None):
+    """Consecutive t_deltas (``steps[i]`` = their trajectory lengths) -> groups [[i, ...]] sampled as one growing batch each: a group
+    holds at most ``max_pairs`` pairs at its end (b replicas per t_delta).  ``S2S_MERGE_DELTAS=0``: one t_delta per group."""
+    max_pairs = _MERGE_MAX_PAIRS if max_pairs is None else max_pairs
+    per = max(1, b) * N * N
+    cap = 1 if os.environ.get("S2S_MERGE_DELTAS", "1") == "0" else max(1, max_pairs // per)
+    return [list(range(i, min(i + cap, len(steps)))) for i in range(0, len(steps), cap)]
+
+
+@torch.no_grad()
+def forward_backward_deltas(net, diffuser, batch: dict, gt_frames_4x4: torch.Tensor, chunks, delta_range, *, num_timesteps: int,
+                            min_t: float = 0.01, noise_scale: float = 1.0, probability_flow: bool = True,
+                            self_conditioning: bool = True, device=None, rng: str = "host", max_pairs: int = None):
+    """All t_deltas of one target (the outer loop of the reference's predict_step, diffusion_module.py:341-367) -> [atom37
+    [sum(hi - lo), N, 37, 3] per t_delta], each exactly what ``forward_backward_chunks`` returns for that t_delta.
+
+    The reference's default block runs 10 t_deltas (0.25 .. 0.70 of 1000 timesteps: trajectories of 250 .. 700 steps) of 100 replicas
+    one after the other; on chains of 35 .. 80 residues every network evaluation is then bound by the latency of its ~83 dependent
+    launches, not by the GPU.  A replica's trajectory does not depend on its batch, and nothing in the network or in the SE(3) step
+    couples the samples of a batch -- so the t_deltas whose replicas fit the pair budget run as ONE batch that GROWS: aligned at
+    their common end (t = min_t), the longest trajectory starts alone and each shorter one joins when as many steps remain as it
+    has, with its own timestep image, step parameters and step size per sample (``_denoise_pass_deltas``).  4750 + 10 evaluations of
+    100 replicas become 700 + 10 of 100 .. 1000.  The host noise stream keeps the reference's order: start frames t_delta by t_delta,
+    chunk by chunk, each chunk's (unused, under the ODE) per-step draws consumed before the next chunk's start frames -- the last
+    chunk's ride in the loop when its trajectory is the longest.  Under the SDE with host noise the per-step draws are part of a
+    trajectory: one t_delta at a time (``forward_backward_chunks``), as the reference does."""
+    device = _require_hip_device(device, net)
+    delta_range = [float(t) for t in delta_range]
+    kw = dict(num_timesteps=num_timesteps, min_t=min_t, noise_scale=noise_scale, probability_flow=probability_flow,
+              self_conditioning=self_conditioning, device=device, rng=rng)
+    N = gt_frames_4x4.shape[-3]
+    b_rank = sum(hi - lo for _, lo, hi in chunks)
+    mergeable = (probability_flow or rng == "device") and len(delta_range) > 1 and b_rank > 0 and all(t > 0 for t in delta_range) \
+        and hasattr(getattr(net, "embedder", None), "time_images")
+    sched = [schedule(t, num_timesteps, min_t) for t in delta_range]
+    plan = merge_delta_groups([s[1] for s in sched], b_rank, N, max_pairs) if mergeable else [[i] for i in range(len(delta_range))]
+    rig0 = lambda bsz: Rigid.from_tensor_4x4(gt_frames_4x4.repeat(bsz, *(1,) * (gt_frames_4x4.ndim - 1)))  # noqa: E731
+    out = [None] * len(delta_range)
+    for grp in plan:
+        if len(grp) == 1:
+            out[grp[0]] = forward_backward_chunks(net, diffuser, batch, gt_frames_4x4, chunks, delta_range[grp[0]], max_pairs=max_pairs, **kw)
+            continue
+        # start frames in the reference's order: t_delta by t_delta, chunk by chunk (host mode: + each chunk's step draws)
+        groups, tail = [], None
+        longest_last = all(sched[grp[-1]][1] >= sched[i][1] for i in grp)
+        for gi, i in enumerate(grp):
+            T, n, dt, ts = sched[i]
+            starts = []
+            for ci, (bsz, lo, hi) in enumerate(chunks):
+                r = _start_frames(diffuser, batch, rig0(bsz), delta_range[i], lo, hi, rng, device)
+                if rng == "host":
+                    if gi + 1 == len(grp) and ci + 1 == len(chunks) and longest_last:
+                        tail = (bsz, len(ts) - 1)      # rides in the loop, behind the GPU (global step == its local step)
+                    else:
+                        _burn_step_draws(bsz, N, len(ts) - 1)
+                if r is not None:
+                    starts.append(r)
+            groups.append(dict(rigids_t=torch.cat(starts) if len(starts) > 1 else starts[0], ts=ts, dt=dt))
+        left = [tail[1] if tail else 0]
+
+        def host_noise(left=left, bsz=tail[0] if tail else 0):
+            if left[0] > 0:
+                left[0] -= 1
+                torch.randn(bsz, N, 3, dtype=torch.float64)
+                torch.randn(bsz, N, 3, dtype=torch.float64)
+            return None
+
+        def run_pass(groups=groups, left=left, tail=tail, host_noise=host_noise):
+            left[0] = tail[1] if tail else 0
+            a, r7, _ = _denoise_pass_deltas(net, diffuser, batch, groups, min_t=min_t, noise_scale=noise_scale,
+                                            probability_flow=probability_flow, self_conditioning=self_conditioning, center_mode=1,
+                                            host_noise=host_noise if tail else None, device=device)
+            return a, r7
+
+        a37 = _range_guarded(net, run_pass, device, host_draws=tail is not None, device_draws=rng == "device" and not probability_flow)[0]
+        for i, a in zip(grp, a37):
+            out[i] = a
+    return out
 
 
 def forward_flops(n_res: int) -> float:

@@ -56,11 +56,24 @@ def _fake_denoise_loop(net, diffuser, feats, rigids_t, ts, dt, *, host_noise=Non
     return out, None, None
 
 
+def _fake_pass_deltas(net, diffuser, batch, groups, *, host_noise=None, **kw):
+    """sampler._denoise_pass_deltas with trajectories that return their start: one host_noise() call per global step."""
+    for _ in range(max(len(g["ts"]) for g in groups) - 1):
+        if host_noise is not None:
+            host_noise()
+    outs = []
+    for g in groups:
+        out = torch.zeros(g["rigids_t"].shape[0], g["rigids_t"].shape[1], 37, 3)
+        out[:, :, 1, :] = g["rigids_t"]
+        outs.append(out)
+    return outs, torch.zeros(1), None
+
+
 class _Net(torch.nn.Module):
     def __init__(self):
         super().__init__()
         self.w = torch.nn.Parameter(torch.zeros(1))
-        self.embedder = type("E", (), {"self_conditioning": True})()
+        self.embedder = type("E", (), {"self_conditioning": True, "time_images": None})()
 
 
 def _predict(rank, world, port, n_replica, rpb, out_dir, q):
@@ -76,6 +89,8 @@ def _predict(rank, world, port, n_replica, rpb, out_dir, q):
     # the sampler's control flow (chunks -> groups -> trajectories, slices, host-generator lock-step) runs as shipped; only the three
     # functions that need the device are replaced
     SM._start_frames, SM.denoise_loop = _fake_start_frames, _fake_denoise_loop
+    SM._denoise_pass_deltas = _fake_pass_deltas                       # (the t_deltas of a target as one batch: forward_backward_deltas)
+    SM._range_guarded = lambda net, run_pass, device, **kw: run_pass()
     SM._require_hip_device = lambda device, net: torch.device("cpu")
     inf = dict(n_replica=n_replica, replica_per_batch=rpb, delta_min=0.5, delta_max=0.6, delta_step=0.1, num_timesteps=4,
                noise_scale=1.0, probability_flow=True, self_conditioning=True, min_t=0.01, output_dir=out_dir, backward_only=False)
@@ -122,6 +137,13 @@ def test_predict_step_multi_rank_files_equal_single_process(tmp_path):
             assert _run_predict(2, n_replica, rpb, str(tmp_path / f"w2_{n_replica}_chunkwise")) == single
         finally:
             del os.environ["S2S_MERGE_CHUNKS"]
+        # ... and one t_delta at a time (the reference's outer loop) against the t_deltas of the target as one batch (the default)
+        os.environ["S2S_MERGE_DELTAS"] = "0"
+        try:
+            assert _run_predict(1, n_replica, rpb, str(tmp_path / f"w1_{n_replica}_deltawise")) == single
+            assert _run_predict(3, n_replica, rpb, str(tmp_path / f"w3_{n_replica}_deltawise")) == single
+        finally:
+            del os.environ["S2S_MERGE_DELTAS"]
 
 
 def _gather_worker(rank, world, port, total, q):

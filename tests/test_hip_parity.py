@@ -1233,6 +1233,62 @@ def test_merged_chunks_equal_chunk_by_chunk(net_smooth, diffuser, monkeypatch):
     assert len(merge_chunk_groups(chunks, 20, mergeable=False)) == 3
 
 
+def test_merged_t_deltas_equal_one_at_a_time(net_smooth, diffuser, monkeypatch):
+    """The t_deltas of a target (the outer loop of the reference's predict_step, diffusion_module.py:341-367) as ONE growing batch
+    (``forward_backward_deltas``: trajectories aligned at their end, per-sample timestep image / step parameters / step size) --
+    bit for bit the t_delta-by-t_delta run (S2S_MERGE_DELTAS=0), in both noise modes, with the host generator ending where the
+    reference's control flow leaves it; a pair budget in between and a rank's slice give the same samples."""
+    from str2str_amd.sampler import forward_backward_chunks, forward_backward_deltas, merge_delta_groups, rank_chunk_slices, schedule
+    from str2str_amd.synth import synth_chain
+
+    deltas = [0.3, 0.5, 0.8]                                         # 6, 10, 16 steps of 20 timesteps
+    for n_res, rng in ((20, "host"), (40, "host"), (33, "device")):
+        feats = synth_chain(n_res)
+        gt4 = feats["rigidgroups_gt_frames"][..., 0, :, :]
+        kw = dict(num_timesteps=20, device=DEV, rng=rng, probability_flow=True)
+        chunks = rank_chunk_slices(5, 3, 0, 1)                       # 3 + 2 replicas
+        steps = [schedule(d, 20, 0.01)[1] for d in deltas]
+        assert steps == [6, 10, 16] and merge_delta_groups(steps, 5, n_res) == [[0, 1, 2]]
+        monkeypatch.setenv("S2S_MERGE_DELTAS", "0")
+        torch.manual_seed(33); torch.cuda.manual_seed(33)
+        ref = forward_backward_deltas(net_smooth, diffuser, feats, gt4, chunks, deltas, **kw)
+        state_ref = torch.get_rng_state()
+        torch.manual_seed(33); torch.cuda.manual_seed(33)
+        one = [forward_backward_chunks(net_smooth, diffuser, feats, gt4, chunks, d, **kw) for d in deltas]   # (= what the switch selects)
+        assert all(torch.equal(a, b) for a, b in zip(ref, one))
+        monkeypatch.setenv("S2S_MERGE_DELTAS", "1")
+        torch.manual_seed(33); torch.cuda.manual_seed(33)
+        got = forward_backward_deltas(net_smooth, diffuser, feats, gt4, chunks, deltas, **kw)
+        assert len(got) == 3 and all(g.shape == (5, n_res, 37, 3) for g in got)
+        for g, r in zip(got, ref):
+            assert torch.isfinite(g).all() and torch.equal(g.cpu(), r.cpu())
+        assert torch.equal(torch.get_rng_state(), state_ref)
+        assert not torch.equal(got[0], got[2])
+        # a pair budget that holds two t_deltas: (0.3, 0.5) | 0.8
+        torch.manual_seed(33); torch.cuda.manual_seed(33)
+        two = forward_backward_deltas(net_smooth, diffuser, feats, gt4, chunks, deltas, max_pairs=2 * 5 * n_res * n_res, **kw)
+        assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(two, ref))
+        if rng == "host":   # two ranks, back to back on this GPU: rank-major concatenation == the single-process run, per t_delta
+            parts = []
+            for r in range(2):
+                torch.manual_seed(33)
+                parts.append(forward_backward_deltas(net_smooth, diffuser, feats, gt4, rank_chunk_slices(5, 3, r, 2), deltas, **kw))
+            for k in range(3):
+                assert torch.equal(torch.cat([parts[0][k], parts[1][k]]).cpu(), ref[k].cpu())
+    # descending t_deltas (the longest trajectory is not the last one drawn): everything is drawn up front, same samples
+    feats = synth_chain(20)
+    gt4 = feats["rigidgroups_gt_frames"][..., 0, :, :]
+    kw = dict(num_timesteps=20, device=DEV, rng="host", probability_flow=True)
+    monkeypatch.setenv("S2S_MERGE_DELTAS", "0")
+    torch.manual_seed(4)
+    ref = forward_backward_deltas(net_smooth, diffuser, feats, gt4, chunks, deltas[::-1], **kw)
+    state_ref = torch.get_rng_state()
+    monkeypatch.setenv("S2S_MERGE_DELTAS", "1")
+    torch.manual_seed(4)
+    got = forward_backward_deltas(net_smooth, diffuser, feats, gt4, chunks, deltas[::-1], **kw)
+    assert all(torch.equal(a.cpu(), b.cpu()) for a, b in zip(got, ref)) and torch.equal(torch.get_rng_state(), state_ref)
+
+
 def test_sharded_sampler_equals_single(net_smooth, diffuser):
     """Replica sharding (2 'ranks' run back to back on one GPU) reproduces the unsharded chunk."""
     from str2str_amd.common.rigid_utils import Rigid
