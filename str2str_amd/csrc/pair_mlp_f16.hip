@@ -17,8 +17,8 @@
 // exact fp32 kernels (str2str_amd/sampler.py) -- an overflow is neither silent nor an error.  Weights with |32 w| >= 65504 are
 // refused at pack time (ops.pack_f16x2_layer).
 //
-// Schedule.  One wave owns 32 pairs; the 4 waves of a workgroup share the weight stream (30 stages of 32 KiB, double buffered in
-// LDS).  A stage is 8 SLOTS of 6 MFMAs / 4 A fragments.  Per pair tile (240 slots):
+// Schedule.  One wave owns 32 pairs; the 4 waves of a workgroup share the weight stream (30 stages of 32 KiB through a ring of
+// LDS buffers, see s_w).  A stage is 8 SLOTS of 6 MFMAs / 4 A fragments.  Per pair tile (240 slots):
 //   A_t  (4 slots)  layer-1 output tile t (32 of the 384 hidden channels) over the 8 k-steps of the 128 edge channels;
 //                   the edge row is split once into 8 x 2 f16 plane registers.
 //   B_t  (12 slots) layer-2 k-steps 2t, 2t+1 (= the 32 channels of a1 tile t) into all 12 output tiles; the 192
@@ -174,15 +174,25 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     float* __restrict__ proj_bias_out, float* __restrict__ proj_pz_out, int* __restrict__ range_flag, float sk) {
     constexpr int kStages = kStagesBase + (PROJ ? 1 : 0);
     constexpr int kSlots = 8 * kStages;
-    __shared__ __attribute__((aligned(16))) char s_w[2][kStageBytes];
+    // Weight stages in LDS.  PROJ (31 stages, every launch of the sampler): a RING of four 32 KiB buffers, stage x in buffer x & 3, the
+    // weight pipe TWO stages ahead (stage x is stored during stage x - 2), and a workgroup barrier only in front of the even stages
+    // (+ stage 29, where the odd stage count breaks the period: stages 29 30 | 0 1 of the next tile sit in buffers 1 2 | 0 1) --
+    // 17 barriers per tile instead of 31.  A buffer is rewritten two stages after its last read and read two stages after its last
+    // write, and with no two consecutive stage boundaries without a barrier there is one in between both times.  (Same-call A/Bs,
+    // profiles/r05_et_barrier_ab.txt: every second barrier skipped, results aside, -1.45 % per launch; this ring -0.4 .. -0.8 %.)  Without the projection (30 stages;
+    // stand-alone callers): two buffers, one stage ahead, a barrier per stage, as before.
+    constexpr int kRing = PROJ ? 4 : 2, kAhead = PROJ ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) char s_w[kRing][kStageBytes];
     __shared__ __attribute__((aligned(16))) float s_vec[768 + 64];  // b2 | bf | gamma | beta | projection bias
     const int lane = threadIdx.x & 63, h = lane >> 5, wave = threadIdx.x >> 6;
 
     // ---- weight pipe (see header).  Each wave moves one contiguous 12 KiB of every stage.
     const unsigned voff = wave * 8192 + lane * 16;
     typedef __attribute__((address_space(3))) char lds_char;
-    lds_char* lds_image[2] = {(lds_char*)&s_w[0][lane * 16], (lds_char*)&s_w[1][lane * 16]};
+    // two base registers (a DS instruction's immediate offset has 16 bits): buffers (0, 1) and (2, 3) of the ring, or the two buffers
+    lds_char* lds_image[2] = {(lds_char*)&s_w[0][lane * 16], (lds_char*)&s_w[kRing / 2][lane * 16]};
     asm volatile("" : "+v"(lds_image[0]), "+v"(lds_image[1]));  // opaque: every LDS access = base register + immediate
+    auto ring_buf = [&](int r) -> lds_char* { return PROJ ? lds_image[r >> 1] + (r & 1) * kStageBytes : lds_image[r]; };   // r: compile-time at every call site
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wblob, 0, kStages * kStageBytes, 0x00020000);
     auto ldw = [&](unsigned vo, int so) -> f32x4 {
         const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, vo, so, 0);
@@ -201,11 +211,11 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         e0 = ldw(voff, so); e1 = ldw(voff + 1024, so); e2 = ldw(voff + 2048, so); e3 = ldw(voff + 3072, so);
     };
     auto cp_store_a = [&](int par) {
-        lds_char* d = lds_image[par] + wave * 8192;
+        lds_char* d = ring_buf(par) + wave * 8192;
         *(lds_f4*)(d) = c0; *(lds_f4*)(d + 1024) = c1; *(lds_f4*)(d + 2048) = c2; *(lds_f4*)(d + 3072) = c3;
     };
     auto cp_store_b = [&](int par) {
-        lds_char* d = lds_image[par] + (wave * 8192 + 4096);
+        lds_char* d = ring_buf(par) + (wave * 8192 + 4096);
         *(lds_f4*)(d) = e0; *(lds_f4*)(d + 1024) = e1; *(lds_f4*)(d + 2048) = e2; *(lds_f4*)(d + 3072) = e3;
     };
     // the same, one 1 KiB piece at a time (k = 0..3): inside the tile loop a piece rides behind a single MFMA
@@ -221,7 +231,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     };
     auto cp_store_piece = [&](auto grp, auto kc, int par) {
         constexpr int k = decltype(kc)::value;
-        lds_char* d = lds_image[par] + (wave * 8192 + (decltype(grp)::value ? 4096 : 0) + 1024 * k);
+        lds_char* d = ring_buf(par) + (wave * 8192 + (decltype(grp)::value ? 4096 : 0) + 1024 * k);
         if constexpr (decltype(grp)::value == 0)
             *(lds_f4*)(d) = k == 0 ? c0 : (k == 1 ? c1 : (k == 2 ? c2 : c3));
         else
@@ -323,6 +333,12 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         cp_store_a(0);
         cp_load_a(1);
         cp_store_b(0);
+        if constexpr (kAhead == 2) {   // the ring starts with stages 0 and 1 in LDS and the first half of stage 2 on its way
+            cp_load_b(1);
+            cp_store_a(1);
+            cp_load_a(2);
+            cp_store_b(1);
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float x[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
@@ -355,7 +371,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     f16x8 xp[2][2];  // layer 2: planes of k-steps 2t, 2t+1 of the current a1 tile; final layer: current / next k-step
     auto fetch = [&](int par, int slot_in_stage, f16x8 (&f)[4]) {
         typedef __attribute__((address_space(3))) f16x8 lds_frag;
-        const lds_frag* s = (const lds_frag*)lds_image[par] + slot_in_stage * 4 * 64;
+        const lds_frag* s = (const lds_frag*)ring_buf(par) + slot_in_stage * 4 * 64;
 #pragma unroll
         for (int k = 0; k < 4; ++k) f[k] = s[64 * k];
     };
@@ -463,7 +479,9 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         constexpr int ns = decltype(sc)::value;      // position in the tile loop: weight-pipe stage ns / 8
         constexpr int s = sched_slot(PROJ, ns);      // slot of the schedule (slot_desc)
         constexpr SlotDesc d = slot_desc(s);
-        constexpr int stage = ns / 8, ss = ns % 8, par = stage & 1;
+        constexpr int stage = ns / 8, ss = ns % 8, par = stage & (kRing - 1);
+        constexpr int st_next = (stage + 1) % kStages, st_fill = (stage + kAhead) % kStages;   // the stage read next; the stage whose weights are stored during this one
+        constexpr bool barrier_here = !PROJ || (st_next & 1) == 0 || st_next == kStages - 2;    // in front of st_next (ring comment at s_w)
 #if defined(S2S_ET_PROBE) && S2S_ET_PROBE == 3   // fine view of one layer-2 block: slot tops 72 .. 87 (B_4 A_6), 88
         if constexpr (s >= 72 && s <= 87) { if constexpr (s == 72) ET_STAMP(0); if constexpr (s == 73) ET_STAMP(1); if constexpr (s == 74) ET_STAMP(2);
             if constexpr (s == 75) ET_STAMP(3); if constexpr (s == 76) ET_STAMP(4); if constexpr (s == 77) ET_STAMP(5); if constexpr (s == 78) ET_STAMP(6);
@@ -503,8 +521,8 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         if constexpr (ss < 7) {
             fetch(par, ss + 1, fr[(ns + 1) & 1]);
         } else {
-            S2S_LDS_BARRIER();
-            fetch(par ^ 1, 0, fr[(ns + 1) & 1]);
+            if constexpr (barrier_here) S2S_LDS_BARRIER();
+            fetch(st_next & (kRing - 1), 0, fr[(ns + 1) & 1]);
         }
         // next tile: context + edge row under the middle final-layer block, seeds of its tile 0 near the end
         // (the edge row in pieces: a burst of 16 loads per wave holds the slot for ~2 k cycles -- the workgroup's 64 KiB through one
@@ -620,10 +638,10 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             constexpr int i = decltype(ic)::value;
             mfma_i(ic);
             if constexpr (i < 4) {
-                if constexpr (ss == 0) cp_load_piece(IC<1>{}, ic, (stage + 1) % kStages);   // the pipe wraps into the next tile's stages 0, 1
-                if constexpr (ss == 4) cp_load_piece(IC<0>{}, ic, (stage + 2) % kStages);
-                if constexpr (ss == 1) cp_store_piece(IC<0>{}, ic, par ^ 1);
-                if constexpr (ss == 5) cp_store_piece(IC<1>{}, ic, par ^ 1);
+                if constexpr (ss == 0) cp_load_piece(IC<1>{}, ic, st_fill);   // the pipe wraps into the next tile's first stages
+                if constexpr (ss == 4) cp_load_piece(IC<0>{}, ic, (stage + kAhead + 1) % kStages);
+                if constexpr (ss == 1) cp_store_piece(IC<0>{}, ic, st_fill & (kRing - 1));
+                if constexpr (ss == 5) cp_store_piece(IC<1>{}, ic, st_fill & (kRing - 1));
             }
             if constexpr (seeds_slot && i < 4) seeds_piece(cur, d.t + 1, i);
             if constexpr (d.phase == 0 && d.t >= 1 && (i == 2 || i == 4)) s_half(a1t[(d.t - 1) & 1], IC<d.a>{}, IC<(i - 2) / 2>{});
@@ -690,11 +708,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     prv = cur;   // a3 holds this tile's final-layer accumulators: LayerNorm, store and projection in the next pass
 #pragma unroll
     for (int i = 0; i < 8; ++i) { xpl[i][0] = xpn[i][0]; xpl[i][1] = xpn[i][1]; }
-    if constexpr (kStages % 2 == 1) {  // odd stage count: the next tile's stage 0 sits in the other buffer
-        lds_char* sw = lds_image[0];
-        lds_image[0] = lds_image[1];
-        lds_image[1] = sw;
-    }
+    // (the next tile's stage 0 sits in buffer 0 again: the ring index is the tile-local stage number)
     if (!has_next) break;
     cur = nxt;
     wt = wt_next;
