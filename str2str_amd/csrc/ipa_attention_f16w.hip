@@ -58,14 +58,27 @@ __device__ __forceinline__ float exp_neg(float x) {
     return __builtin_fmaf(r, e * LN2, r);
 }
 
+// two values -> element pair `at / 2` of the planes (x_h = rn16(x), x_l = rn16(x - x_h)) in 3 instructions: v_cvt_pk_f16_f32 for both
+// x_h, then ONE fused multiply-add per value that reads x_h as f16 and rounds to f16 -- (-x_h) * 1.0 + x, whose exact fp32 result is
+// the difference -- the bits of convert back, subtract, convert (pair_mlp_f16.hip split2_f16; hipcc's expansion of the C form: 5 per value)
+typedef unsigned u32x4p __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split2(float x0, float x1, f16x8& ph, f16x8& pl, int at) {
+    unsigned hh, ll;
+    asm volatile(
+        "v_cvt_pk_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, -%0, 1.0, %2 op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %1, -%0, 1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(hh), "=&v"(ll)
+        : "v"(x0), "v"(x1));
+    u32x4p hv = __builtin_bit_cast(u32x4p, ph), lv = __builtin_bit_cast(u32x4p, pl);
+    hv[at / 2] = hh;
+    lv[at / 2] = ll;
+    ph = __builtin_bit_cast(f16x8, hv);
+    pl = __builtin_bit_cast(f16x8, lv);
+}
 __device__ __forceinline__ void split8(const float* v, f16x8& ph, f16x8& pl) {   // x_h, x_l
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float xv = v[j];
-        asm volatile("" : "+v"(xv));   // one materialised fp32 value feeds both planes (see node_gemm.hip split8_f16)
-        const _Float16 a_ = (_Float16)xv;
-        ph[j] = a_; pl[j] = (_Float16)(xv - (float)a_);
-    }
+    for (int j = 0; j < 8; j += 2) split2(v[j], v[j + 1], ph, pl, j);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -467,18 +480,17 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
     f32x4v lg[4], lg1[4];   // logits of the tile whose probabilities are formed next (and of tile 1 across the phase change)
     float tmax = -INFINITY;
     float4 k2g, kmg;   // per-key scalars of the 4 keys 8g + 4h .. of the element group being evaluated
-    auto logit_elem = [&](int tp, int r, const float4 (&xa)[4], const float4 (&xb)[4], float (&sl)[16]) {
+    auto logit_elem = [&](int tp, int r, const float4 (&xa)[4], float (&sl)[16]) {
         const int g = r >> 2, e = r & 3;
         if (e == 0) {
             k2g = *reinterpret_cast<const float4*>(&st.k2[tp & 3][8 * g + 4 * h]);
             kmg = *reinterpret_cast<const float4*>(&st.km[tp & 3][8 * g + 4 * h]);
         }
         const float sa = e == 0 ? xa[g].x : (e == 1 ? xa[g].y : (e == 2 ? xa[g].z : xa[g].w));
-        const float sb = e == 0 ? xb[g].x : (e == 1 ? xb[g].y : (e == 2 ? xb[g].z : xb[g].w));
         const float bv = e == 0 ? bias_prev[g].x : (e == 1 ? bias_prev[g].y : (e == 2 ? bias_prev[g].z : bias_prev[g].w));
         const float k2v = e == 0 ? k2g.x : (e == 1 ? k2g.y : (e == 2 ? k2g.z : k2g.w));
         const float kmv = e == 0 ? kmg.x : (e == 1 ? kmg.y : (e == 2 ? kmg.z : kmg.w));
-        float x = (sa + sb) * c1 + c2 * bv;
+        float x = sa * c1 + c2 * bv;
         x = x + (q2_i + k2v);
         x = x + a.inf * (mask_i * kmv - 1.0f);
         sl[r] = x;
@@ -499,10 +511,10 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
         const int par = t & 1;
         IPROBE(6 * t + 0);
         // S^T of tile t-1
-        float4 xa[4], xb[4];
+        float4 xa[4];
         if constexpr (prev) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { xa[g] = xkeep[g]; xb[g] = make_float4(0.f, 0.f, 0.f, 0.f); }   // S^T of tile t-1 (this wave's own)
+            for (int g = 0; g < 4; ++g) xa[g] = xkeep[g];   // S^T of tile t-1 (this wave's own)
 #pragma unroll
             for (int g = 0; g < 4; ++g) bias_prev[g] = bias_cur[g];
         }
@@ -535,11 +547,11 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
                 // copy slots 2x, 2x+1 (ten in all): image t + 1 -> LDS (its buffer was released by the barrier of tile t - 1),
                 // image t + 2 -> registers; two logit elements of tile t - 1 per k-step
                 S0 = mfma_f16(k[1], q[0], S0); S1 = mfma_f16(k[0], q[1], S1);   // k_l q_h, k_h q_l
-                if (prev && 2 * x < 16) logit_elem(t - 1, 2 * x, xa, xb, sl);   // (same scheduling region as the MFMA pair)
+                if (prev && 2 * x < 16) logit_elem(t - 1, 2 * x, xa, sl);   // (same scheduling region as the MFMA pair)
                 stage_slot(t + 1, 2 * x);
                 __builtin_amdgcn_sched_barrier(0);
                 if (x & 1) S1 = mfma_f16(k[0], q[0], S1); else S0 = mfma_f16(k[0], q[0], S0);   // k_h q_h, chains alternate
-                if (prev && 2 * x + 1 < 16) logit_elem(t - 1, 2 * x + 1, xa, xb, sl);
+                if (prev && 2 * x + 1 < 16) logit_elem(t - 1, 2 * x + 1, xa, sl);
                 stage_slot(t + 1, 2 * x + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -560,7 +572,7 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
 #pragma unroll
             for (int p = 0; p < 10; ++p) stage_slot(t + 1, p);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) logit_elem(t - 1, r, xa, xb, sl);   // the last tile's logits: nothing left to hide them under
+            for (int r = 0; r < 16; ++r) logit_elem(t - 1, r, xa, sl);   // the last tile's logits: nothing left to hide them under
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ... and they must have reached L2 before phase 2 reads them back
         }
         if constexpr (flush) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // logits stored so far have reached L2
@@ -641,13 +653,7 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
         // tile t + 2 requested in group 16 (lg is dead by then); the next tile group's fragments are requested in this one's first groups.
         auto split_pair = [&](auto jc) {   // elements 2j, 2j+1 of 2^10 pe -> element pair (j & 3) of the planes of k-step j >> 2
             constexpr int j = decltype(jc)::value;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                float v = pe[2 * j + q] * 1024.0f;
-                asm volatile("" : "+v"(v));
-                const _Float16 a_ = (_Float16)v;
-                pn[j >> 2][0][2 * (j & 3) + q] = a_; pn[j >> 2][1][2 * (j & 3) + q] = (_Float16)(v - (float)a_);
-            }
+            split2(pe[2 * j] * 1024.0f, pe[2 * j + 1] * 1024.0f, pn[j >> 2][0], pn[j >> 2][1], 2 * (j & 3));
             asm volatile("" : "+v"(pn[j >> 2][0]), "+v"(pn[j >> 2][1]) :: "memory");   // done here, not at the loop tail
         };
         auto ride = [&](auto gc) {
@@ -735,13 +741,7 @@ __global__ void __launch_bounds__(256) ipa_attention_f16w_kernel(PlaneArgs a) {
                 for (int j = 0; j < 8; ++j) v[j] = O[x][8 * u + j] * inv;
                 // this output is an INPUT of the node stream (linear_out, s2s_node_linear): f16 pair planes (x_h, x_l)
                 f16x8 ph, pl;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    float xv = v[j];
-                    asm volatile("" : "+v"(xv));   // one materialised fp32 value feeds both planes (see node_gemm.hip split8_f16)
-                    const _Float16 hh = (_Float16)xv;
-                    ph[j] = hh; pl[j] = (_Float16)(xv - (float)hh);
-                }
+                split8(v, ph, pl);
                 f16x8* q = o + ((2 * T + u) * 2) * 64;
                 if (row_ok) { q[0] = ph; q[64] = pl; }
             }
