@@ -37,7 +37,7 @@ UNITS = {
     #  tools/ubench/mfma_valu_overlap.hip; -0.3 .. -1.1 % per edge-transition launch, same-call A/B)
     "pair_mlp_f16.hip": ["-mllvm", "-pragma-unroll-threshold=10000000", "-fno-slp-vectorize"],
     "ipa_attention.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
-    "ipa_attention_f16w.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
+    "ipa_attention_f16w.hip": ["-mllvm", "-pragma-unroll-threshold=10000000", "-fno-slp-vectorize"],   # (as above; -0.5 .. -1.5 % per IPA block)
     "node_gemm.hip": ["-mllvm", "-pragma-unroll-threshold=10000000", "-fno-slp-vectorize"],   # (as above: node layers -2.4 %)
     # contraction off: the packed-plane output must be the exact split of the SAME rounded value the fp32 output stores
     "enc_attention.hip": ["-mllvm", "-pragma-unroll-threshold=10000000", "-ffp-contract=off", "-fno-slp-vectorize"],   # (-5 %)

@@ -2,9 +2,9 @@
 for rep in 1 2; do
 for L in "$@"; do
   for shape in "128 256" "1000 35" "1000 80" "32 512"; do
-    set -- $shape
+    bb=${shape% *}; nn=${shape#* }
     if [ $L = tree ]; then P=""; else P="STR2STR_HIP_LIB=$PWD/$L"; fi
-    echo -n "$L B=$1 N=$2: "; env $P python tools/ipa_fold_ab.py --B $1 --N $2 --iters 10 --only-folded 2>/dev/null | tail -2 | tr '\n' ' '; echo
+    echo -n "$L: "; env $P python tools/ipa_fold_ab.py --B $bb --N $nn --iters 10 --only-folded 2>/dev/null | tail -2 | tr '\n' ' '; echo
   done
 done
 done
