@@ -110,7 +110,8 @@ def traffic_from_profiles(pairs, mode):
         try:
             with open(path) as f:
                 return (json.load(f)["kernels"][key]["bytes_per_pair_corrected"] * pairs,
-                        f"profiles/{os.path.basename(path)} (PMC pass at B=16, N=256, scaled per pair)")
+                        f"profiles/{os.path.basename(path)} (PMC pass at B=16, N=256, scaled per pair; the counters sit on the L2's fabric side and include "
+                        "Infinity-Cache hits: ~150 B/pair of it are weight-stream re-fetches of workgroups in lockstep, DESIGN section 4 K5)")
         except Exception:
             continue
     return None, None

@@ -303,6 +303,12 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     // the edge row is requested two loads per slot, 16+ slots ahead of its use (kXv0 below), lockstep costs nothing, while the start
     // delay (up to 15/16 of a tile: ~45 us) is added to every launch: same-call A/B (profiles/r04t_et_phase_stagger_ab.txt)
     // 11.290 -> 11.274 ms at cfg2, 0.245 -> 0.215 ms at 100 x 35^2 pairs (3.7 tiles per workgroup), 1.019 -> 1.002 at 100 x 80^2.
+    // What lockstep does cost is fabric READ REQUESTS, not time: PMC FETCH_SIZE 378 instead of 301 B per pair (1256 / 1104 B per pair
+    // of corrected traffic against 1013 algorithmic, profiles/r05d_pmc_hbm_traffic*.json, round 5).  The pair stream flows through
+    // the XCD's 4 MiB L2 and evicts the 0.97 MB weight stream between two uses of a stage when all 32 workgroups use it at the same
+    // moment once per tile (~43 us); staggered, some workgroup touches every stage every ~3 us and it stays resident.  The re-fetches
+    // are served by the 256 MiB Infinity Cache (the counter sits on the L2's fabric side and includes its hits), two stages ahead of
+    // their use.  A fine stagger (32 x 0.5 us, one L2 miss apart) changes neither time nor the counter (1245 -> 1225, r05e).
     if constexpr (S2S_ET_PHASES > 1) {
         const int phase = (blockIdx.x >> 3) % S2S_ET_PHASES;
         for (int i = 0; i < phase * (16 / (S2S_ET_PHASES > 16 ? 16 : S2S_ET_PHASES)); ++i) __builtin_amdgcn_s_sleep(98);   // 98 x 64 cycles = 1/16 tile
