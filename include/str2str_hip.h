@@ -405,6 +405,14 @@ long long s2s_write_pdb_models(const char* path, int append, const float* atom37
 /* pdb_utils.merge_pdbfiles (src/common/pdb_utils.py:31-83): MODELs of the inputs, in order, renumbered from 1. */
 long long s2s_merge_pdb_files(const char* const* paths, int n_paths, const char* out_path);
 
+/* ---- Host noise stream (parity mode) ----
+ * Discard n_outputs 32-bit outputs of the Mersenne twister behind torch's CPU generator: state624 = the engine's 624 words in 64-bit
+ * slots, *left / *next = its counters, as torch.get_rng_state() serialises them.  The reference draws -- and, under the probability-flow
+ * ODE, never uses -- two float64 normal tensors of the whole chunk per denoise step (src/models/score/so3.py:360, src/models/score/r3.py:109);
+ * a float64 normal tensor of n >= 16 elements costs 2 (n + (n % 16 ? 16 : 0)) engine outputs, and this call leaves the generator where
+ * those draws leave it without computing them (host code; returns 0, or 1 for fields outside the engine's ranges). */
+int s2s_mt19937_discard(unsigned long long* state624, int* left, unsigned long long* next, unsigned long long n_outputs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,6 +26,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-I", os.path.
 UNITS = {
     "abi.hip": [],
     "pdb_format.cpp": [],   # host-only C++ (PDB text writer / merger behind the C ABI)
+    "host_rng.cpp": [],     # host-only C++ (fast-forward of the CPU generator over the reference's discarded step draws)
     "rigid_kernels.hip": ["-ffp-contract=off"],
     "se3_step.hip": ["-ffp-contract=off"],
     "forward_marginal.hip": ["-ffp-contract=off"],

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 _lib = None
 _tables_loaded = False
@@ -58,6 +58,7 @@ _SIGNATURES = {
     "s2s_format_pdb_models": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _ll],
     "s2s_write_pdb_models": [ctypes.c_char_p, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i],
     "s2s_merge_pdb_files": [_vp, _i, ctypes.c_char_p],
+    "s2s_mt19937_discard": [_vp, _vp, _vp, ctypes.c_ulonglong],
 }
 _LL_RETURN = ("s2s_format_pdb_models", "s2s_write_pdb_models", "s2s_merge_pdb_files")
 EXPORTS = tuple(_SIGNATURES)
@@ -1382,6 +1383,71 @@ def merge_pdb_files(paths, out_path: str) -> int:
     enc = [os.fsencode(p) for p in paths]
     arr = (ctypes.c_char_p * len(enc))(*enc)
     return _pdb_rc(lib.s2s_merge_pdb_files(ctypes.cast(arr, _vp), len(enc), os.fsencode(out_path)), "merge")
+
+
+# ------------------------------------------------------------------------------------------ host noise stream (parity mode)
+_HOST_RNG_OK = None   # None: not checked yet; True / False: the fast-forward reproduces torch's own draws on this build (or not)
+_ST_LEFT, _ST_NEXT, _ST_WORDS, _ST_END = 8, 16, 24, 24 + 624 * 8   # byte offsets in torch.get_rng_state(): seed u64 | left i32 | seeded i32 | next u64 | 624 x u64
+
+
+def float64_normal_outputs(n_elements: int) -> int:
+    """32-bit engine outputs one float64 ``torch.randn`` of ``n_elements`` >= 16 consumes (ATen normal_fill: n uniform doubles of two
+    outputs each, and the last block of 16 once more when n is not a multiple of 16)."""
+    return 2 * (n_elements + (16 if n_elements % 16 else 0))
+
+
+def _host_rng_discard_raw(n_outputs: int) -> bool:
+    st = torch.get_rng_state()
+    if st.numel() < _ST_END or st.dtype != torch.uint8:
+        return False
+    buf = st.numpy()          # (shares memory with st)
+    left = ctypes.c_int(int(np.frombuffer(buf, np.int32, 1, _ST_LEFT)[0]))
+    nxt = ctypes.c_ulonglong(int(np.frombuffer(buf, np.uint64, 1, _ST_NEXT)[0]))
+    words = np.frombuffer(buf, np.uint64, 624, _ST_WORDS)
+    if load_library().s2s_mt19937_discard(words.ctypes.data, ctypes.byref(left), ctypes.byref(nxt), ctypes.c_ulonglong(int(n_outputs))) != 0:
+        return False
+    np.frombuffer(buf, np.int32, 1, _ST_LEFT)[0] = left.value
+    np.frombuffer(buf, np.uint64, 1, _ST_NEXT)[0] = nxt.value
+    torch.set_rng_state(st)
+    return True
+
+
+def host_rng_fast_forward_ok() -> bool:
+    """Does ``host_rng_discard`` leave torch's CPU generator exactly where real float64 normal draws leave it?  Checked ONCE per process
+    against the draws themselves (sizes with and without the re-drawn tail block, across several twists of the engine); the
+    generator is left as it was found.  False (layout of another torch build, no library) -> callers draw for real."""
+    global _HOST_RNG_OK
+    if _HOST_RNG_OK is None:
+        keep = torch.get_rng_state()
+        try:
+            ok = True
+            for seed, sizes in ((1234567, (48, 50, 4800, 17)), (7, (15360, 3780, 3780, 16))):
+                torch.manual_seed(seed)
+                torch.rand(3)                                   # an engine position that is not a block boundary
+                start = torch.get_rng_state()
+                for n in sizes:
+                    torch.randn(n, dtype=torch.float64)
+                want, probe = torch.get_rng_state(), torch.rand(4)
+                torch.set_rng_state(start)
+                ok = ok and _host_rng_discard_raw(sum(float64_normal_outputs(n) for n in sizes))
+                ok = ok and torch.equal(torch.get_rng_state(), want) and torch.equal(torch.rand(4), probe)
+            _HOST_RNG_OK = bool(ok)
+        except Exception:
+            _HOST_RNG_OK = False
+        finally:
+            torch.set_rng_state(keep)
+    return _HOST_RNG_OK
+
+
+def host_rng_discard_float64_normals(n_elements: int, n_tensors: int) -> bool:
+    """Advance torch's CPU generator as ``n_tensors`` draws ``torch.randn(n_elements, dtype=float64)`` would, without computing them
+    (s2s_mt19937_discard).  -> False if that is not possible here (tensors below 16 elements take ATen's scalar path; an unknown state
+    layout): the caller draws for real."""
+    if n_tensors <= 0:
+        return True
+    if n_elements < 16 or os.environ.get("S2S_HOST_RNG_FAST", "1") == "0" or not host_rng_fast_forward_ok():
+        return False
+    return _host_rng_discard_raw(float64_normal_outputs(n_elements) * int(n_tensors))
 
 
 _registered = False

@@ -391,7 +391,11 @@ def _start_frames(diffuser, batch: dict, rigids_0: Rigid, t_delta: float, lo: in
 
 def _burn_step_draws(B_total: int, N: int, n_draw_steps: int):
     """The reference consumes two float64 normal draws of the whole chunk per step even under the probability-flow ODE
-    (so3.py:360, r3.py:109): consume them so that the host generator is where the reference's is for the next chunk."""
+    (so3.py:360, r3.py:109): consume them so that the host generator is where the reference's is for the next chunk.  Nothing reads the
+    values, so the generator is fast-forwarded over them where that is exact (ops.host_rng_discard_float64_normals: the engine's
+    position after the draws, checked against real draws once per process); otherwise they are drawn."""
+    if ops.host_rng_discard_float64_normals(B_total * N * 3, 2 * n_draw_steps):
+        return
     for _ in range(n_draw_steps):
         torch.randn(B_total, N, 3, dtype=torch.float64)
         torch.randn(B_total, N, 3, dtype=torch.float64)

@@ -382,3 +382,45 @@ def test_chunk_merging_groups(monkeypatch):
     assert merge_chunk_groups(ref_default, 35, mergeable=False) == [[c] for c in ref_default]
     monkeypatch.setenv("S2S_MERGE_CHUNKS", "0")
     assert merge_chunk_groups(ref_default, 35) == [[c] for c in ref_default]
+
+
+def test_host_generator_fast_forward_equals_the_discarded_draws(built_library, monkeypatch):
+    """Parity mode consumes the reference's per-step float64 draws that the probability-flow ODE never uses (so3.py:360, r3.py:109 there).
+    ``sampler._burn_step_draws`` fast-forwards torch's CPU generator over them (s2s_mt19937_discard behind
+    ops.host_rng_discard_float64_normals): the generator state -- and everything drawn afterwards -- must be exactly what the real
+    draws leave, for chunk sizes with and without ATen's re-drawn tail block, from any engine position, across many twists; tensors
+    below 16 elements (ATen's scalar path) and S2S_HOST_RNG_FAST=0 take the real draws."""
+    import torch
+
+    from str2str_amd import ops
+    from str2str_amd.sampler import _burn_step_draws
+
+    monkeypatch.delenv("S2S_HOST_RNG_FAST", raising=False)
+    assert ops.host_rng_fast_forward_ok()
+    assert ops.float64_normal_outputs(48) == 96 and ops.float64_normal_outputs(50) == 132
+
+    def real(B, N, steps):
+        for _ in range(steps):
+            torch.randn(B, N, 3, dtype=torch.float64)
+            torch.randn(B, N, 3, dtype=torch.float64)
+
+    for seed, pre, (B, N, steps) in [(0, 0, (64, 80, 40)), (1, 5, (36, 35, 57)), (2, 623, (3, 7, 9)), (3, 1, (1, 6, 11)), (4, 300, (100, 10, 700)),
+                                     (5, 2, (1, 5, 4))]:          # (1 x 5 x 3 = 15 elements: the scalar path, drawn for real)
+        torch.manual_seed(seed)
+        torch.rand(pre)
+        start = torch.get_rng_state()
+        real(B, N, steps)
+        want, after = torch.get_rng_state(), torch.randn(7)
+        torch.set_rng_state(start)
+        _burn_step_draws(B, N, steps)
+        assert torch.equal(torch.get_rng_state(), want) and torch.equal(torch.randn(7), after), (seed, B, N, steps)
+    assert not ops.host_rng_discard_float64_normals(15, 4)          # below ATen's block path: the caller draws
+    monkeypatch.setenv("S2S_HOST_RNG_FAST", "0")
+    assert not ops.host_rng_discard_float64_normals(4800, 4)
+    torch.manual_seed(9)
+    start = torch.get_rng_state()
+    real(4, 20, 3)
+    want = torch.get_rng_state()
+    torch.set_rng_state(start)
+    _burn_step_draws(4, 20, 3)
+    assert torch.equal(torch.get_rng_state(), want)
