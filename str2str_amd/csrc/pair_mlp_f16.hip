@@ -116,6 +116,15 @@ __device__ __forceinline__ void split4_f16(const float (&x)[4], f16x8& ph, f16x8
     pl = __builtin_bit_cast(f16x8, lv);
 }
 
+// max(x, 0) as ONE instruction.  fmaxf() of a value the compiler cannot see through (a pinned register, an MFMA result) is preceded by
+// a canonicalising v_max_f32 x, x (IEEE quieting of a signalling NaN): 128 of the edge embedding's ~1500 VALU instructions per tile.
+// v_max_f32 itself returns the other operand for any NaN input, which is what the two-instruction form computes as well.
+__device__ __forceinline__ float relu1(float x) {
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 template <int I> struct IC { static constexpr int value = I; };
 template <int B, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -897,8 +906,8 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
     };
     // ReLU + split of first-layer k-step ks (registers 8ks .. 8ks+7 of g1: chain order) into planes
     auto g1_split = [&](f16x8 (&dst)[2], int ks) {
-        const float x0[4] = {fmaxf(g1[8 * ks + 0], 0.f), fmaxf(g1[8 * ks + 1], 0.f), fmaxf(g1[8 * ks + 2], 0.f), fmaxf(g1[8 * ks + 3], 0.f)};
-        const float x1[4] = {fmaxf(g1[8 * ks + 4], 0.f), fmaxf(g1[8 * ks + 5], 0.f), fmaxf(g1[8 * ks + 6], 0.f), fmaxf(g1[8 * ks + 7], 0.f)};
+        const float x0[4] = {relu1(g1[8 * ks + 0]), relu1(g1[8 * ks + 1]), relu1(g1[8 * ks + 2]), relu1(g1[8 * ks + 3])};
+        const float x1[4] = {relu1(g1[8 * ks + 4]), relu1(g1[8 * ks + 5]), relu1(g1[8 * ks + 6]), relu1(g1[8 * ks + 7])};
         split4(x0, dst[0], dst[1], 0);
         split4(x1, dst[0], dst[1], 4);
     };
@@ -947,8 +956,8 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int rq = 2 * (k & 1) + u;
-            const float xx[4] = {fmaxf(a2[t][4 * rq + 0], 0.f) * kInvWS, fmaxf(a2[t][4 * rq + 1], 0.f) * kInvWS,
-                                 fmaxf(a2[t][4 * rq + 2], 0.f) * kInvWS, fmaxf(a2[t][4 * rq + 3], 0.f) * kInvWS};
+            const float xx[4] = {relu1(a2[t][4 * rq + 0]) * kInvWS, relu1(a2[t][4 * rq + 1]) * kInvWS,
+                                 relu1(a2[t][4 * rq + 2]) * kInvWS, relu1(a2[t][4 * rq + 3]) * kInvWS};
             split4(xx, xp[k][0], xp[k][1], 4 * u);
         }
         pin_frag(xp[k]);
