@@ -7,6 +7,7 @@ Tolerances (float32 path; the reference itself is float32).  Every bound is at m
   one network eval  <= 1e-4 absolute on frames (the oracle itself meets the reference at 2e-4)
   free-running trajectory with contractive weights: backbone RMSD <= 1e-4 Angstrom (north star; achieved <= 3.4e-5)
 """
+import os
 import numpy as np
 import pytest
 import torch
@@ -1062,6 +1063,52 @@ def test_range_guard_falls_back_per_kernel_family(diffuser, caplog, where, scale
     # what the guard saw: the offending family's bucket is at or above 2^15, the others well below
     head = ops.range_headroom()
     assert set(head) == set(FAMILIES)
+
+
+def test_range_guard_covers_merged_t_deltas(diffuser, caplog):
+    """The t_deltas of a target as one growing batch (``forward_backward_deltas``) run under the same range guard as a single
+    trajectory: a network whose EdgeTransition hidden layer leaves f16's range (8e3 x, restored by the next layer) raises the flag in
+    the merged pass, the edge transitions get their block exponent, the pass is repeated from the same start frames and host noise,
+    and the samples are bit for bit those of the t_delta-by-t_delta run of the network with the exponent set by hand; the host
+    generator ends where one pass leaves it."""
+    import logging
+
+    from str2str_amd.factory import build_synthetic_net
+    from str2str_amd.sampler import forward_backward_deltas, rank_chunk_slices
+    from str2str_amd.synth import synth_chain
+
+    def build():
+        net = build_synthetic_net(seed=0, sigma_final=0.002, device=DEV)
+        with torch.no_grad():
+            et = net.translator.trunk["edge_transition_1"]
+            et.trunk[0].weight.mul_(8.0e3); et.trunk[0].bias.mul_(8.0e3)
+            et.trunk[2].weight.div_(8.0e3)
+        return net
+
+    feats = synth_chain(21)
+    gt4 = feats["rigidgroups_gt_frames"][..., 0, :, :]
+    chunks, deltas = rank_chunk_slices(4, 3, 0, 1), [0.4, 0.7]
+    kw = dict(num_timesteps=10, device=DEV, rng="host", probability_flow=True)
+    ref_net = build()
+    for m in ref_net.modules():
+        if hasattr(m, "prescale_exp"):
+            m.prescale_exp = 5
+    os.environ["S2S_MERGE_DELTAS"] = "0"
+    try:
+        torch.manual_seed(12)
+        want = forward_backward_deltas(ref_net, diffuser, feats, gt4, chunks, deltas, **kw)
+        end_state = torch.get_rng_state()
+    finally:
+        del os.environ["S2S_MERGE_DELTAS"]
+    assert not getattr(ref_net, "range_fallback", None)
+    hot = build()
+    torch.manual_seed(12)
+    with caplog.at_level(logging.WARNING, logger="str2str_amd.sampler"):
+        got = forward_backward_deltas(hot, diffuser, feats, gt4, chunks, deltas, **kw)
+    assert any("range guard" in r.getMessage() and "block exponent" in r.getMessage() for r in caplog.records)
+    assert hot.range_prescale == {"edge_transition": 5} and not getattr(hot, "range_fallback", None)
+    assert all(torch.isfinite(g).all() and torch.equal(g, w) for g, w in zip(got, want))
+    assert torch.equal(torch.get_rng_state(), end_state)
 
 
 @pytest.mark.parametrize("fixture", ["net_b2n24_trained_like.npz", "net_b1n256_trained_like.npz"])
