@@ -496,7 +496,11 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         constexpr SlotDesc d = slot_desc(s);
         constexpr int stage = ns / 8, ss = ns % 8, par = stage & (kRing - 1);
         constexpr int st_next = (stage + 1) % kStages, st_fill = (stage + kAhead) % kStages;   // the stage read next; the stage whose weights are stored during this one
+#ifdef S2S_ET_ALL_BARRIERS   // (debug builds: a barrier in front of every stage -- the reference the ring's barrier placement is stress-tested against, tools/et_ring_stress.py)
+        constexpr bool barrier_here = true;
+#else
         constexpr bool barrier_here = !PROJ || (st_next & 1) == 0 || st_next == kStages - 2;    // in front of st_next (ring comment at s_w)
+#endif
 #if defined(S2S_ET_PROBE) && S2S_ET_PROBE == 3   // fine view of one layer-2 block: slot tops 72 .. 87 (B_4 A_6), 88
         if constexpr (s >= 72 && s <= 87) { if constexpr (s == 72) ET_STAMP(0); if constexpr (s == 73) ET_STAMP(1); if constexpr (s == 74) ET_STAMP(2);
             if constexpr (s == 75) ET_STAMP(3); if constexpr (s == 76) ET_STAMP(4); if constexpr (s == 77) ET_STAMP(5); if constexpr (s == 78) ET_STAMP(6);
