@@ -331,7 +331,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     float amax = 0.f;   // range guard (range_flag.h): running maximum of every value that is split into f16 planes
     // Block exponent of the hidden activations (sk = 2^-prescale_exp, 1 by default): the planes of h1 = relu(layer 1) and of
     // relu(layer 2) + x hold sk x the value -- relu is positively homogeneous, so the factor rides in constants that exist anyway
-    // (layer 1: acc * (sk / 32) + sk * seeds, the caller hands node_ab in pre-scaled; layer 2: relu(acc / 32 + sk b2) + sk x; final layer:
+    // (layer 1: (acc + 32 B_j) * (sk / 32) + sk A_i, the caller hands node_ab in as [sk A_i | 32 B_j]; layer 2: relu(acc / 32 + sk b2) + sk x; final layer:
     // start value 32 sk bf) and LayerNorm removes it (eps scaled alike).  Exact for powers of two; sk = 1 gives today's bits.
     const float inv1 = kInvWS * sk;
     // planes (x_h, x_l), see the header
@@ -365,22 +365,31 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     f32x16 a2[12];     // layer-2 accumulators, then relu(.)+residual = the final layer's input
     f32x16 a3[4];
     f32x16 pq[2];      // fused projection accumulators (64 padded output rows)
-    float sa[16], sb[16];  // per-node seeds A_i(+b1), B_j of the a1 tile that is split next
+    float sa[16];  // per-node seeds A_i(+b1) of the a1 tile that is split next (the j-side seeds B_j start the tile's accumulators: seedc_piece)
     // quarter rq of the seeds of tile t (C layout: register 4rq + e = channel 32t + 8rq + 4h + e): A_i + b1 (384 channels) and B_j of
     // the per-node first-layer halves [B,N,768].  (The j-side rows differ from lane to lane -- 16 B in each of 32 rows per load
     // instruction.  Reading them from a column-blocked copy [B][96][N][4], 8 cache lines per instruction as in the edge embedding,
     // was measured: 2 % fewer cycles in the layer-2 blocks, no change in launch time; not worth a second copy of the node vectors.)
     auto seeds_piece = [&](const PairCtx& c, int t, int rq) {
         const float4 x = ldg4(node_ab + (unsigned long long)c.bi * 768u + 32 * t, rq, h);
-        const float4 y = ldg4(node_ab + (unsigned long long)c.bj * 768u + 384 + 32 * t, rq, h);
         sa[4 * rq + 0] = x.x; sa[4 * rq + 1] = x.y; sa[4 * rq + 2] = x.z; sa[4 * rq + 3] = x.w;
-        sb[4 * rq + 0] = y.x; sb[4 * rq + 1] = y.y; sb[4 * rq + 2] = y.z; sb[4 * rq + 3] = y.w;
+    };
+    // The j-side seeds are the START VALUE of the layer-1 accumulators (round 5): the caller hands the second half of node_ab in as
+    // 32 B_j -- the accumulators' scale -- and quarter rq of tile t is loaded straight into the accumulator registers of a1t[t & 1]
+    // (dead from the split of tile t - 2 on; hipcc loads into the accumulator file directly), so that the tile's first product lands
+    // on it and the epilogue is relu(acc (sk / 32) + sk A_i): one add per hidden value less (-208 VALU instructions per tile on the
+    // ISA, -0.5 % per launch in a same-call A/B).
+    auto seedc_piece = [&](const PairCtx& c, int t, int rq) {
+        const float4 y = ldg4(node_ab + (unsigned long long)c.bj * 768u + 384 + 32 * t, rq, h);
+        a1t[t & 1][4 * rq + 0] = y.x; a1t[t & 1][4 * rq + 1] = y.y; a1t[t & 1][4 * rq + 2] = y.z; a1t[t & 1][4 * rq + 3] = y.w;
     };
     auto seeds_load = [&](const PairCtx& c, int t) {
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) seeds_piece(c, t, rq);
     };
     seeds_load(cur, 0);
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) { seedc_piece(cur, 0, rq); seedc_piece(cur, 1, rq); }
 
     f16x8 fr[2][4];  // A fragments of the current / next slot: (W_h, W_l) of two (k-step, tile) units
     f16x8 xp[2][2];  // layer 2: planes of k-steps 2t, 2t+1 of the current a1 tile; final layer: current / next k-step
@@ -395,14 +404,14 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         constexpr int qd = decltype(qc)::value;
         float x[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = fmaxf(__builtin_fmaf(tile_acc[4 * qd + j], inv1, sa[4 * qd + j] + sb[4 * qd + j]), 0.f);
+        for (int j = 0; j < 4; ++j) x[j] = fmaxf(__builtin_fmaf(tile_acc[4 * qd + j], inv1, sa[4 * qd + j]), 0.f);
         split4(x, xp[qd >> 1][0], xp[qd >> 1][1], 4 * (qd & 1));
     };
     // the same in two halves (values 2hh, 2hh+1 of the quarter): 10 VALU instructions, small enough to sit behind one MFMA
     auto s_half = [&](const f32x16& tile_acc, auto qc, auto hc) {
         constexpr int qd = decltype(qc)::value, j0 = 4 * qd + 2 * decltype(hc)::value;
-        const float x0 = fmaxf(__builtin_fmaf(tile_acc[j0], inv1, sa[j0] + sb[j0]), 0.f);
-        const float x1 = fmaxf(__builtin_fmaf(tile_acc[j0 + 1], inv1, sa[j0 + 1] + sb[j0 + 1]), 0.f);
+        const float x0 = fmaxf(__builtin_fmaf(tile_acc[j0], inv1, sa[j0]), 0.f);
+        const float x1 = fmaxf(__builtin_fmaf(tile_acc[j0 + 1], inv1, sa[j0 + 1]), 0.f);
         split2_f16(x0, x1, xp[qd >> 1][0], xp[qd >> 1][1], 4 * (qd & 1) + 2 * decltype(hc)::value, amax);
     };
     // residual rows n'_i (block 1) and n'_j (block 2) of  x = [e | n'_i | n'_j]  in accumulator layout, two 16 B groups per call
@@ -556,6 +565,9 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             xv[i + 1] = ldrow(er, i + 1);
         }
         if constexpr (s == 236) seeds_load(nxt, 0);
+        // ... and the start values of its first two layer-1 tiles (both accumulator tiles are dead from slot 179 on)
+        if constexpr (s == 237) { seedc_piece(nxt, 0, 0); seedc_piece(nxt, 0, 1); seedc_piece(nxt, 0, 2); seedc_piece(nxt, 0, 3); }
+        if constexpr (s == 238) { seedc_piece(nxt, 1, 0); seedc_piece(nxt, 1, 1); seedc_piece(nxt, 1, 2); seedc_piece(nxt, 1, 3); }
         // seeds of a1 tile t+1 are fetched in the middle of B_t, in a slot without weight-pipe work (consumed under A_{t+2}, 6+ slots
         // later; a fetch 3 slots ahead of its use cost ~300 cycles at the fetch and ~300 at the use: tools/et_phase_probe.py --block)
         constexpr bool seeds_slot = d.phase == 1 && d.a == 1 && d.b == 0 && d.t + 1 < 12;   // a quarter behind each of its first 4 MFMAs
@@ -616,7 +628,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
                 f32x16& acc = a1t[d.t & 1];
                 const f16x8 (&x)[2] = xpl[2 * d.a + (i >= 3)];
                 constexpr int fa = (i == 0 ? 1 : (i < 3 ? 0 : (i == 3 ? 3 : 2))), xa = (i == 1 || i == 4) ? 1 : 0;   // W_l x_h, W_h x_l, W_h x_h
-                if constexpr (d.a == 0 && i == 0) acc = mfma_f16(f[fa], x[xa], zero16); else acc = mfma_f16(f[fa], x[xa], acc);
+                acc = mfma_f16(f[fa], x[xa], acc);   // (a tile's first product lands on its start value 32 B_j: seedc_piece)
             } else {
                 constexpr bool fin = d.phase == 2, prj = d.phase == 3;
                 constexpr bool first = i < 2 && (prj ? d.a == 0 : (fin ? false : (d.t == 0 && d.a == 0)));   // (final layer: onto 32 bf)
@@ -663,6 +675,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
                 if constexpr (ss == 5) cp_store_piece(IC<1>{}, ic, st_fill & (kRing - 1));
             }
             if constexpr (seeds_slot && i < 4) seeds_piece(cur, d.t + 1, i);
+            if constexpr (seeds_slot && i < 4 && d.t + 2 < 12) seedc_piece(cur, d.t + 2, i);   // start value of a1 tile t + 2 (A_{t+2} follows this block)
             if constexpr (d.phase == 0 && d.t >= 1 && (i == 2 || i == 4)) s_half(a1t[(d.t - 1) & 1], IC<d.a>{}, IC<(i - 2) / 2>{});
             if constexpr (ep_blk > 0 && (i == 2 || i == 4)) ep_half(IC<ep_q>{}, IC<(i - 2) / 2>{}, ep_b);
             if constexpr (ep_blk == 0 && i >= 1 && i <= 4) {   // pieces ep_q (halves behind MFMAs 1, 2) and ep_q + 1 (3, 4)

@@ -398,14 +398,18 @@ class TranslationIPA(nn.Module):
             specs = [(w["bb"], dict(pre_scale=dm))]
             if has_et:
                 nl = et.node_layers()
-                specs += [(nl["init"], {}), (nl["ab_s"], {})]
+                if et.arith == "f16x3":   # node_ab in the pair kernel's form: the column half x 2^5, as a layer of its own into the same buffer
+                    node_ab16, ab_specs = et.ab16_specs(nl, True, M, s_a.device)
+                    specs += [(nl["init"], {})] + ab_specs
+                else:
+                    specs += [(nl["init"], {}), (nl["ab_s"], {})]
             else:
                 specs += [(W["tor"]["l1"], dict(relu=True, want_f32=False, want_xp=True))]
             outs = ops.node_apply_multi(s_a, specs, M)
             upd = outs[0][0]
             curr7 = torch.ops.str2str_amd.rigid_compose_update(curr7, upd, diffuse_mask)   # (the padded [M, 32] output in place: no copy)
             if has_et:
-                n_p, node_ab = outs[1][0], outs[2][0]
+                n_p, node_ab = outs[1][0], (node_ab16 if et.arith == "f16x3" else outs[2][0])
                 nxt = T[f"ipa_{b + 1}"].pair_proj_weights() if self.fuse_pair_projection else None
                 # f16x3 with fused projections: the pair tensor stays in the kernels' tiled layout, and the last EdgeTransition's
                 # output (read by nothing but the projections it already carries) is not written
@@ -417,7 +421,7 @@ class TranslationIPA(nn.Module):
                 if not et16 and isinstance(edge_embed, ops.PairTiled):
                     edge_embed = ops.pair_untiled(edge_embed)
                 res = et.pair_mlp(edge_embed, node_ab.view(B, N, -1), n_p.view(B, N, -1), node_mask, nxt,
-                                  **({"out_layout": lay} if lay != "rowmajor" else {}))
+                                  **({"out_layout": lay} if lay != "rowmajor" else {}), **({"ab_kernel_form": True} if et16 else {}))
                 if nxt is not None:
                     edge_embed, *proj = res
                 else:

@@ -162,16 +162,40 @@ class EdgeTransition(nn.Module):
             w64, ie64 = w_ab.detach().double().cpu(), ie.weight.detach().double().cpu()
             w_abs = (w64 @ ie64).float().to(w_ab.device)
             b_abs = (w64 @ ie.bias.detach().double().cpu() + b_ab.detach().double().cpu()).float().to(w_ab.device)
+            # "abA" + "abB" / "ab_sA" + "ab_sB": the same layers in the FORM the f16x3 pair kernel reads (include/str2str_hip.h) -- the column
+            # half B_j starts the layer-1 accumulators, which carry 2^5 x the layer output.  The factor does not go into the weights (it
+            # would cost the f16x3 packing five bits of its weight range): the column half is its own layer whose epilogue scales the row
+            # by 32 (``pre_scale``: acc (32 / 32) + 32 b, exact) and writes columns 384.. of the same [M, 768] buffer (``node_ab16``)
+            h2 = w_ab.shape[0] // 2
             return {"init": ops.pack_node_layer(ie.weight, ie.bias), "ab": ops.pack_node_layer(w_ab, b_ab),
-                    "ab_s": ops.pack_node_layer(w_abs, b_abs)}
+                    "ab_s": ops.pack_node_layer(w_abs, b_abs),
+                    "abA": ops.pack_node_layer(w_ab[:h2].contiguous(), b_ab[:h2].contiguous()),
+                    "abB": ops.pack_node_layer(w_ab[h2:].contiguous(), 32.0 * b_ab[h2:]),
+                    "ab_sA": ops.pack_node_layer(w_abs[:h2].contiguous(), b_abs[:h2].contiguous()),
+                    "ab_sB": ops.pack_node_layer(w_abs[h2:].contiguous(), 32.0 * b_abs[h2:])}
 
         return self._node_cache.get([w1.weight, w1.bias, ie.weight, ie.bias], build)
 
-    def node_parts(self, s_act, n_rows: int):
-        """-> (n' [M,128] fp32, node_ab [M,768] fp32) from the node activations (packed planes or fp32, see ops.node_apply)."""
+    @staticmethod
+    def ab16_specs(nl: dict, from_s: bool, n_rows: int, device):
+        """node_ab in the f16x3 pair kernel's form [A_i + b1 | 32 B_j] as two layers into one buffer -> (buffer [M, 768], specs for
+        ``ops.node_apply_multi`` / ``ops.node_apply``)."""
+        ab = torch.empty(n_rows, 768, device=device, dtype=torch.float32)
+        c32 = ops.const_rows(n_rows, 32.0, device)
+        ka, kb = ("ab_sA", "ab_sB") if from_s else ("abA", "abB")
+        return ab, [(nl[ka], dict(out_f32=ab, out_col0=0)), (nl[kb], dict(out_f32=ab, out_col0=384, pre_scale=c32))]
+
+    def node_parts(self, s_act, n_rows: int, kernel_form: bool = False):
+        """-> (n' [M,128] fp32, node_ab [M,768] fp32) from the node activations (packed planes or fp32, see ops.node_apply).
+        ``kernel_form``: node_ab as the f16x3 pair kernel reads it (column half x 2^5; ``pair_mlp(..., ab_kernel_form=True)``)."""
         nl = self.node_layers()
         n_p, n_pa = ops.node_apply(s_act, nl["init"], n_rows, want_xp=True)
-        node_ab, _ = ops.node_apply(n_pa, nl["ab"], n_rows)
+        if kernel_form:
+            node_ab, specs = self.ab16_specs(nl, False, n_rows, n_p.device)
+            for layer, kw in specs:
+                ops.node_apply(n_pa, layer, n_rows, **kw)
+        else:
+            node_ab, _ = ops.node_apply(n_pa, nl["ab"], n_rows)
         return n_p, node_ab
 
     def forward(self, node_embed: torch.Tensor, edge_embed: torch.Tensor, edge_mask_1d: Optional[torch.Tensor] = None,
@@ -183,7 +207,7 @@ class EdgeTransition(nn.Module):
         n_p, node_ab = self.node_parts(ops.to_act(node_embed.reshape(B * N, -1).float().contiguous(), self.arith), B * N)
         return self.pair_mlp(edge_embed, node_ab.view(B, N, -1), n_p.view(B, N, -1), edge_mask_1d, next_proj)
 
-    def pair_mlp(self, edge_embed, node_ab, n_p, edge_mask_1d=None, next_proj=None, out_layout: str = "rowmajor"):
+    def pair_mlp(self, edge_embed, node_ab, n_p, edge_mask_1d=None, next_proj=None, out_layout: str = "rowmajor", ab_kernel_form: bool = False):
         """The N x N part given the per-node vectors n' = initial_embed(node) [B,N,128] and
         node_ab = [W1[:,128:256] n' + b1 | W1[:,256:] n'] [B,N,768] (``node_parts``).  Arithmetic "f16x3" only: ``edge_embed`` may be
         an ``ops.PairTiled`` and ``out_layout`` "tiled" / "none" (ops.edge_transition_f16x3) -- how the trunk chains its pair kernels."""
@@ -202,12 +226,13 @@ class EdgeTransition(nn.Module):
             z, bias, pz = torch.ops.str2str_amd.edge_transition_f16x3_chain(
                 edge_embed.buf if tiled_in else edge_embed.contiguous(), tiled_in, B, N, node_ab, n_p,
                 pk["wstream_f16"] if proj is None else proj[0], self.trunk[2].bias, self.final_layer.bias, self.layer_norm.weight,
-                self.layer_norm.bias, mask, self.layer_norm.eps, None if proj is None else proj[1], out_layout, int(self.prescale_exp))
+                self.layer_norm.bias, mask, self.layer_norm.eps, None if proj is None else proj[1], out_layout, int(self.prescale_exp),
+                bool(ab_kernel_form))
             if out_layout == "tiled":
                 z = ops.PairTiled(B, N, buf=z)
             return z if proj is None else (z, bias, pz)
-        if out_layout != "rowmajor" or isinstance(edge_embed, ops.PairTiled):
-            raise ops.HipLibraryError("EdgeTransition: the tiled pair layout belongs to the f16x3 kernels")
+        if out_layout != "rowmajor" or isinstance(edge_embed, ops.PairTiled) or ab_kernel_form:
+            raise ops.HipLibraryError("EdgeTransition: the tiled pair layout and the scaled node_ab belong to the f16x3 kernels")
         pk = self._packed_f32()
         return ops.edge_transition(edge_embed.contiguous(), node_ab, n_p, pk["w1p"], pk["w2p"], pk["wfp"],
                                    self.trunk[2].bias, self.final_layer.bias, self.layer_norm.weight,

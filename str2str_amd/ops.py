@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 _lib = None
 _tables_loaded = False
@@ -331,21 +331,27 @@ def pair_untiled(t: PairTiled) -> torch.Tensor:
 
 
 def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps=1e-5, out=None, proj=None,
-                          out_layout: str = "rowmajor", prescale_exp: int = 0):
+                          out_layout: str = "rowmajor", prescale_exp: int = 0, ab_kernel_form: bool = False):
     """EdgeTransition on split-f16 MFMA (fp32-equivalent accuracy; csrc/pair_mlp_f16.hip); same contract as ``edge_transition``.
     ``proj`` = (31-stage stream = this layer's 30 stages (``pack_f16x3_stream``) + the next IPA block's projection stage
     (``pack_f16x2_layer``), bias64) also returns that block's (attn_bias [B,8,N,N], pair_z [B,N,N,32]).
     ``edge`` may be a ``PairTiled``; ``out_layout``: "rowmajor" (the reference's tensor), "tiled" (-> ``PairTiled``) or "none" (the pair
     vectors are not written: only with ``proj``, for the last EdgeTransition of a trunk; returns None in their place).
     ``prescale_exp`` = e (0 .. 15): the kernel keeps its hidden activations as f16 planes of 2^-e x the value (a block exponent: exact,
-    same speed) -- what the sampler sets when the range guard reports hidden activations of 2^15 and beyond."""
+    same speed) -- what the sampler sets when the range guard reports hidden activations of 2^15 and beyond.
+    ``node_ab`` = [W1[:,128:256] n' + b1 | W1[:,256:] n'] as ``EdgeTransition.node_parts`` gives it; ``ab_kernel_form``: its column half
+    already carries the accumulators' 2^5 (the trunk's per-node layer "ab_s16" produces it so: no extra launch), see the C header."""
     lib = load_library()
     B, N = edge.shape[0], edge.shape[1]
     in_tiled = isinstance(edge, PairTiled)
     if not 0 <= int(prescale_exp) <= 15:
         raise HipLibraryError(f"edge_transition_f16x3: prescale_exp {prescale_exp} outside 0 .. 15")
-    if prescale_exp:
-        node_ab = node_ab * (2.0 ** -int(prescale_exp))     # the per-node seeds of layer 1 enter at the planes' scale (C ABI: the caller's job)
+    # C ABI: node_ab = [2^-e (A_i + b1) | 2^5 B_j] -- the row half at the planes' scale, the column half at the accumulators' (the caller's job)
+    if not ab_kernel_form or prescale_exp:
+        sc = node_ab.new_ones(768)
+        sc[:384] = 2.0 ** -int(prescale_exp)
+        sc[384:] = 1.0 if ab_kernel_form else 32.0
+        node_ab = node_ab * sc
     if out_layout not in ("rowmajor", "tiled", "none") or (out_layout == "none" and proj is None):
         raise HipLibraryError(f"edge_transition_f16x3: out_layout {out_layout!r}" + (" needs proj" if out_layout == "none" else ""))
     _req(edge.buf if in_tiled else edge, name="edge")
@@ -1225,6 +1231,20 @@ def node_apply_chain(x, layers, n_rows: int, relu, **kw):
                                             kw.pop("want_xp", False), k0, first_res, first_out)
 
 
+_CONST_ROWS = {}
+
+
+def const_rows(n_rows: int, value: float, device) -> torch.Tensor:
+    """A cached [n_rows] float32 device tensor of ``value`` (a constant ``pre_scale`` of a node layer)."""
+    key = (int(n_rows), float(value), str(device))
+    t = _CONST_ROWS.get(key)
+    if t is None:
+        if len(_CONST_ROWS) > 64:
+            _CONST_ROWS.clear()
+        t = _CONST_ROWS[key] = torch.full((n_rows,), float(value), device=device, dtype=torch.float32)
+    return t
+
+
 def node_apply_multi(x, specs, n_rows: int):
     """Several layers of ONE input in one launch: ``specs`` = [(layer, kwargs)], kwargs as for ``node_apply`` restricted to what the
     multi-problem kernel carries (relu, pre_scale, out_f32 / out_col0 / want_f32, out_xp / out_xp_k / out_xp_k0 / want_xp).
@@ -1478,13 +1498,14 @@ def _op_node_linear_f32(x, wpk32, bias, n_rows, k_in, n_out, tiles, pre_scale=No
 
 
 def _op_edge_transition_f16x3_chain(edge, in_tiled, B, N, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps, proj_bias64,
-                                    out_layout, prescale_exp=0):
+                                    out_layout, prescale_exp=0, ab_kernel_form=False):
     """The trunk's form of the edge transition: pair tensor in either layout (``edge`` = the flat tiled buffer when ``in_tiled``), the
     next IPA block's projections fused in when ``proj_bias64`` is given (``wstream`` is then the 31-stage stream).
     -> (pair tensor (row-major [B,N,N,128] | flat tiled buffer | None), attn_bias | None, pair_z | None)"""
     e = PairTiled(B, N, buf=edge) if in_tiled else edge
     r = edge_transition_f16x3(e, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps,
-                              proj=None if proj_bias64 is None else (wstream, proj_bias64), out_layout=out_layout, prescale_exp=prescale_exp)
+                              proj=None if proj_bias64 is None else (wstream, proj_bias64), out_layout=out_layout, prescale_exp=prescale_exp,
+                              ab_kernel_form=ab_kernel_form)
     z, bias, pz = r if proj_bias64 is not None else (r, None, None)
     return (z.buf if isinstance(z, PairTiled) else z), bias, pz
 
@@ -1497,7 +1518,8 @@ _TORCH_OPS = {
     "Tensor gamma, Tensor beta, Tensor? mask, float ln_eps, int prescale_exp=0) -> Tensor":
         lambda e, nab, np_, ws, b2, bf, g, b, m, eps, pe=0: edge_transition_f16x3(e, nab, np_, ws, b2, bf, g, b, m, eps, prescale_exp=pe),
     "edge_transition_f16x3_chain(Tensor edge, bool in_tiled, int B, int N, Tensor node_ab, Tensor node_p, Tensor wstream, Tensor b2, "
-    "Tensor bf, Tensor gamma, Tensor beta, Tensor? mask, float ln_eps, Tensor? proj_bias64, str out_layout, int prescale_exp=0) "
+    "Tensor bf, Tensor gamma, Tensor beta, Tensor? mask, float ln_eps, Tensor? proj_bias64, str out_layout, int prescale_exp=0, "
+    "bool ab_kernel_form=False) "
     "-> (Tensor?, Tensor?, Tensor?)":
         _op_edge_transition_f16x3_chain,
     "edge_embed(Tensor node_a, Tensor node_b, Tensor rel_table, Tensor bin_table, Tensor bin_lower, Tensor residue_idx, Tensor ca, "

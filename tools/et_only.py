@@ -28,11 +28,11 @@ edge = torch.randn(a.B, a.N, a.N, 128, device="cuda", generator=g)
 mask = torch.ones(a.B, a.N, device="cuda")
 if a.layout != "rowmajor":   # the trunk's chaining: tiled in, tiled (or no) out; per-node parts outside the timed call
     from str2str_amd import ops
-    n_p, node_ab = et.node_parts(ops.to_act(node.reshape(a.B * a.N, -1).contiguous(), "f16x3"), a.B * a.N)
+    n_p, node_ab = et.node_parts(ops.to_act(node.reshape(a.B * a.N, -1).contiguous(), "f16x3"), a.B * a.N, kernel_form=True)
     zt = ops.pair_tiled(edge)
     del edge
     et = lambda *_, **__: net.translator.trunk["edge_transition_0"].pair_mlp(zt, node_ab.view(a.B, a.N, -1), n_p.view(a.B, a.N, -1), mask,
-                                                                          kw.get("next_proj"), out_layout=a.layout)
+                                                                          kw.get("next_proj"), out_layout=a.layout, ab_kernel_form=True)
     edge = None
 with torch.no_grad():
     for _ in range(2):

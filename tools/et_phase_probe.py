@@ -31,11 +31,11 @@ g = torch.Generator(device="cuda").manual_seed(0)
 node = torch.randn(a.B, a.N, 256, device="cuda", generator=g)
 edge = torch.randn(a.B, a.N, a.N, 128, device="cuda", generator=g)
 mask = torch.ones(a.B, a.N, device="cuda")
-n_p, node_ab = et.node_parts(ops.to_act(node.reshape(a.B * a.N, -1).contiguous(), "f16x3"), a.B * a.N)
+n_p, node_ab = et.node_parts(ops.to_act(node.reshape(a.B * a.N, -1).contiguous(), "f16x3"), a.B * a.N, kernel_form=True)
 n_p, node_ab = n_p.view(a.B, a.N, -1), node_ab.view(a.B, a.N, -1)
 if a.layout != "rowmajor":
     edge = ops.pair_tiled(edge)
-run = lambda: et.pair_mlp(edge, node_ab, n_p, mask, kw["next_proj"], out_layout=a.layout)
+run = lambda: et.pair_mlp(edge, node_ab, n_p, mask, kw["next_proj"], out_layout=a.layout, ab_kernel_form=True)
 buf = np.zeros(512 * 17, dtype=np.uint64)
 with torch.no_grad():
     for _ in range(2):

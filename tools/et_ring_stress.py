@@ -28,12 +28,12 @@ with torch.no_grad():
         mask = (torch.rand(B, N, device="cuda", generator=g) > 0.05).float()
         for blk in (0, 1):
             et = tr[f"edge_transition_{blk}"]
-            n_p, node_ab = et.node_parts(ops.to_act(node.reshape(B * N, -1).contiguous(), "f16x3"), B * N)
+            n_p, node_ab = et.node_parts(ops.to_act(node.reshape(B * N, -1).contiguous(), "f16x3"), B * N, kernel_form=True)
             zt = ops.pair_tiled(edge)
             proj = tr[f"ipa_{blk + 1}"].pair_proj_weights()
             sums = []
             for rep in range(a.reps):
-                z, bias, pz = et.pair_mlp(zt, node_ab.view(B, N, -1), n_p.view(B, N, -1), mask, proj, out_layout="tiled")
+                z, bias, pz = et.pair_mlp(zt, node_ab.view(B, N, -1), n_p.view(B, N, -1), mask, proj, out_layout="tiled", ab_kernel_form=True)
                 h = hashlib.sha1()
                 for t in (ops.pair_untiled(z), bias, pz):   # (the valid pairs: the padding of a partial last tile is never written)
                     h.update(t.cpu().numpy().tobytes())

@@ -53,14 +53,14 @@ def main():
     # pair output, all three with the next block's fused projections -- (2 x 1184 + 672) / 3 algorithmic bytes per pair and launch
     et = tr["edge_transition_0"]
     if et.arith == "f16x3":
-        n_p, node_ab = et.node_parts(ops.to_act(node.reshape(B * N, -1).contiguous(), "f16x3"), B * N)
+        n_p, node_ab = et.node_parts(ops.to_act(node.reshape(B * N, -1).contiguous(), "f16x3"), B * N, kernel_form=True)
         n_p, node_ab, nxt = n_p.view(B, N, -1), node_ab.view(B, N, -1), tr["ipa_1"].pair_proj_weights()
         zt = ops.pair_tiled(edge)
 
         def trunk_mix():
-            et.pair_mlp(zt, node_ab, n_p, mask, nxt, out_layout="tiled")
-            et.pair_mlp(zt, node_ab, n_p, mask, nxt, out_layout="tiled")
-            et.pair_mlp(zt, node_ab, n_p, mask, nxt, out_layout="none")
+            et.pair_mlp(zt, node_ab, n_p, mask, nxt, out_layout="tiled", ab_kernel_form=True)
+            et.pair_mlp(zt, node_ab, n_p, mask, nxt, out_layout="tiled", ab_kernel_form=True)
+            et.pair_mlp(zt, node_ab, n_p, mask, nxt, out_layout="none", ab_kernel_form=True)
 
         ms = timeit(trunk_mix, a.iters) / 3
         del zt
