@@ -95,6 +95,7 @@ def _graph_read_tensors(net):
         for v in vars(m).values():
             if isinstance(v, ParamCache):
                 tensors(v.pinned(), keep)
+    keep += list(ops._CONST_ROWS.values())   # constant pre-scale rows of the node layers (a bounded cache that may drop them later)
     return keep
 
 
