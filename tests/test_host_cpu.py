@@ -424,3 +424,26 @@ def test_host_generator_fast_forward_equals_the_discarded_draws(built_library, m
     torch.set_rng_state(start)
     _burn_step_draws(4, 20, 3)
     assert torch.equal(torch.get_rng_state(), want)
+
+
+def test_t_delta_merging_groups(monkeypatch):
+    """sampler.merge_delta_groups: consecutive t_deltas of a target are sampled as one growing batch while their replicas fit the pair
+    budget at the batch's end (the reference's default block: ten t_deltas x 100 replicas on chains of 35 .. 80 residues -> one batch);
+    larger targets fall back to fewer t_deltas per batch, down to one (cfg2-sized chunks); the switch keeps one t_delta per batch."""
+    from str2str_amd.sampler import merge_delta_groups, schedule
+
+    monkeypatch.delenv("S2S_MERGE_DELTAS", raising=False)
+    deltas = [round(0.25 + 0.05 * k, 2) for k in range(10)]
+    steps = [schedule(d, 1000, 0.01)[1] for d in deltas]
+    assert steps == [250, 300, 350, 400, 450, 500, 550, 600, 650, 700]
+    assert schedule(0.25, 1000, 0.01)[2] == 1.0 / 250 and schedule(-1.0, 1000, 0.01)[1] == 1000      # dt = 1 / int(num_timesteps T); prior: T = 1
+    assert merge_delta_groups(steps, 100, 35) == [list(range(10))] and merge_delta_groups(steps, 100, 80) == [list(range(10))]
+    assert merge_delta_groups(steps, 100, 160) == [[0, 1, 2], [3, 4, 5], [6, 7, 8], [9]]             # 3 x 100 x 160^2 <= 8 Mi pairs < 4 x ...
+    assert merge_delta_groups(steps, 128, 256) == [[i] for i in range(10)]                           # a cfg2-sized chunk per t_delta
+    assert merge_delta_groups(steps, 0, 80) == [list(range(10))]                                     # (a rank without replicas: nothing to hold)
+    for b, n in [(100, 35), (64, 200), (1000, 20), (7, 512)]:
+        groups = merge_delta_groups(steps, b, n)
+        assert [i for g in groups for i in g] == list(range(10))
+        assert all(len(g) == 1 or len(g) * b * n * n <= 8 << 20 for g in groups)
+    monkeypatch.setenv("S2S_MERGE_DELTAS", "0")
+    assert merge_delta_groups(steps, 100, 35) == [[i] for i in range(10)]
