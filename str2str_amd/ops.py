@@ -1459,13 +1459,18 @@ def host_rng_fast_forward_ok() -> bool:
     return _HOST_RNG_OK
 
 
+def host_rng_can_discard(n_elements: int) -> bool:
+    """Would ``host_rng_discard_float64_normals`` fast-forward over float64 normal tensors of ``n_elements`` elements here?"""
+    return n_elements >= 16 and os.environ.get("S2S_HOST_RNG_FAST", "1") != "0" and host_rng_fast_forward_ok()
+
+
 def host_rng_discard_float64_normals(n_elements: int, n_tensors: int) -> bool:
     """Advance torch's CPU generator as ``n_tensors`` draws ``torch.randn(n_elements, dtype=float64)`` would, without computing them
     (s2s_mt19937_discard).  -> False if that is not possible here (tensors below 16 elements take ATen's scalar path; an unknown state
     layout): the caller draws for real."""
     if n_tensors <= 0:
         return True
-    if n_elements < 16 or os.environ.get("S2S_HOST_RNG_FAST", "1") == "0" or not host_rng_fast_forward_ok():
+    if not host_rng_can_discard(n_elements):
         return False
     return _host_rng_discard_raw(float64_normal_outputs(n_elements) * int(n_tensors))
 

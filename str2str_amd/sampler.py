@@ -379,12 +379,22 @@ def _start_frames(diffuser, batch: dict, rigids_0: Rigid, t_delta: float, lo: in
             dmask = batch["residue_mask"].to(device).float().reshape(1, N).expand(b, N).contiguous()
             return diffuser.forward_marginal_device(rigids_0[lo:hi].to_tensor_4x4().to(device), t_delta, dmask)
         return diffuser.forward_marginal_device(None, None, shape=(b, N))
-    if t_delta > 0:
-        rigids_t = diffuser.forward_marginal(rigids_0=rigids_0.to(device="cpu"), t=t_delta * torch.ones(B_total),
-                                             diffuse_mask=batch["residue_mask"].cpu().repeat(B_total, 1),
-                                             as_tensor_7=True)["rigids_t"]
-    else:
-        rigids_t = diffuser.sample_prior(shape=rigids_0.shape, device="cpu", as_tensor_7=True)["rigids_t"]
+    # ~300 small host tensor operations on [B, N, 3..9] values: with every core of the host in torch's intra-op pool each of them pays
+    # the pool's wake-up (tens of ms per chunk on a 128-thread box, in front of the GPU work); element-wise arithmetic and reductions
+    # over the last axis do not depend on the thread count, so the frames are the same bits.  S2S_HOST_FM_THREADS=0: leave the pool alone.
+    nt, keep = int(os.environ.get("S2S_HOST_FM_THREADS", "1")), torch.get_num_threads()
+    if nt > 0 and nt != keep:
+        torch.set_num_threads(nt)
+    try:
+        if t_delta > 0:
+            rigids_t = diffuser.forward_marginal(rigids_0=rigids_0.to(device="cpu"), t=t_delta * torch.ones(B_total),
+                                                 diffuse_mask=batch["residue_mask"].cpu().repeat(B_total, 1),
+                                                 as_tensor_7=True)["rigids_t"]
+        else:
+            rigids_t = diffuser.sample_prior(shape=rigids_0.shape, device="cpu", as_tensor_7=True)["rigids_t"]
+    finally:
+        if nt > 0 and nt != keep:
+            torch.set_num_threads(keep)
     if b == 0:
         return None
     return rigids_t[lo:hi].to(device).float().contiguous()
@@ -400,6 +410,13 @@ def _burn_step_draws(B_total: int, N: int, n_draw_steps: int):
     for _ in range(n_draw_steps):
         torch.randn(B_total, N, 3, dtype=torch.float64)
         torch.randn(B_total, N, 3, dtype=torch.float64)
+
+
+def _skips_unused_draws(probability_flow: bool, B_total: int, N: int) -> bool:
+    """Under the probability-flow ODE the reference's per-step draws are consumed, not used.  Where the host generator can be
+    fast-forwarded over them (``_burn_step_draws``: milliseconds per chunk) that happens right behind the chunk's start frames;
+    otherwise they are drawn step by step inside the loop, behind the GPU work (``host_noise`` of the callers)."""
+    return probability_flow and ops.host_rng_can_discard(B_total * N * 3)
 
 
 @torch.no_grad()
@@ -426,9 +443,10 @@ def forward_backward(net, diffuser, batch: dict, rigids_0: Rigid, t_delta: float
     N = rigids_0.shape[1]
 
     rigids_t = _start_frames(diffuser, batch, rigids_0, t_delta, lo, hi, rng, device)
+    skip_ahead = rng == "host" and (rigids_t is None or _skips_unused_draws(probability_flow, B_total, N))
+    if skip_ahead:      # nothing reads the chunk's step draws: the generator goes straight to where they leave it
+        _burn_step_draws(B_total, N, len(ts) - 1)
     if rigids_t is None:
-        if rng == "host":
-            _burn_step_draws(B_total, N, len(ts) - 1)
         return torch.zeros(0, N, 37, 3, device=device)
     feats = {k: batch[k].to(device).repeat(b, *(1,) * (batch[k].ndim - 1)) for k in _REPEAT_KEYS if k in batch}
 
@@ -443,7 +461,7 @@ def forward_backward(net, diffuser, batch: dict, rigids_0: Rigid, t_delta: float
 
     atom37, r7, psi = denoise_loop(net, diffuser, feats, rigids_t, ts, dt, min_t=min_t, noise_scale=noise_scale,
                                    probability_flow=probability_flow, self_conditioning=self_conditioning, center_mode=1,
-                                   host_noise=host_noise if rng == "host" else None, trace=trace)
+                                   host_noise=host_noise if rng == "host" and not skip_ahead else None, trace=trace)
     if return_rigids:
         return atom37, r7, psi
     return atom37
@@ -504,10 +522,10 @@ def forward_backward_chunks(net, diffuser, batch: dict, gt_frames_4x4: torch.Ten
             if hi > lo or rng == "host":
                 r = _start_frames(diffuser, batch, rig0(bsz), float(t_delta), lo, hi, rng, device)
                 if rng == "host":
-                    if i + 1 < len(group):
+                    if i + 1 < len(group) or _skips_unused_draws(probability_flow, bsz, N):
                         _burn_step_draws(bsz, N, len(ts) - 1)   # the next chunk's start frames come after this chunk's step draws
                     else:
-                        tail_burn = bsz                          # the last chunk's ride in the loop, behind the GPU (as in forward_backward)
+                        tail_burn = bsz                          # drawn for real: the last chunk's ride in the loop, behind the GPU
                 if r is not None:
                     starts.append(r)
         if not starts:
@@ -673,8 +691,8 @@ def forward_backward_deltas(net, diffuser, batch: dict, gt_frames_4x4: torch.Ten
             for ci, (bsz, lo, hi) in enumerate(chunks):
                 r = _start_frames(diffuser, batch, rig0(bsz), delta_range[i], lo, hi, rng, device)
                 if rng == "host":
-                    if gi + 1 == len(grp) and ci + 1 == len(chunks) and longest_last:
-                        tail = (bsz, len(ts) - 1)      # rides in the loop, behind the GPU (global step == its local step)
+                    if gi + 1 == len(grp) and ci + 1 == len(chunks) and longest_last and not _skips_unused_draws(probability_flow, bsz, N):
+                        tail = (bsz, len(ts) - 1)      # drawn for real: rides in the loop, behind the GPU (global step == its local step)
                     else:
                         _burn_step_draws(bsz, N, len(ts) - 1)
                 if r is not None:

@@ -180,6 +180,28 @@ def test_forward_marginal_and_prior_match_reference_noise(tmp_path):
     assert maxdiff(pr, g["prior"]) < 5e-6
 
 
+def test_start_frames_do_not_depend_on_the_host_thread_count(tmp_path):
+    """sampler._start_frames draws and assembles a chunk's frames on ONE intra-op thread (S2S_HOST_FM_THREADS): the same bits as with
+    the whole pool, at a size above torch's parallel grain (64 x 256 residues)."""
+    from str2str_amd.common.rigid_utils import Rigid
+    from str2str_amd.factory import build_diffuser
+
+    d = build_diffuser(str(tmp_path))
+    B, N = 64, 256
+    q = torch.randn(N, 4, generator=torch.Generator().manual_seed(3))
+    r0 = Rigid.from_tensor_7(torch.cat([q / q.norm(dim=-1, keepdim=True), 10 * torch.randn(N, 3, generator=torch.Generator().manual_seed(4))], -1)[None].repeat(B, 1, 1))
+    keep, out = torch.get_num_threads(), []
+    try:
+        for nt in (1, max(2, keep)):
+            torch.set_num_threads(nt)
+            torch.manual_seed(11)
+            out.append(d.forward_marginal(rigids_0=r0, t=0.4 * torch.ones(B), diffuse_mask=torch.ones(B, N))["rigids_t"])
+            out.append(d.sample_prior(shape=r0.shape, device="cpu", as_tensor_7=True)["rigids_t"])
+    finally:
+        torch.set_num_threads(keep)
+    assert torch.equal(out[0], out[2]) and torch.equal(out[1], out[3])
+
+
 def test_schedule_and_step_params(tmp_path):
     from str2str_amd.factory import build_diffuser
     from str2str_amd.sampler import schedule, shard_range
