@@ -396,8 +396,14 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     auto fetch = [&](int par, int slot_in_stage, f16x8 (&f)[4]) {
         typedef __attribute__((address_space(3))) f16x8 lds_frag;
         const lds_frag* s = (const lds_frag*)ring_buf(par) + slot_in_stage * 4 * 64;
+#ifndef S2S_ET_FETCH_INORDER
+        // fragment 1 (W_l of the first unit) is what a slot's FIRST MFMA reads: requested last, the wait in front of that MFMA covers all
+        // four reads (LDS returns in order) and the slot's other MFMAs need none -- one s_waitcnt per slot instead of two or three
+        f[0] = s[0]; f[2] = s[128]; f[3] = s[192]; f[1] = s[64];
+#else
 #pragma unroll
         for (int k = 0; k < 4; ++k) f[k] = s[64 * k];
+#endif
     };
     // quarter qd (registers 4qd..4qd+3) of  relu(a1 tile + seeds)  -> planes of k-step qd>>1, elements 4(qd&1)..
     auto s_quarter = [&](const f32x16& tile_acc, auto qc) {
@@ -671,8 +677,14 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             if constexpr (i < 4) {
                 if constexpr (ss == 0) cp_load_piece(IC<1>{}, ic, st_fill);   // the pipe wraps into the next tile's first stages
                 if constexpr (ss == 4) cp_load_piece(IC<0>{}, ic, (stage + kAhead + 1) % kStages);
+#ifndef S2S_ET_STORE_INORDER
+                // (the piece loaded LAST is stored first: its wait on the in-order counter covers the group, three waits fewer per slot)
+                if constexpr (ss == 1) cp_store_piece(IC<0>{}, IC<3 - i>{}, st_fill & (kRing - 1));
+                if constexpr (ss == 5) cp_store_piece(IC<1>{}, IC<3 - i>{}, st_fill & (kRing - 1));
+#else
                 if constexpr (ss == 1) cp_store_piece(IC<0>{}, ic, st_fill & (kRing - 1));
                 if constexpr (ss == 5) cp_store_piece(IC<1>{}, ic, st_fill & (kRing - 1));
+#endif
             }
             if constexpr (seeds_slot && i < 4) seeds_piece(cur, d.t + 1, i);
             if constexpr (seeds_slot && i < 4 && d.t + 2 < 12) seedc_piece(cur, d.t + 2, i);   // start value of a1 tile t + 2 (A_{t+2} follows this block)
