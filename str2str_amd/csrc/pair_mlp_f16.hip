@@ -808,12 +808,12 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
         e0 = ldw(voff, so); e1 = ldw(voff + 1024, so); e2 = ldw(voff + 2048, so); e3 = ldw(voff + 3072, so);
     };
     auto cp_store_a = [&](int par) {
-        lds_char* d = lds_image[par] + wave * 8192;
-        *(lds_f4*)(d) = c0; *(lds_f4*)(d + 1024) = c1; *(lds_f4*)(d + 2048) = c2; *(lds_f4*)(d + 3072) = c3;
+        lds_char* d = lds_image[par] + wave * 8192;   // (last-loaded piece first: its counter wait covers the group)
+        *(lds_f4*)(d + 3072) = c3; *(lds_f4*)(d + 2048) = c2; *(lds_f4*)(d + 1024) = c1; *(lds_f4*)(d) = c0;
     };
     auto cp_store_b = [&](int par) {
         lds_char* d = lds_image[par] + (wave * 8192 + 4096);
-        *(lds_f4*)(d) = e0; *(lds_f4*)(d + 1024) = e1; *(lds_f4*)(d + 2048) = e2; *(lds_f4*)(d + 3072) = e3;
+        *(lds_f4*)(d + 3072) = e3; *(lds_f4*)(d + 2048) = e2; *(lds_f4*)(d + 1024) = e1; *(lds_f4*)(d) = e0;
     };
     cp_load_a(0);
     cp_load_b(0);
@@ -928,7 +928,7 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
     };
     auto row_add = [&](float scale) {  // pinned: left alone, the compiler sinks these adds to the splits 20 slots later and keeps
 #pragma unroll                         // (spills) all four loaded rows until then
-        for (int i = 0; i < 64; ++i) {
+        for (int i = 63; i >= 0; --i) {   // (last-loaded values first: one counter wait for the whole row instead of one per load)
             g1[i] = __fmaf_rn(scale, tmp[i], g1[i]);  // (explicit: both template variants must round alike)
             asm volatile("" : "+v"(g1[i]));
         }
@@ -966,8 +966,7 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
     auto fetch = [&](int par, int slot_in_stage, f16x8 (&f)[4]) {
         typedef __attribute__((address_space(3))) f16x8 lds_frag;
         const lds_frag* s = (const lds_frag*)lds_image[par] + slot_in_stage * 4 * 64;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) f[k] = s[64 * k];
+        f[0] = s[0]; f[2] = s[128]; f[3] = s[192]; f[1] = s[64];   // (the slot's first MFMA reads f[1]: one counter wait per slot, as in the edge transition)
     };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // The VALU work of a tile is cut into per-k-step pieces, each pinned (empty asm on its inputs / outputs: otherwise the

@@ -5,7 +5,10 @@
 N=$1; shift
 U=${UNIT:-pair_mlp_f16}
 D=str2str_amd/csrc/build
-hipcc -x hip -c str2str_amd/csrc/$U.hip -o $D/${U}_$N.o -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I include -I str2str_amd/csrc -mllvm -pragma-unroll-threshold=10000000 "$@" || exit 1
+# the unit's own flags come from str2str_amd/build.py (e.g. -fno-slp-vectorize of the MFMA units: a variant built without them is not comparable)
+FLAGS=$(python -c "from str2str_amd.build import UNITS, COMMON; print(' '.join(COMMON + UNITS['$U.hip']))")
+SRC=${SRC:-str2str_amd/csrc/$U.hip}     # SRC=<file>: another version of the unit's source (e.g. from git show)
+hipcc -x hip -c $SRC -o $D/${U}_$N.o $FLAGS -w "$@" || exit 1
 OBJS=""
 for u in $(python -c "from str2str_amd.build import UNITS; print(' '.join(k.rsplit('.',1)[0] for k in UNITS))"); do
   if [ $u == $U ]; then OBJS="$OBJS $D/${U}_$N.o"; else OBJS="$OBJS $D/$u.o"; fi
