@@ -1783,6 +1783,27 @@ def test_forward_marginal_device_distribution(diffuser):
     # and a rank-seeded throughput-mode trajectory runs end to end with no host noise
 
 
+def test_host_start_frames_thread_count_and_draw_skipping_change_nothing(net_smooth, diffuser, monkeypatch):
+    """Parity mode's host-side shortcuts: start frames assembled on one intra-op thread (S2S_HOST_FM_THREADS) and the ODE's unused
+    step draws skipped by fast-forwarding the generator (S2S_HOST_RNG_FAST) -- same samples bit for bit, same generator state
+    afterwards, torch's thread count left as it was."""
+    from str2str_amd.common.rigid_utils import Rigid
+    from str2str_amd.sampler import forward_backward
+    from str2str_amd.synth import synth_chain
+
+    feats = synth_chain(24)
+    rig0 = Rigid.from_tensor_4x4(feats["rigidgroups_gt_frames"][..., 0, :, :].repeat(5, 1, 1, 1))
+    keep, outs, states = torch.get_num_threads(), [], []
+    for fm, fast in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("S2S_HOST_FM_THREADS", fm)
+        monkeypatch.setenv("S2S_HOST_RNG_FAST", fast)
+        torch.manual_seed(21)
+        outs.append(forward_backward(net_smooth, diffuser, feats, rig0, 0.6, num_timesteps=10, device=DEV).cpu())
+        states.append(torch.get_rng_state())
+        assert torch.get_num_threads() == keep
+    assert all(torch.equal(outs[0], o) for o in outs[1:]) and all(torch.equal(states[0], st) for st in states[1:])
+
+
 def test_empty_replica_slice_keeps_host_generator_in_lockstep(net_smooth, diffuser):
     """A rank whose slice of a chunk is empty (more ranks than replicas, remainder chunks) must consume the chunk's host draws
     exactly like a rank that samples it, or every later chunk / t_delta / target would see a different noise stream."""
