@@ -74,20 +74,24 @@ int s2s_edge_transition(const float* edge, const float* node_ab, const float* no
  *   (B N N rounded up to 32 pairs; the padding is never read as data).
  *     io_layout bit 0: edge is tiled;  bit 1: out is written tiled;  bit 2: out is not written at all (out may be NULL; needs the
  *     fused projection -- the last EdgeTransition of the trunk, whose pair vectors only feed the next block's projections).
- *   node_ab HERE is [ 2^-e (W1[:,128:256].n' + b1) | 2^5 W1[:,256:384].n' ]  (e = prescale_exp below): the column half B_j is the
- *   START VALUE of the layer-1 accumulators, which carry 2^5 x the layer output, and is loaded straight into them; the row half A_i
- *   is added in the epilogue at the planes' scale.  Both factors are powers of two: the caller folds them into the weights of the
- *   per-node layer that produces node_ab (EdgeTransition.node_layers "ab16" / "ab_s16") or scales a plain node_ab
- *   (ops.edge_transition_f16x3 does, unless told that node_ab has this form already). */
+ *   node_ab HERE is [B,N,896] = [ 2^-e (W1[:,128:256].n' + b1) | 2^5 W1[:,256:384].n' | 2^(5-e) (Wf[:,256:384].n' + bf) ]  (e = prescale_exp
+ *   below; W1 = the first hidden layer, Wf / bf = final_layer): everything the pair (i, j) takes from its two NODES through a linear
+ *   layer, computed once per node.  The column half B_j (384) is the START VALUE of the layer-1 accumulators, which carry 2^5 x the
+ *   layer output, and is loaded straight into them; the row half A_i (384) is added in the epilogue at the planes' scale; the third
+ *   group G_j (128) is the start value of the FINAL layer's accumulators: the layer reads x = h2 + [e | n'_i | n'_j]
+ *   (layers.py:181), and the part of it that depends on node j alone, Wf[:,256:384].n'_j + bf, does not have to be added to the
+ *   hidden values of every pair.  (The i-side residual n'_i is still added in the kernel: node_p [B,N,128] = n'.)  All factors are
+ *   powers of two: the caller folds them into the per-node layers that produce node_ab (EdgeTransition.ab16_specs) or scales a plain
+ *   node_ab (ops.edge_transition_f16x3 does, unless told that node_ab has this form already). */
 int s2s_edge_transition_f16x3(const float* edge, const float* node_ab, const float* node_p, const void* weight_stream,
-                              const float* b2, const float* bf, const float* ln_gamma, const float* ln_beta,
+                              const float* b2, const float* ln_gamma, const float* ln_beta,
                               const float* mask, float* out, int n_samples, int n_res, float ln_eps, int io_layout,
                               const float* proj_bias_cat64, float* proj_attn_bias, float* proj_pair_z, int prescale_exp,
                               void* stream);
 /*   prescale_exp = e in 0 .. 15 (0: none): BLOCK EXPONENT of the hidden activations.  The two hidden layers' outputs (relu(layer 1),
  *   relu(layer 2) + x) are kept as f16 planes of 2^-e x their value: relu is positively homogeneous, so the factor rides in
  *   constants the epilogues apply anyway and LayerNorm removes it -- exact for a power of two, no extra instruction, e = 0 is bit
- *   for bit the unscaled kernel.  The row half of node_ab must then be handed in multiplied by 2^-e (see above).
+ *   for bit the unscaled kernel.  The row half and the third group of node_ab must then be handed in multiplied by 2^-e (see above).
  *   It moves the kernel's usable range from 2^15 to 2^(15+e) at the price of f16's subnormal spacing on activations below
  *   2^(e-3) (absolute error 2^(e-25): far below the large activations' own rounding); the range guard sees the SCALED values. */
 

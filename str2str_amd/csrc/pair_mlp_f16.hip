@@ -177,7 +177,7 @@ __device__ unsigned long long g_et_probe[512 * 17];
 template <bool PROJ>
 __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     const float* __restrict__ edge, const float* __restrict__ node_ab, const float* __restrict__ node_p,
-    const char* __restrict__ wblob, const float* __restrict__ b2, const float* __restrict__ bf,
+    const char* __restrict__ wblob, const float* __restrict__ b2,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mask,
     float* __restrict__ out, long long M, int N, float ln_eps, int io_layout, unsigned mask_stride, const float* __restrict__ proj_b,
     float* __restrict__ proj_bias_out, float* __restrict__ proj_pz_out, int* __restrict__ range_flag, float sk) {
@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
 #pragma unroll
         for (int i = 0; i < 16; ++i) xv[i] = ldrow(erow_of(cur), i);  // accumulator ("chain") channel order, see xpl
         for (int i = threadIdx.x; i < 768; i += 256)
-            s_vec[i] = i < 384 ? sk * b2[i] : (i < 512 ? (kWS * sk) * bf[i - 384] : (i < 640 ? gamma[i - 512] : beta[i - 640]));   // 32 bf: start value of the final layer's accumulators
+            s_vec[i] = i < 384 ? sk * b2[i] : (i < 512 ? 0.f : (i < 640 ? gamma[i - 512] : beta[i - 640]));   // (384..511 unused: bf rides in the per-node start values G_j)
         if (PROJ && threadIdx.x < 64) s_vec[768 + threadIdx.x] = proj_b[threadIdx.x];
         cp_store_a(0);
         cp_load_a(1);
@@ -371,7 +371,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     // instruction.  Reading them from a column-blocked copy [B][96][N][4], 8 cache lines per instruction as in the edge embedding,
     // was measured: 2 % fewer cycles in the layer-2 blocks, no change in launch time; not worth a second copy of the node vectors.)
     auto seeds_piece = [&](const PairCtx& c, int t, int rq) {
-        const float4 x = ldg4(node_ab + (unsigned long long)c.bi * 768u + 32 * t, rq, h);
+        const float4 x = ldg4(node_ab + (unsigned long long)c.bi * 896u + 32 * t, rq, h);
         sa[4 * rq + 0] = x.x; sa[4 * rq + 1] = x.y; sa[4 * rq + 2] = x.z; sa[4 * rq + 3] = x.w;
     };
     // The j-side seeds are the START VALUE of the layer-1 accumulators (round 5): the caller hands the second half of node_ab in as
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     // on it and the epilogue is relu(acc (sk / 32) + sk A_i): one add per hidden value less (-208 VALU instructions per tile on the
     // ISA, -0.5 % per launch in a same-call A/B).
     auto seedc_piece = [&](const PairCtx& c, int t, int rq) {
-        const float4 y = ldg4(node_ab + (unsigned long long)c.bj * 768u + 384 + 32 * t, rq, h);
+        const float4 y = ldg4(node_ab + (unsigned long long)c.bj * 896u + 384 + 32 * t, rq, h);
         a1t[t & 1][4 * rq + 0] = y.x; a1t[t & 1][4 * rq + 1] = y.y; a1t[t & 1][4 * rq + 2] = y.z; a1t[t & 1][4 * rq + 3] = y.w;
     };
     auto seeds_load = [&](const PairCtx& c, int t) {
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         split2_f16(x0, x1, xp[qd >> 1][0], xp[qd >> 1][1], 4 * (qd & 1) + 2 * decltype(hc)::value, amax);
     };
     // residual rows n'_i (block 1) and n'_j (block 2) of  x = [e | n'_i | n'_j]  in accumulator layout, two 16 B groups per call
-    float rs[64], rs2[64];
+    float rs[64];
     auto row_load2 = [&](const float* r, float (&dst)[64], int g0) {
 #pragma unroll
         for (int g = g0; g < g0 + 2; ++g) {
@@ -579,7 +579,6 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         constexpr bool seeds_slot = d.phase == 1 && d.a == 1 && d.b == 0 && d.t + 1 < 12;   // a quarter behind each of its first 4 MFMAs
         // residual rows of the layer-2 epilogue blocks 1 (n'_i, under B_11) and 2 (n'_j, under the first final-layer block)
         if constexpr (s >= 184 && s < 192) row_load2(node_p + (unsigned long long)cur.bi * 128u, rs, 2 * (s - 184));
-        if constexpr (s >= 200 && s < 208) row_load2(node_p + (unsigned long long)cur.bj * 128u, rs2, 2 * (s - 200));
         // bias of this slot's layer-2 epilogue pieces (below): block 0 two pieces per slot under the second half of B_11, blocks 1 and 2 one
         constexpr int ep_blk = (s >= 184 && s < 192) ? 0 : ((s >= 192 && s < 224) ? 1 + (s - 192) / 16 : -1);
         constexpr int ep_q = ep_blk == 0 ? 2 * (s - 184) : (s - 192) % 16;
@@ -593,16 +592,27 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
 #pragma unroll
             for (int k = 0; k < 2; ++k) { lnv[2 * k] = ldg4(s_vec + 512, 2 * ln_k + k, h); lnv[2 * k + 1] = ldg4(s_vec + 640, 2 * ln_k + k, h); }
         }
-        // final layer: its accumulators start at 32 bf (tiles 0, 1 in slot 192, tiles 2, 3 in slot 193) -- the LayerNorm pieces only read them
-        if constexpr (s == 192 || s == 193) {
+        // final layer: its accumulators start at G_j = 32 sk (Wf[:, 256:] n'_j + bf), the third column group of node_ab -- the j-side residual
+        // of the layer's input x = h2 + [e | n'_i | n'_j] (layers.py:181) taken through the layer per NODE instead of being added to 64
+        // hidden values per lane and tile: -64 multiply-adds, -64 registers (the rows n'_j), the bias out of LDS.  Loaded straight into
+        // the accumulator registers (dead since the previous tile's LayerNorm), two 16 B pieces per slot in slots 182 .. 189: tile t is
+        // complete 4+ slots before its first product (slot 192 / 193) and not live while the layer-2 blocks need every register --
+        // same-call A/B against the kernel before (profiles/r05p_et_gseed_ab.txt): four pieces per slot from 184 -0.35 %, from 176 +1.7 %
+        // (spills), two per slot from 180 / 182 / 184: -0.67 / -0.70 / -0.45 %.  (Bound: the kernel with that residual simply left out, -1.3 %.)
+#ifndef S2S_ET_GSLOT
+#define S2S_ET_GSLOT 182
+#endif
+#ifndef S2S_ET_GPER
+#define S2S_ET_GPER 2
+#endif
+        if constexpr (s >= S2S_ET_GSLOT && s < S2S_ET_GSLOT + 16 / S2S_ET_GPER) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int rq = 0; rq < 4; ++rq) {
-                    const float4 v = ldg4(s_vec + 384, 4 * (2 * (s - 192) + u) + rq, h);
-                    a3[2 * (s - 192) + u][4 * rq + 0] = v.x; a3[2 * (s - 192) + u][4 * rq + 1] = v.y;
-                    a3[2 * (s - 192) + u][4 * rq + 2] = v.z; a3[2 * (s - 192) + u][4 * rq + 3] = v.w;
-                }
+            for (int u = 0; u < S2S_ET_GPER; ++u) {
+                constexpr int p0 = (s - S2S_ET_GSLOT) * S2S_ET_GPER;
+                const int t3 = (p0 + u) / 4, rq = (p0 + u) % 4;
+                const float4 v = ldg4(node_ab + (unsigned long long)cur.bj * 896u + 768 + 32 * t3, rq, h);
+                a3[t3][4 * rq + 0] = v.x; a3[t3][4 * rq + 1] = v.y; a3[t3][4 * rq + 2] = v.z; a3[t3][4 * rq + 3] = v.w;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 
@@ -650,7 +660,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
             constexpr int q = decltype(qc)::value, hh = decltype(hc)::value, t = q / 4, rq = q % 4, j0 = 4 * rq + 2 * hh, e0 = 4 * (rq & 1) + 2 * hh;
             const f32x16& a = a2[4 * (ep_blk < 0 ? 0 : ep_blk) + t];
             f16x8 (&P)[2] = ep_blk == 1 ? xq[2 * t + (rq >> 1)] : xpl[2 * t + (rq >> 1)];
-            float r0, r1;
+            float r0 = 0.f, r1 = 0.f;
             if constexpr (ep_blk == 0) {   // the residual of block 0 is the edge row = x_h + x_l of the planes this piece replaces (to 2^-24 |x|)
 #ifndef S2S_ET_NO_MIXRES
                 // (float) x_h + (float) x_l as ONE v_fma_mix_f32 per value (x_h * 1.0 + x_l with both read as f16: the same single rounding
@@ -662,13 +672,15 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
                 r0 = (float)P[0][e0] + (float)P[1][e0];
                 r1 = (float)P[0][e0 + 1] + (float)P[1][e0 + 1];
 #endif
-            } else {
-                const float (&row)[64] = ep_blk == 1 ? rs : rs2;
-                r0 = row[16 * t + j0];
-                r1 = row[16 * t + j0 + 1];
+            } else if constexpr (ep_blk == 1) {
+                r0 = rs[16 * t + j0];
+                r1 = rs[16 * t + j0 + 1];
             }
-            const float x0 = __builtin_fmaf(r0, sk, fmaxf(__builtin_fmaf(a[j0], kInvWS, hh ? bq.z : bq.x), 0.f));   // (sk = 1: r0 + relu(.), exactly)
-            const float x1 = __builtin_fmaf(r1, sk, fmaxf(__builtin_fmaf(a[j0 + 1], kInvWS, hh ? bq.w : bq.y), 0.f));
+            float x0 = fmaxf(__builtin_fmaf(a[j0], kInvWS, hh ? bq.z : bq.x), 0.f), x1 = fmaxf(__builtin_fmaf(a[j0 + 1], kInvWS, hh ? bq.w : bq.y), 0.f);
+            if constexpr (ep_blk != 2) {   // block 2's residual n'_j went through the final layer on the node side: G_j, the accumulators' start value
+                x0 = __builtin_fmaf(r0, sk, x0);   // (sk = 1: r0 + relu(.), exactly)
+                x1 = __builtin_fmaf(r1, sk, x1);
+            }
             split2_f16(x0, x1, P[0], P[1], e0, amax);
         };
         static_for<0, 6>([&](auto ic) {
@@ -1249,7 +1261,7 @@ long long tile_aligned_samples(long long NN) {
 }  // namespace
 
 extern "C" int s2s_edge_transition_f16x3(const float* edge, const float* node_ab, const float* node_p,
-                                         const void* weight_stream, const float* b2, const float* bf,
+                                         const void* weight_stream, const float* b2,
                                          const float* ln_gamma, const float* ln_beta, const float* mask, float* out,
                                          int n_samples, int n_res, float ln_eps, int io_layout, const float* proj_bias_cat64,
                                          float* proj_attn_bias, float* proj_pair_z, int prescale_exp, void* stream) {
@@ -1282,18 +1294,18 @@ extern "C" int s2s_edge_transition_f16x3(const float* edge, const float* node_ab
         const long long wg_tiles = (M + 127) / 128;
         const long long grid = wg_tiles < n_cu ? wg_tiles : n_cu;
         const float* e = edge + b0 * NN * 128;
-        const float* nab = node_ab + rows0 * 768;
+        const float* nab = node_ab + rows0 * 896;
         const float* np = node_p + rows0 * 128;
         const float* mk = mask ? mask + rows0 : one;
         const unsigned mks = mask ? 1u : 0u;
         float* o = out ? out + b0 * NN * 128 : nullptr;
         if (proj_attn_bias)
             hipLaunchKernelGGL(edge_transition_f16_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, e, nab, np,
-                               (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mk, o, M, n_res, ln_eps, io_layout, mks, proj_bias_cat64,
+                               (const char*)weight_stream, b2, ln_gamma, ln_beta, mk, o, M, n_res, ln_eps, io_layout, mks, proj_bias_cat64,
                                proj_attn_bias + b0 * 8 * NN, proj_pair_z + b0 * NN * 32, s2s::g_range_flag, sk);
         else
             hipLaunchKernelGGL(edge_transition_f16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, e, nab, np,
-                               (const char*)weight_stream, b2, bf, ln_gamma, ln_beta, mk, o, M, n_res, ln_eps, io_layout, mks,
+                               (const char*)weight_stream, b2, ln_gamma, ln_beta, mk, o, M, n_res, ln_eps, io_layout, mks,
                                (const float*)nullptr, (float*)nullptr, (float*)nullptr, s2s::g_range_flag, sk);
     }
     return (int)hipGetLastError();

@@ -149,14 +149,16 @@ class EdgeTransition(nn.Module):
             "wfp": ops.pack_weight(wf.weight.float(), tile_major=True)})
 
     def node_layers(self):
-        """The per-node parts as node-stream layers: n' = initial_embed(node) and the node halves of layer 1 applied to it,
-        [W1[:, ce:ce+cb] n' + b1 | W1[:, ce+cb:] n']."""
-        w1, ie = self.trunk[0], self.initial_embed
+        """The per-node parts as node-stream layers: n' = initial_embed(node) and everything a pair (i, j) takes from ONE of its nodes
+        through a linear layer, [W1[:, ce:ce+cb] n' + b1 | W1[:, ce+cb:] n' | Wf[:, ce+cb:] n' + bf]  (384 + 384 + 128 columns): the row
+        half A_i and the column half B_j of the first hidden layer, and G_j = the j-side residual of the final layer's input
+        x = h2 + [e | n'_i | n'_j] (reference layers.py:181) taken through that layer, its bias included."""
+        w1, ie, wf = self.trunk[0], self.initial_embed, self.final_layer
 
         def build():
             ce, cb = self._shape[0], self._shape[1]
-            w_ab = torch.cat([w1.weight[:, ce:ce + cb], w1.weight[:, ce + cb:]], dim=0).float().contiguous()
-            b_ab = torch.cat([w1.bias, torch.zeros_like(w1.bias)]).float().contiguous()
+            w_ab = torch.cat([w1.weight[:, ce:ce + cb], w1.weight[:, ce + cb:], wf.weight[:, ce + cb:]], dim=0).float().contiguous()
+            b_ab = torch.cat([w1.bias, torch.zeros_like(w1.bias), wf.bias]).float().contiguous()
             # "ab_s": the same vectors straight from s -- W_ab (W_ie s + b_ie) + b_ab = (W_ab W_ie) s + (W_ab b_ie + b_ab), folded in float64 on
             # the host -- so that both per-node parts read the block's node activations and run in ONE launch with the backbone update
             w64, ie64 = w_ab.detach().double().cpu(), ie.weight.detach().double().cpu()
@@ -166,7 +168,7 @@ class EdgeTransition(nn.Module):
             # half B_j starts the layer-1 accumulators, which carry 2^5 x the layer output.  The factor does not go into the weights (it
             # would cost the f16x3 packing five bits of its weight range): the column half is its own layer whose epilogue scales the row
             # by 32 (``pre_scale``: acc (32 / 32) + 32 b, exact) and writes columns 384.. of the same [M, 768] buffer (``node_ab16``)
-            h2 = w_ab.shape[0] // 2
+            h2 = self._shape[2]     # 384: A | B | G(128); B and G are accumulator start values (x 2^5): ONE layer of 512 columns
             return {"init": ops.pack_node_layer(ie.weight, ie.bias), "ab": ops.pack_node_layer(w_ab, b_ab),
                     "ab_s": ops.pack_node_layer(w_abs, b_abs),
                     "abA": ops.pack_node_layer(w_ab[:h2].contiguous(), b_ab[:h2].contiguous()),
@@ -174,20 +176,20 @@ class EdgeTransition(nn.Module):
                     "ab_sA": ops.pack_node_layer(w_abs[:h2].contiguous(), b_abs[:h2].contiguous()),
                     "ab_sB": ops.pack_node_layer(w_abs[h2:].contiguous(), 32.0 * b_abs[h2:])}
 
-        return self._node_cache.get([w1.weight, w1.bias, ie.weight, ie.bias], build)
+        return self._node_cache.get([w1.weight, w1.bias, ie.weight, ie.bias, wf.weight, wf.bias], build)
 
     @staticmethod
     def ab16_specs(nl: dict, from_s: bool, n_rows: int, device):
-        """node_ab in the f16x3 pair kernel's form [A_i + b1 | 32 B_j] as two layers into one buffer -> (buffer [M, 768], specs for
-        ``ops.node_apply_multi`` / ``ops.node_apply``)."""
-        ab = torch.empty(n_rows, 768, device=device, dtype=torch.float32)
+        """node_ab in the f16x3 pair kernel's form [A_i + b1 | 32 B_j | 32 G_j] as two layers into one buffer -> (buffer [M, 896], specs
+        for ``ops.node_apply_multi`` / ``ops.node_apply``)."""
+        ab = torch.empty(n_rows, 896, device=device, dtype=torch.float32)
         c32 = ops.const_rows(n_rows, 32.0, device)
         ka, kb = ("ab_sA", "ab_sB") if from_s else ("abA", "abB")
         return ab, [(nl[ka], dict(out_f32=ab, out_col0=0)), (nl[kb], dict(out_f32=ab, out_col0=384, pre_scale=c32))]
 
     def node_parts(self, s_act, n_rows: int, kernel_form: bool = False):
-        """-> (n' [M,128] fp32, node_ab [M,768] fp32) from the node activations (packed planes or fp32, see ops.node_apply).
-        ``kernel_form``: node_ab as the f16x3 pair kernel reads it (column half x 2^5; ``pair_mlp(..., ab_kernel_form=True)``)."""
+        """-> (n' [M,128] fp32, node_ab [M,896] fp32) from the node activations (packed planes or fp32, see ops.node_apply).
+        ``kernel_form``: node_ab as the f16x3 pair kernel reads it (column half and G x 2^5; ``pair_mlp(..., ab_kernel_form=True)``)."""
         nl = self.node_layers()
         n_p, n_pa = ops.node_apply(s_act, nl["init"], n_rows, want_xp=True)
         if kernel_form:
@@ -209,7 +211,7 @@ class EdgeTransition(nn.Module):
 
     def pair_mlp(self, edge_embed, node_ab, n_p, edge_mask_1d=None, next_proj=None, out_layout: str = "rowmajor", ab_kernel_form: bool = False):
         """The N x N part given the per-node vectors n' = initial_embed(node) [B,N,128] and
-        node_ab = [W1[:,128:256] n' + b1 | W1[:,256:] n'] [B,N,768] (``node_parts``).  Arithmetic "f16x3" only: ``edge_embed`` may be
+        node_ab = [W1[:,128:256] n' + b1 | W1[:,256:] n' | Wf[:,256:] n' + bf] [B,N,896] (``node_parts``).  Arithmetic "f16x3" only: ``edge_embed`` may be
         an ``ops.PairTiled`` and ``out_layout`` "tiled" / "none" (ops.edge_transition_f16x3) -- how the trunk chains its pair kernels."""
         if self._shape != (128, 128, 384, 128, 2):
             raise ops.HipLibraryError(f"EdgeTransition kernel is built for c_z=128, c_s=256 (got {self._shape})")
@@ -225,7 +227,7 @@ class EdgeTransition(nn.Module):
             B, N = edge_embed.shape[0], edge_embed.shape[1]
             z, bias, pz = torch.ops.str2str_amd.edge_transition_f16x3_chain(
                 edge_embed.buf if tiled_in else edge_embed.contiguous(), tiled_in, B, N, node_ab, n_p,
-                pk["wstream_f16"] if proj is None else proj[0], self.trunk[2].bias, self.final_layer.bias, self.layer_norm.weight,
+                pk["wstream_f16"] if proj is None else proj[0], self.trunk[2].bias, self.layer_norm.weight,
                 self.layer_norm.bias, mask, self.layer_norm.eps, None if proj is None else proj[1], out_layout, int(self.prescale_exp),
                 bool(ab_kernel_form))
             if out_layout == "tiled":
@@ -234,7 +236,7 @@ class EdgeTransition(nn.Module):
         if out_layout != "rowmajor" or isinstance(edge_embed, ops.PairTiled) or ab_kernel_form:
             raise ops.HipLibraryError("EdgeTransition: the tiled pair layout and the scaled node_ab belong to the f16x3 kernels")
         pk = self._packed_f32()
-        return ops.edge_transition(edge_embed.contiguous(), node_ab, n_p, pk["w1p"], pk["w2p"], pk["wfp"],
+        return ops.edge_transition(edge_embed.contiguous(), node_ab[..., :768].contiguous(), n_p, pk["w1p"], pk["w2p"], pk["wfp"],
                                    self.trunk[2].bias, self.final_layer.bias, self.layer_norm.weight,
                                    self.layer_norm.bias, mask, self.layer_norm.eps,
                                    proj=None if next_proj is None else (next_proj["wp"], next_proj["b64"]))

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 _lib = None
 _tables_loaded = False
@@ -27,7 +27,7 @@ _SIGNATURES = {
     "s2s_abi_version": [],
     "s2s_set_range_flag": [_vp],
     "s2s_edge_transition": [_vp] * 12 + [_i, _i, _f, _vp, _vp, _vp, _vp, _vp],
-    "s2s_edge_transition_f16x3": [_vp] * 10 + [_i, _i, _f, _i, _vp, _vp, _vp, _i, _vp],
+    "s2s_edge_transition_f16x3": [_vp] * 9 + [_i, _i, _f, _i, _vp, _vp, _vp, _i, _vp],
     "s2s_edge_embed": [_vp] * 15 + [_i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "s2s_edge_embed_f16x3": [_vp] * 14 + [_i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
     "s2s_pair_project": [_vp] * 5 + [_i, _i, _vp],
@@ -330,7 +330,7 @@ def pair_untiled(t: PairTiled) -> torch.Tensor:
     return t.buf.view(-1, 16, 2, 32, 4).permute(0, 3, 1, 2, 4).reshape(-1, 128)[:M].reshape(t.B, t.N, t.N, 128).contiguous()
 
 
-def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps=1e-5, out=None, proj=None,
+def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, gamma, beta, mask, ln_eps=1e-5, out=None, proj=None,
                           out_layout: str = "rowmajor", prescale_exp: int = 0, ab_kernel_form: bool = False):
     """EdgeTransition on split-f16 MFMA (fp32-equivalent accuracy; csrc/pair_mlp_f16.hip); same contract as ``edge_transition``.
     ``proj`` = (31-stage stream = this layer's 30 stages (``pack_f16x3_stream``) + the next IPA block's projection stage
@@ -339,25 +339,29 @@ def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, m
     vectors are not written: only with ``proj``, for the last EdgeTransition of a trunk; returns None in their place).
     ``prescale_exp`` = e (0 .. 15): the kernel keeps its hidden activations as f16 planes of 2^-e x the value (a block exponent: exact,
     same speed) -- what the sampler sets when the range guard reports hidden activations of 2^15 and beyond.
-    ``node_ab`` = [W1[:,128:256] n' + b1 | W1[:,256:] n'] as ``EdgeTransition.node_parts`` gives it; ``ab_kernel_form``: its column half
-    already carries the accumulators' 2^5 (the trunk's per-node layer "ab_s16" produces it so: no extra launch), see the C header."""
+    ``node_ab`` [B,N,896] = [W1[:,128:256] n' + b1 | W1[:,256:] n' | Wf[:,256:] n' + bf] as ``EdgeTransition.node_parts`` gives it (the
+    pair's per-node linear parts: row half and column half of the first layer, the j-side residual taken through the final layer incl.
+    its bias); ``ab_kernel_form``: the column half and the third group already carry the accumulators' 2^5 (the trunk's per-node layers
+    produce them so: no extra launch), see the C header."""
     lib = load_library()
     B, N = edge.shape[0], edge.shape[1]
     in_tiled = isinstance(edge, PairTiled)
     if not 0 <= int(prescale_exp) <= 15:
         raise HipLibraryError(f"edge_transition_f16x3: prescale_exp {prescale_exp} outside 0 .. 15")
-    # C ABI: node_ab = [2^-e (A_i + b1) | 2^5 B_j] -- the row half at the planes' scale, the column half at the accumulators' (the caller's job)
+    # C ABI: node_ab = [2^-e (A_i + b1) | 2^5 B_j | 2^(5-e) G_j] -- the row half at the planes' scale, the column half and the final layer's
+    # start values at the accumulators' (the caller's job)
     if not ab_kernel_form or prescale_exp:
-        sc = node_ab.new_ones(768)
+        sc = node_ab.new_ones(896)
         sc[:384] = 2.0 ** -int(prescale_exp)
-        sc[384:] = 1.0 if ab_kernel_form else 32.0
+        sc[384:768] = 1.0 if ab_kernel_form else 32.0
+        sc[768:] = (1.0 if ab_kernel_form else 32.0) * 2.0 ** -int(prescale_exp)
         node_ab = node_ab * sc
     if out_layout not in ("rowmajor", "tiled", "none") or (out_layout == "none" and proj is None):
         raise HipLibraryError(f"edge_transition_f16x3: out_layout {out_layout!r}" + (" needs proj" if out_layout == "none" else ""))
     _req(edge.buf if in_tiled else edge, name="edge")
-    if tuple(edge.shape) != (B, N, N, 128) or node_ab.shape != (B, N, 768) or node_p.shape != (B, N, 128):
-        raise HipLibraryError("edge_transition_f16x3: bad shapes")
-    for n, t in (("node_ab", node_ab), ("node_p", node_p), ("b2", b2), ("bf", bf), ("gamma", gamma), ("beta", beta)):
+    if tuple(edge.shape) != (B, N, N, 128) or node_ab.shape != (B, N, 896) or node_p.shape != (B, N, 128):
+        raise HipLibraryError("edge_transition_f16x3: bad shapes (node_ab is [B, N, 896]: EdgeTransition.node_parts)")
+    for n, t in (("node_ab", node_ab), ("node_p", node_p), ("b2", b2), ("gamma", gamma), ("beta", beta)):
         _req(t, name=n)
     pb = pbias = ppz = None
     if proj is not None:
@@ -381,7 +385,7 @@ def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, bf, gamma, beta, m
     io = (1 if in_tiled else 0) | {"rowmajor": 0, "tiled": 2, "none": 4}[out_layout]
     range_flag()
     _check(_timed("s2s_edge_transition", lambda: lib.s2s_edge_transition_f16x3(
-        _p(edge.buf if in_tiled else edge), _p(node_ab), _p(node_p), _p(wstream), _p(b2), _p(bf), _p(gamma), _p(beta),
+        _p(edge.buf if in_tiled else edge), _p(node_ab), _p(node_p), _p(wstream), _p(b2), _p(gamma), _p(beta),
         _p(mask),
         _p(out.buf if isinstance(out, PairTiled) else out), B, N, ln_eps, io, _p(pb), _p(pbias), _p(ppz), int(prescale_exp), _stream())),
         "s2s_edge_transition_f16x3")
@@ -1502,13 +1506,13 @@ def _op_node_linear_f32(x, wpk32, bias, n_rows, k_in, n_out, tiles, pre_scale=No
                            residual=residual, ln=_ln3(ln_gamma, ln_beta, ln_eps), post_mask=post_mask, out=out, out_col0=out_col0)
 
 
-def _op_edge_transition_f16x3_chain(edge, in_tiled, B, N, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps, proj_bias64,
+def _op_edge_transition_f16x3_chain(edge, in_tiled, B, N, node_ab, node_p, wstream, b2, gamma, beta, mask, ln_eps, proj_bias64,
                                     out_layout, prescale_exp=0, ab_kernel_form=False):
     """The trunk's form of the edge transition: pair tensor in either layout (``edge`` = the flat tiled buffer when ``in_tiled``), the
     next IPA block's projections fused in when ``proj_bias64`` is given (``wstream`` is then the 31-stage stream).
     -> (pair tensor (row-major [B,N,N,128] | flat tiled buffer | None), attn_bias | None, pair_z | None)"""
     e = PairTiled(B, N, buf=edge) if in_tiled else edge
-    r = edge_transition_f16x3(e, node_ab, node_p, wstream, b2, bf, gamma, beta, mask, ln_eps,
+    r = edge_transition_f16x3(e, node_ab, node_p, wstream, b2, gamma, beta, mask, ln_eps,
                               proj=None if proj_bias64 is None else (wstream, proj_bias64), out_layout=out_layout, prescale_exp=prescale_exp,
                               ab_kernel_form=ab_kernel_form)
     z, bias, pz = r if proj_bias64 is not None else (r, None, None)
@@ -1519,11 +1523,11 @@ _TORCH_OPS = {
     # ---- pair stream
     "edge_transition(Tensor edge, Tensor node_ab, Tensor node_p, Tensor w1p, Tensor w2p, Tensor wfp, Tensor b2, "
     "Tensor bf, Tensor gamma, Tensor beta, Tensor? mask, float ln_eps) -> Tensor": lambda *a: edge_transition(*a),
-    "edge_transition_f16x3(Tensor edge, Tensor node_ab, Tensor node_p, Tensor wstream, Tensor b2, Tensor bf, "
+    "edge_transition_f16x3(Tensor edge, Tensor node_ab, Tensor node_p, Tensor wstream, Tensor b2, "
     "Tensor gamma, Tensor beta, Tensor? mask, float ln_eps, int prescale_exp=0) -> Tensor":
-        lambda e, nab, np_, ws, b2, bf, g, b, m, eps, pe=0: edge_transition_f16x3(e, nab, np_, ws, b2, bf, g, b, m, eps, prescale_exp=pe),
+        lambda e, nab, np_, ws, b2, g, b, m, eps, pe=0: edge_transition_f16x3(e, nab, np_, ws, b2, g, b, m, eps, prescale_exp=pe),
     "edge_transition_f16x3_chain(Tensor edge, bool in_tiled, int B, int N, Tensor node_ab, Tensor node_p, Tensor wstream, Tensor b2, "
-    "Tensor bf, Tensor gamma, Tensor beta, Tensor? mask, float ln_eps, Tensor? proj_bias64, str out_layout, int prescale_exp=0, "
+    "Tensor gamma, Tensor beta, Tensor? mask, float ln_eps, Tensor? proj_bias64, str out_layout, int prescale_exp=0, "
     "bool ab_kernel_form=False) "
     "-> (Tensor?, Tensor?, Tensor?)":
         _op_edge_transition_f16x3_chain,

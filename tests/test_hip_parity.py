@@ -683,7 +683,7 @@ def test_torch_ops_registration(net_rough):
     node, edge = torch.randn(1, 9, 256, generator=gen).to(DEV), torch.randn(1, 9, 9, 128, generator=gen).to(DEV)
     n_p, node_ab = et.node_parts(ops.pack_planes(node.reshape(9, 256)), 9)
     o = torch.ops.str2str_amd.edge_transition_f16x3(edge, node_ab.view(1, 9, -1), n_p.view(1, 9, -1), pk["wstream_f16"], et.trunk[2].bias,
-                                                    et.final_layer.bias, et.layer_norm.weight, et.layer_norm.bias, None, et.layer_norm.eps)
+                                                    et.layer_norm.weight, et.layer_norm.bias, None, et.layer_norm.eps)
     assert torch.equal(o, et(node, edge))
 
 
@@ -844,8 +844,10 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
     n_p, node_ab = n_p.view(B, N, -1), node_ab.view(B, N, -1)
     pk, pk32 = et._packed(), et._packed_f32()
     common = (et.trunk[2].bias, et.final_layer.bias, et.layer_norm.weight, et.layer_norm.bias, mask, et.layer_norm.eps)
-    assert torch.equal(K.edge_transition(z, node_ab, n_p, pk32["w1p"], pk32["w2p"], pk32["wfp"], *common),
-                       ops.edge_transition(z, node_ab, n_p, pk32["w1p"], pk32["w2p"], pk32["wfp"], *common))
+    ab32 = node_ab[..., :768].contiguous()    # the exact kernel takes the first layer's two halves; the final layer's bias as an argument
+    assert torch.equal(K.edge_transition(z, ab32, n_p, pk32["w1p"], pk32["w2p"], pk32["wfp"], *common),
+                       ops.edge_transition(z, ab32, n_p, pk32["w1p"], pk32["w2p"], pk32["wfp"], *common))
+    common = common[:1] + common[2:]          # (f16x3: the final layer's bias rides in node_ab's third group)
     nxt = tr["ipa_1"].pair_proj_weights()
     stream = torch.cat([pk["wstream_f16"], nxt["wp_f16x2"]])
     zt = ops.pair_tiled(z)
