@@ -174,7 +174,7 @@ __device__ unsigned long long g_et_probe[512 * 17];
 // PROJ: also emit the NEXT IPA block's linear_b / down_z (ipa.py:177,253) of the pair vector just produced -- one more
 // weight stage (64 x 128 Wcat, chain-packed), 8 more slots on the LayerNorm output while it is still in registers,
 // attention bias written head-major [B,8,N,N], pair_z [B,N,N,32].  Saves the 512 B/pair re-read of z by s2s_pair_project.
-template <bool PROJ>
+template <bool PROJ, bool STAGE>
 __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     const float* __restrict__ edge, const float* __restrict__ node_ab, const float* __restrict__ node_p,
     const char* __restrict__ wblob, const float* __restrict__ b2,
@@ -193,6 +193,8 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     constexpr int kRing = PROJ ? 4 : 2, kAhead = PROJ ? 2 : 1;
     __shared__ __attribute__((aligned(16))) char s_w[kRing][kStageBytes];
     __shared__ __attribute__((aligned(16))) float s_vec[768 + 64];  // b2 | bf | gamma | beta | projection bias
+    // STAGE (chains of 32+ residues): the two rows A_i (+ b1) of node_ab a wave's tile can touch, staged per tile (see stage_rows below)
+    __shared__ __attribute__((aligned(16))) float s_rows[STAGE ? 4 * 2 * 384 : 4];
     const int lane = threadIdx.x & 63, h = lane >> 5, wave = threadIdx.x >> 6;
 
     // ---- weight pipe (see header).  Each wave moves one contiguous 12 KiB of every stage.
@@ -255,6 +257,7 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     // 512-register limit, and one more long-lived VGPR costs hundreds of spills.
     struct PairCtx {
         unsigned p, bi, bj, boff;  // flat pair index; flat node rows of i and j; offset of head 0 of this pair in a head-major [B,8,N,N] tensor
+        unsigned r0, aoff;         // STAGE: the tile's first node row (wave-uniform), this lane's byte offset of its row's 16 B groups in s_rows
         float em_i, em_j;          // the two node masks, multiplied where the edge mask is used: a product formed here would wait
         bool valid;                // for the loads (vmcnt(0): the whole weight pipe) in the middle of the final layer
     };
@@ -282,6 +285,8 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         c.p = p;
         c.bi = bi;
         c.bj = bb * (unsigned)N + j;
+        c.r0 = (unsigned)__builtin_amdgcn_readfirstlane((int)bi);   // consecutive pairs of a chain of 32+ residues: rows r0 and r0 + 1 at most
+        c.aoff = (unsigned)wave * 3072u + (bi != c.r0 ? 1536u : 0u) + 16u * (unsigned)h;
         c.boff = p + 7u * bb * NNu;
         // (no branch on the mask's presence: a value merged from two paths is materialised -- and waited for -- at the join;
         //  the launcher passes a one-element "1.0" and stride 0 for an absent mask)
@@ -370,9 +375,42 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     // the per-node first-layer halves [B,N,768].  (The j-side rows differ from lane to lane -- 16 B in each of 32 rows per load
     // instruction.  Reading them from a column-blocked copy [B][96][N][4], 8 cache lines per instruction as in the edge embedding,
     // was measured: 2 % fewer cycles in the layer-2 blocks, no change in launch time; not worth a second copy of the node vectors.)
+    // The row seeds A_i are the same for every pair of a row: 32 consecutive pairs of a chain of 32+ residues touch two rows at most, and
+    // a wave used to fetch them with 48 load instructions per tile whose 64 lanes ask for one or two addresses -- the kernel without those
+    // loads ran 2.2 % faster (tile 0's seeds for all tiles; timing only).  STAGE: the tile's rows r0, r0 + 1 (2 x 1536 B) go through LDS,
+    // three contiguous 1 KiB loads + three LDS stores per wave and tile (stage_load / stage_store: requested right after the next tile's
+    // setup, stored five slots later, first read 20+ slots after that; this tile's last read is ~40 slots before the store -- one
+    // private region per wave, LDS operations of a wave are in order: no barrier), and a quarter of seeds is one ds_read_b128.
+    f32x4 g_st0, g_st1, g_st2;   // staging registers of the row copy
+    const unsigned n_node_rows = (unsigned)(M / N);
+    auto stage_load = [&](const PairCtx& c) {
+        if constexpr (STAGE) {
+            const unsigned r1 = c.r0 + 1 < n_node_rows ? c.r0 + 1 : c.r0;
+            auto piece = [&](int k) -> f32x4 {
+                const unsigned o = (unsigned)k * 1024u + 16u * (unsigned)lane;   // byte o of [row r0 | row r1]
+                const bool second = o >= 1536u;
+                const float* src = node_ab + (unsigned long long)(second ? r1 : c.r0) * 896u + ((second ? o - 1536u : o) >> 2);
+                const float4 v = *reinterpret_cast<const float4*>(src);
+                return f32x4{v.x, v.y, v.z, v.w};
+            };
+            g_st0 = piece(0); g_st1 = piece(1); g_st2 = piece(2);
+        }
+    };
+    auto stage_store = [&]() {
+        if constexpr (STAGE) {
+            typedef __attribute__((address_space(3))) f32x4 lds_v4;
+            lds_v4* d = (lds_v4*)((__attribute__((address_space(3))) char*)s_rows + wave * 3072 + lane * 16);
+            d[0] = g_st0; d[64] = g_st1; d[128] = g_st2;
+        }
+    };
     auto seeds_piece = [&](const PairCtx& c, int t, int rq) {
-        const float4 x = ldg4(node_ab + (unsigned long long)c.bi * 896u + 32 * t, rq, h);
-        sa[4 * rq + 0] = x.x; sa[4 * rq + 1] = x.y; sa[4 * rq + 2] = x.z; sa[4 * rq + 3] = x.w;
+        if constexpr (STAGE) {
+            const f32x4 x = *(const lds_f4*)((__attribute__((address_space(3))) const char*)s_rows + c.aoff + (32 * t + 8 * rq) * 4);
+            sa[4 * rq + 0] = x[0]; sa[4 * rq + 1] = x[1]; sa[4 * rq + 2] = x[2]; sa[4 * rq + 3] = x[3];
+        } else {
+            const float4 x = ldg4(node_ab + (unsigned long long)c.bi * 896u + 32 * t, rq, h);
+            sa[4 * rq + 0] = x.x; sa[4 * rq + 1] = x.y; sa[4 * rq + 2] = x.z; sa[4 * rq + 3] = x.w;
+        }
     };
     // The j-side seeds are the START VALUE of the layer-1 accumulators (round 5): the caller hands the second half of node_ab in as
     // 32 B_j -- the accumulators' scale -- and quarter rq of tile t is loaded straight into the accumulator registers of a1t[t & 1]
@@ -387,6 +425,8 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) seeds_piece(c, t, rq);
     };
+    stage_load(cur);
+    stage_store();
     seeds_load(cur, 0);
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) { seedc_piece(cur, 0, rq); seedc_piece(cur, 1, rq); }
@@ -564,6 +604,8 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         //  next counter wait (the weight store 4+ slots later) is at least 6 slots away: HBM latency fits in between.)
         constexpr int kXv0 = 208;
         if constexpr (s == kXv0) nxt = setup(has_next ? wt_next : wt);
+        if constexpr (s == kXv0 + 3) stage_load(nxt);     // (slots ss = 3, 0 of the next stage: none of the edge row's loads)
+        if constexpr (s == kXv0 + 8) stage_store();
         if constexpr (s > kXv0 && s <= kXv0 + 16 && ((s & 3) == 1 || (s & 3) == 2)) {
             constexpr int i = 4 * ((s - kXv0) / 4) + 2 * ((s & 3) - 1);   // 2 loads in each of the slots ss = 1, 2, 5, 6 of two stages
             const float* er = erow_of(nxt);
@@ -1299,12 +1341,15 @@ extern "C" int s2s_edge_transition_f16x3(const float* edge, const float* node_ab
         const float* mk = mask ? mask + rows0 : one;
         const unsigned mks = mask ? 1u : 0u;
         float* o = out ? out + b0 * NN * 128 : nullptr;
+        const bool stage = n_res >= 32;   // (shorter chains: a 32-pair tile spans more than two rows, the row seeds stay per-lane loads)
+        auto k_proj = stage ? &edge_transition_f16_kernel<true, true> : &edge_transition_f16_kernel<true, false>;
+        auto k_plain = stage ? &edge_transition_f16_kernel<false, true> : &edge_transition_f16_kernel<false, false>;
         if (proj_attn_bias)
-            hipLaunchKernelGGL(edge_transition_f16_kernel<true>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, e, nab, np,
+            hipLaunchKernelGGL(k_proj, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, e, nab, np,
                                (const char*)weight_stream, b2, ln_gamma, ln_beta, mk, o, M, n_res, ln_eps, io_layout, mks, proj_bias_cat64,
                                proj_attn_bias + b0 * 8 * NN, proj_pair_z + b0 * NN * 32, s2s::g_range_flag, sk);
         else
-            hipLaunchKernelGGL(edge_transition_f16_kernel<false>, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, e, nab, np,
+            hipLaunchKernelGGL(k_plain, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, e, nab, np,
                                (const char*)weight_stream, b2, ln_gamma, ln_beta, mk, o, M, n_res, ln_eps, io_layout, mks,
                                (const float*)nullptr, (float*)nullptr, (float*)nullptr, s2s::g_range_flag, sk);
     }
