@@ -37,6 +37,9 @@ UNITS = {
     #  fp32 instruction issued between MFMAs costs 6-10 matrix-pipe cycles against 2 x 2.3 for the two plain ones it replaces:
     #  tools/ubench/mfma_valu_overlap.hip; -0.3 .. -1.1 % per edge-transition launch, same-call A/B)
     "pair_mlp_f16.hip": ["-mllvm", "-pragma-unroll-threshold=10000000", "-fno-slp-vectorize"],
+    # (the same source as two more translation units, compiled side by side: short-chain edge transition; edge embedding)
+    "pair_mlp_f16_b.hip": ["-mllvm", "-pragma-unroll-threshold=10000000", "-fno-slp-vectorize"],
+    "pair_mlp_f16_c.hip": ["-mllvm", "-pragma-unroll-threshold=10000000", "-fno-slp-vectorize"],
     "ipa_attention.hip": ["-mllvm", "-pragma-unroll-threshold=10000000"],
     "ipa_attention_f16w.hip": ["-mllvm", "-pragma-unroll-threshold=10000000", "-fno-slp-vectorize"],   # (as above; -0.5 .. -1.5 % per IPA block)
     "node_gemm.hip": ["-mllvm", "-pragma-unroll-threshold=10000000", "-fno-slp-vectorize"],   # (as above: node layers -2.4 %)
@@ -69,7 +72,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         src, extra = item
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
-        if force or _stale(o, [s] + headers):
+        inc = [os.path.join(CSRC, "pair_mlp_f16.hip")] if src.startswith("pair_mlp_f16_") else []   # (units that include another unit's source)
+        if force or _stale(o, [s] + inc + headers):
             if src.endswith(".cpp"):
                 cmd = [cc, "-x", "c++", "-c", s, "-o", o] + [c for c in COMMON if not c.startswith("--offload-arch")] + extra
             else:

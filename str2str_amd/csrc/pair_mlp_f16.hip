@@ -53,6 +53,13 @@
 #include "range_flag.h"
 #include "str2str_hip.h"
 
+// Three translation units from this one source (the four edge-transition instantiations + the two of the edge embedding took 7.5 minutes
+// of a forced build as one unit): S2S_PM_PART 1 (this file compiled directly) = the edge transition for chains of 32+ residues and the
+// public entry point, 2 (pair_mlp_f16_b.hip) = its per-lane-seed form for shorter chains, 3 (pair_mlp_f16_c.hip) = the edge embedding.
+#ifndef S2S_PM_PART
+#define S2S_PM_PART 1
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1300,13 +1307,10 @@ long long tile_aligned_samples(long long NN) {
     return 32 / q;
 }
 
-}  // namespace
-
-extern "C" int s2s_edge_transition_f16x3(const float* edge, const float* node_ab, const float* node_p,
-                                         const void* weight_stream, const float* b2,
-                                         const float* ln_gamma, const float* ln_beta, const float* mask, float* out,
-                                         int n_samples, int n_res, float ln_eps, int io_layout, const float* proj_bias_cat64,
-                                         float* proj_attn_bias, float* proj_pair_z, int prescale_exp, void* stream) {
+template <bool STAGE>
+int et_launch(const float* edge, const float* node_ab, const float* node_p, const void* weight_stream, const float* b2,
+              const float* ln_gamma, const float* ln_beta, const float* mask, float* out, int n_samples, int n_res, float ln_eps,
+              int io_layout, const float* proj_bias_cat64, float* proj_attn_bias, float* proj_pair_z, int prescale_exp, void* stream) {
     if (n_samples <= 0 || n_res <= 0) return 0;
     if ((io_layout & ~7) || ((io_layout & 4) && !proj_attn_bias) || (!(io_layout & 4) && !out)) return (int)hipErrorInvalidValue;
     if (prescale_exp < 0 || prescale_exp > 15) return (int)hipErrorInvalidValue;
@@ -1341,9 +1345,8 @@ extern "C" int s2s_edge_transition_f16x3(const float* edge, const float* node_ab
         const float* mk = mask ? mask + rows0 : one;
         const unsigned mks = mask ? 1u : 0u;
         float* o = out ? out + b0 * NN * 128 : nullptr;
-        const bool stage = n_res >= 32;   // (shorter chains: a 32-pair tile spans more than two rows, the row seeds stay per-lane loads)
-        auto k_proj = stage ? &edge_transition_f16_kernel<true, true> : &edge_transition_f16_kernel<true, false>;
-        auto k_plain = stage ? &edge_transition_f16_kernel<false, true> : &edge_transition_f16_kernel<false, false>;
+        auto k_proj = &edge_transition_f16_kernel<true, STAGE>;
+        auto k_plain = &edge_transition_f16_kernel<false, STAGE>;
         if (proj_attn_bias)
             hipLaunchKernelGGL(k_proj, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, e, nab, np,
                                (const char*)weight_stream, b2, ln_gamma, ln_beta, mk, o, M, n_res, ln_eps, io_layout, mks, proj_bias_cat64,
@@ -1356,7 +1359,25 @@ extern "C" int s2s_edge_transition_f16x3(const float* edge, const float* node_ab
     return (int)hipGetLastError();
 }
 
-#if defined(S2S_ET_PROBE) || defined(S2S_EE_PROBE)
+}  // namespace
+
+#define S2S_ET_ARGS const float* edge, const float* node_ab, const float* node_p, const void* weight_stream, const float* b2, \
+                    const float* ln_gamma, const float* ln_beta, const float* mask, float* out, int n_samples, int n_res, float ln_eps, \
+                    int io_layout, const float* proj_bias_cat64, float* proj_attn_bias, float* proj_pair_z, int prescale_exp, void* stream
+#define S2S_ET_PASS edge, node_ab, node_p, weight_stream, b2, ln_gamma, ln_beta, mask, out, n_samples, n_res, ln_eps, io_layout, \
+                    proj_bias_cat64, proj_attn_bias, proj_pair_z, prescale_exp, stream
+// chains below 32 residues: a 32-pair tile spans more than two rows, the row seeds stay per-lane loads (its own translation unit)
+extern "C" __attribute__((visibility("hidden"))) int s2s_et_f16x3_short_chains(S2S_ET_ARGS);   // (inside the library only)
+#if S2S_PM_PART == 2
+extern "C" int s2s_et_f16x3_short_chains(S2S_ET_ARGS) { return et_launch<false>(S2S_ET_PASS); }
+#endif
+#if S2S_PM_PART == 1
+extern "C" int s2s_edge_transition_f16x3(S2S_ET_ARGS) {
+    return n_res >= 32 ? et_launch<true>(S2S_ET_PASS) : s2s_et_f16x3_short_chains(S2S_ET_PASS);
+}
+#endif
+
+#if (defined(S2S_ET_PROBE) && S2S_PM_PART == 1) || (defined(S2S_EE_PROBE) && S2S_PM_PART == 3)   // (a probe build replaces the one unit its kernel lives in)
 extern "C" int s2s_et_probe_read(unsigned long long* host_out, int reset) {   // 512 x 17 counters
     hipError_t e = hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_et_probe), sizeof(unsigned long long) * 512 * 17);
     if (e == hipSuccess && reset) {
@@ -1367,6 +1388,7 @@ extern "C" int s2s_et_probe_read(unsigned long long* host_out, int reset) {   //
 }
 #endif
 
+#if S2S_PM_PART == 3
 extern "C" int s2s_edge_embed_f16x3(const float* node_a, const float* node_b, const float* rel_table, const float* bin_table,
                                      const float* bin_lower, const long long* residue_idx, const float* ca_xyz,
                                      const void* weight_stream, const float* b2, const float* b3, const float* ln_gamma,
@@ -1413,3 +1435,4 @@ extern "C" int s2s_edge_embed_f16x3(const float* node_a, const float* node_b, co
     }
     return (int)hipGetLastError();
 }
+#endif   // S2S_PM_PART == 3
