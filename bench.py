@@ -33,7 +33,38 @@ FLOPS_PER_PAIR_ET = 491520          # 2*(128*384 + 384*384 + 384*128)
 MFMA_FP32_PEAK = 157.3e12           # /opt/skills/guides/MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32)
 MFMA_F16_PEAK = 2500e12             # dense f16 / bf16 MFMA (v_mfma_f32_32x32x16_f16), /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK = 8e12
+MFMA_F16_SUSTAINED = 1800e12        # tools/ubench/mfma_shape_power.hip: what the 1400 W cap leaves of the nominal peak, random operands, every SIMD busy
+FLOPS_PER_PAIR_EE_MATRIX = 65536    # edge embedding, layers 2 and 3 (2 x 128x128 multiply-adds x2); the first layer (120 -> 128) is a table
+FLOPS_PER_PAIR_EE_SURVEY = 96256    #   lookup in the kernel -- SURVEY 8(d) counts it as the reference's GEMM: 2*(120*128 + 2*128*128)
+BYTES_PER_PAIR_EE = 672             # writes: z 512 B + the first IPA block's attn_bias 32 B + pair_z 128 B (inputs are O(N))
+BYTES_PER_PAIR_ET = 1013            # edge row read 512 + written 512 (+ proj outputs / mask, per-node parts amortised)
 METRIC = "sampled conformations/sec (whole node), 256-res chain, 100 denoise steps"
+
+
+def mfma_block(kernel, alg_flops, seconds, mode, **more):
+    """SURVEY 8(d) roofline block of an MFMA-bound kernel.  ``frac`` = ALGORITHMIC flops / time / dense peak of the MFMA dtype the kernel
+    issues (f16 for the split-f16 arithmetic, fp32-matrix for the exact one).  The f16x3 scheme issues every product three times
+    (x_h w_h + x_h w_l + x_l w_h): that figure is ``mfma_issue_frac`` -- matrix-pipe occupancy, not useful work."""
+    split = 3 if mode == "f16x3" else 1
+    peak = MFMA_F16_PEAK if mode == "f16x3" else MFMA_FP32_PEAK
+    ach = alg_flops / seconds
+    blk = {"bound": "mfma", "kernel": kernel, "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
+           "peak_source": ("nominal dense f16 MFMA 2.5 PFLOP/s" if mode == "f16x3" else "nominal fp32-matrix MFMA 157.3 TFLOP/s")
+                          + " (/opt/skills/guides/MI355X_MICROARCH.md)",
+           "mfma_issue_frac": split * ach / peak, "products_issued_per_fp32_product": split,
+           "vs_fp32_matrix_peak": ach / MFMA_FP32_PEAK, "algorithmic_flops": alg_flops, "seconds": seconds}
+    if mode == "f16x3":
+        blk["frac_of_sustained_peak"] = ach / MFMA_F16_SUSTAINED
+        blk["sustained_peak_note"] = "1.8 PFLOP/s = f16 MFMA rate this chip sustains under its power cap (tools/ubench/README.md); mfma_issue_frac x 2.5/1.8 = issue rate vs that"
+    blk.update(more)
+    return blk
+
+
+def hbm_block(kernel, alg_bytes, seconds, **more):
+    blk = {"bound": "hbm", "kernel": kernel, "achieved": alg_bytes / seconds / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+           "frac": alg_bytes / seconds / HBM_PEAK, "algorithmic_bytes": alg_bytes, "seconds": seconds}
+    blk.update(more)
+    return blk
 
 
 def cpu_model():
@@ -142,17 +173,26 @@ def main():
                                      plan_mixed_work, sample_mixed_lengths, schedule)
     from str2str_amd.synth import synth_chain
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    from str2str_amd.utils.launch import in_distributed_job, relaunch
+
+    # One command, any device count (as the reference's `trainer=ddp` run, src/eval.py:129,154): from a bare shell `--gpus N` starts its
+    # own N ranks under torch.distributed.run; inside a job (the driver's launch line, WORLD_SIZE set) this IS one of the ranks.
+    use_dist = in_distributed_job()
+    if a.gpus > 1 and not use_dist:
+        sys.exit(relaunch(a.gpus, __file__, sys.argv[1:]))
+    world = int(os.environ.get("WORLD_SIZE", "1")) if use_dist else 1
+    rank = int(os.environ.get("RANK", "0")) if use_dist else 0
+    local = int(os.environ.get("LOCAL_RANK", "0")) if use_dist else 0
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but this process is rank {rank} of a {world}-rank torch.distributed.run job "
+                 f"(pass --gpus {world}, or start it from a bare shell and let bench.py launch its own ranks)")
     # S2S_BENCH_BACKEND=gloo is a TEST hook: it lets the multi-rank control flow (rendezvous, barriers, max-over-ranks
     # timing, gather, rank-0-only output) run with several ranks sharing one GPU; the measured configuration is nccl (RCCL).
     backend = os.environ.get("S2S_BENCH_BACKEND", "nccl")
     local = local % torch.cuda.device_count() if backend == "gloo" else local
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if use_dist:   # (also a 1-rank job: `torch.distributed.run --nproc-per-node 1` runs the RCCL path end to end on one GPU)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
@@ -165,7 +205,7 @@ def main():
     # processes on `world` distinct devices are in the job before anything is timed (reported as distributed.ranks_seen / devices_seen).
     uuid = str(getattr(torch.cuda.get_device_properties(dev), "uuid", f"device{local}"))
     seen = [(rank, uuid)]
-    if world > 1:
+    if use_dist:
         seen = [None] * world
         dist.all_gather_object(seen, (rank, uuid))
 
@@ -185,7 +225,7 @@ def main():
         rig0 = Rigid.from_tensor_4x4(feats["rigidgroups_gt_frames"][..., 0, :, :].repeat(B, 1, 1, 1))
         # the gather carries the compact backbone [B, N, 5, 3] (N, CA, C, CB, O: everything compute_backbone fills of atom37's 37
         # slots, all_atom.py:141-173): 2.0 instead of 14.5 MB per rank at cfg2
-        gathered = [torch.empty(B, N, 5, 3, device=gdev) for _ in range(world)] if (world > 1 and rank == 0) else None
+        gathered = [torch.empty(B, N, 5, 3, device=gdev) for _ in range(world)] if (use_dist and rank == 0) else None
         per_rank = B
         workload = (f"configs[{1 if a.config == 'cfg2' else 3}]: single {N}-residue synthetic chain, {B} replicas per GPU x {S} "
                     f"denoise steps (+1 self-conditioning forward), probability-flow ODE, seeded synthetic weights")
@@ -198,7 +238,7 @@ def main():
             atom37 = forward_backward(net, diff, feats, rig0, 1.0, num_timesteps=S, min_t=0.01, probability_flow=True,
                                       self_conditioning=True, device=dev, rng=a.rng)
             bb = atom37[..., :5, :].contiguous()
-            if world > 1:
+            if use_dist:
                 dist.gather(bb.to(gdev), gathered, dst=0)
                 out = torch.stack(gathered) if rank == 0 else bb
             else:
@@ -235,7 +275,7 @@ def main():
                 rig0 = Rigid.from_tensor_4x4(tg["rigidgroups_gt_frames"][..., 0, :, :].repeat(B, 1, 1, 1))
                 a37 = forward_backward(net, diff, tg, rig0, 1.0, num_timesteps=S, min_t=0.01, probability_flow=True,
                                        self_conditioning=True, device=dev, rng=a.rng)
-                if world > 1:
+                if use_dist:
                     bufs = [torch.empty_like(a37, device=gdev) for _ in range(world)] if rank == 0 else None
                     dist.gather(a37.to(gdev), bufs, dst=0)
                     a37 = torch.cat(bufs) if rank == 0 else a37
@@ -309,7 +349,7 @@ def main():
                                           shard=(my, plan_world), plan=plan)
             # compact backbone [.,5,3] per piece, flattened: ONE gather of a padded flat buffer per step
             flat = torch.cat([p[..., :5, :].reshape(-1) for ps in pieces for _, p in ps]) if per_rank else torch.zeros(0, device=dev)
-            if world > 1:
+            if use_dist:
                 size = torch.tensor([flat.numel()], device=gdev)
                 sizes = [torch.zeros_like(size) for _ in range(world)]
                 dist.all_gather(sizes, size)
@@ -322,7 +362,7 @@ def main():
             return flat.cpu() if rank == 0 else None
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -347,7 +387,7 @@ def main():
     el = torch.tensor([elapsed], device=gdev, dtype=torch.float64)
     mine = torch.tensor([my_elapsed], device=gdev, dtype=torch.float64)
     per_rank_s = [mine.clone() for _ in range(world)]
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_gather(per_rank_s, mine)
     elapsed = float(el.item())
@@ -386,60 +426,64 @@ def main():
                        "rng_note": "device Philox noise (throughput mode): checked for finite results and the forward-marginal distribution; "
                                    "the fixed-seed parity runs of tests/ use --rng host" if a.rng == "device" else "host generator, reference draw order",
                        "step_definition": "one replica chunk (cfg3: all 12 targets; cfg5: the rank's plan) sampled end to end incl. gather + D2H"},
-            "distributed": {"backend": (dist.get_backend() if world > 1 else None), "world_size": world,
+            "distributed": {"backend": (dist.get_backend() if use_dist else None), "world_size": world,
                             "ranks_seen": sorted(int(r) for r, _ in seen), "devices_seen": len({u for _, u in seen}),
                             "per_rank_conformations_per_s": [a.steps * per_rank / float(x.item()) for x in per_rank_s]},
         }
         line["config"].update(extra)
+        ipa_name = ("s2s_ipa_attention_f16w" if mode == "f16x3" else "s2s_ipa_attention") + " + s2s_ipa_opair"
+        folded = mode == "f16x3" and os.environ.get("S2S_IPA_FOLD", "1") != "0"
+        et_name = "s2s_edge_transition" + {"f16x3": "_f16x3 (edge_transition_f16_kernel)"}.get(mode, " (edge_transition_kernel)")
         if a.config in ("cfg2", "cfg4") and et_n:
+            # the dominant kernel, per launch, from HIP events on the launch stream INSIDE the timed region
             pairs = pairs_main
-            alg = pairs * FLOPS_PER_PAIR_ET                       # fp32 multiply-add flops the operator needs
-            executed = alg * {"f16x3": 3}.get(mode, 1)   # 16-bit products executed per fp32 product
-            peak = MFMA_FP32_PEAK if mode == "f32" else MFMA_F16_PEAK
-            ach = executed / (et_ms * 1e-3)
             traffic, traffic_src = traffic_from_profiles(pairs, mode)
-            ipa_bytes = B * 4 * (9512 * N + 40 * N * N)
-            line["roofline"] = {
-                "bound": "mfma",
-                "kernel": "s2s_edge_transition" + {"f16x3": "_f16x3 (edge_transition_f16_kernel)"}.get(mode, " (edge_transition_kernel)"),
-                "achieved": ach / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": ach / peak,
+            line["roofline"] = mfma_block(
+                et_name, pairs * FLOPS_PER_PAIR_ET, et_ms * 1e-3, mode,
                 # `traffic` (HBM bytes per launch from PMC counters) cannot be collected inside this process: the counters need rocprofv3
                 # around it, in passes of their own (tools/pmc_hbm_traffic.sh).  The committed pass of the same kernel is quoted
                 # under its own name, scaled per pair.
-                "traffic": None, "traffic_from_profile": traffic, "traffic_source": traffic_src, "launches_timed": et_n, "mean_launch_ms": et_ms,
-                "algorithmic_flops_per_launch": alg, "executed_mfma_flops_per_launch": executed,
-                "fp32_equivalent_tflops": alg / (et_ms * 1e-3) / 1e12,
-                "fp32_equivalent_vs_fp32_mfma_peak": alg / (et_ms * 1e-3) / MFMA_FP32_PEAK}
-            ipa_name = {"f16x3": "s2s_ipa_attention_f16w"}.get(mode, "s2s_ipa_attention")
-            line["ipa_kernel"] = {"bound": "hbm", "kernel": f"{ipa_name} + s2s_ipa_opair", "mean_launch_ms": ipa_ms,
-                                  "launches_timed": ipa_n, "achieved": ipa_bytes / (ipa_ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9,
-                                  "unit": "GB/s", "frac": ipa_bytes / (ipa_ms * 1e-3) / HBM_PEAK,
-                                  "algorithmic_bytes_per_launch": ipa_bytes,
-                                  # SURVEY 8(d) counts the operator as the reference states it (q, k, v per head).  The default f16 path
-                                  # folds W_k / W_v away and reads s as K and V of every head (models/net/ipa.py _folded_packs): what the
-                                  # launch pair must move then is 3584 floats per residue less
-                                  "operands": "K = V = s (folded projections)" if mode == "f16x3" and os.environ.get("S2S_IPA_FOLD", "1") != "0" else "per-head k / v",
-                                  "algorithmic_bytes_per_launch_folded_operands": B * 4 * (5928 * N + 40 * N * N)}
+                traffic=None, traffic_from_profile=traffic, traffic_source=traffic_src, launches_timed=et_n, mean_launch_ms=et_ms,
+                pairs_per_launch=pairs, flops_per_pair=FLOPS_PER_PAIR_ET, algorithmic_bytes_per_launch=pairs * BYTES_PER_PAIR_ET,
+                formula="frac = pairs_per_launch x flops_per_pair / mean_launch_ms / peak (SURVEY 8d; 491 520 = 2 x (128x384 + 384x384 + 384x128) x 2 "
+                        "minus nothing: the G_j pre-product is O(N))")
+            ipa_bytes = B * 4 * (9512 * N + 40 * N * N)
+            ipa_moved = B * 4 * (5928 * N + 40 * N * N) if folded else ipa_bytes
+            line["ipa_kernel"] = hbm_block(
+                ipa_name, ipa_bytes, ipa_ms * 1e-3, mean_launch_ms=ipa_ms, launches_timed=ipa_n, algorithmic_bytes_per_launch=ipa_bytes,
+                # SURVEY 8(d) counts the operator as the reference states it (q, k, v per head).  The default f16 path folds W_k / W_v
+                # away and reads s as K and V of every head (models/net/ipa.py _folded_packs): what the launch must move then is 3584
+                # floats per residue less -- `frac_moved_bytes` prices the kernel on those
+                operands="K = V = s (folded projections)" if folded else "per-head k / v",
+                moved_bytes_per_launch=ipa_moved, frac_moved_bytes=ipa_moved / (ipa_ms * 1e-3) / HBM_PEAK,
+                formula="frac = B x 4 x (9512 N + 40 N^2) / mean_launch_ms / 8 TB/s (SURVEY 8d)")
         if table is not None:
             line["kernel_times"] = table
             n_eval = S + 1
-            et, ipa = table["s2s_edge_transition"], table["s2s_ipa_attention"]
+            et, ipa, ee, nl = (table[k] for k in ("s2s_edge_transition", "s2s_ipa_attention", "s2s_edge_embed", "s2s_node_linear"))
+            src = "kernel_times (one extra step with per-launch HIP events, HIP graphs off)"
             if a.config in ("cfg3", "cfg5") and et["launches"] and ipa["launches"]:
                 # efficiency statements for the small-protein / mixed-length regimes, on the REAL (unpadded) work of the step:
-                # 3 edge transitions and 4 attention launch pairs per network evaluation
-                alg = 3 * n_eval * eval_pairs * FLOPS_PER_PAIR_ET
-                executed = alg * {"f16x3": 3}.get(mode, 1)
-                peak = MFMA_FP32_PEAK if mode == "f32" else MFMA_F16_PEAK
-                line["roofline"] = {"bound": "mfma", "kernel": "s2s_edge_transition" + ("_f16x3" if mode == "f16x3" else ""),
-                                    "achieved": executed / (et["total_ms"] * 1e-3) / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                                    "frac": executed / (et["total_ms"] * 1e-3) / peak, "traffic": None,
-                                    "launches_timed": et["launches"], "total_ms": et["total_ms"],
-                                    "source": "kernel_times (one extra step with per-launch HIP events, HIP graphs off)"}
+                # 3 edge transitions and 4 attention launches per network evaluation
+                line["roofline"] = mfma_block(et_name, 3 * n_eval * eval_pairs * FLOPS_PER_PAIR_ET, et["total_ms"] * 1e-3, mode, traffic=None,
+                                              launches_timed=et["launches"], total_ms=et["total_ms"], source=src)
                 ib = 4 * n_eval * eval_ipa_bytes
-                line["ipa_kernel"] = {"bound": "hbm", "kernel": ("s2s_ipa_attention_f16w" if mode == "f16x3" else "s2s_ipa_attention") + " + s2s_ipa_opair",
-                                      "achieved": ib / (ipa["total_ms"] * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                                      "frac": ib / (ipa["total_ms"] * 1e-3) / HBM_PEAK, "launches_timed": ipa["launches"],
-                                      "total_ms": ipa["total_ms"], "algorithmic_bytes": ib}
+                line["ipa_kernel"] = hbm_block(ipa_name, ib, ipa["total_ms"] * 1e-3, launches_timed=ipa["launches"], total_ms=ipa["total_ms"], source=src)
+            if eval_pairs and ee["launches"]:
+                # edge embedding: one launch per evaluation; both of its roofs (it is bound by neither: VALU issue)
+                eef = n_eval * eval_pairs * FLOPS_PER_PAIR_EE_MATRIX
+                blk = mfma_block("s2s_edge_embed" + ("_f16x3 (edge_embed_f16_kernel)" if mode == "f16x3" else ""), eef, ee["total_ms"] * 1e-3, mode,
+                                 launches_timed=ee["launches"], total_ms=ee["total_ms"], flops_per_pair=FLOPS_PER_PAIR_EE_MATRIX, source=src,
+                                 flops_per_pair_survey_8d=FLOPS_PER_PAIR_EE_SURVEY,
+                                 note="the 120 -> 128 first layer is a table lookup in the kernel: matrix work = layers 2 and 3")
+                blk["frac_survey_flops"] = blk["frac"] * FLOPS_PER_PAIR_EE_SURVEY / FLOPS_PER_PAIR_EE_MATRIX
+                blk["hbm"] = hbm_block("(same launches)", n_eval * eval_pairs * BYTES_PER_PAIR_EE, ee["total_ms"] * 1e-3, bytes_per_pair=BYTES_PER_PAIR_EE)
+                line["edge_embed_kernel"] = blk
+            if nl["launches"] and kp.work.get("s2s_node_linear", [0])[0]:
+                line["node_kernel"] = mfma_block("s2s_node_linear / _multi / _chain / _vfrag (node_gemm.hip)", kp.work["s2s_node_linear"][0],
+                                                 nl["total_ms"] * 1e-3, mode, launches_timed=nl["launches"], total_ms=nl["total_ms"], source=src,
+                                                 note="flops = sum over launches of 2 M K N as launched; ~11 launches of 0.1 ms each per IPA block at cfg2: "
+                                                      "launch- and latency-bound, the fraction is reported for completeness")
         if world == 1 and not a.no_cpu_baseline and a.config == "cfg2":
             line["cpu_baseline"] = cpu_baseline(N, S, steps_sampled=a.cpu_steps)
         if world == 1 and a.config == "cfg2" and not a.no_other_configs and a.n_res is None and a.replicas is None and a.denoise_steps is None:
@@ -453,17 +497,24 @@ def main():
             for cfg in ("cfg3", "cfg4", "cfg5", "ref_default"):
                 t_sub = time.perf_counter()
                 try:
+                    # (cfg4 times its kernels inside the timed region like cfg2; cfg3 / cfg5 run under HIP graphs, so their kernel
+                    #  fractions come from one more step with per-launch events: the kernel table)
                     r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", "1", "--warmup", "0",
-                                        "--no-cpu-baseline", "--no-kernel-table"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                                        "--no-cpu-baseline"] + ([] if cfg in ("cfg3", "cfg5") else ["--no-kernel-table"]), capture_output=True, text=True, timeout=900, cwd=ROOT,
+                                       env={k: v for k, v in os.environ.items() if k not in   # (side runs are plain 1-GPU processes)
+                                            ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")})
                     sub = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
                     line["other_configs"][cfg] = {"value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"], "steps": 1,
                                                   "warmup": 0, "workload": sub["config"]["workload"],
                                                   "range_fallback": sub["config"].get("range_fallback"),
+                                                  **{k: {kk: vv for kk, vv in sub[k].items() if kk in ("kernel", "bound", "achieved", "peak", "unit", "frac", "mfma_issue_frac",
+                                                                                                      "frac_moved_bytes", "launches_timed", "mean_launch_ms", "total_ms")}
+                                                     for k in ("roofline", "ipa_kernel", "edge_embed_kernel") if k in sub},
                                                   "process_wall_s": round(time.perf_counter() - t_sub, 1)}
                 except Exception as e:   # a failed side run must not cost the headline line
                     line["other_configs"][cfg] = {"error": f"{type(e).__name__}: {e}"[:300]}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

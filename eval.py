@@ -119,7 +119,20 @@ def evaluate(cfg):
 def main(argv=None):
     logging.basicConfig(level=logging.INFO, format="[%(asctime)s][%(name)s][%(levelname)s] - %(message)s")
     load_dotenv(os.path.join(ROOT, ".env"))
-    cfg = C.compose(os.path.join(ROOT, "configs"), "eval.yaml", list(sys.argv[1:] if argv is None else argv))
+    args = list(sys.argv[1:] if argv is None else argv)
+    cfg = C.compose(os.path.join(ROOT, "configs"), "eval.yaml", args)
+    # `trainer.devices=N` / `trainer=ddp` from a bare shell: start N ranks, one per GPU, as Lightning does behind the reference's
+    # trainer.predict (src/eval.py:129,154; configs/trainer/ddp.yaml).  Inside a torch.distributed.run job this is one of the ranks.
+    from str2str_amd.utils.launch import in_distributed_job, relaunch, resolve_devices
+
+    n_dev = resolve_devices(cfg.trainer.get("devices", 1)) if cfg.trainer.get("accelerator", "gpu") != "cpu" else 1
+    if n_dev > 1 and not in_distributed_job() and not cfg.get("dry_run") and not (cfg.get("pred_dir") and os.path.isdir(cfg.get("pred_dir"))):
+        rc = relaunch(n_dev, __file__, args)
+        if argv is None:
+            sys.exit(rc)
+        if rc:
+            raise RuntimeError(f"eval.py: the {n_dev}-rank job exited with code {rc}")
+        return None
     if cfg.get("extras", {}).get("print_config") and int(os.environ.get("RANK", "0")) == 0:
         import yaml
 

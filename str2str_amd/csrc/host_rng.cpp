@@ -25,7 +25,12 @@ inline uint32_t mix(uint32_t u, uint32_t v) {
 // vectorises, and the compiler emits one clone per instruction set for the loader to pick (43 M outputs = the step draws of one
 // 64-replica chunk of an 80-residue target over 700 steps: 26-38 ms as one scalar pass per twist through the 64-bit slots, 8-14 ms so
 // on the x86-64 baseline).
-__attribute__((target_clones("avx512f", "avx2", "default"))) void twist_n(uint32_t* __restrict w, unsigned long long n) {
+#if defined(__x86_64__) && defined(__ELF__) && defined(__gnu_linux__)
+#define S2S_TWIST_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))
+#else   // (function multi-versioning is x86 + ifunc only; elsewhere the plain function: an optional speed-up must not break the build)
+#define S2S_TWIST_CLONES
+#endif
+S2S_TWIST_CLONES void twist_n(uint32_t* __restrict w, unsigned long long n) {
     for (unsigned long long t = 0; t < n; ++t) {
         for (int j = 0; j < kD; ++j) w[j] = w[j + kM] ^ mix(w[j], w[j + 1]);
         for (int j = kD; j < 2 * kD; ++j) w[j] = w[j - kD] ^ mix(w[j], w[j + 1]);

@@ -343,8 +343,8 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
     float amax = 0.f;   // range guard (range_flag.h): running maximum of every value that is split into f16 planes
     // Block exponent of the hidden activations (sk = 2^-prescale_exp, 1 by default): the planes of h1 = relu(layer 1) and of
     // relu(layer 2) + x hold sk x the value -- relu is positively homogeneous, so the factor rides in constants that exist anyway
-    // (layer 1: (acc + 32 B_j) * (sk / 32) + sk A_i, the caller hands node_ab in as [sk A_i | 32 B_j]; layer 2: relu(acc / 32 + sk b2) + sk x; final layer:
-    // start value 32 sk bf) and LayerNorm removes it (eps scaled alike).  Exact for powers of two; sk = 1 gives today's bits.
+    // (layer 1: (acc + 32 B_j) * (sk / 32) + sk A_i, the caller hands node_ab in as [sk A_i | 32 B_j | 32 sk G_j]; layer 2: relu(acc / 32 + sk b2) + sk x; final
+    // layer: the per-node start value 32 sk G_j, which carries the bias b_f) and LayerNorm removes it (eps scaled alike).  Exact for powers of two; sk = 1 gives today's bits.
     const float inv1 = kInvWS * sk;
     // planes (x_h, x_l), see the header
     auto split4 = [&](const float (&x)[4], f16x8& ph, f16x8& pm, int at) {

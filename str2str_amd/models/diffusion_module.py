@@ -26,7 +26,7 @@ import torch
 
 from ..common.pdb_utils import AsyncPdbWriter, atom37_to_pdb, merge_pdbfiles
 from ..common.rigid_utils import Rigid
-from ..sampler import (forward_backward, forward_backward_chunks, forward_backward_deltas, plan_mixed_work, rank_chunk_slices,
+from ..sampler import (forward_backward, forward_backward_chunks, iter_forward_backward_deltas, plan_mixed_work, rank_chunk_slices,
                        sample_mixed_lengths, shard_range)
 
 try:  # pragma: no cover - depends on the environment
@@ -43,17 +43,34 @@ def _ns(obj):
     return obj  # OmegaConf DictConfig / namespace: attribute access already works
 
 
+BACKBONE_SLOTS = 5   # compute_backbone fills atom37 slots 0..4 (N, CA, C, CB, O) and nothing else (reference all_atom.py:141-173)
+
+
+def compact_backbone(atom37: torch.Tensor) -> torch.Tensor:
+    """[.., N, 37, 3] -> the five slots that carry coordinates, [.., N, 5, 3] (what travels over xGMI: 7.4x less than atom37)."""
+    return atom37[..., :BACKBONE_SLOTS, :].contiguous()
+
+
+def expand_backbone(bb: torch.Tensor) -> torch.Tensor:
+    """Inverse of ``compact_backbone``: the other 32 slots of atom37 are exact zeros in ``compute_backbone``'s output."""
+    out = bb.new_zeros(tuple(bb.shape[:-2]) + (37, 3))
+    out[..., :BACKBONE_SLOTS, :] = bb
+    return out
+
+
 def gather_replicas(atom37: torch.Tensor, total: int, group=None) -> Optional[torch.Tensor]:
-    """Gather every rank's replica slice [b_r, N, 37, 3] to rank 0 in replica order (one collective).
+    """Gather every rank's replica slice [b_r, N, 37, 3] to rank 0 in replica order (ONE collective; RCCL gathers the device tensors,
+    each rank over its own xGMI link to rank 0).  The payload is the compact backbone [per, N, 5, 3]; rank 0 gets atom37 back.
     Slices follow ``shard_range`` (ceil split), so they are padded to the common size for the gather."""
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     per = -(-total // world)
+    bb = compact_backbone(atom37)
     if dist.get_backend(group) == "gloo":   # (CPU collectives: the multi-process tests; RCCL gathers device tensors)
-        atom37 = atom37.cpu()
-    pad = atom37.new_zeros((per,) + tuple(atom37.shape[1:]))
-    pad[: atom37.shape[0]] = atom37
+        bb = bb.cpu()
+    pad = bb.new_zeros((per,) + tuple(bb.shape[1:]))
+    pad[: bb.shape[0]] = bb
     bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
     dist.gather(pad, bufs, dst=0, group=group)
     if rank != 0:
@@ -62,7 +79,7 @@ def gather_replicas(atom37: torch.Tensor, total: int, group=None) -> Optional[to
     for r, buf in enumerate(bufs):
         lo, hi = shard_range(total, r, world)
         parts.append(buf[: hi - lo])
-    return torch.cat(parts, dim=0)
+    return expand_backbone(torch.cat(parts, dim=0))
 
 
 class DiffusionLitModule(_Base):
@@ -99,7 +116,7 @@ class DiffusionLitModule(_Base):
             delta_range = [-1.0]
         assert batch["aatype"].shape[0] == 1, "Batch size must be 1 for correct inference."
         device = next(self.net.parameters()).device
-        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        distributed = dist.is_available() and dist.is_initialized()   # (also a 1-rank group: the same collective path at every world size)
         shard = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
         if self.rng_mode == "device" and not getattr(self, "_device_rng_seeded", False):
             # throughput mode draws on the device generator: decorrelate the ranks once (they all start from the same
@@ -111,24 +128,27 @@ class DiffusionLitModule(_Base):
         kw = dict(num_timesteps=inf.num_timesteps, min_t=inf.min_t, noise_scale=inf.noise_scale,
                   probability_flow=inf.probability_flow, self_conditioning=self_cond, device=device, rng=self.rng_mode)
         self.last_samples = {}   # t_delta -> atom37 [n_replica, N, 37, 3] device tensor of the last target (rank 0; programmatic callers)
-        # files are written behind the sampler (the GPU goes on with the next t_delta meanwhile); the context manager stops the worker
+        # files are written behind the sampler (a group of t_deltas is gathered and queued as soon as it is sampled; the GPU goes on
+        # with the next group meanwhile -- groups of ONE t_delta for targets too large to merge); the context manager stops the worker
         # and frees its page-locked buffers on every path -- after an exception the files still queued are dropped, not written
         with AsyncPdbWriter() as writer:
             gt4 = batch["rigidgroups_gt_frames"][..., 0, :, :].clone()
             # The reference's chunks (and its loop over t_delta) are units of its host noise stream, not of the arithmetic: the chunks --
-            # and the t_deltas -- of a target whose replicas fit a pair budget are sampled as ONE batch (sampler.forward_backward_deltas:
+            # and the t_deltas -- of a target whose replicas fit a pair budget are sampled as ONE batch (sampler.iter_forward_backward_deltas:
             # same samples file for file, far fewer launches; S2S_MERGE_DELTAS=0 = one t_delta at a time, S2S_MERGE_CHUNKS=0 = one
             # trajectory per chunk); an empty slice still advances the host generator in lock-step with the other ranks
-            samples = forward_backward_deltas(self.net, self.diffuser, batch, gt4, rank_chunk_slices(n_replica, replica_per_batch, *shard),
-                                              [float(t) for t in delta_range], **kw)
-            for t_delta, a37 in zip(delta_range, samples):
-                if distributed:
-                    a37 = gather_replicas(a37, n_replica)   # ONE collective per (target, t_delta)
-                if shard[0] == 0:
-                    self.last_samples[float(t_delta)] = a37
-                    t_dir = os.path.join(output_dir, f"{t_delta}")
-                    os.makedirs(t_dir, exist_ok=True)
-                    writer.submit(a37, os.path.join(t_dir, f"{accession_code}.pdb"), **extra)
+            groups = iter_forward_backward_deltas(self.net, self.diffuser, batch, gt4, rank_chunk_slices(n_replica, replica_per_batch, *shard),
+                                                  [float(t) for t in delta_range], **kw)
+            for idx, samples in groups:   # a group's gather + files run while the GPU is already sampling the next group
+                for i, a37 in zip(idx, samples):
+                    t_delta = delta_range[i]
+                    if distributed:
+                        a37 = gather_replicas(a37, n_replica)   # ONE collective per (target, t_delta)
+                    if shard[0] == 0:
+                        self.last_samples[float(t_delta)] = a37
+                        t_dir = os.path.join(output_dir, f"{t_delta}")
+                        os.makedirs(t_dir, exist_ok=True)
+                        writer.submit(a37, os.path.join(t_dir, f"{accession_code}.pdb"), **extra)
             saved = writer.results()
         all_dir = os.path.join(output_dir, "all_delta")
         if shard[0] == 0:
@@ -145,7 +165,7 @@ class DiffusionLitModule(_Base):
         diffusion_module.py:249, and its padding semantics would be wrong for it); here padding is exact (sampler.
         sample_mixed_lengths), so every chain is sampled as if it ran alone.  Same hyper-parameters, same output tree
         (``<output_dir>/<t_delta>/<accession>.pdb`` + ``all_delta``).  The (chain, replica block) items are distributed over the
-        ranks by FLOP weight (``plan_mixed_work``); ONE gather of a flat coordinate buffer per t_delta brings them to rank 0.  The
+        ranks by FLOP weight (``plan_mixed_work``); ONE gather of a flat buffer of compact backbones [., 5, 3] per t_delta brings them to rank 0.  The
         noise stream is per (chain, block) -- not the reference's per-target chunk order -- so this is the throughput mode: same
         distribution, different draws than ``predict_step`` under the same seed."""
         import torch.distributed as dist
@@ -158,7 +178,7 @@ class DiffusionLitModule(_Base):
             delta_range = [-1.0]
         self_cond = bool(inf.self_conditioning) and bool(self.net.embedder.self_conditioning)
         device = next(self.net.parameters()).device
-        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        distributed = dist.is_available() and dist.is_initialized()
         rank, world = (dist.get_rank(), dist.get_world_size()) if distributed else (0, 1)
         if self.rng_mode == "device" and not getattr(self, "_device_rng_seeded", False):
             torch.cuda.manual_seed(torch.initial_seed() + 7919 * rank)
@@ -178,14 +198,14 @@ class DiffusionLitModule(_Base):
                                           seed_base=seed_base)
             # this rank's pieces in plan order (chain, replica_lo, replica_hi) -> one flat buffer
             mine = [(k, lo, p) for k, ps in enumerate(pieces) for lo, p in ps]
-            flat = torch.cat([p.reshape(-1) for _, _, p in mine]) if mine else torch.zeros(0, device=device)
+            flat = torch.cat([compact_backbone(p).reshape(-1) for _, _, p in mine]) if (mine and distributed) else torch.zeros(0, device=device)
             per_chain = {k: [] for k in range(len(targets))}
             if distributed:
                 cpu = dist.get_backend() == "gloo"
                 buf_dev = torch.device("cpu") if cpu else device
                 # every rank can compute every rank's piece list from the plan: sizes are known, only the payload travels
                 layout = [sorted(((k, lo, hi) for b in plan[r] for k, lo, hi in b["items"]), key=lambda x: (x[0], x[1])) for r in range(world)]
-                sizes = [sum((hi - lo) * lens[k] * 37 * 3 for k, lo, hi in layout[r]) for r in range(world)]
+                sizes = [sum((hi - lo) * lens[k] * BACKBONE_SLOTS * 3 for k, lo, hi in layout[r]) for r in range(world)]   # compact [., 5, 3]
                 pad = torch.zeros(max(sizes), device=buf_dev)
                 pad[: flat.numel()] = flat.to(buf_dev)
                 bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
@@ -194,8 +214,8 @@ class DiffusionLitModule(_Base):
                     for r in range(world):
                         o = 0
                         for k, lo, hi in layout[r]:
-                            n = (hi - lo) * lens[k] * 37 * 3
-                            per_chain[k].append((lo, bufs[r][o:o + n].view(hi - lo, lens[k], 37, 3)))
+                            n = (hi - lo) * lens[k] * BACKBONE_SLOTS * 3
+                            per_chain[k].append((lo, expand_backbone(bufs[r][o:o + n].view(hi - lo, lens[k], BACKBONE_SLOTS, 3))))
                             o += n
             else:
                 for k, lo, p in mine:

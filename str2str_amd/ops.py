@@ -81,6 +81,7 @@ class KernelTimer:
     def __init__(self, *names):
         self.names = set(names)
         self.events = {n: [] for n in names}
+        self.work = {n: [0, 0] for n in names}   # algorithmic [flops, bytes] of the timed launches, where the wrapper states them
 
     def __enter__(self):
         KernelTimer.active = self if self.names else None   # no names: a no-op context (HIP graphs stay enabled)
@@ -100,10 +101,12 @@ class KernelTimer:
         return sum(a.elapsed_time(b) for a, b in ev), len(ev)
 
 
-def _timed(name, launch):
+def _timed(name, launch, flops=0, nbytes=0):
     kt = KernelTimer.active
     if kt is None or name not in kt.names:
         return launch()
+    kt.work[name][0] += int(flops)
+    kt.work[name][1] += int(nbytes)
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     rc = launch()
@@ -350,6 +353,10 @@ def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, gamma, beta, mask,
         raise HipLibraryError(f"edge_transition_f16x3: prescale_exp {prescale_exp} outside 0 .. 15")
     # C ABI: node_ab = [2^-e (A_i + b1) | 2^5 B_j | 2^(5-e) G_j] -- the row half at the planes' scale, the column half and the final layer's
     # start values at the accumulators' (the caller's job)
+    if tuple(edge.shape) != (B, N, N, 128) or tuple(node_ab.shape) != (B, N, 896) or tuple(node_p.shape) != (B, N, 128):
+        raise HipLibraryError(f"edge_transition_f16x3: bad shapes (edge {tuple(edge.shape)}, node_ab {tuple(node_ab.shape)}, node_p {tuple(node_p.shape)}): "
+                              "edge is [B, N, N, 128], node_p [B, N, 128] and node_ab [B, N, 896] = EdgeTransition.node_parts (row half | column half | "
+                              "j-side residual through the final layer; the 768-column form of earlier ABI versions is not accepted)")
     if not ab_kernel_form or prescale_exp:
         sc = node_ab.new_ones(896)
         sc[:384] = 2.0 ** -int(prescale_exp)
@@ -359,8 +366,6 @@ def edge_transition_f16x3(edge, node_ab, node_p, wstream, b2, gamma, beta, mask,
     if out_layout not in ("rowmajor", "tiled", "none") or (out_layout == "none" and proj is None):
         raise HipLibraryError(f"edge_transition_f16x3: out_layout {out_layout!r}" + (" needs proj" if out_layout == "none" else ""))
     _req(edge.buf if in_tiled else edge, name="edge")
-    if tuple(edge.shape) != (B, N, N, 128) or node_ab.shape != (B, N, 896) or node_p.shape != (B, N, 128):
-        raise HipLibraryError("edge_transition_f16x3: bad shapes (node_ab is [B, N, 896]: EdgeTransition.node_parts)")
     for n, t in (("node_ab", node_ab), ("node_p", node_p), ("b2", b2), ("gamma", gamma), ("beta", beta)):
         _req(t, name=n)
     pb = pbias = ppz = None
@@ -931,7 +936,7 @@ def node_linear(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles: int, *
         _p(xp), _p(wpk), _p(bias), n_rows, k_in, n_out, tiles, _p(pre_scale), int(bool(relu)), _p(pre_mask), _p(residual),
         residual.shape[-1] if residual is not None else 0, _p(g), _p(b), float(eps), _p(post_mask), _p(out_f32),
         out_f32.shape[-1] if out_f32 is not None else 0, out_col0, _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16,
-        map_pad, map_src, _stream())), "s2s_node_linear")
+        map_pad, map_src, _stream()), flops=2 * n_rows * k_in * n_out), "s2s_node_linear")
     return out_f32, out_xp
 
 
@@ -955,7 +960,7 @@ def node_linear_f32(x, wpk32, bias, n_rows: int, k_in: int, n_out: int, tiles: i
     _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_f32(
         _p(x), x.shape[1], _p(wpk32), _p(bias), n_rows, k_in, n_out, tiles, _p(pre_scale), int(bool(relu)), _p(pre_mask), _p(residual),
         residual.shape[-1] if residual is not None else 0, _p(g), _p(b), float(eps), _p(post_mask), _p(out), out.shape[-1], out_col0,
-        _stream())), "s2s_node_linear_f32")
+        _stream()), flops=2 * n_rows * k_in * n_out), "s2s_node_linear_f32")
     return out
 
 
@@ -1072,7 +1077,7 @@ def node_linear_vfrag(xp, wpk, bias, n_rows: int, k_in: int, n_out: int, tiles_p
     map_pad, map_src = row_map if row_map is not None else (0, 0)
     range_flag()
     _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_vfrag(_p(xp), _p(wpk), _p(bias), n_rows, k_in, n_out, tiles_per_head,
-                                                                       _p(out), map_pad, map_src, _stream())),
+                                                                       _p(out), map_pad, map_src, _stream()), flops=2 * n_rows * k_in * n_out),
            "s2s_node_linear_vfrag")
     return out
 
@@ -1113,7 +1118,8 @@ def node_linear_multi(xp, w, bias, pre_scale, dims, out_f32, out_xp):
             _req(out_xp[i], torch.int16, "out_xp")
             p.out_xp, p.out_xp_ksteps, p.out_xp_kstep0 = out_xp[i].data_ptr(), xk // 16, xk0 // 16
     range_flag()
-    _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_multi(ctypes.byref(arr), n, _stream())), "s2s_node_linear_multi")
+    _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_multi(ctypes.byref(arr), n, _stream()),
+                  flops=sum(2 * arr[i].n_rows * arr[i].k_in * arr[i].n_out for i in range(n))), "s2s_node_linear_multi")
 
 
 def ipa_projections(s_xp, q, k, v, qp, kvp, n_rows: int, n_rows_padded: int, row_map: Optional[tuple] = None, tiles_per_head: int = 8):
@@ -1152,7 +1158,8 @@ def ipa_projections(s_xp, q, k, v, qp, kvp, n_rows: int, n_rows_padded: int, row
     fill(qp, n_rows, out_f32=qp_o.data_ptr(), out_ld=qp["n"])
     fill(kvp, n_rows, out_f32=kvp_o.data_ptr(), out_ld=kvp["n"])
     range_flag()
-    _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_multi(ctypes.byref(arr), n, _stream())), "s2s_node_linear_multi")
+    _check(_timed("s2s_node_linear", lambda: lib.s2s_node_linear_multi(ctypes.byref(arr), n, _stream()),
+                  flops=sum(2 * arr[i].n_rows * arr[i].k_in * arr[i].n_out for i in range(n))), "s2s_node_linear_multi")
     return q_xp, k_xp, v_vf, qp_o, kvp_o
 
 
@@ -1200,7 +1207,7 @@ def node_chain(xp, w_row, bias, relu, n_rows: int, width: int, pre_mask=None, re
         _p(xp), ctypes.byref(arr), n, n_rows, width, k0, _p(mid_residual), mid_residual.shape[-1] if mid_residual is not None else 0,
         _p(mid_out_f32), mid_out_f32.shape[-1] if mid_out_f32 is not None else 0, _p(pre_mask), _p(residual), residual.shape[-1] if residual is not None else 0,
         _p(ln_gamma), _p(ln_beta), float(ln_eps), _p(post_mask), _p(out_f32), out_f32.shape[-1] if out_f32 is not None else 0, out_col0,
-        _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16, _stream())), "s2s_node_chain")
+        _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16, _stream()), flops=2 * n_rows * width * (k0 + (n - 1) * width)), "s2s_node_chain")
     return out_f32, out_xp
 
 
@@ -1446,7 +1453,7 @@ def host_rng_fast_forward_ok() -> bool:
         try:
             ok = True
             for seed, sizes in ((1234567, (48, 50, 4800, 17)), (7, (15360, 3780, 3780, 16))):
-                torch.manual_seed(seed)
+                torch.default_generator.manual_seed(seed)       # the CPU generator ONLY (torch.manual_seed would reseed every device generator too)
                 torch.rand(3)                                   # an engine position that is not a block boundary
                 start = torch.get_rng_state()
                 for n in sizes:

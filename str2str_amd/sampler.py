@@ -649,10 +649,19 @@ def merge_delta_groups(steps, b: int, N: int, max_pairs: int = None):
     return [list(range(i, min(i + cap, len(steps)))) for i in range(0, len(steps), cap)]
 
 
-@torch.no_grad()
-def forward_backward_deltas(net, diffuser, batch: dict, gt_frames_4x4: torch.Tensor, chunks, delta_range, *, num_timesteps: int,
-                            min_t: float = 0.01, noise_scale: float = 1.0, probability_flow: bool = True,
-                            self_conditioning: bool = True, device=None, rng: str = "host", max_pairs: int = None):
+def forward_backward_deltas(net, diffuser, batch: dict, gt_frames_4x4: torch.Tensor, chunks, delta_range, **kw):
+    """``iter_forward_backward_deltas`` collected: [atom37 [sum(hi - lo), N, 37, 3] per t_delta] in ``delta_range`` order."""
+    delta_range = list(delta_range)
+    out = [None] * len(delta_range)
+    for idx, a37s in iter_forward_backward_deltas(net, diffuser, batch, gt_frames_4x4, chunks, delta_range, **kw):
+        for i, a in zip(idx, a37s):
+            out[i] = a
+    return out
+
+
+def iter_forward_backward_deltas(net, diffuser, batch: dict, gt_frames_4x4: torch.Tensor, chunks, delta_range, *, num_timesteps: int,
+                                 min_t: float = 0.01, noise_scale: float = 1.0, probability_flow: bool = True,
+                                 self_conditioning: bool = True, device=None, rng: str = "host", max_pairs: int = None):
     """All t_deltas of one target (the outer loop of the reference's predict_step, diffusion_module.py:341-367) -> [atom37
     [sum(hi - lo), N, 37, 3] per t_delta], each exactly what ``forward_backward_chunks`` returns for that t_delta.
 
@@ -664,23 +673,25 @@ def forward_backward_deltas(net, diffuser, batch: dict, gt_frames_4x4: torch.Ten
     has, with its own timestep image, step parameters and step size per sample (``_denoise_pass_deltas``).  4750 + 10 evaluations of
     100 replicas become 700 + 10 of 100 .. 1000.  The host noise stream keeps the reference's order: start frames t_delta by t_delta,
     chunk by chunk, each chunk's (unused, under the ODE) per-step draws consumed before the next chunk's start frames -- the last
-    chunk's ride in the loop when its trajectory is the longest.  Under the SDE with host noise the per-step draws are part of a
-    trajectory: one t_delta at a time (``forward_backward_chunks``), as the reference does."""
+    chunk's ride in the loop when its trajectory is the longest.  Under the SDE the per-step draws are part of a trajectory (host
+    noise: in the reference's order; device noise: a merged batch would draw them for the growing batch, i.e. other samples than one
+    t_delta at a time under the same seed): one t_delta at a time (``forward_backward_chunks``), as the reference does."""
     device = _require_hip_device(device, net)
     delta_range = [float(t) for t in delta_range]
     kw = dict(num_timesteps=num_timesteps, min_t=min_t, noise_scale=noise_scale, probability_flow=probability_flow,
               self_conditioning=self_conditioning, device=device, rng=rng)
     N = gt_frames_4x4.shape[-3]
     b_rank = sum(hi - lo for _, lo, hi in chunks)
-    mergeable = (probability_flow or rng == "device") and len(delta_range) > 1 and b_rank > 0 and all(t > 0 for t in delta_range) \
+    mergeable = probability_flow and len(delta_range) > 1 and b_rank > 0 and all(t > 0 for t in delta_range) \
         and hasattr(getattr(net, "embedder", None), "time_images")
     sched = [schedule(t, num_timesteps, min_t) for t in delta_range]
     plan = merge_delta_groups([s[1] for s in sched], b_rank, N, max_pairs) if mergeable else [[i] for i in range(len(delta_range))]
     rig0 = lambda bsz: Rigid.from_tensor_4x4(gt_frames_4x4.repeat(bsz, *(1,) * (gt_frames_4x4.ndim - 1)))  # noqa: E731
-    out = [None] * len(delta_range)
     for grp in plan:
         if len(grp) == 1:
-            out[grp[0]] = forward_backward_chunks(net, diffuser, batch, gt_frames_4x4, chunks, delta_range[grp[0]], max_pairs=max_pairs, **kw)
+            with torch.no_grad():   # (never yield inside the context: the caller would inherit the grad mode)
+                one = forward_backward_chunks(net, diffuser, batch, gt_frames_4x4, chunks, delta_range[grp[0]], max_pairs=max_pairs, **kw)
+            yield grp, [one]
             continue
         # start frames in the reference's order: t_delta by t_delta, chunk by chunk (host mode: + each chunk's step draws)
         groups, tail = [], None
@@ -689,7 +700,8 @@ def forward_backward_deltas(net, diffuser, batch: dict, gt_frames_4x4: torch.Ten
             T, n, dt, ts = sched[i]
             starts = []
             for ci, (bsz, lo, hi) in enumerate(chunks):
-                r = _start_frames(diffuser, batch, rig0(bsz), delta_range[i], lo, hi, rng, device)
+                with torch.no_grad():
+                    r = _start_frames(diffuser, batch, rig0(bsz), delta_range[i], lo, hi, rng, device)
                 if rng == "host":
                     if gi + 1 == len(grp) and ci + 1 == len(chunks) and longest_last and not _skips_unused_draws(probability_flow, bsz, N):
                         tail = (bsz, len(ts) - 1)      # drawn for real: rides in the loop, behind the GPU (global step == its local step)
@@ -714,10 +726,9 @@ def forward_backward_deltas(net, diffuser, batch: dict, gt_frames_4x4: torch.Ten
                                             host_noise=host_noise if tail else None, device=device)
             return a, r7
 
-        a37 = _range_guarded(net, run_pass, device, host_draws=tail is not None, device_draws=rng == "device" and not probability_flow)[0]
-        for i, a in zip(grp, a37):
-            out[i] = a
-    return out
+        with torch.no_grad():
+            a37 = _range_guarded(net, run_pass, device, host_draws=tail is not None, device_draws=False)[0]
+        yield grp, list(a37)
 
 
 def forward_flops(n_res: int) -> float:

@@ -32,7 +32,10 @@ class Trainer:
         import torch.distributed as dist
 
         dev = self._device()
-        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+        from .launch import in_distributed_job
+
+        # (a 1-rank torch.distributed.run job initialises RCCL too: the collective path is the same code at every world size)
+        if in_distributed_job() and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if os.environ.get("S2S_DIST_BACKEND", "nccl") == "gloo":   # TEST hook: several ranks sharing one GPU (RCCL wants one each)
                 dist.init_process_group("gloo")

@@ -181,3 +181,74 @@ def test_gather_keeps_replica_order():
     assert _run_gather(6) == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
     assert _run_gather(5) == [0.0, 1.0, 2.0, 3.0, 4.0]           # uneven split
     assert _run_gather(2, world=3) == [0.0, 1.0]                 # a rank with an empty slice
+
+
+def _compact_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from str2str_amd.models.diffusion_module import compact_backbone, expand_backbone, gather_replicas
+    from str2str_amd.sampler import shard_range
+
+    total, N = 5, 7
+    full = torch.zeros(total, N, 37, 3)
+    full[:, :, :5] = torch.randn(total, N, 5, 3, generator=torch.Generator().manual_seed(11))   # what compute_backbone fills: N, CA, C, CB, O
+    assert torch.equal(expand_backbone(compact_backbone(full)), full) and compact_backbone(full).shape == (total, N, 5, 3)
+    lo, hi = shard_range(total, rank, world)
+    out = gather_replicas(full[lo:hi], total)
+    if rank == 0:
+        q.put(bool(torch.equal(out, full)) and tuple(out.shape) == (total, N, 37, 3))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_payload_is_the_compact_backbone_and_atom37_comes_back_exactly():
+    """gather_replicas moves [., N, 5, 3] (the five slots compute_backbone fills, reference all_atom.py:141-173) and rank 0 gets the
+    atom37 tensor back bit for bit -- at world 2 and in a ONE-rank group (the collective path is the same code at every world size:
+    what the 1-rank RCCL test on the GPU box runs with device tensors)."""
+    for world in (1, 2):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_compact_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        assert q.get(timeout=120) is True
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+
+
+def test_entry_points_start_their_own_ranks(tmp_path):
+    """`bench.py --gpus N` / `eval.py trainer.devices=N` from a bare shell re-execute under torch.distributed.run (reference: Lightning
+    spawns the ranks behind trainer.predict, src/eval.py:129,154): utils.launch.relaunch runs a script as N ranks on 127.0.0.1 and
+    hands its exit code on; inside a job nothing is re-launched, and a --gpus / WORLD_SIZE mismatch is a clear error, not an assert."""
+    import subprocess
+    import sys
+
+    from str2str_amd.utils import launch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "who.py"
+    script.write_text("import os, sys\nprint('rank', os.environ['RANK'], 'of', os.environ['WORLD_SIZE'], 'addr', os.environ['MASTER_ADDR'], sys.argv[1:], flush=True)\n"
+                      "sys.exit(3 if '--fail' in sys.argv and os.environ['RANK'] == '1' else 0)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    code = "import sys; from str2str_amd.utils.launch import relaunch; sys.exit(relaunch(2, sys.argv[1], sys.argv[2:]))"
+    r = subprocess.run([sys.executable, "-c", code, str(script), "--x", "1"], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "rank 0 of 2 addr 127.0.0.1 ['--x', '1']" in r.stdout and "rank 1 of 2 addr 127.0.0.1 ['--x', '1']" in r.stdout
+    r = subprocess.run([sys.executable, "-c", code, str(script), "--fail"], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0                                              # a failing rank fails the job
+    cmd = launch.launch_command(8, "bench.py", ["--gpus", "8"], port=1234)
+    assert cmd[1:8] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port"]
+    assert [launch.resolve_devices(d) for d in (1, "2", [0, 1, 2], "0,1", None, 4)] == [1, 2, 3, 2, 1, 4]
+    assert not launch.in_distributed_job() or "WORLD_SIZE" in os.environ
+    # bench.py inside a job whose world size is not --gpus: a message that names both, before any device is touched
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "4"], cwd=root, env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "--gpus 4" in r.stderr and "2-rank" in r.stderr
+    # eval.py trainer=ddp dry_run=true composes the reference's ddp trainer keys and does not launch anything
+    r = subprocess.run([sys.executable, "eval.py", "task_name=inference", "ckpt_path=null", "trainer=ddp", "dry_run=true", "extras.print_config=false",
+                        "data.dataset.accession_code_fillter=[CLN025]", f"paths.output_dir={tmp_path}/out"], cwd=root,
+                       env=dict(env, TEST_DATA=os.path.join(root, "tests", "golden", "pdb"), CACHE_DIR=str(tmp_path / "cache"), PROJECT_ROOT=str(tmp_path)),
+                       capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and "dry_run" in (r.stderr + r.stdout), r.stderr[-1500:]

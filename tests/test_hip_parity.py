@@ -1528,6 +1528,135 @@ def test_multirank_entry_points_share_one_gpu(tmp_path):
         assert outs[1][k].count("MODEL ") in (5, 10) and outs[1][k] == outs[2][k], k
 
 
+def test_bench_and_eval_start_their_own_ranks_from_a_bare_shell(tmp_path):
+    """`python bench.py --gpus 2 ...` and `python eval.py trainer.devices=2 ...` typed into a bare shell (no torch.distributed.run, no
+    WORLD_SIZE): the entry points launch their own ranks (str2str_amd/utils/launch.py; the reference's `trainer=ddp` needs no launcher
+    either, src/eval.py:129,154).  Two ranks share this box's GPU through the gloo hooks."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import GOLDEN, ROOT
+
+    bare = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "PYTEST_CURRENT_TEST")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--n-res", "32", "--replicas", "3", "--denoise-steps", "4", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline", "--no-kernel-table"], cwd=ROOT, env=dict(bare, S2S_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["distributed"]["ranks_seen"] == [0, 1] and d["distributed"]["backend"] == "gloo" and d["value"] > 0
+    outs = {}
+    for n in (1, 2):
+        root = tmp_path / f"bare{n}"
+        env = dict(bare, S2S_DIST_BACKEND="gloo", TEST_DATA=os.path.join(GOLDEN, "pdb"), CACHE_DIR=str(tmp_path / "cache"), PROJECT_ROOT=str(root))
+        r = subprocess.run([sys.executable, "eval.py", "task_name=inference", "ckpt_path=null", "seed=7", "data.dataset.accession_code_fillter=[CLN025]",
+                            f"trainer.devices={n}", "model.inference.n_replica=3", "model.inference.replica_per_batch=2", "model.inference.num_timesteps=4",
+                            "model.inference.delta_min=0.5", "model.inference.delta_max=0.5", "extras.print_config=false", f"paths.output_dir={root}/out"],
+                           cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[n] = open(os.path.join(root, "out", "samples", "all_delta", "CLN025.pdb")).read()
+    assert outs[1].count("MODEL ") == 3 and outs[1] == outs[2]
+
+
+def test_rccl_one_rank_job_runs_the_device_collectives(tmp_path):
+    """The `nccl` backend (= RCCL) on this MI355X: a ONE-rank torch.distributed.run job of each entry point -- librccl is loaded, the
+    communicator is bound to the device (`device_id`), and DEVICE tensors go through the same gathers an 8-GPU node runs
+    (gather_replicas, predict_mixed's flat gather, bench.py's gather + all_reduce + all_gather): the branch the gloo rehearsals
+    cannot reach.  The files of the 1-rank RCCL job equal those of the plain single-process run byte for byte."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from conftest import GOLDEN, ROOT
+
+    script = tmp_path / "rccl_gather.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from str2str_amd.models.diffusion_module import gather_replicas\n"
+        "dev = torch.device('cuda', int(os.environ['LOCAL_RANK']))\n"
+        "torch.cuda.set_device(dev)\n"
+        "dist.init_process_group('nccl', device_id=dev)\n"
+        "x = torch.zeros(5, 9, 37, 3, device=dev)\n"
+        "x[:, :, :5] = torch.randn(5, 9, 5, 3, device=dev)\n"
+        "out = gather_replicas(x, 5)\n"
+        "assert out.is_cuda and torch.equal(out, x), 'device gather'\n"
+        "t = torch.ones(3, device=dev)\n"
+        "dist.all_reduce(t)\n"
+        "torch.cuda.synchronize()\n"
+        "print('RCCL_OK', dist.get_backend(), dist.get_world_size(), tuple(out.shape), flush=True)\n"
+        "dist.barrier()\n"
+        "dist.destroy_process_group()\n")
+    r = _torchrun(1, [str(script)], {}, ROOT, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK nccl 1 (5, 9, 37, 3)" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+
+    r = _torchrun(1, ["bench.py", "--gpus", "1", "--n-res", "32", "--replicas", "4", "--denoise-steps", "4", "--steps", "1", "--warmup", "0",
+                      "--no-cpu-baseline", "--no-kernel-table", "--no-other-configs"], {}, ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["distributed"]["backend"] == "nccl" and d["distributed"]["world_size"] == 1 and d["distributed"]["devices_seen"] == 1 and d["value"] > 0
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "rccl_one_rank_bench_line.json"), "w") as f:   # (copied to profiles/ for the record)
+        json.dump(d, f)
+
+    base = ["eval.py", "task_name=inference", "ckpt_path=null", "seed=7", "model.inference.n_replica=3", "model.inference.num_timesteps=4",
+            "model.inference.delta_min=0.5", "model.inference.delta_max=0.6", "model.inference.delta_step=0.1", "extras.print_config=false"]
+    for tag, extra in (("step", ["data.dataset.accession_code_fillter=[CLN025]", "model.inference.replica_per_batch=2"]),
+                       ("mixed", ["data.dataset.accession_code_fillter=[CLN025,2JOF]", "model.inference.mixed_batch=true"])):
+        files = {}
+        for how in ("plain", "rccl"):
+            root = tmp_path / f"{tag}_{how}"
+            env = {"TEST_DATA": os.path.join(GOLDEN, "pdb"), "CACHE_DIR": str(tmp_path / "cache"), "PROJECT_ROOT": str(root)}
+            args = base + extra + [f"paths.output_dir={root}/out"]
+            if how == "rccl":
+                r = _torchrun(1, args, env, ROOT, timeout=300)
+            else:
+                bare = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "PYTEST_CURRENT_TEST")}
+                r = subprocess.run([sys.executable] + args, cwd=ROOT, env=dict(bare, **env), capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, (tag, how, r.stderr[-2000:])
+            files[how] = {os.path.relpath(os.path.join(dp, f), root): open(os.path.join(dp, f)).read()
+                          for dp, _, fs in os.walk(root) for f in fs if f.endswith(".pdb")}
+        assert files["plain"] and files["plain"] == files["rccl"], tag
+
+
+def test_full_size_batch_is_invariant_at_the_headline_shape(net_smooth, diffuser):
+    """BASELINE configs[1] at its FULL batch: 128 replicas of the 256-residue chain as ONE trajectory (n_replica 128 in the reference's
+    chunks of replica_per_batch 2, merged: 8 388 608 pairs per launch, the persistent workgroups walk many tiles each) for the 5 + 1
+    evaluations of the `traj_free_n256_s5` fixture.  A replica's result must not depend on its batch (reference
+    diffusion_module.py:341-352: chunks are independent): replicas 0-1 are the reference's own B = 2 run of the fixture (< 1e-4 A) and
+    equal this build's B = 2 launch BIT FOR BIT; a 2-rank shard of the 128 (64 + 64) equals the single run bit for bit."""
+    from str2str_amd.common.rigid_utils import Rigid
+    from str2str_amd.sampler import forward_backward, forward_backward_chunks, rank_chunk_slices
+    from str2str_amd.synth import synth_chain
+
+    g = golden("traj_free_n256_s5.npz")
+    N, S = int(g["n_res"]), int(g["num_timesteps"])
+    assert (N, int(g["B"])) == (256, 2)
+    feats = synth_chain(N)
+    gt4 = feats["rigidgroups_gt_frames"][..., 0, :, :]
+    kw = dict(num_timesteps=S, device=DEV)
+    torch.manual_seed(int(g["seed"]))
+    full = forward_backward_chunks(net_smooth, diffuser, feats, gt4, rank_chunk_slices(128, 2, 0, 1), float(g["t_delta"]), **kw)
+    assert tuple(full.shape) == (128, N, 37, 3) and torch.isfinite(full).all()
+    rmsd = backbone_rmsd(full[:2].cpu().numpy()[..., :5, :], g["atom37"])
+    record_margin("full batch B=128, N=256: replicas 0-1 backbone RMSD vs the reference's B=2 run (A)", rmsd, 1e-4)
+    assert rmsd < 1e-4, rmsd
+    torch.manual_seed(int(g["seed"]))
+    two = forward_backward(net_smooth, diffuser, feats, Rigid.from_tensor_4x4(gt4.repeat(2, 1, 1, 1)), float(g["t_delta"]), **kw)
+    assert torch.equal(two, full[:2])
+    ca = full[:, :, 1].reshape(128, -1)
+    assert float(torch.cdist(ca, ca).fill_diagonal_(1e9).min()) > 1e-2        # 128 different conformations
+    parts = []
+    for r in range(2):
+        torch.manual_seed(int(g["seed"]))
+        parts.append(forward_backward_chunks(net_smooth, diffuser, feats, gt4, rank_chunk_slices(128, 2, r, 2), float(g["t_delta"]), **kw))
+    assert parts[0].shape[0] == 64 and torch.equal(torch.cat(parts), full)
+
+
 @pytest.mark.parametrize("cfg,extra", [("cfg4", ["--n-res", "32", "--replicas", "2", "--denoise-steps", "3"]),
                                        ("cfg5", ["--replicas", "1", "--denoise-steps", "2"])])
 def test_bench_world8_rehearsal(cfg, extra):
