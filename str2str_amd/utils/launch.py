@@ -1,7 +1,7 @@
 """One command, any device count: the entry points start their own ranks.
 
 The reference gets its multi-device run from Lightning (``trainer=ddp`` spawns one process per device behind
-``trainer.predict``, /root/reference/src/eval.py:129,154 and configs/trainer/ddp.yaml:4-9).  Here ``bench.py --gpus N`` and
+``trainer.predict``, reference src/eval.py:129,154 and configs/trainer/ddp.yaml:4-9).  Here ``bench.py --gpus N`` and
 ``eval.py trainer.devices=N`` do the same thing without Lightning: when they find themselves OUTSIDE a torch.distributed.run job
 (no WORLD_SIZE in the environment) and more than one device is asked for, they re-execute themselves under
 ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N`` on 127.0.0.1 with a free rendezvous port, one process per GPU,
