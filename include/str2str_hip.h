@@ -388,9 +388,11 @@ int s2s_ca_sample_stats(const float* ca, int n_samples, int n_res, float clash_b
 
 /* js_pwd (metrics.py:140-166): per pair channel (i, j >= i + offset; np.triu_indices order) the Jensen-Shannon distance between
  * the n_bins-bin histograms (range = the reference ensemble's [min, max], numpy's float32 bin arithmetic, + pseudo_count) of the
- * predicted and the reference ensemble -> js_per_channel [(L-offset)(L-offset+1)/2] float64 (the metric is their mean). */
+ * predicted and the reference ensemble -> js_per_channel [(L-offset)(L-offset+1)/2] float64 (the metric is their mean).
+ * ref_weights [n_ref] / pred_weights [n_pred]: per-sample float64 histogram weights (the reference's `weights=`, metrics.py:139-150;
+ * NULL = all ones, both NULL = integer counts). */
 int s2s_ca_pwd_js(const float* ref_ca, int n_ref, const float* pred_ca, int n_pred, int n_res, int offset, int n_bins,
-                  double pseudo_count, double* js_per_channel, void* stream);
+                  double pseudo_count, double* js_per_channel, const double* ref_weights, const double* pred_weights, void* stream);
 
 /* ---- PDB text at the exit of the path (HOST pointers, host code; byte-identical to the reference's writers) ---- */
 

@@ -6,7 +6,7 @@ namespace s2s {
 int* g_range_flag = nullptr;
 }
 
-extern "C" int s2s_abi_version(void) { return 31; }
+extern "C" int s2s_abi_version(void) { return 32; }
 
 extern "C" int s2s_set_range_flag(int* device_words) {   // kRangeWords ints (range_flag.h)
     s2s::g_range_flag = device_words;

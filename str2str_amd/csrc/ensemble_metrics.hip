@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+#include <type_traits>
+
 #include "str2str_hip.h"
 
 namespace {
@@ -79,10 +81,14 @@ __device__ __forceinline__ int np_bin(float x, float first, float last, int bins
     return idx;
 }
 
-template <int BINS>
+// WEIGHTED: per-sample float64 weights (the reference's `weights=`, metrics.py:139-150: np.histogram(..., weights=w) sums the weights of
+// a bin's samples in float64; here in the order the lanes' atomics land -- the sums differ from numpy's in the last bits only).
+template <int BINS, bool WEIGHTED>
 __global__ void __launch_bounds__(256) ca_pwd_js_kernel(const float* __restrict__ ref, int Rt, const float* __restrict__ pred, int R, int L,
-                                                        int offset, long long n_ch, double pseudo, double* __restrict__ js) {
-    __shared__ int s_hist[4][2][BINS];
+                                                        int offset, long long n_ch, double pseudo, double* __restrict__ js,
+                                                        const double* __restrict__ w_ref, const double* __restrict__ w_pred) {
+    typedef typename std::conditional<WEIGHTED, double, int>::type hist_t;
+    __shared__ hist_t s_hist[4][2][BINS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long ch = (long long)blockIdx.x * 4 + wave;
     if (ch >= n_ch) return;  // wave-uniform; only wave-level synchronisation below
@@ -107,7 +113,14 @@ __global__ void __launch_bounds__(256) ca_pwd_js_kernel(const float* __restrict_
         for (int s = lane; s < n; s += 64) {
             const float* x = base + (long long)s * L * 3;
             const float d = dist_f32(x + 3 * j, x + 3 * i);
-            if (d >= dmin && d <= dmax) atomicAdd(&s_hist[wave][e][np_bin(d, dmin, dmax, BINS)], 1);
+            if (d >= dmin && d <= dmax) {
+                if constexpr (WEIGHTED) {
+                    const double* w = e ? w_pred : w_ref;
+                    atomicAdd(&s_hist[wave][e][np_bin(d, dmin, dmax, BINS)], w ? w[s] : 1.0);
+                } else {
+                    atomicAdd(&s_hist[wave][e][np_bin(d, dmin, dmax, BINS)], 1);
+                }
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -139,11 +152,16 @@ extern "C" int s2s_ca_sample_stats(const float* ca, int n_samples, int n_res, fl
 }
 
 extern "C" int s2s_ca_pwd_js(const float* ref_ca, int n_ref, const float* pred_ca, int n_pred, int n_res, int offset, int n_bins,
-                             double pseudo_count, double* js_per_channel, void* stream) {
+                             double pseudo_count, double* js_per_channel, const double* ref_weights, const double* pred_weights,
+                             void* stream) {
     if (!ref_ca || !pred_ca || n_ref <= 0 || n_pred <= 0 || offset < 1 || n_res <= offset || n_bins != 50 || !js_per_channel)
         return (int)hipErrorInvalidValue;
     const long long n_ch = (long long)(n_res - offset) * (n_res - offset + 1) / 2;
-    hipLaunchKernelGGL((ca_pwd_js_kernel<50>), dim3((unsigned)((n_ch + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ref_ca, n_ref, pred_ca,
-                       n_pred, n_res, offset, n_ch, pseudo_count, js_per_channel);
+    if (ref_weights || pred_weights)
+        hipLaunchKernelGGL((ca_pwd_js_kernel<50, true>), dim3((unsigned)((n_ch + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ref_ca, n_ref,
+                           pred_ca, n_pred, n_res, offset, n_ch, pseudo_count, js_per_channel, ref_weights, pred_weights);
+    else
+        hipLaunchKernelGGL((ca_pwd_js_kernel<50, false>), dim3((unsigned)((n_ch + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ref_ca, n_ref,
+                           pred_ca, n_pred, n_res, offset, n_ch, pseudo_count, js_per_channel, (const double*)nullptr, (const double*)nullptr);
     return (int)hipGetLastError();
 }

@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("STR2STR_HIP_LIB") or os.path.join(_HERE, "libstr2str_hip.so")  # env override: A/B builds
-ABI_VERSION = 31
+ABI_VERSION = 32
 
 _lib = None
 _tables_loaded = False
@@ -54,7 +54,7 @@ _SIGNATURES = {
     "s2s_encoder_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "s2s_encoder_attention_f16x3": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "s2s_ca_sample_stats": [_vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
-    "s2s_ca_pwd_js": [_vp, _i, _vp, _i, _i, _i, _i, _d, _vp, _vp],
+    "s2s_ca_pwd_js": [_vp, _i, _vp, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp],
     "s2s_format_pdb_models": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _ll],
     "s2s_write_pdb_models": [ctypes.c_char_p, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i],
     "s2s_merge_pdb_files": [_vp, _i, ctypes.c_char_p],
@@ -1324,16 +1324,23 @@ def ca_sample_stats(ca: torch.Tensor, clash_bar: float = 3.0, k_exclusion: int =
     return nc, am, rg
 
 
-def ca_pwd_js(ref_ca: torch.Tensor, pred_ca: torch.Tensor, offset: int = 3, n_bins: int = 50, pseudo: float = 1e-6) -> torch.Tensor:
-    """Per pair channel Jensen-Shannon distance between the distance histograms of two CA ensembles -> [D] fp64."""
+def ca_pwd_js(ref_ca: torch.Tensor, pred_ca: torch.Tensor, offset: int = 3, n_bins: int = 50, pseudo: float = 1e-6,
+              ref_weights: Optional[torch.Tensor] = None, pred_weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Per pair channel Jensen-Shannon distance between the distance histograms of two CA ensembles -> [D] fp64.
+    ``ref_weights`` / ``pred_weights``: per-sample float64 histogram weights (device tensors), None = ones."""
     lib = load_library()
     _req(ref_ca, name="ref_ca"); _req(pred_ca, name="pred_ca")
     L = ref_ca.shape[1]
     if pred_ca.shape[1] != L:
         raise HipLibraryError("ca_pwd_js: the ensembles have different lengths")
+    for nme, w, n in (("ref_weights", ref_weights, ref_ca.shape[0]), ("pred_weights", pred_weights, pred_ca.shape[0])):
+        if w is not None:
+            _req(w, torch.float64, nme)
+            if w.numel() != n:
+                raise HipLibraryError(f"ca_pwd_js: {nme} has {w.numel()} entries for {n} samples")
     out = torch.empty((L - offset) * (L - offset + 1) // 2, dtype=torch.float64, device=ref_ca.device)
     _check(lib.s2s_ca_pwd_js(_p(ref_ca), ref_ca.shape[0], _p(pred_ca), pred_ca.shape[0], L, int(offset), int(n_bins), float(pseudo),
-                             _p(out), _stream()), "s2s_ca_pwd_js")
+                             _p(out), _p(ref_weights), _p(pred_weights), _stream()), "s2s_ca_pwd_js")
     return out
 
 

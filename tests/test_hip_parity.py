@@ -1480,6 +1480,34 @@ def test_js_tica_device_distances_and_tica():
     assert res["target"] == 0.0 and res["same"] == 0.0 and 0.05 < res["pred"] <= 1.0 and tics["pred"].shape == (T_, 2)
 
 
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_js_tica_and_weighted_metrics_match_the_reference_driven_fixture(tag):
+    """metrics.js_tica / js_pwd / js_rg incl. per-sample ``weights=`` (reference src/metrics/metrics.py:139-217) on the device path,
+    against tests/golden/tica.npz: the values the REFERENCE's functions returned.  For js_tica the estimator behind the reference's
+    call is the third-party deeptime TICA (0.4.4), absent here -- the fixture was produced by the reference's js_tica driving the
+    restatement of its published algorithm in oracle/tica.py (make_golden_tica.py), not by a run of deeptime; js_pwd / js_rg with
+    weights are the reference alone.  Rounded scores equal, projections to 1e-6 of their scale, weighted per-channel js_pwd to 1e-9."""
+    from str2str_amd import ops
+    from str2str_amd.metrics import metrics as M
+
+    g = golden("tica.npz")
+    d = {"target": g[f"{tag}_target"], "pred": g[f"{tag}_pred"]}
+    w, lag = g[f"{tag}_weights"], int(g[f"{tag}_lag"])
+    res, tics = M.js_tica(d, ref_key="target", lagtime=lag)
+    assert res["target"] == 0.0 and abs(res["pred"] - float(g[f"{tag}_js_tica"])) < 1.5e-4, (res, g[f"{tag}_js_tica"])
+    for k in ("target", "pred"):
+        scale = np.abs(g[f"{tag}_tic_{k}"]).max()
+        check(f"js_tica {tag}: |projection - reference-driven restatement| / scale ({k})", float(np.abs(tics[k] - g[f"{tag}_tic_{k}"]).max() / scale), 1e-6)
+    assert abs(M.js_tica(d, ref_key="target", lagtime=lag, weights={"pred": w}, return_tic=False)["pred"] - float(g[f"{tag}_js_tica_w"])) < 1.5e-4
+    assert M.js_pwd(d, ref_key="target", weights={"pred": w})["pred"] == float(g[f"{tag}_js_pwd_w"])
+    assert M.js_rg(d, ref_key="target", weights={"pred": w})["pred"] == float(g[f"{tag}_js_rg_w"])
+    ch = ops.ca_pwd_js(T(d["target"]).to(DEV), T(d["pred"]).to(DEV), 3, 50, 1e-6, pred_weights=T(w).to(DEV)).cpu().numpy()
+    check(f"js_pwd weighted {tag}: per-channel |JS - reference|", float(np.abs(ch - g[f"{tag}_js_pwd_w_channels"]).max()), 1e-9)
+    # weights of ones are the unweighted metric, bit for bit in the rounded score
+    ones = {"pred": np.ones(len(w)), "target": np.ones(len(d["target"]))}
+    assert M.js_pwd(d, weights=ones) == M.js_pwd(d) and M.js_rg(d, weights=ones) == M.js_rg(d)
+
+
 def test_multirank_entry_points_share_one_gpu(tmp_path):
     """The N > 1 control flow of BOTH entry points, launched exactly as the driver launches them (torch.distributed.run, one
     process per rank), with two ranks sharing this box's single GPU through the gloo test hooks (RCCL wants a GPU per rank; the

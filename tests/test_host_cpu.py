@@ -299,6 +299,44 @@ def test_tica_fit_recovers_the_slow_mode_of_a_two_state_process():
     assert np.abs(proj[4:]).max() < 1e3          # neither the constant nor the sub-cut-off copy is blown up by the whitening
 
 
+def test_tica_restatement_and_product_estimator_agree_with_the_reference_driven_fixture():
+    """`js_tica` (reference src/metrics/metrics.py:166-200).  The estimator is the third-party deeptime.decomposition.TICA
+    (deeptime==0.4.4), absent here: oracle/tica.py restates its published algorithm -- NOT a run of deeptime -- and
+    tests/golden/tica.npz holds what the REFERENCE's own js_tica returned when it drove that restatement
+    (tests/golden/make_golden_tica.py).  Here, on CPU: (1) the oracle's stand-alone js_tica (its own histogram / weights tail)
+    reproduces the reference-driven values, so oracle.tica.js_tica == reference js_tica around the same estimator; (2) the product's
+    numpy estimator (metrics.tica_fit: what runs when deeptime is not installed) gives the restatement's projections -- magnitude
+    ordering with a NEGATIVE second eigenvalue (case a), canonical signs and kinetic-map scale included."""
+    import numpy as np
+
+    from conftest import golden
+    from oracle import tica as OT
+    from str2str_amd.metrics.metrics import tica_fit
+
+    g = golden("tica.npz")
+
+    def pwd(x, k=1):   # reference pairwise_distance_ca (metrics.py:38-50), float32
+        d = np.sqrt(np.sum((x[..., None, :, :] - x[..., None, :]) ** 2, axis=-1))
+        r, c = np.triu_indices(x.shape[-2], k=k)
+        return d[..., r, c]
+
+    for tag in ("a", "b"):
+        lag = int(g[f"{tag}_lag"])
+        feats = {"target": pwd(g[f"{tag}_target"]), "pred": pwd(g[f"{tag}_pred"])}
+        res, tics = OT.js_tica(feats, lagtime=lag)
+        assert np.around(res["pred"], 4) == float(g[f"{tag}_js_tica"])
+        assert np.abs(tics["pred"] - g[f"{tag}_tic_pred"]).max() < 1e-9 and np.abs(tics["target"] - g[f"{tag}_tic_target"]).max() < 1e-9
+        res_w, _ = OT.js_tica(feats, lagtime=lag, weights={"pred": g[f"{tag}_weights"]})
+        assert np.around(res_w["pred"], 4) == float(g[f"{tag}_js_tica_w"]) and res_w["pred"] != res["pred"]
+        est = OT.TICA(dim=2, lagtime=lag).fit(feats["target"])
+        assert np.allclose(est.eigenvalues[:4], g[f"{tag}_tica_eigenvalues"], rtol=1e-9)
+        mean, proj = tica_fit(feats["target"], lag, dim=2)
+        scale = np.abs(est.coefficients).max()
+        assert np.abs(mean - est.mean).max() < 1e-12 and np.abs(proj - est.coefficients).max() < 1e-8 * scale
+        assert np.abs((feats["pred"].astype(np.float64) - mean) @ proj - g[f"{tag}_tic_pred"]).max() < 1e-8 * np.abs(g[f"{tag}_tic_pred"]).max()
+    assert g["a_tica_eigenvalues"][1] < 0          # the edge case the magnitude ordering exists for
+
+
 def test_pair_tiled_layout_matches_the_header():
     """ops.pair_tiled / pair_untiled against the formula of include/str2str_hip.h ("Pair-tensor layouts"): channel 8 g + 4 h + q of pair
     32 b + n at float offset 4096 b + 256 g + 128 h + 4 n + q; whole blocks, zero padding; round trip."""
