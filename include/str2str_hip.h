@@ -336,12 +336,14 @@ int s2s_node_linear_multi(const s2s_node_problem* problems, int n_problems, void
  * operand layout of the next); bit for bit the separate launches.  w_packed: ops.pack_node_weight(W, width / 32).
  * The FIRST layer may contract over k_in0 != width columns (320 -> 256) and may add a residual (mid_residual [n_rows, ld]) and store its
  * fp32 result (mid_out_f32 [n_rows, ld]) -- which may then be the last layer's ``residual``: trunk.linear + NodeTransition
- * (src/models/net/ipa.py:358-359, layers.py:128-145) as one launch.  Also: the encoder layers' feed-forward (ipa.py:312-317), the
- * embedder's node MLP (denoising_ipa.py:113-120). */
+ * (src/models/net/ipa.py:358-359, layers.py:128-145) as one launch.  The first layer may also carry a LayerNorm of its own behind that
+ * residual (mid_ln_gamma / mid_ln_beta [width], mid_ln_eps; NULL = none): an nn.TransformerEncoderLayer's post-attention half --
+ * out_proj + residual + norm1, linear1, relu, linear2 + residual (= the stored norm1 output) + norm2 (ipa.py:312-317) -- as one launch.
+ * Also: the embedder's node MLP (denoising_ipa.py:113-120). */
 typedef struct s2s_chain_layer { const void* w_packed; const float* bias; int relu; } s2s_chain_layer;
 int s2s_node_chain(const void* xp, const s2s_chain_layer* layers, int n_layers, long long n_rows, int width, int k_in0,
-                   const float* mid_residual, int mid_residual_ld, float* mid_out_f32, int mid_out_ld, const float* pre_mask,
-                   const float* residual, int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                   const float* mid_residual, int mid_residual_ld, float* mid_out_f32, int mid_out_ld, const float* mid_ln_gamma,
+                   const float* mid_ln_beta, float mid_ln_eps, const float* pre_mask, const float* residual, int residual_ld, const float* ln_gamma, const float* ln_beta, float ln_eps,
                    const float* post_mask, float* out_f32, int out_ld, int out_col0, void* out_xp, int out_xp_ksteps,
                    int out_xp_kstep0, void* stream);
 
@@ -385,6 +387,10 @@ int s2s_forward_marginal(const float* rigids0_4x4, const float* z_axis, const fl
  * (:12-23; bonding_validity :124-137 compares it with the reference ensemble's), the radius of gyration (:53-77, float64). */
 int s2s_ca_sample_stats(const float* ca, int n_samples, int n_res, float clash_bar, int k_exclusion, int* n_clash,
                         float* adjacent_max, double* radius_of_gyration, void* stream);
+
+/* pairwise_distance_ca (metrics.py:38-50): out [n_samples, D] float32, D = (L-offset)(L-offset+1)/2 upper-triangular CA distances per sample
+ * in np.triu_indices(L, k=offset) order, in numpy's float32 arithmetic (bit for bit): the features of js_tica (:166-200).  n_samples <= 65535. */
+int s2s_ca_pairwise_distances(const float* ca, int n_samples, int n_res, int offset, float* out, void* stream);
 
 /* js_pwd (metrics.py:140-166): per pair channel (i, j >= i + offset; np.triu_indices order) the Jensen-Shannon distance between
  * the n_bins-bin histograms (range = the reference ensemble's [min, max], numpy's float32 bin arithmetic, + pseudo_count) of the

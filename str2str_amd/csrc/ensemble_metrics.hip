@@ -66,6 +66,23 @@ __global__ void __launch_bounds__(256) ca_sample_stats_kernel(const float* __res
     }
 }
 
+// pairwise_distance_ca (metrics.py:38-50): the upper-triangular CA distances of every sample, [R, D] float32 in np.triu_indices(L, k)
+// order (row i holds the L - k - i pairs (i, j >= i + k)) -- the features of js_tica.  dist_f32 is numpy's arithmetic on float32 input, so the
+// features equal the reference's bit for bit (the TICA whitening amplifies a last-bit difference of the features by 1 / (smallest kept
+// eigenvalue of C00): scores moved in the third decimal with torch's own reduction).
+__global__ void __launch_bounds__(256) ca_pairwise_kernel(const float* __restrict__ ca, int R, int L, int offset, long long D,
+                                                          float* __restrict__ out) {
+    const int s = blockIdx.y;
+    const float* x = ca + (long long)s * L * 3;
+    for (long long ch = (long long)blockIdx.x * 256 + threadIdx.x; ch < D; ch += (long long)gridDim.x * 256) {
+        long long rem = ch;
+        int i = 0;
+        while (rem >= (long long)(L - offset - i)) { rem -= L - offset - i; ++i; }
+        const int j = i + offset + (int)rem;
+        out[(long long)s * D + ch] = dist_f32(x + 3 * j, x + 3 * i);
+    }
+}
+
 // numpy's uniform-bin index for x in [first, last] (numpy/lib/_histograms_impl.py, the `range=` fast path), float32 arithmetic:
 //   f = (x - first) / (last - first) * bins;  idx = (int)f;  idx == bins -> bins - 1;  then the two edge corrections against
 //   edges[k] = linspace(first, last, bins + 1) in float32 (start + k * step, last edge = stop).
@@ -148,6 +165,15 @@ extern "C" int s2s_ca_sample_stats(const float* ca, int n_samples, int n_res, fl
     if (!ca || n_res < 2 || !n_clash || !adjacent_max || !radius_of_gyration || k_exclusion < 0) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(ca_sample_stats_kernel, dim3(n_samples), dim3(256), 0, (hipStream_t)stream, ca, n_samples, n_res, clash_bar,
                        k_exclusion, n_clash, adjacent_max, radius_of_gyration);
+    return (int)hipGetLastError();
+}
+
+extern "C" int s2s_ca_pairwise_distances(const float* ca, int n_samples, int n_res, int offset, float* out, void* stream) {
+    if (n_samples <= 0) return 0;
+    if (!ca || !out || offset < 0 || n_res <= offset || n_samples > 65535) return (int)hipErrorInvalidValue;
+    const long long D = (long long)(n_res - offset) * (n_res - offset + 1) / 2;
+    const unsigned gx = (unsigned)((D + 255) / 256 < 4096 ? (D + 255) / 256 : 4096);
+    hipLaunchKernelGGL(ca_pairwise_kernel, dim3(gx, (unsigned)n_samples), dim3(256), 0, (hipStream_t)stream, ca, n_samples, n_res, offset, D, out);
     return (int)hipGetLastError();
 }
 

@@ -530,6 +530,9 @@ struct ChainArgs {
     // residual of the chain's last layer -- read back from memory by the lanes that wrote it)
     const float* mid_residual; int mid_res_ld;
     float* mid_out; int mid_out_ld;
+    // ... and a LayerNorm of its own behind that residual (an encoder layer's out_proj + residual + norm1 in front of its feed-forward:
+    // the chain is then the whole post-attention half of the layer, ipa.py:312-317)
+    const float* mid_ln_gamma; const float* mid_ln_beta; float mid_ln_eps;
 };
 template <int I> struct CI { static constexpr int value = I; };
 template <int B, int E, class F>
@@ -643,6 +646,7 @@ __global__ void __launch_bounds__(256, 1) node_chain_kernel(ChainArgs c) {
         if (l == 0) {
             inner.residual = c.mid_residual; inner.res_ld = c.mid_res_ld;
             inner.out_f32 = c.mid_out; inner.out_ld = c.mid_out_ld; inner.out_col0 = 0;
+            inner.ln_gamma = c.mid_ln_gamma; inner.ln_beta = c.mid_ln_beta; inner.ln_eps = c.mid_ln_eps;
         }
         node_epilogue<TG>(acc, inner, rt, n_rt, lane, 0, kInvWS);
         if (l == 0 && c.mid_out) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the rows are read back as the last layer's residual
@@ -970,6 +974,7 @@ extern "C" int s2s_node_probe_read(unsigned long long* host_out, int reset) {
 // Up to six independent layers (bias / ReLU epilogues only) in ONE launch: see node_gemm_multi_kernel.
 extern "C" int s2s_node_chain(const void* xp, const s2s_chain_layer* layers, int n_layers, long long n_rows, int width, int k_in0,
                               const float* mid_residual, int mid_residual_ld, float* mid_out_f32, int mid_out_ld,
+                              const float* mid_ln_gamma, const float* mid_ln_beta, float mid_ln_eps,
                               const float* pre_mask, const float* residual, int residual_ld, const float* ln_gamma, const float* ln_beta,
                               float ln_eps, const float* post_mask, float* out_f32, int out_ld, int out_col0, void* out_xp,
                               int out_xp_ksteps, int out_xp_kstep0, void* stream) {
@@ -978,7 +983,8 @@ extern "C" int s2s_node_chain(const void* xp, const s2s_chain_layer* layers, int
     if (!xp || !layers || n_layers < 2 || n_layers > kChainMax || width % 32 || (TG != 8 && TG != 10) || (!out_f32 && !out_xp) ||
         check_epilogue(width, TG, ln_gamma, ln_beta, out_f32, out_ld, out_col0, residual, residual_ld) ||
         (out_xp && (out_xp_kstep0 < 0 || out_xp_kstep0 % 2 || out_xp_kstep0 + width / 16 > out_xp_ksteps)) ||
-        (k_in0 != width && !(TG == 8 && k_in0 == 320)) || (mid_residual && mid_residual_ld % 4) || (mid_out_f32 && (mid_out_ld % 4 || mid_out_ld < width)))
+        (k_in0 != width && !(TG == 8 && k_in0 == 320)) || (mid_residual && mid_residual_ld % 4) || (mid_out_f32 && (mid_out_ld % 4 || mid_out_ld < width)) ||
+        ((mid_ln_gamma != nullptr) != (mid_ln_beta != nullptr)))
         return (int)hipErrorInvalidValue;
     ChainArgs c{};
     c.a = GemmArgs{(const f16x8*)xp, nullptr, nullptr, nullptr, pre_mask, residual, ln_gamma, ln_beta, post_mask, out_f32, (f16x8*)out_xp,
@@ -986,6 +992,7 @@ extern "C" int s2s_node_chain(const void* xp, const s2s_chain_layer* layers, int
                    s2s::g_range_flag, 0, 0};
     c.n_layers = n_layers;
     c.mid_residual = mid_residual; c.mid_res_ld = mid_residual_ld; c.mid_out = mid_out_f32; c.mid_out_ld = mid_out_ld;
+    c.mid_ln_gamma = mid_ln_gamma; c.mid_ln_beta = mid_ln_beta; c.mid_ln_eps = mid_ln_eps;
     for (int l = 0; l < n_layers; ++l) {
         if (!layers[l].w_packed) return (int)hipErrorInvalidValue;
         c.w[l] = (const char*)layers[l].w_packed; c.bias[l] = layers[l].bias; c.relu[l] = layers[l].relu;

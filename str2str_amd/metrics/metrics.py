@@ -90,12 +90,9 @@ def js_rg(ca_coords_dict, ref_key="target", n_bins=50, weights=None):
 
 
 def pairwise_distance_ca(coords, k=1) -> np.ndarray:
-    """reference :38-50: upper-triangular CA distances [B, L (L - k + ...)/2], float32, computed on the device."""
-    x = _dev(coords)
-    d = (x[:, :, None, :] - x[:, None, :, :]).square().sum(-1).sqrt()
-    L = d.shape[-1]
-    row, col = np.triu_indices(L, k=k)
-    return d[:, torch.as_tensor(row, device=d.device), torch.as_tensor(col, device=d.device)].cpu().numpy()
+    """reference :38-50: upper-triangular CA distances [B, (L - k)(L - k + 1)/2], float32, computed on the device in numpy's own
+    float32 arithmetic (s2s_ca_pairwise_distances): bit for bit the reference's features."""
+    return ops.ca_pairwise_distances(_dev(coords), k).cpu().numpy()
 
 
 def tica_fit(x: np.ndarray, lagtime: int, dim: int = 2, epsilon: float = 1e-6):

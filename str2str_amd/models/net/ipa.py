@@ -27,6 +27,7 @@ from ... import ops
 from ...arith import default_arith
 from ...common.rigid_utils import Rigid, Rotation
 _CHAIN4 = os.environ.get("S2S_CHAIN4", "1") != "0"   # trunk.linear + NodeTransition as one launch (s2s_node_chain)
+_ENC_CHAIN3 = os.environ.get("S2S_ENC_CHAIN3", "1") != "0"   # an encoder layer's out_proj + norm1 + feed-forward + norm2 as one launch
 from .layers import BackboneUpdate, EdgeTransition, Linear, NodeTransition, ParamCache, TorsionAngleHead
 
 
@@ -374,11 +375,19 @@ class TranslationIPA(nn.Module):
             for layer, lw in zip(T[f"transformer_{b}"].layers, w["layers"]):
                 qkv, _ = lin(xx, lw["in"])
                 sa_f32, sa_xp = torch.ops.str2str_amd.encoder_attention(qkv, key_bias, B, N, layer.self_attn.num_heads, not f16, f16, self.arith)
-                x1, x1a = lin(sa_xp if f16 else sa_f32, lw["o"], residual=xf, ln=(layer.norm1.weight, layer.norm1.bias, layer.norm1.eps),
-                              want_xp=True)
-                # feed-forward linear1 -> relu -> linear2 (+ residual, norm2): one launch, the hidden activations stay in registers
-                xf, xx = ops.node_apply_chain(x1a, [lw["l1"], lw["l2"]], M, (True, False), residual=x1,
-                                              ln=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), want_xp=True)
+                # the post-attention half of the layer as ONE launch (s2s_node_chain): out_proj + residual + norm1 (its fp32 result is
+                # stored: the residual of norm2), linear1 -> relu -> linear2 + that residual + norm2; the hidden activations stay in
+                # registers.  (S2S_ENC_CHAIN3=0: out_proj on its own, then the two feed-forward layers as a chain -- the same bits)
+                if _ENC_CHAIN3:
+                    x1 = torch.empty(M, D, device=dev, dtype=torch.float32)
+                    xf, xx = ops.node_apply_chain(sa_xp if f16 else sa_f32, [lw["o"], lw["l1"], lw["l2"]], M, (False, True, False),
+                                                  first_residual=xf, first_out_f32=x1, first_ln=(layer.norm1.weight, layer.norm1.bias, layer.norm1.eps),
+                                                  residual=x1, ln=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), want_xp=True)
+                else:
+                    x1, x1a = lin(sa_xp if f16 else sa_f32, lw["o"], residual=xf, ln=(layer.norm1.weight, layer.norm1.bias, layer.norm1.eps),
+                                  want_xp=True)
+                    xf, xx = ops.node_apply_chain(x1a, [lw["l1"], lw["l2"]], M, (True, False), residual=x1,
+                                                  ln=(layer.norm2.weight, layer.norm2.bias, layer.norm2.eps), want_xp=True)
             # ---- node_embed + linear(tr) (:358), NodeTransition (:359, layers.py:128-145), mask (:360)
             # ... as ONE launch: trunk.linear's fp32 result is stored and read back as NodeTransition's residual (s2s_node_chain)
             nt = T[f"node_transition_{b}"]

@@ -47,13 +47,14 @@ _SIGNATURES = {
     "s2s_node_linear": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp],
     "s2s_node_linear_f32": [_vp, _i, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp],
     "s2s_node_linear_multi": [_vp, _i, _vp],
-    "s2s_node_chain": [_vp, _vp, _i, _ll, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
+    "s2s_node_chain": [_vp, _vp, _i, _ll, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
     "s2s_embed_assemble": [_vp, _ll, _vp, _ll, _vp, _vp, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp],
     "s2s_row_layernorm": [_vp, _i, _ll, _i, _vp, _vp, _f, _vp, _vp, _i, _i, _vp, _i, _i, _vp],
     "s2s_node_linear_vfrag": [_vp, _vp, _vp, _ll, _i, _i, _i, _vp, _i, _i, _vp],
     "s2s_encoder_attention": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "s2s_encoder_attention_f16x3": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "s2s_ca_sample_stats": [_vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp],
+    "s2s_ca_pairwise_distances": [_vp, _i, _i, _i, _vp, _vp],
     "s2s_ca_pwd_js": [_vp, _i, _vp, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp],
     "s2s_format_pdb_models": [_vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _ll],
     "s2s_write_pdb_models": [ctypes.c_char_p, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i],
@@ -1172,15 +1173,17 @@ CHAIN_WIDTHS = (256, 320)
 
 def node_chain(xp, w_row, bias, relu, n_rows: int, width: int, pre_mask=None, residual=None, ln_gamma=None, ln_beta=None, ln_eps: float = 0.0,
                post_mask=None, out_f32=None, out_col0: int = 0, want_f32=True, out_xp=None, out_xp_k: Optional[int] = None,
-               out_xp_k0: int = 0, want_xp=False, k_in0: Optional[int] = None, mid_residual=None, mid_out_f32=None):
+               out_xp_k0: int = 0, want_xp=False, k_in0: Optional[int] = None, mid_residual=None, mid_out_f32=None, mid_ln=None):
     """2 .. 4 layers of one output width (``width`` = 256 | 320) in one launch (s2s_node_chain): relu?(W x + b) between, the last layer with
     ``node_linear``'s epilogue and outputs; hidden activations stay in registers.  ``w_row``: per layer the weights packed with one
     column block (pack_node_layer(..)["w_row"]), ``bias`` / ``relu`` per layer.  Bit for bit the separate launches.
     The FIRST layer may contract over ``k_in0`` != width columns (320 -> 256), add ``mid_residual`` and store its fp32 result in
-    ``mid_out_f32`` (which may be the last layer's ``residual``).  -> (out_f32, out_xp) like ``node_linear``."""
+    ``mid_out_f32`` (which may be the last layer's ``residual``); ``mid_ln`` = (gamma, beta, eps): a LayerNorm of the first layer behind
+    that residual (an encoder layer's out_proj + residual + norm1 in front of its feed-forward).  -> (out_f32, out_xp) like ``node_linear``."""
     lib = load_library()
     _req(xp, torch.int16, "xp")
     n = len(w_row)
+    mg, mb, meps = mid_ln if mid_ln is not None else (None, None, 0.0)
     k0 = width if k_in0 is None or k_in0 < 0 else int(k_in0)
     if n not in (2, 3, 4) or len(bias) != n or len(relu) != n or width not in CHAIN_WIDTHS or (k0 != width and (width, k0) != (256, 320)):
         raise HipLibraryError("node_chain: 2 .. 4 layers of width 256 or 320 (first layer: 320 -> 256 allowed)")
@@ -1192,7 +1195,7 @@ def node_chain(xp, w_row, bias, relu, n_rows: int, width: int, pre_mask=None, re
             raise HipLibraryError("node_chain: weights must be packed with one column block of the layer's width")
         arr[i].w_packed, arr[i].bias, arr[i].relu = w_row[i].data_ptr(), bias[i].data_ptr(), int(bool(relu[i]))
     for nme, t in (("pre_mask", pre_mask), ("residual", residual), ("ln_gamma", ln_gamma), ("ln_beta", ln_beta), ("post_mask", post_mask),
-                   ("mid_residual", mid_residual), ("mid_out_f32", mid_out_f32)):
+                   ("mid_residual", mid_residual), ("mid_out_f32", mid_out_f32), ("mid_ln.gamma", mg), ("mid_ln.beta", mb)):
         if t is not None:
             _req(t, name=nme)
     if out_f32 is None and want_f32:
@@ -1205,7 +1208,7 @@ def node_chain(xp, w_row, bias, relu, n_rows: int, width: int, pre_mask=None, re
     range_flag()
     _check(_timed("s2s_node_linear", lambda: lib.s2s_node_chain(
         _p(xp), ctypes.byref(arr), n, n_rows, width, k0, _p(mid_residual), mid_residual.shape[-1] if mid_residual is not None else 0,
-        _p(mid_out_f32), mid_out_f32.shape[-1] if mid_out_f32 is not None else 0, _p(pre_mask), _p(residual), residual.shape[-1] if residual is not None else 0,
+        _p(mid_out_f32), mid_out_f32.shape[-1] if mid_out_f32 is not None else 0, _p(mg), _p(mb), float(meps), _p(pre_mask), _p(residual), residual.shape[-1] if residual is not None else 0,
         _p(ln_gamma), _p(ln_beta), float(ln_eps), _p(post_mask), _p(out_f32), out_f32.shape[-1] if out_f32 is not None else 0, out_col0,
         _p(out_xp), (out_xp_k or 0) // 16, out_xp_k0 // 16, _stream()), flops=2 * n_rows * width * (k0 + (n - 1) * width)), "s2s_node_chain")
     return out_f32, out_xp
@@ -1216,7 +1219,7 @@ def node_apply_chain(x, layers, n_rows: int, relu, **kw):
     the layers one after the other otherwise (fp32 activations of the "f32" arithmetic; other widths).  ``relu``: per layer;
     ``kw``: the LAST layer's epilogue / outputs as for ``node_apply`` (residual, ln, pre_mask, post_mask, out_*, want_*)."""
     width = layers[0]["n"]
-    first_res, first_out = kw.pop("first_residual", None), kw.pop("first_out_f32", None)
+    first_res, first_out, first_ln = kw.pop("first_residual", None), kw.pop("first_out_f32", None), kw.pop("first_ln", None)
     k0 = layers[0]["k"]
     ok = (x.dtype == torch.int16 and len(layers) in (2, 3, 4) and width in CHAIN_WIDTHS and (k0 == width or (width, k0) == (256, 320))
           and all(L["n"] == width for L in layers) and all(L["k"] == width for L in layers[1:])
@@ -1229,7 +1232,7 @@ def node_apply_chain(x, layers, n_rows: int, relu, **kw):
     if not ok:
         act = x
         for i, L in enumerate(layers[:-1]):
-            fk = dict(residual=first_res, out_f32=first_out, want_f32=first_out is not None) if i == 0 else dict(want_f32=False)
+            fk = dict(residual=first_res, out_f32=first_out, want_f32=first_out is not None, ln=first_ln) if i == 0 else dict(want_f32=False)
             _, act = node_apply(act, L, n_rows, relu=relu[i], want_xp=True, **fk)
         return node_apply(act, layers[-1], n_rows, relu=relu[-1], **kw)
     kw = dict(kw)
@@ -1239,7 +1242,8 @@ def node_apply_chain(x, layers, n_rows: int, relu, **kw):
                                             kw.pop("pre_mask", None), kw.pop("residual", None), g, b, float(eps), kw.pop("post_mask", None),
                                             kw.pop("out_f32", None), kw.pop("out_col0", 0), kw.pop("want_f32", True), kw.pop("out_xp", None),
                                             -1 if kw.get("out_xp_k") is None else kw.pop("out_xp_k"), kw.pop("out_xp_k0", 0),
-                                            kw.pop("want_xp", False), k0, first_res, first_out)
+                                            kw.pop("want_xp", False), k0, first_res, first_out,
+                                            *(first_ln if first_ln is not None else (None, None, 0.0)))
 
 
 _CONST_ROWS = {}
@@ -1322,6 +1326,21 @@ def ca_sample_stats(ca: torch.Tensor, clash_bar: float = 3.0, k_exclusion: int =
     rg = torch.empty(R, dtype=torch.float64, device=ca.device)
     _check(lib.s2s_ca_sample_stats(_p(ca), R, L, float(clash_bar), int(k_exclusion), _p(nc), _p(am), _p(rg), _stream()), "s2s_ca_sample_stats")
     return nc, am, rg
+
+
+def ca_pairwise_distances(ca: torch.Tensor, offset: int = 1) -> torch.Tensor:
+    """Upper-triangular CA distances [R, D] float32 of every sample (np.triu_indices(L, k=offset) order) in numpy's float32 arithmetic."""
+    lib = load_library()
+    _req(ca, name="ca")
+    R, L = ca.shape[0], ca.shape[1]
+    if ca.ndim != 3 or ca.shape[2] != 3 or L <= offset:
+        raise HipLibraryError(f"ca_pairwise_distances: coordinates {tuple(ca.shape)}, offset {offset}")
+    D = (L - offset) * (L - offset + 1) // 2
+    out = torch.empty(R, D, dtype=torch.float32, device=ca.device)
+    for r0 in range(0, R, 65535):
+        n = min(65535, R - r0)
+        _check(lib.s2s_ca_pairwise_distances(_p(ca[r0:r0 + n]), n, L, int(offset), _p(out[r0:r0 + n]), _stream()), "s2s_ca_pairwise_distances")
+    return out
 
 
 def ca_pwd_js(ref_ca: torch.Tensor, pred_ca: torch.Tensor, offset: int = 3, n_bins: int = 50, pseudo: float = 1e-6,
@@ -1592,9 +1611,11 @@ _TORCH_OPS = {
     "node_chain(Tensor xp, Tensor[] w_row, Tensor[] bias, bool[] relu, int n_rows, int width, Tensor? pre_mask=None, Tensor? residual=None, "
     "Tensor? ln_gamma=None, Tensor? ln_beta=None, float ln_eps=0.0, Tensor? post_mask=None, Tensor(a!)? out_f32=None, int out_col0=0, "
     "bool want_f32=True, Tensor(b!)? out_xp=None, int out_xp_k=-1, int out_xp_k0=0, bool want_xp=False, int k_in0=-1, "
-    "Tensor? mid_residual=None, Tensor(c!)? mid_out_f32=None) -> (Tensor?, Tensor?)":
+    "Tensor? mid_residual=None, Tensor(c!)? mid_out_f32=None, Tensor? mid_ln_gamma=None, Tensor? mid_ln_beta=None, float mid_ln_eps=0.0) "
+    "-> (Tensor?, Tensor?)":
         lambda xp, w, b, r, m, wd, pm=None, res=None, g=None, be=None, eps=0.0, pom=None, of=None, oc=0, wf=True, ox=None, ok=-1, ok0=0, wx=False,
-        k0=-1, mr=None, mo=None: node_chain(xp, w, b, r, m, wd, pm, res, g, be, eps, pom, of, oc, wf, ox, _opt_int(ok), ok0, wx, k0, mr, mo),
+        k0=-1, mr=None, mo=None, mg=None, mb=None, me=0.0: node_chain(xp, w, b, r, m, wd, pm, res, g, be, eps, pom, of, oc, wf, ox, _opt_int(ok), ok0, wx,
+                                                                      k0, mr, mo, (mg, mb, me) if mg is not None else None),
     "row_layernorm(Tensor x, int n_rows, int n_cols, Tensor gamma, Tensor beta, float eps, Tensor? post_mask=None, Tensor(a!)? out_f32=None, "
     "int out_col0=0, bool want_f32=True, Tensor(b!)? out_xp=None, int out_xp_k=-1, int out_xp_k0=0, bool want_xp=False) -> (Tensor?, Tensor?)":
         lambda x, m, n, g, b, eps, pm=None, of=None, oc=0, wf=True, ox=None, ok=-1, ok0=0, wx=False: row_layernorm(

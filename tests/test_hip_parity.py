@@ -787,6 +787,23 @@ def test_every_torch_op_equals_its_ops_function(net_rough, diffuser):
         want = ops.node_apply(ha_, lw0["l2"], Mc, **kwe)
         got = ops.node_apply_chain(xe, [lw0["l1"], lw0["l2"]], Mc, (True, False), **kwe)
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), Mc
+        # ... and the layer's whole post-attention half: out_proj + residual + norm1 (stored: norm2's residual), linear1, relu, linear2 +
+        # residual + norm2 (reference ipa.py:312-317) as ONE launch -- the kernel itself (s2s_node_chain with the first layer's LayerNorm;
+        # node_apply_chain would pick the separate launches at this row count) and through node_apply_chain
+        ln1 = (enc.norm1.weight, enc.norm1.bias, enc.norm1.eps)
+        x1_want, x1a_ = ops.node_apply(xe, lw0["o"], Mc, residual=rese, ln=ln1, want_xp=True)
+        _, ha_ = ops.node_apply(x1a_, lw0["l1"], Mc, relu=True, want_f32=False, want_xp=True)
+        want = ops.node_apply(ha_, lw0["l2"], Mc, residual=x1_want, ln=kwe["ln"], want_xp=True)
+        lyr3 = [lw0["o"], lw0["l1"], lw0["l2"]]
+        x1_got = torch.full((Mc, 320), float("nan"), device=DEV)
+        got = ops.node_chain(xe, [L_["w_row"] for L_ in lyr3], [L_["b"] for L_ in lyr3], [False, True, False], Mc, 320, residual=x1_got,
+                             ln_gamma=enc.norm2.weight, ln_beta=enc.norm2.bias, ln_eps=enc.norm2.eps, want_xp=True, mid_residual=rese,
+                             mid_out_f32=x1_got, mid_ln=ln1)
+        assert torch.equal(x1_got, x1_want) and torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), Mc
+        x1_got2 = torch.full((Mc, 320), float("nan"), device=DEV)
+        got = ops.node_apply_chain(xe, lyr3, Mc, (False, True, False), first_residual=rese, first_out_f32=x1_got2, first_ln=ln1,
+                                   residual=x1_got2, ln=kwe["ln"], want_xp=True)
+        assert torch.equal(x1_got2, x1_want) and torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]), Mc
     # the embedder's per-evaluation assembly: one launch == the elementwise expressions it replaced, bit for bit (fp32 adds, relu, split)
     Le = 40
     timg, ncst, fa_ = rn(512), rn(B * Le, 256), rn(B, Le, 128)
@@ -1493,6 +1510,12 @@ def test_js_tica_and_weighted_metrics_match_the_reference_driven_fixture(tag):
     g = golden("tica.npz")
     d = {"target": g[f"{tag}_target"], "pred": g[f"{tag}_pred"]}
     w, lag = g[f"{tag}_weights"], int(g[f"{tag}_lag"])
+    # the features: numpy's float32 arithmetic on the device, bit for bit (reference pairwise_distance_ca, metrics.py:38-50)
+    for k_off in (1, 3):
+        x = d["pred"]
+        dm = np.sqrt(np.sum((x[..., None, :, :] - x[..., None, :]) ** 2, axis=-1))
+        r_, c_ = np.triu_indices(x.shape[1], k=k_off)
+        assert np.array_equal(M.pairwise_distance_ca(x, k=k_off), dm[..., r_, c_])
     res, tics = M.js_tica(d, ref_key="target", lagtime=lag)
     assert res["target"] == 0.0 and abs(res["pred"] - float(g[f"{tag}_js_tica"])) < 1.5e-4, (res, g[f"{tag}_js_tica"])
     for k in ("target", "pred"):
