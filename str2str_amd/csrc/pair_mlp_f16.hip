@@ -312,7 +312,23 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         return base + ((unsigned long long)blk * mul + in_blk);
     };
     auto erow_of = [&](const PairCtx& c) -> const float* { return row_of(edge, c.p, in_tiled); };
-    auto ldrow = [&](const float* r, int g) -> float4 { return *reinterpret_cast<const float4*>(r + g * in_step); };
+    // The pair stream is NON-TEMPORAL (round 6): every edge row is read once and every output row written once per launch (4.3 GB each way at
+    // cfg2), and as ordinary accesses they push the 0.97 MB weight stream -- which all 32 workgroups of an XCD re-read every tile -- out of the
+    // 4 MiB L2 between two uses (the re-fetches from the Infinity Cache showed in FETCH_SIZE: 378 instead of 301 B per pair).  With the nt bit
+    // on the row loads and the output stores: -0.5 .. -1.2 % per launch at every shape measured (same-call A/B, profiles/r06_et_nt_ab.txt;
+    // loads alone -0.4 %; nt on the fused projection's stores as well: no further gain, not kept).  -DS2S_ET_NT=0 restores plain accesses.
+#ifndef S2S_ET_NT
+#define S2S_ET_NT 2
+#endif
+    typedef float f32x4nt __attribute__((ext_vector_type(4)));
+    auto ldrow = [&](const float* r, int g) -> float4 {
+        if constexpr (S2S_ET_NT >= 1) {
+            const f32x4nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4nt*>(r + g * in_step));
+            return make_float4(v.x, v.y, v.z, v.w);
+        } else {
+            return *reinterpret_cast<const float4*>(r + g * in_step);
+        }
+    };
     const long long n_wt = (M + 127) / 128;
     long long wt = blockIdx.x;
 #ifndef S2S_ET_PHASES
@@ -513,7 +529,10 @@ __global__ void __launch_bounds__(256) edge_transition_f16_kernel(
         o.y = ((a3[t][4 * rq + 1] - ln_mean) * ln_rstd * ga.y + be.y) * ln_em;
         o.z = ((a3[t][4 * rq + 2] - ln_mean) * ln_rstd * ga.z + be.z) * ln_em;
         o.w = ((a3[t][4 * rq + 3] - ln_mean) * ln_rstd * ga.w + be.w) * ln_em;
-        if (prv.valid && !no_out) *reinterpret_cast<float4*>(ln_orow + q * out_step) = o;
+        if (prv.valid && !no_out) {
+            if constexpr (S2S_ET_NT >= 2) __builtin_nontemporal_store(f32x4nt{o.x, o.y, o.z, o.w}, reinterpret_cast<f32x4nt*>(ln_orow + q * out_step));
+            else *reinterpret_cast<float4*>(ln_orow + q * out_step) = o;
+        }
         if constexpr (PROJ) {
             const float x[4] = {o.x, o.y, o.z, o.w};
             split4(x, xln[2 * t + (rq >> 1)][0], xln[2 * t + (rq >> 1)][1], 4 * (rq & 1));
@@ -1088,8 +1107,11 @@ __global__ void __launch_bounds__(256) edge_embed_f16_kernel(
             o.y = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 1] - ln_mean, ln_rstd), ga.y, be.y), c.em);
             o.z = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 2] - ln_mean, ln_rstd), ga.z, be.z), c.em);
             o.w = __fmul_rn(__fmaf_rn(__fmul_rn(a3[t][4 * rq + 3] - ln_mean, ln_rstd), ga.w, be.w), c.em);
+#ifndef S2S_EE_NT
+#define S2S_EE_NT 0
+#endif
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)},
-                                                   rs_out, out_lane + (unsigned)g * out_step, 0, 0);
+                                                   rs_out, out_lane + (unsigned)g * out_step, 0, S2S_EE_NT ? 2 : 0);   // (aux bit 1 = nt)
             if constexpr (PROJ) {
                 const float xx[4] = {o.x, o.y, o.z, o.w};
                 split4(xx, xq[k & 1][0], xq[k & 1][1], 4 * u);
