@@ -127,22 +127,26 @@ def cpu_baseline(n_res, denoise_steps, steps_sampled=10, replicas=4):
 
 def traffic_from_profiles(pairs, mode):
     """HBM bytes per launch of the dominant kernel.  NOT measured in this run: PMC counters need rocprofv3 around the
-    process (separate --pmc passes, tools/pmc_hbm_traffic.sh), so the committed pass at B = 16, N = 256 is scaled by the
-    pairs of this launch and labelled as such.  (None, None) if the file is absent."""
+    process (separate --pmc passes, tools/pmc_hbm_traffic.sh), so the newest committed pass (profiles/r<round><run>_pmc_hbm_traffic[_b<B>].json;
+    the file states its shape) is scaled by the pairs of this launch and labelled as such.  (None, None) if there is none."""
     import glob
     import re
 
-    def _order(path):   # newest evidence run first: round number, then the run's letter (r04l > r04a > r03h ...)
-        m = re.match(r"r(\d+)([a-z]*)_pmc_hbm_traffic\.json$", os.path.basename(path))
+    def _order(path):   # newest evidence run first: round number, then the run's letter (r06e > r06 > r05d ...)
+        m = re.match(r"r(\d+)([a-z]*)_pmc_hbm_traffic(_b\d+)?\.json$", os.path.basename(path))
         return (int(m.group(1)), m.group(2)) if m else (-1, "")
 
     key = {"f16x3": "edge_transition_f16x3"}.get(mode, "edge_transition")
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), key=_order, reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.json")), key=_order, reverse=True):
+        if _order(path)[0] < 0:
+            continue
         try:
             with open(path) as f:
-                return (json.load(f)["kernels"][key]["bytes_per_pair_corrected"] * pairs,
-                        f"profiles/{os.path.basename(path)} (PMC pass at B=16, N=256, scaled per pair; the counters sit on the L2's fabric side and include "
-                        "Infinity-Cache hits: ~150 B/pair of it are weight-stream re-fetches of workgroups in lockstep, DESIGN section 4 K5)")
+                d = json.load(f)
+            sh = d.get("shape", {})
+            return (d["kernels"][key]["bytes_per_pair_corrected"] * pairs,
+                    f"profiles/{os.path.basename(path)} (PMC pass at B={sh.get('B', '?')}, N={sh.get('N', '?')}: FETCH_SIZE x 2 + WRITE_SIZE, separate passes, "
+                    "scaled per pair; mean of the trunk's three launches; the counters sit on the L2's fabric side and include Infinity-Cache hits)")
         except Exception:
             continue
     return None, None
