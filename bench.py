@@ -183,6 +183,8 @@ def main():
     # own N ranks under torch.distributed.run; inside a job (the driver's launch line, WORLD_SIZE set) this IS one of the ranks.
     use_dist = in_distributed_job()
     if a.gpus > 1 and not use_dist:
+        if os.environ.get("S2S_BENCH_BACKEND", "nccl") == "nccl" and torch.cuda.device_count() < a.gpus:
+            sys.exit(f"bench.py: --gpus {a.gpus} but {torch.cuda.device_count()} GPU(s) are visible here (RCCL wants one device per rank)")
         sys.exit(relaunch(a.gpus, __file__, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1")) if use_dist else 1
     rank = int(os.environ.get("RANK", "0")) if use_dist else 0

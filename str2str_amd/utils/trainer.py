@@ -25,6 +25,9 @@ class Trainer:
         local = int(os.environ.get("LOCAL_RANK", "0"))
         if os.environ.get("S2S_DIST_BACKEND", "nccl") == "gloo":
             local %= torch.cuda.device_count()
+        if local >= torch.cuda.device_count():
+            raise ops.HipLibraryError(f"rank with LOCAL_RANK={local} but {torch.cuda.device_count()} GPU(s) are visible (one device per rank; "
+                                      "trainer.devices must not exceed the node's GPUs)")
         torch.cuda.set_device(local)
         return torch.device("cuda", local)
 
