@@ -59,6 +59,8 @@ class FrameDiffuser:
     def sample_prior(self, shape, device=None, reference_rigids: Rigid = None, diffuse_mask: torch.Tensor = None,
                      as_tensor_7: bool = False):
         if reference_rigids is not None or diffuse_mask is not None:
+            # (the reference's own motif branch asserts reference_rigids.shape[:-1] == shape, frame.py:224 -- i.e. it only accepts a sample
+            #  shape WITHOUT the residue axis and then broadcasts ONE prior draw over all residues of a sample; predict_step never takes it)
             raise NotImplementedError("motif-conditioned priors are outside the sampling path")
         shape = tuple(shape)
         rot = self.rot_diffuser.sample_prior(shape=shape + (3,))
