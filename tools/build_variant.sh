@@ -3,6 +3,8 @@
 # (UNIT=pair_mlp_f16 by default = the edge transition for chains of 32+ residues; UNIT=pair_mlp_f16_b its short-chain form, UNIT=pair_mlp_f16_c the
 # edge embedding -- three translation units of one source, with SRC=<file> for _b / _c a wrapper that includes the other version; e.g. UNIT=ipa_attention tools/build_variant.sh qr0 -DS2S_IPA_QR=0).  Run
 # `python -m str2str_amd.build` first: the other units are linked from its objects.
+# NOTE: .gpurunignore lists str2str_amd/csrc/build/ab_*.so (45 stale variants once cost every lease a 73 MB push): comment that line out for an
+# A/B session and delete the variants afterwards (rm str2str_amd/csrc/build/ab_*.so).
 N=$1; shift
 U=${UNIT:-pair_mlp_f16}
 D=str2str_amd/csrc/build
