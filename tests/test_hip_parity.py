@@ -1708,6 +1708,38 @@ def test_full_size_batch_is_invariant_at_the_headline_shape(net_smooth, diffuser
     assert parts[0].shape[0] == 64 and torch.equal(torch.cat(parts), full)
 
 
+def test_full_size_batch_is_invariant_at_n512(net_smooth, diffuser):
+    """BASELINE configs[3]'s chain length at the largest batch a trajectory holds (32 replicas x 512^2 = 8 388 608 pairs per launch: the
+    pair budget of a merged trajectory; the bench's 128 replicas per GPU run as four of these), for the 10 + 1 evaluations of the
+    `traj_free_n512_s10` fixture: replica 0 is the reference's own B = 1 run (< 1e-4 A) and equals this build's B = 1 launch bit for
+    bit; a 2-rank shard of the 32 equals the single run bit for bit."""
+    from str2str_amd.common.rigid_utils import Rigid
+    from str2str_amd.sampler import forward_backward, forward_backward_chunks, rank_chunk_slices
+
+    from str2str_amd.synth import synth_chain
+
+    g = golden("traj_free_n512_s10.npz")
+    N, S = int(g["n_res"]), int(g["num_timesteps"])
+    assert (N, int(g["B"])) == (512, 1)
+    feats = synth_chain(N)
+    gt4 = feats["rigidgroups_gt_frames"][..., 0, :, :]
+    kw = dict(num_timesteps=S, device=DEV)
+    torch.manual_seed(int(g["seed"]))
+    full = forward_backward_chunks(net_smooth, diffuser, feats, gt4, rank_chunk_slices(32, 1, 0, 1), float(g["t_delta"]), **kw)
+    assert tuple(full.shape) == (32, N, 37, 3) and torch.isfinite(full).all()
+    rmsd = backbone_rmsd(full[:1].cpu().numpy()[..., :5, :], g["atom37"])
+    record_margin("full batch B=32, N=512: replica 0 backbone RMSD vs the reference's B=1 run (A)", rmsd, 1e-4)
+    assert rmsd < 1e-4, rmsd
+    torch.manual_seed(int(g["seed"]))
+    one = forward_backward(net_smooth, diffuser, feats, Rigid.from_tensor_4x4(gt4.repeat(1, 1, 1, 1)), float(g["t_delta"]), **kw)
+    assert torch.equal(one, full[:1])
+    parts = []
+    for r in range(2):
+        torch.manual_seed(int(g["seed"]))
+        parts.append(forward_backward_chunks(net_smooth, diffuser, feats, gt4, rank_chunk_slices(32, 1, r, 2), float(g["t_delta"]), **kw))
+    assert parts[0].shape[0] == 16 and torch.equal(torch.cat(parts), full)
+
+
 @pytest.mark.parametrize("cfg,extra", [("cfg4", ["--n-res", "32", "--replicas", "2", "--denoise-steps", "3"]),
                                        ("cfg5", ["--replicas", "1", "--denoise-steps", "2"])])
 def test_bench_world8_rehearsal(cfg, extra):
