@@ -121,8 +121,10 @@ def cpu_baseline(n_res, denoise_steps, steps_sampled=10, replicas=4):
             "cpu_model": cpu_model(), "nproc": nproc,
             "thread_sweep_s_per_replica_evaluation": {str(k): round(v, 4) for k, v in sweep.items()},
             "sample": f"{replicas} replicas x (1 self-conditioning + {steps_sampled} denoise) network evaluations of the "
-                      f"{n_res}-residue workload = {dt:.1f} s on {best} host threads (best of the sweep), scaled linearly to "
-                      f"{denoise_steps}+1 evaluations (SURVEY 8d asks 2 x 100 steps: bounded here to keep the default run in minutes)"}
+                      f"{n_res}-residue workload = {dt:.1f} s on {best} host threads (best of the sweep)"
+                      + ("" if steps_sampled == denoise_steps else f", scaled linearly to {denoise_steps}+1 evaluations (SURVEY 8d asks 2 x 100 steps: bounded here to "
+                         "keep the default run in minutes; the full sample, --cpu-replicas 2 --cpu-steps 100, measured 0.01287 conformations/s = the scaled "
+                         "figure: profiles/r06_cpu_baseline_full_sample.json)")}
 
 
 def traffic_from_profiles(pairs, mode):
@@ -163,6 +165,7 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=None)
     ap.add_argument("--rng", default="device", choices=["device", "host"], help="noise source (host = reference-order parity mode)")
     ap.add_argument("--cpu-steps", type=int, default=10, help="denoise steps of the CPU-oracle sample (4 replicas at the best thread count of a sweep; ~60 s of host time at N = 256)")
+    ap.add_argument("--cpu-replicas", type=int, default=4, help="replicas of the CPU-oracle sample (SURVEY 8d's full sample: --cpu-replicas 2 --cpu-steps 100, ~3 min of host time)")
     ap.add_argument("--no-other-configs", action="store_true", help="default cfg2 line at 1 GPU: do not append one step each of cfg3 / cfg4 / cfg5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the extra (untimed) step that times the kernel families")
@@ -491,7 +494,7 @@ def main():
                                                  note="flops = sum over launches of 2 M K N as launched; ~11 launches of 0.1 ms each per IPA block at cfg2: "
                                                       "launch- and latency-bound, the fraction is reported for completeness")
         if world == 1 and not a.no_cpu_baseline and a.config == "cfg2":
-            line["cpu_baseline"] = cpu_baseline(N, S, steps_sampled=a.cpu_steps)
+            line["cpu_baseline"] = cpu_baseline(N, S, steps_sampled=a.cpu_steps, replicas=a.cpu_replicas)
         if world == 1 and a.config == "cfg2" and not a.no_other_configs and a.n_res is None and a.replicas is None and a.denoise_steps is None:
             # the other single-GPU workloads of BASELINE.json and the reference's default inference block (configs/model/diffusion.yaml:88-100
             # there: the workload its users run), ONE step each (their own processes, after the timed region and the CPU baseline):

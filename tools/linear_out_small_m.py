@@ -26,7 +26,7 @@ dev = "cuda"
 w = torch.randn(256, 2688, device=dev) / 50
 lo = ops.pack_node_layer(w, torch.zeros(256, device=dev), True)
 g, b = torch.ones(256, device=dev), torch.zeros(256, device=dev)
-for M in (1260, 2240, 2880, 5120, 8192):
+for M in ((1260, 2240, 2880, 5120, 8192) if len(sys.argv) < 2 else [int(a) for a in sys.argv[1:]]):
     fx = ops.pack_planes(torch.randn(M, 2688, device=dev))
     res, pm = torch.randn(M, 256, device=dev), torch.ones(M, device=dev)
     kw = dict(pre_mask=pm, residual=res, ln=(g, b, 1e-5), post_mask=pm, want_xp=True)
